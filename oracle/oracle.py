@@ -1,0 +1,168 @@
+"""ctypes front-end of the CPU oracle (oracle/classic_control.c).
+
+TEST INFRASTRUCTURE ONLY — see the header of classic_control.c.  Importable only from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; gym_amd/ never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
+
+ENV_IDS = {"CartPole": 0, "Pendulum": 1, "Acrobot": 2, "MountainCar": 3, "MountainCarContinuous": 4}
+MAX_PARAMS = 12
+DISCRETE = {0: 2, 2: 3, 3: 3}  # env_id -> number of actions
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile). Returns the library path."""
+    src = os.path.join(_HERE, "classic_control.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u64, i64, i32, u32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32
+        vp = C.c_void_p
+        L.orc_state_dim.restype = C.c_int
+        L.orc_obs_dim.restype = C.c_int
+        L.orc_default_params.argtypes = [C.c_int, vp]
+        L.orc_default_reset_bounds.argtypes = [C.c_int, vp]
+        L.orc_philox4x32_10.argtypes = [vp, vp, vp]
+        L.orc_sample_actions.argtypes = [C.c_int, i64, u64, u64, u64, vp, vp, vp]
+        L.orc_vec_reset.argtypes = [C.c_int, i64, u64, vp, u64, u64, u32, vp, vp, vp, vp, vp]
+        L.orc_vec_step.argtypes = [C.c_int, i64, u64, vp, C.c_int, C.c_int, vp, u64, u64, vp, vp, vp,
+                                   vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orc_vec_step.restype = i64
+        L.orc_rollout.argtypes = [C.c_int, i64, u64, vp, C.c_int, u64, u64, u64, C.c_int, vp, vp, vp,
+                                  vp, vp, vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def philox4x32_10(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+def default_params(env_id: int) -> np.ndarray:
+    P = np.zeros(MAX_PARAMS, dtype=np.float64)
+    lib().orc_default_params(env_id, _p(P))
+    return P
+
+
+def default_reset_bounds(env_id: int) -> np.ndarray:
+    b = np.zeros(2, dtype=np.float64)
+    lib().orc_default_reset_bounds(env_id, _p(b))
+    return b
+
+
+class OracleVecEnv:
+    """Batched CPU twin of the device engine: same state layout (SoA fp64), same RNG contract,
+    same step/reset/autoreset semantics as SyncVectorEnv over TimeLimit-wrapped classic-control envs."""
+
+    def __init__(self, env_id: int, num_envs: int, max_episode_steps: int, seed: int = 0,
+                 action_seed: int = 0, env_offset: int = 0, params=None, autoreset: bool = True):
+        self.env_id = int(env_id)
+        self.n = int(num_envs)
+        self.S = lib().orc_state_dim(self.env_id)
+        self.O = lib().orc_obs_dim(self.env_id)
+        self.max_episode_steps = int(max_episode_steps)
+        self.base_seed = int(seed) & (2**64 - 1)
+        self.action_seed = int(action_seed) & (2**64 - 1)
+        self.env0 = int(env_offset)
+        self.autoreset = bool(autoreset)
+        self.P = default_params(self.env_id) if params is None else np.array(params, dtype=np.float64)
+        self.bounds = default_reset_bounds(self.env_id)
+        self.seeds = None  # optional per-env uint64 seeds
+        self.state = np.zeros((self.S, self.n), dtype=np.float64)
+        self.elapsed = np.zeros(self.n, dtype=np.int32)
+        self.t = 0  # vector-step index since seeding
+        self.r = 0  # explicit reset ordinal since seeding
+        self.discrete = self.env_id in DISCRETE
+
+    # -- RNG-contract helpers ---------------------------------------------------------
+    def sample_actions(self, t=None):
+        t = self.t if t is None else t
+        ai = np.zeros(self.n, dtype=np.int64)
+        af = np.zeros(self.n, dtype=np.float32)
+        lib().orc_sample_actions(self.env_id, self.n, self.env0, self.action_seed, t, _p(self.P), _p(ai), _p(af))
+        return ai if self.discrete else af
+
+    def reset(self, seed=None, mask=None, bounds=None):
+        """Explicit reset. seed: None (continue streams), int (base seed) or array of per-env seeds."""
+        if seed is not None:
+            if np.ndim(seed) == 0:
+                self.base_seed = int(seed) & (2**64 - 1)
+                self.seeds = None
+            else:
+                self.seeds = np.asarray(seed, dtype=np.uint64).copy()
+            self.t = 0
+            self.r = 0
+        self.r += 1
+        b = self.bounds if bounds is None else np.asarray(bounds, dtype=np.float64)
+        obs = np.zeros((self.n, self.O), dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_vec_reset(self.env_id, self.n, self.env0, _p(self.seeds), self.base_seed, self.t, self.r,
+                            _p(b), _p(m), _p(self.state), _p(self.elapsed), _p(obs))
+        return obs
+
+    def step(self, actions):
+        n, O = self.n, self.O
+        obs = np.zeros((n, O), dtype=np.float32)
+        reward = np.zeros(n, dtype=np.float64)
+        term = np.zeros(n, dtype=np.uint8)
+        trunc = np.zeros(n, dtype=np.uint8)
+        final_obs = np.zeros((n, O), dtype=np.float32)
+        final_mask = np.zeros(n, dtype=np.uint8)
+        if self.discrete:
+            ai = np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
+            af = None
+        else:
+            af = np.ascontiguousarray(actions, dtype=np.float32).reshape(n)
+            ai = None
+        bad = lib().orc_vec_step(self.env_id, n, self.env0, _p(self.P), self.max_episode_steps,
+                                 int(self.autoreset), _p(self.seeds), self.base_seed, self.t, _p(self.bounds),
+                                 _p(ai), _p(af), _p(self.state), _p(self.elapsed), _p(obs), _p(reward),
+                                 _p(term), _p(trunc), _p(final_obs), _p(final_mask))
+        if bad:
+            raise AssertionError(f"{bad} invalid discrete action(s)")
+        self.t += 1
+        return obs, reward, term.astype(bool), trunc.astype(bool), final_obs, final_mask.astype(bool)
+
+    def rollout(self, K: int):
+        """K random-action steps (Philox action stream). Returns (sum_reward, num_done)."""
+        n, O = self.n, self.O
+        ai = np.zeros(n, dtype=np.int64)
+        af = np.zeros(n, dtype=np.float32)
+        obs = np.zeros((n, O), dtype=np.float32)
+        reward = np.zeros(n, dtype=np.float64)
+        term = np.zeros(n, dtype=np.uint8)
+        trunc = np.zeros(n, dtype=np.uint8)
+        sr = C.c_double(0.0)
+        nd = C.c_int64(0)
+        lib().orc_rollout(self.env_id, n, self.env0, _p(self.P), self.max_episode_steps, self.base_seed,
+                          self.action_seed, self.t, int(K), _p(self.bounds), _p(self.state), _p(self.elapsed),
+                          _p(ai), _p(af), _p(obs), _p(reward), _p(term), _p(trunc), C.byref(sr), C.byref(nd))
+        self.t += int(K)
+        return sr.value, nd.value, obs, reward, term.astype(bool), trunc.astype(bool)
