@@ -1,0 +1,288 @@
+"""ctypes binding of the C ABI in include/mxv.h (gym_amd/_lib/libmxv.so).
+
+This is the only door into the engine: there is no CPU fallback.  If the shared library has
+not been built (`python __graft_entry__.py` or gym_amd/csrc/build.sh) importing this module
+raises; if no HIP device is visible `Handle(...)` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# MXV_LIB_PATH: tuning hook (tools/kbench.py loads envs-per-lane build variants through it)
+LIB_PATH = os.environ.get("MXV_LIB_PATH") or os.path.join(_HERE, "_lib", "libmxv.so")
+
+# env kinds / flags / status codes: keep in sync with include/mxv.h
+CARTPOLE, PENDULUM, ACROBOT, MOUNTAINCAR, MOUNTAINCAR_CONT = range(5)
+FLAG_ACTION_I32 = 1
+FLAG_REWARD_F32 = 2
+FLAG_NO_AUTORESET = 4
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_HIP = -2
+ERR_INVALID_ACTION = -3
+ERR_RESET_NEEDED = -4
+ERR_UNSUPPORTED = -5
+MAX_PARAMS = 12
+ENV_ALIGN = 4
+
+EXPORTS = (
+    "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
+    "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
+    "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
+    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+)
+
+
+class MxvConfig(C.Structure):
+    _fields_ = [
+        ("env_id", C.c_int32),
+        ("device", C.c_int32),
+        ("num_envs", C.c_int64),
+        ("env_offset", C.c_int64),
+        ("max_episode_steps", C.c_int32),
+        ("flags", C.c_int32),
+        ("seed", C.c_uint64),
+        ("action_seed", C.c_uint64),
+    ]
+
+
+class MxvError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mxv error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or gym_amd/csrc/build.sh). gym_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
+    sig = {
+        "mxv_env_dims": ([i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], C.c_int),
+        "mxv_default_params": ([i32, vp], C.c_int),
+        "mxv_default_reset_bounds": ([i32, vp], C.c_int),
+        "mxv_version": ([], C.c_char_p),
+        "mxv_create": ([C.POINTER(MxvConfig), C.POINTER(vp)], C.c_int),
+        "mxv_destroy": ([vp], C.c_int),
+        "mxv_last_error": ([vp], C.c_char_p),
+        "mxv_seed": ([vp, u64, vp], C.c_int),
+        "mxv_seed_actions": ([vp, u64], C.c_int),
+        "mxv_reset": ([vp, vp, vp, vp], C.c_int),
+        "mxv_step": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
+        "mxv_step_sampled": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
+        "mxv_rollout": ([vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "mxv_sample_actions": ([vp, vp], C.c_int),
+        "mxv_reset_host": ([vp, vp, vp, vp], C.c_int),
+        "mxv_step_host": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
+        "mxv_get_state": ([vp, vp, vp], C.c_int),
+        "mxv_set_state": ([vp, vp, vp], C.c_int),
+        "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
+        "mxv_set_counters": ([vp, u64, u32], C.c_int),
+        "mxv_get_params": ([vp, vp], C.c_int),
+        "mxv_set_params": ([vp, vp], C.c_int),
+        "mxv_sync": ([vp], C.c_int),
+        "mxv_get_stream": ([vp, C.POINTER(vp)], C.c_int),
+        "mxv_set_stream": ([vp, vp], C.c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
+lib = _load()
+
+
+def env_dims(env_id: int):
+    s, o, na = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.mxv_env_dims(env_id, C.byref(s), C.byref(o), C.byref(na))
+    if rc != OK:
+        raise MxvError(rc, f"unknown env_id {env_id}")
+    return s.value, o.value, na.value
+
+
+def default_params(env_id: int) -> np.ndarray:
+    p = np.zeros(MAX_PARAMS, dtype=np.float64)
+    rc = lib.mxv_default_params(env_id, p.ctypes.data)
+    if rc != OK:
+        raise MxvError(rc, f"unknown env_id {env_id}")
+    return p
+
+
+def default_reset_bounds(env_id: int) -> np.ndarray:
+    b = np.zeros(2, dtype=np.float64)
+    rc = lib.mxv_default_reset_bounds(env_id, b.ctypes.data)
+    if rc != OK:
+        raise MxvError(rc, f"unknown env_id {env_id}")
+    return b
+
+
+def _ptr(x):
+    """Device pointer (int / torch tensor) or host ndarray -> c_void_p value."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()  # torch tensor
+
+
+class Handle:
+    """One engine handle = one device + one stream + N device-resident envs (see include/mxv.h)."""
+
+    def __init__(self, env_id: int, num_envs: int, max_episode_steps: int, *, device: int = 0, env_offset: int = 0,
+                 seed: int = 0, action_seed: int = 0, flags: int = 0):
+        self.env_id = int(env_id)
+        self.num_envs = int(num_envs)
+        self.S, self.O, self.NA = env_dims(self.env_id)
+        self.flags = int(flags)
+        self.device = int(device)
+        self.env_offset = int(env_offset)
+        cfg = MxvConfig(self.env_id, self.device, self.num_envs, self.env_offset, int(max_episode_steps), self.flags,
+                        int(seed) & (2**64 - 1), int(action_seed) & (2**64 - 1))
+        h = C.c_void_p()
+        rc = lib.mxv_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
+        self._h = h
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_last_error(self._h) or b"").decode())
+
+    @property
+    def action_dtype(self):
+        if self.NA > 0:
+            return np.int32 if self.flags & FLAG_ACTION_I32 else np.int64
+        return np.float32
+
+    @property
+    def reward_dtype(self):
+        return np.float32 if self.flags & FLAG_REWARD_F32 else np.float64
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.mxv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ABI calls ------------------------------------------------------------------------
+    def seed(self, base_seed: int, per_env_seeds=None):
+        p = None
+        if per_env_seeds is not None:
+            per_env_seeds = np.ascontiguousarray(per_env_seeds, dtype=np.uint64)
+            assert per_env_seeds.shape == (self.num_envs,)
+            p = per_env_seeds.ctypes.data
+        self._check(lib.mxv_seed(self._h, int(base_seed) & (2**64 - 1), p))
+
+    def seed_actions(self, action_seed: int):
+        self._check(lib.mxv_seed_actions(self._h, int(action_seed) & (2**64 - 1)))
+
+    @staticmethod
+    def _bounds(bounds):
+        if bounds is None:
+            return None, None
+        b = np.ascontiguousarray(bounds, dtype=np.float64)
+        return b, b.ctypes.data
+
+    def reset(self, obs_dev=None, mask_dev=None, bounds=None):
+        b, bp = self._bounds(bounds)
+        self._check(lib.mxv_reset(self._h, _ptr(mask_dev), bp, _ptr(obs_dev)))
+
+    def step(self, actions_dev, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None):
+        self._check(lib.mxv_step(self._h, _ptr(actions_dev), _ptr(obs_dev), _ptr(reward_dev), _ptr(terminated_dev),
+                                 _ptr(truncated_dev), _ptr(final_obs_dev)))
+
+    def step_sampled(self, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None,
+                     actions_out_dev=None):
+        self._check(lib.mxv_step_sampled(self._h, _ptr(actions_out_dev), _ptr(obs_dev), _ptr(reward_dev),
+                                         _ptr(terminated_dev), _ptr(truncated_dev), _ptr(final_obs_dev)))
+
+    def rollout(self, K, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None,
+                actions_out_dev=None, per_step=False, use_graph=False):
+        self._check(lib.mxv_rollout(self._h, int(K), int(per_step), int(use_graph), _ptr(actions_out_dev),
+                                    _ptr(obs_dev), _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev),
+                                    _ptr(final_obs_dev)))
+
+    def sample_actions(self, actions_out_dev):
+        self._check(lib.mxv_sample_actions(self._h, _ptr(actions_out_dev)))
+
+    def reset_host(self, mask=None, bounds=None) -> np.ndarray:
+        obs = np.empty((self.num_envs, self.O), dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        b, bp = self._bounds(bounds)
+        self._check(lib.mxv_reset_host(self._h, _ptr(m), bp, obs.ctypes.data))
+        return obs
+
+    def step_host(self, actions, want_final=True):
+        n, O = self.num_envs, self.O
+        a = np.ascontiguousarray(actions, dtype=self.action_dtype).reshape(n)
+        obs = np.empty((n, O), dtype=np.float32)
+        rew = np.empty(n, dtype=self.reward_dtype)
+        term = np.empty(n, dtype=np.uint8)
+        trunc = np.empty(n, dtype=np.uint8)
+        fin = np.zeros((n, O), dtype=np.float32) if want_final else None
+        self._check(lib.mxv_step_host(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+                                      trunc.ctypes.data, _ptr(fin)))
+        return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin
+
+    def get_state(self):
+        st = np.empty((self.S, self.num_envs), dtype=np.float64)
+        el = np.empty(self.num_envs, dtype=np.int32)
+        self._check(lib.mxv_get_state(self._h, st.ctypes.data, el.ctypes.data))
+        return st, el
+
+    def set_state(self, state=None, elapsed=None):
+        st = None if state is None else np.ascontiguousarray(state, dtype=np.float64)
+        el = None if elapsed is None else np.ascontiguousarray(elapsed, dtype=np.int32)
+        if st is not None:
+            assert st.shape == (self.S, self.num_envs), st.shape
+        if el is not None:
+            assert el.shape == (self.num_envs,)
+        self._check(lib.mxv_set_state(self._h, _ptr(st), _ptr(el)))
+
+    def get_counters(self):
+        t, r = C.c_uint64(), C.c_uint32()
+        self._check(lib.mxv_get_counters(self._h, C.byref(t), C.byref(r)))
+        return t.value, r.value
+
+    def set_counters(self, t: int, r: int):
+        self._check(lib.mxv_set_counters(self._h, int(t), int(r)))
+
+    def get_params(self) -> np.ndarray:
+        p = np.zeros(MAX_PARAMS, dtype=np.float64)
+        self._check(lib.mxv_get_params(self._h, p.ctypes.data))
+        return p
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        assert p.shape == (MAX_PARAMS,)
+        self._check(lib.mxv_set_params(self._h, p.ctypes.data))
+
+    def sync(self):
+        self._check(lib.mxv_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        self._check(lib.mxv_get_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def set_stream(self, stream_ptr: int):
+        self._check(lib.mxv_set_stream(self._h, C.c_void_p(stream_ptr)))

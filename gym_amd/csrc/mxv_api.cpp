@@ -1,0 +1,572 @@
+// mxv_api.cpp — host side of the C ABI declared in include/mxv.h.
+// Owns the device-resident env state, the HIP stream, the step/reset bookkeeping (step index t,
+// explicit-reset ordinal r), the staging buffers of the *_host convenience calls and the
+// hipGraph cache of mxv_rollout.  No torch types, no C++ types cross the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "mxv_kernels.hpp"
+
+using namespace mxv;
+
+namespace {
+
+constexpr int kStateDim[MXV_NUM_ENV_KINDS] = {4, 2, 4, 2, 2};
+constexpr int kObsDim[MXV_NUM_ENV_KINDS] = {4, 3, 6, 2, 2};
+constexpr int kNumActions[MXV_NUM_ENV_KINDS] = {2, 0, 3, 3, 0};
+
+thread_local std::string g_create_error;
+
+void default_params(int env_id, double *P) {
+    std::memset(P, 0, sizeof(double) * MXV_MAX_PARAMS);
+    switch (env_id) {
+        case MXV_CARTPOLE:  // cartpole.py:90-102
+            P[0] = 9.8; P[1] = 1.0; P[2] = 0.1; P[3] = P[2] + P[1]; P[4] = 0.5; P[5] = P[2] * P[4];
+            P[6] = 10.0; P[7] = 0.02; P[8] = 12 * 2 * kPi / 360; P[9] = 2.4; P[10] = 0.0;
+            break;
+        case MXV_PENDULUM:  // pendulum.py:95-101
+            P[0] = 8.0; P[1] = 2.0; P[2] = 0.05; P[3] = 10.0; P[4] = 1.0; P[5] = 1.0;
+            break;
+        case MXV_ACROBOT:  // acrobot.py:143-165
+            P[0] = 0.2; P[1] = 1.0; P[2] = 1.0; P[3] = 1.0; P[4] = 1.0; P[5] = 0.5; P[6] = 0.5; P[7] = 1.0;
+            P[8] = 4 * kPi; P[9] = 9 * kPi; P[10] = 0.0; P[11] = 0.0;
+            break;
+        case MXV_MOUNTAINCAR:  // mountain_car.py:103-111
+            P[0] = -1.2; P[1] = 0.6; P[2] = 0.07; P[3] = 0.5; P[4] = 0.0; P[5] = 0.001; P[6] = 0.0025;
+            break;
+        case MXV_MOUNTAINCAR_CONT:  // continuous_mountain_car.py:108-118
+            P[0] = -1.0; P[1] = 1.0; P[2] = -1.2; P[3] = 0.6; P[4] = 0.07; P[5] = 0.45; P[6] = 0.0; P[7] = 0.0015;
+            break;
+        default: break;
+    }
+}
+
+void default_bounds(int env_id, double *b) {
+    switch (env_id) {
+        case MXV_CARTPOLE: b[0] = -0.05; b[1] = 0.05; break;  // cartpole.py:199-201
+        case MXV_PENDULUM: b[0] = kPi; b[1] = 1.0; break;     // pendulum.py:14-15 (x_init, y_init)
+        case MXV_ACROBOT: b[0] = -0.1; b[1] = 0.1; break;     // acrobot.py:185-187
+        default: b[0] = -0.6; b[1] = -0.4; break;             // mountain_car.py:159, continuous_mountain_car.py:181
+    }
+}
+
+}  // namespace
+
+struct mxv_handle {
+    mxv_config cfg{};
+    int S = 0, O = 0, NA = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double *state = nullptr;
+    int32_t *elapsed = nullptr;
+    uint64_t *seeds = nullptr;  // optional per-env seeds
+    uint64_t *t_dev = nullptr;  // device-resident step index for graph replay
+    int32_t *err = nullptr;     // latched kernel error word
+    uint64_t base_seed = 0, action_seed = 0;
+    uint64_t t = 0;
+    uint32_t r = 0;
+    bool was_reset = false;
+    EnvParams P{};
+    bool default_params = true;
+    double bounds[2] = {0, 0};
+    // staging for *_host calls
+    void *st_actions = nullptr;
+    float *st_obs = nullptr, *st_final = nullptr;
+    void *st_reward = nullptr;
+    uint8_t *st_term = nullptr, *st_trunc = nullptr, *st_mask = nullptr;
+    // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
+    using GraphKey = std::tuple<int, int, void *, void *, void *, void *, void *, void *>;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::string error;
+
+    size_t action_bytes() const {
+        if (NA > 0) return (cfg.flags & MXV_FLAG_ACTION_I32) ? 4 : 8;
+        return 4;
+    }
+    size_t reward_bytes() const { return (cfg.flags & MXV_FLAG_REWARD_F32) ? 4 : 8; }
+};
+
+namespace {
+
+int fail(mxv_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h)
+        h->error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define MXV_HIP(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail((h), MXV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define MXV_CHECK_HANDLE(h) \
+    if (!(h)) return fail(nullptr, MXV_ERR_INVALID_ARG, "NULL handle")
+
+int use_device(mxv_handle *h) {
+    MXV_HIP(h, hipSetDevice(h->cfg.device));
+    return MXV_OK;
+}
+
+int check_latched(mxv_handle *h) {
+    int32_t e = 0;
+    MXV_HIP(h, hipMemcpyAsync(&e, h->err, sizeof e, hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    if (e != 0) {
+        MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+        if (e & 1)
+            return fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA);
+        return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
+    }
+    return MXV_OK;
+}
+
+void fill_step_args(mxv_handle *h, StepArgs &a) {
+    a.state = h->state;
+    a.elapsed = h->elapsed;
+    a.seeds = h->seeds;
+    a.t_dev = nullptr;
+    a.err = h->err;
+    a.n = h->cfg.num_envs;
+    a.env0 = (uint64_t)h->cfg.env_offset;
+    a.base_seed = h->base_seed;
+    a.action_seed = h->action_seed;
+    a.t = h->t;
+    a.b0 = h->bounds[0];
+    a.b1 = h->bounds[1];
+    a.max_steps = h->cfg.max_episode_steps;
+    a.flags = h->cfg.flags;
+    a.P = h->P;
+}
+
+int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, void *reward, uint8_t *term,
+            uint8_t *trunc, float *final_obs) {
+    if (!h->was_reset)
+        return fail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
+    if (!obs) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    StepArgs a{};
+    fill_step_args(h, a);
+    a.actions = actions;
+    a.actions_out = actions_out;
+    a.obs = obs;
+    a.reward = reward;
+    a.terminated = term;
+    a.truncated = trunc;
+    a.final_obs = final_obs;
+    MXV_HIP(h, launch_step(h->cfg.env_id, h->default_params, a, h->stream));
+    h->t += 1;
+    return MXV_OK;
+}
+
+int parse_bounds(mxv_handle *h, const double *b, double *out) {
+    if (!b) {
+        default_bounds(h->cfg.env_id, out);
+        return MXV_OK;
+    }
+    if (std::isnan(b[0]) || std::isnan(b[1])) return fail(h, MXV_ERR_INVALID_ARG, "reset bounds are NaN");
+    if (h->cfg.env_id != MXV_PENDULUM && b[0] > b[1])  // classic_control/utils.py:41-44
+        return fail(h, MXV_ERR_INVALID_ARG, "Lower bound (%g) must be lower than higher bound (%g).", b[0], b[1]);
+    out[0] = b[0];
+    out[1] = b[1];
+    return MXV_OK;
+}
+
+int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float *obs_dev) {
+    if (int rc = use_device(h)) return rc;
+    double b[2];
+    if (int rc = parse_bounds(h, bounds, b)) return rc;
+    h->r += 1;
+    ResetArgs a{};
+    a.state = h->state;
+    a.elapsed = h->elapsed;
+    a.obs = obs_dev;
+    a.mask = mask_dev;
+    a.seeds = h->seeds;
+    a.n = h->cfg.num_envs;
+    a.env0 = (uint64_t)h->cfg.env_offset;
+    a.base_seed = h->base_seed;
+    a.t = h->t;
+    a.r = h->r;
+    a.b0 = b[0];
+    a.b1 = b[1];
+    MXV_HIP(h, launch_reset(h->cfg.env_id, a, h->stream));
+    h->was_reset = true;
+    return MXV_OK;
+}
+
+int ensure_staging(mxv_handle *h) {
+    if (h->st_obs) return MXV_OK;
+    const size_t n = (size_t)h->cfg.num_envs;
+    MXV_HIP(h, hipMalloc(&h->st_actions, n * 8));
+    MXV_HIP(h, hipMalloc((void **)&h->st_obs, n * h->O * sizeof(float)));
+    MXV_HIP(h, hipMalloc((void **)&h->st_final, n * h->O * sizeof(float)));
+    MXV_HIP(h, hipMalloc(&h->st_reward, n * 8));
+    MXV_HIP(h, hipMalloc((void **)&h->st_term, n));
+    MXV_HIP(h, hipMalloc((void **)&h->st_trunc, n));
+    MXV_HIP(h, hipMalloc((void **)&h->st_mask, n));
+    return MXV_OK;
+}
+
+void free_graphs(mxv_handle *h) {
+    for (auto &kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mxv_version(void) { return "mxv 0.1.0 (gfx950)"; }
+
+int mxv_env_dims(int32_t env_id, int32_t *state_dim, int32_t *obs_dim, int32_t *num_actions) {
+    if (env_id < 0 || env_id >= MXV_NUM_ENV_KINDS) return MXV_ERR_INVALID_ARG;
+    if (state_dim) *state_dim = kStateDim[env_id];
+    if (obs_dim) *obs_dim = kObsDim[env_id];
+    if (num_actions) *num_actions = kNumActions[env_id];
+    return MXV_OK;
+}
+
+int mxv_default_params(int32_t env_id, double *params_host) {
+    if (env_id < 0 || env_id >= MXV_NUM_ENV_KINDS || !params_host) return MXV_ERR_INVALID_ARG;
+    default_params(env_id, params_host);
+    return MXV_OK;
+}
+
+int mxv_default_reset_bounds(int32_t env_id, double *bounds2_host) {
+    if (env_id < 0 || env_id >= MXV_NUM_ENV_KINDS || !bounds2_host) return MXV_ERR_INVALID_ARG;
+    default_bounds(env_id, bounds2_host);
+    return MXV_OK;
+}
+
+const char *mxv_last_error(const mxv_handle *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int mxv_create(const mxv_config *cfg, mxv_handle **out) {
+    if (!cfg || !out) return fail(nullptr, MXV_ERR_INVALID_ARG, "NULL config or output pointer");
+    *out = nullptr;
+    if (cfg->env_id < 0 || cfg->env_id >= MXV_NUM_ENV_KINDS)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "unknown env_id %d", cfg->env_id);
+    if (cfg->num_envs <= 0) return fail(nullptr, MXV_ERR_INVALID_ARG, "num_envs must be positive (got %lld)", (long long)cfg->num_envs);
+    if (cfg->env_offset < 0 || cfg->env_offset % MXV_ENV_ALIGN != 0)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "env_offset must be a non-negative multiple of %d", MXV_ENV_ALIGN);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, MXV_ERR_HIP, "no HIP device available (%s): the engine has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+    mxv_handle *h = new (std::nothrow) mxv_handle();
+    if (!h) return fail(nullptr, MXV_ERR_INVALID_ARG, "out of host memory");
+    h->cfg = *cfg;
+    h->S = kStateDim[cfg->env_id];
+    h->O = kObsDim[cfg->env_id];
+    h->NA = kNumActions[cfg->env_id];
+    h->base_seed = cfg->seed;
+    h->action_seed = cfg->action_seed;
+    default_params(cfg->env_id, h->P.p);
+    default_bounds(cfg->env_id, h->bounds);
+    const size_t n = (size_t)cfg->num_envs;
+#define MXV_CREATE_HIP(expr)                                                                \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            fail(nullptr, MXV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));             \
+            mxv_destroy(h);                                                                 \
+            return MXV_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+    MXV_CREATE_HIP(hipSetDevice(cfg->device));
+    MXV_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    MXV_CREATE_HIP(hipMalloc((void **)&h->state, n * h->S * sizeof(double)));
+    MXV_CREATE_HIP(hipMalloc((void **)&h->elapsed, n * sizeof(int32_t)));
+    MXV_CREATE_HIP(hipMalloc((void **)&h->t_dev, sizeof(uint64_t)));
+    MXV_CREATE_HIP(hipMalloc((void **)&h->err, sizeof(int32_t)));
+    MXV_CREATE_HIP(hipMemsetAsync(h->state, 0, n * h->S * sizeof(double), h->stream));
+    MXV_CREATE_HIP(hipMemsetAsync(h->elapsed, 0, n * sizeof(int32_t), h->stream));
+    MXV_CREATE_HIP(hipMemsetAsync(h->t_dev, 0, sizeof(uint64_t), h->stream));
+    MXV_CREATE_HIP(hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+    MXV_CREATE_HIP(hipStreamSynchronize(h->stream));
+#undef MXV_CREATE_HIP
+    *out = h;
+    return MXV_OK;
+}
+
+int mxv_destroy(mxv_handle *h) {
+    if (!h) return MXV_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_graphs(h);
+    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->st_actions, h->st_obs, h->st_final,
+                    h->st_reward, h->st_term, h->st_trunc, h->st_mask};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MXV_OK;
+}
+
+int mxv_seed(mxv_handle *h, uint64_t base_seed, const uint64_t *per_env_seeds_host) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);  // captured kernel arguments hold the old seeds
+    h->base_seed = base_seed;
+    h->t = 0;
+    h->r = 0;
+    if (per_env_seeds_host) {
+        const size_t bytes = (size_t)h->cfg.num_envs * sizeof(uint64_t);
+        if (!h->seeds) MXV_HIP(h, hipMalloc((void **)&h->seeds, bytes));
+        MXV_HIP(h, hipMemcpyAsync(h->seeds, per_env_seeds_host, bytes, hipMemcpyHostToDevice, h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+    } else if (h->seeds) {
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+        MXV_HIP(h, hipFree(h->seeds));
+        h->seeds = nullptr;
+    }
+    return MXV_OK;
+}
+
+int mxv_seed_actions(mxv_handle *h, uint64_t action_seed) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);
+    h->action_seed = action_seed;
+    return MXV_OK;
+}
+
+int mxv_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds2_host, float *obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    return do_reset(h, mask_dev, bounds2_host, obs_dev);
+}
+
+int mxv_step(mxv_handle *h, const void *actions_dev, float *obs_dev, void *reward_dev, uint8_t *terminated_dev,
+             uint8_t *truncated_dev, float *final_obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (!actions_dev) return fail(h, MXV_ERR_INVALID_ARG, "actions pointer is NULL (use mxv_step_sampled)");
+    return do_step(h, actions_dev, nullptr, obs_dev, reward_dev, terminated_dev, truncated_dev, final_obs_dev);
+}
+
+int mxv_step_sampled(mxv_handle *h, void *actions_out_dev, float *obs_dev, void *reward_dev, uint8_t *terminated_dev,
+                     uint8_t *truncated_dev, float *final_obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    return do_step(h, nullptr, actions_out_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, final_obs_dev);
+}
+
+int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t use_graph, void *actions_out_dev, float *obs_dev,
+                void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (K <= 0) return fail(h, MXV_ERR_INVALID_ARG, "K must be positive");
+    if (!h->was_reset)
+        return fail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
+    if (!obs_dev) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    auto slice = [&](void *p, size_t elem_bytes, int k) -> void * {
+        if (!p) return nullptr;
+        return per_step ? (void *)((char *)p + (size_t)k * n * elem_bytes) : p;
+    };
+    auto launch_k = [&](int k, const uint64_t *t_dev, uint64_t t) -> hipError_t {
+        StepArgs a{};
+        fill_step_args(h, a);
+        a.t_dev = t_dev;
+        a.t = t;
+        a.actions = nullptr;
+        a.actions_out = slice(actions_out_dev, h->action_bytes(), k);
+        a.obs = (float *)slice(obs_dev, h->O * sizeof(float), k);
+        a.reward = slice(reward_dev, h->reward_bytes(), k);
+        a.terminated = (uint8_t *)slice(terminated_dev, 1, k);
+        a.truncated = (uint8_t *)slice(truncated_dev, 1, k);
+        a.final_obs = (float *)slice(final_obs_dev, h->O * sizeof(float), k);
+        return launch_step(h->cfg.env_id, h->default_params, a, h->stream);
+    };
+    if (!use_graph) {
+        for (int k = 0; k < K; ++k) MXV_HIP(h, launch_k(k, nullptr, h->t + (uint64_t)k));
+    } else {
+        // The captured launches read the base step index from device memory (t_dev) and add their
+        // own offset k, so one instantiated graph replays for any t.  Seeds, bounds and params are
+        // baked into the captured kernel arguments: the cache is dropped whenever they change.
+        mxv_handle::GraphKey key{K, per_step, actions_out_dev, obs_dev, reward_dev, terminated_dev, truncated_dev,
+                                 final_obs_dev};
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            MXV_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            hipError_t le = hipSuccess;
+            for (int k = 0; k < K && le == hipSuccess; ++k) le = launch_k(k, h->t_dev, (uint64_t)k);
+            hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+            if (le != hipSuccess) return fail(h, MXV_ERR_HIP, "graph capture launch: %s", hipGetErrorString(le));
+            MXV_HIP(h, ce);
+            hipGraphExec_t exec = nullptr;
+            MXV_HIP(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            MXV_HIP(h, hipGraphDestroy(graph));
+            it = h->graphs.emplace(key, exec).first;
+        }
+        MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
+        MXV_HIP(h, hipGraphLaunch(it->second, h->stream));
+    }
+    h->t += (uint64_t)K;
+    return MXV_OK;
+}
+
+int mxv_sample_actions(mxv_handle *h, void *actions_out_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (!actions_out_dev) return fail(h, MXV_ERR_INVALID_ARG, "actions_out pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    SampleArgs a{};
+    a.actions_out = actions_out_dev;
+    a.t_dev = nullptr;
+    a.n = h->cfg.num_envs;
+    a.env0 = (uint64_t)h->cfg.env_offset;
+    a.action_seed = h->action_seed;
+    a.t = h->t;
+    a.flags = h->cfg.flags;
+    a.P = h->P;
+    MXV_HIP(h, launch_sample(h->cfg.env_id, h->default_params, a, h->stream));
+    return MXV_OK;
+}
+
+int mxv_reset_host(mxv_handle *h, const uint8_t *mask_host, const double *bounds2_host, float *obs_host) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_staging(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (mask_host) MXV_HIP(h, hipMemcpyAsync(h->st_mask, mask_host, n, hipMemcpyHostToDevice, h->stream));
+    if (int rc = do_reset(h, mask_host ? h->st_mask : nullptr, bounds2_host, obs_host ? h->st_obs : nullptr)) return rc;
+    if (obs_host)
+        MXV_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void *reward_host, uint8_t *terminated_host,
+                  uint8_t *truncated_host, float *final_obs_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!actions_host || !obs_host) return fail(h, MXV_ERR_INVALID_ARG, "actions/obs pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_staging(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    MXV_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * h->action_bytes(), hipMemcpyHostToDevice, h->stream));
+    if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, reward_host ? h->st_reward : nullptr,
+                         terminated_host ? h->st_term : nullptr, truncated_host ? h->st_trunc : nullptr,
+                         final_obs_host ? h->st_final : nullptr))
+        return rc;
+    MXV_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (reward_host)
+        MXV_HIP(h, hipMemcpyAsync(reward_host, h->st_reward, n * h->reward_bytes(), hipMemcpyDeviceToHost, h->stream));
+    if (terminated_host)
+        MXV_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
+    if (truncated_host)
+        MXV_HIP(h, hipMemcpyAsync(truncated_host, h->st_trunc, n, hipMemcpyDeviceToHost, h->stream));
+    if (final_obs_host)
+        MXV_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * h->O * sizeof(float), hipMemcpyDeviceToHost,
+                                  h->stream));
+    int rc = check_latched(h);  // synchronises
+    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
+    return rc;
+}
+
+int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (state_soa_host)
+        MXV_HIP(h, hipMemcpyAsync(state_soa_host, h->state, n * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (elapsed_host)
+        MXV_HIP(h, hipMemcpyAsync(elapsed_host, h->elapsed, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *elapsed_host) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (state_soa_host)
+        MXV_HIP(h, hipMemcpyAsync(h->state, state_soa_host, n * h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (elapsed_host)
+        MXV_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    h->was_reset = true;  // an injected state stands in for reset() (parity harness, checkpoint restore)
+    return MXV_OK;
+}
+
+int mxv_get_counters(mxv_handle *h, uint64_t *t, uint32_t *r) {
+    MXV_CHECK_HANDLE(h);
+    if (t) *t = h->t;
+    if (r) *r = h->r;
+    return MXV_OK;
+}
+
+int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
+    MXV_CHECK_HANDLE(h);
+    h->t = t;
+    h->r = r;
+    return MXV_OK;
+}
+
+int mxv_get_params(mxv_handle *h, double *params_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!params_host) return fail(h, MXV_ERR_INVALID_ARG, "params pointer is NULL");
+    std::memcpy(params_host, h->P.p, sizeof h->P.p);
+    return MXV_OK;
+}
+
+int mxv_set_params(mxv_handle *h, const double *params_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!params_host) return fail(h, MXV_ERR_INVALID_ARG, "params pointer is NULL");
+    if (h->cfg.env_id == MXV_ACROBOT && params_host[10] != 0.0)
+        return fail(h, MXV_ERR_UNSUPPORTED, "Acrobot torque_noise_max != 0 is not supported");
+    std::memcpy(h->P.p, params_host, sizeof h->P.p);
+    double d[MXV_MAX_PARAMS];
+    default_params(h->cfg.env_id, d);
+    h->default_params = std::memcmp(d, h->P.p, sizeof d) == 0;
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);  // captured kernel arguments hold the old parameters
+    return MXV_OK;
+}
+
+int mxv_sync(mxv_handle *h) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    return check_latched(h);
+}
+
+int mxv_get_stream(mxv_handle *h, void **stream) {
+    MXV_CHECK_HANDLE(h);
+    if (!stream) return fail(h, MXV_ERR_INVALID_ARG, "stream pointer is NULL");
+    *stream = (void *)h->stream;
+    return MXV_OK;
+}
+
+int mxv_set_stream(mxv_handle *h, void *stream) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (h->stream) MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);
+    if (h->own_stream && h->stream) MXV_HIP(h, hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return MXV_OK;
+}
+
+}  // extern "C"

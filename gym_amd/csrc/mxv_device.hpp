@@ -1,0 +1,395 @@
+// mxv_device.hpp — device-side building blocks of the classic-control step kernels (gfx950).
+//
+// One lane owns E environments; everything here is per-environment scalar fp64 code that
+// the kernels in mxv_kernels.hip instantiate E times per lane (independent chains = ILP).
+// Arithmetic follows the reference operation by operation (file:line cited per function;
+// paths relative to the reference root, openai/gym 0.26.2) and the translation unit is built
+// with -ffp-contract=off so no a*b+c is fused: the reference rounds every operation.
+// Python's x**2 is written x*x (correctly rounded; libm pow(x,2) is within 1 ulp of it).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mxv.h"
+
+namespace mxv {
+
+struct EnvParams {
+    double p[MXV_MAX_PARAMS];
+};
+
+// Parameter access policy: DEF = true folds the reference's default attribute values into the
+// instruction stream as constants; DEF = false reads the broadcast values set through
+// mxv_set_params() (VectorEnv.set_attr) from the kernel argument segment (SGPRs).
+template <bool DEF>
+struct Par {
+    const EnvParams &P;
+    __device__ __forceinline__ explicit Par(const EnvParams &p) : P(p) {}
+    __device__ __forceinline__ double get(int i, double dflt) const { return DEF ? dflt : P.p[i]; }
+};
+
+constexpr double kPi = 3.141592653589793;
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Counter-based: no RNG state is kept in memory.
+// ------------------------------------------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = hi1 ^ c.y ^ k0;
+        n.y = lo1;
+        n.z = hi0 ^ c.w ^ k1;
+        n.w = lo0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+constexpr uint32_t kStreamAction = 1u;
+constexpr uint32_t kStreamReset = 2u;
+
+// u in (0,1): (w + 0.5) * 2^-32, exact in fp64.
+__device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+
+// Action-stream words of the 4 envs of group g (global env indices 4g..4g+3) at vector step t.
+__device__ __forceinline__ U4 action_words(uint64_t action_seed, uint64_t t, uint64_t g) {
+    U4 c;
+    c.x = (uint32_t)g;
+    c.y = (uint32_t)(g >> 32);
+    c.z = (uint32_t)t;
+    c.w = ((uint32_t)(t >> 32) & 0x0fffffffu) | (kStreamAction << 28);
+    return philox4x32_10(c, (uint32_t)action_seed, (uint32_t)(action_seed >> 32));
+}
+
+// Reset-stream words of one env (seed = that env's 64-bit seed) for the reset at step t, ordinal r.
+__device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r) {
+    U4 c;
+    c.x = (uint32_t)t;
+    c.y = (uint32_t)(t >> 32);
+    c.z = r;
+    c.w = (kStreamReset << 28);
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-env traits: S state scalars, O observation scalars, NA discrete actions (0 = Box).
+// step(): dynamics only.  s[] in/out (fp64), `fresh` = elapsed == 0 (first step after reset),
+// ai / af = discrete / continuous action.  Returns terminated; writes reward and obs.
+// ------------------------------------------------------------------------------------------
+template <int ENV>
+struct Env;
+
+// ---- CartPole: gym/envs/classic_control/cartpole.py:130-188 -------------------------------
+template <>
+struct Env<MXV_CARTPOLE> {
+    static constexpr int S = 4, O = 4, NA = 2;
+    template <bool DEF>
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
+                                                float *obs) {
+        const double gravity = P.get(0, 9.8), masspole = P.get(2, 0.1), total_mass = P.get(3, 0.1 + 1.0);
+        const double length = P.get(4, 0.5), polemass_length = P.get(5, 0.1 * 0.5), force_mag = P.get(6, 10.0);
+        const double tau = P.get(7, 0.02), theta_thr = P.get(8, 12 * 2 * kPi / 360), x_thr = P.get(9, 2.4);
+        const bool semi_implicit = P.get(10, 0.0) != 0.0;
+        double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+        const double force = (ai == 1) ? force_mag : -force_mag;  // :135
+        double sintheta, costheta;
+        sincos(theta, &sintheta, &costheta);                      // :136-137
+        const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;  // :141-143
+        const double thetaacc = (gravity * sintheta - costheta * temp) /
+                                (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));  // :144-146
+        const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;                   // :147
+        if (!semi_implicit) {  // "euler" :149-153
+            x = x + tau * x_dot;
+            x_dot = x_dot + tau * xacc;
+            theta = theta + tau * theta_dot;
+            theta_dot = theta_dot + tau * thetaacc;
+        } else {  // :154-158
+            x_dot = x_dot + tau * xacc;
+            x = x + tau * x_dot;
+            theta_dot = theta_dot + tau * thetaacc;
+            theta = theta + tau * theta_dot;
+        }
+        s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+        reward = 1.0;  // :169-184 (autoreset: steps_beyond_terminated is always None)
+        obs[0] = (float)x; obs[1] = (float)x_dot; obs[2] = (float)theta; obs[3] = (float)theta_dot;  // :188
+        return (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);          // :162-167
+    }
+    __device__ __forceinline__ static void observe(const double *s, float *obs) {  // :207
+        obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
+    }
+    // np_random.uniform(low, high, size=(4,)) :202
+    __device__ __forceinline__ static void reset(U4 w, double b0, double b1, double *s) {
+        s[0] = b0 + (b1 - b0) * u01(w.x);
+        s[1] = b0 + (b1 - b0) * u01(w.y);
+        s[2] = b0 + (b1 - b0) * u01(w.z);
+        s[3] = b0 + (b1 - b0) * u01(w.w);
+    }
+};
+
+// ---- Pendulum: gym/envs/classic_control/pendulum.py:119-139,161-163,270-271 ---------------
+// state fp64, action fp32; python-float (op) np.float32 stays float32 under NumPy-2 promotion.
+__device__ __forceinline__ double np_remainder(double a, double b) {  // numpy float64 `%`
+    double mod = fmod(a, b);
+    if (b == 0.0) return mod;
+    if (mod != 0.0) {
+        if ((b < 0) != (mod < 0)) mod += b;
+    } else {
+        mod = copysign(0.0, b);
+    }
+    return mod;
+}
+
+template <>
+struct Env<MXV_PENDULUM> {
+    static constexpr int S = 2, O = 3, NA = 0;
+    __device__ __forceinline__ static void observe(const double *s, float *obs) {  // :161-163
+        double sn, cs;
+        sincos(s[0], &sn, &cs);
+        obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
+    }
+    template <bool DEF>
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int, float a0, double &reward,
+                                                float *obs) {
+        const double max_speed = P.get(0, 8.0), max_torque = P.get(1, 2.0), dt = P.get(2, 0.05);
+        const double g = P.get(3, 10.0), m = P.get(4, 1.0), l = P.get(5, 1.0);
+        const double th = s[0], thdot = s[1];
+        const float lo = (float)(-max_torque), hi = (float)max_torque;  // np.clip(u, -max_torque, max_torque)[0] :127
+        float u = a0;
+        if (u < lo) u = lo;
+        if (u > hi) u = hi;
+        const float uterm = (float)0.001 * (u * u);                       // 0.001 * (u**2) in float32 :129
+        const double an = np_remainder(th + kPi, 2 * kPi) - kPi;           // angle_normalize :270-271
+        const double costs = an * an + 0.1 * (thdot * thdot) + (double)uterm;
+        const double A = 3 * g / (2 * l);                                  // python floats :131
+        const float B = (float)(3.0 / (m * (l * l)));
+        const float Bu = B * u;                                            // python float * np.float32 -> f32
+        double newthdot = thdot + (A * sin(th) + (double)Bu) * dt;
+        if (newthdot < -max_speed) newthdot = -max_speed;                  // np.clip :132
+        if (newthdot > max_speed) newthdot = max_speed;
+        const double newth = th + newthdot * dt;                           // :133
+        s[0] = newth; s[1] = newthdot;
+        reward = -costs;                                                   // :139
+        observe(s, obs);
+        return false;
+    }
+    // high = (x_init, y_init), low = -high; np_random.uniform(low, high) :141-154
+    __device__ __forceinline__ static void reset(U4 w, double b0, double b1, double *s) {
+        s[0] = -b0 + (b0 - (-b0)) * u01(w.x);
+        s[1] = -b1 + (b1 - (-b1)) * u01(w.y);
+    }
+};
+
+// ---- Acrobot: gym/envs/classic_control/acrobot.py:196-277 (step, _dsdt), 378-465 (wrap, bound, rk4) ----
+template <>
+struct Env<MXV_ACROBOT> {
+    static constexpr int S = 4, O = 6, NA = 3;
+    template <bool DEF>
+    __device__ __forceinline__ static void dsdt(const Par<DEF> &P, const double *sa, double a, double *out) {
+        const double m1 = P.get(3, 1.0), m2 = P.get(4, 1.0), l1 = P.get(1, 1.0);
+        const double lc1 = P.get(5, 0.5), lc2 = P.get(6, 0.5), I1 = P.get(7, 1.0), I2 = P.get(7, 1.0);
+        const bool nips = P.get(11, 0.0) != 0.0;
+        const double g = 9.8;  // :245
+        const double theta1 = sa[0], theta2 = sa[1], dtheta1 = sa[2], dtheta2 = sa[3];
+        double s2, c2;
+        sincos(theta2, &s2, &c2);
+        const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;  // :252-257
+        const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;                                          // :258
+        const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - kPi / 2.0);                                // :259
+        const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                            (m1 * lc1 + m2 * l1) * g * cos(theta1 - kPi / 2) + phi2;                        // :260-265
+        double ddtheta2;
+        if (nips) {  // :266-269
+            ddtheta2 = (a + d2 / d1 * phi1 - phi2) / (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+        } else {  // "book" :270-275
+            ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                       (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+        }
+        const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;  // :276
+        out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2;  // :277 (5th component is 0.0)
+    }
+    __device__ __forceinline__ static double wrap(double x, double m, double M) {  // :378-396
+        const double diff = M - m;
+        while (x > M) x = x - diff;
+        while (x < m) x = x + diff;
+        return x;
+    }
+    __device__ __forceinline__ static double bound(double x, double m, double M) {  // :399-415 min(max(x, m), M)
+        const double t = (m > x) ? m : x;
+        return (M < t) ? M : t;
+    }
+    __device__ __forceinline__ static void observe(const double *s, float *obs) {  // :225-230
+        double s0, c0, s1, c1;
+        sincos(s[0], &s0, &c0);
+        sincos(s[1], &s1, &c1);
+        obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
+        obs[4] = (float)s[2]; obs[5] = (float)s[3];
+    }
+    template <bool DEF>
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
+                                                float *obs) {
+        const double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
+        const double dt = P.get(0, 0.2) - 0;    // t[i+1] - this, t = [0, self.dt] :210,449
+        const double dt2 = dt / 2.0;            // :450
+        const double y0[4] = {s[0], s[1], s[2], s[3]};
+        double k1[4], k2[4], k3[4], k4[4], y[4];
+        dsdt(P, y0, torque, k1);  // :453  (the augmented torque component has derivative 0.0: it stays `torque`)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k1[k];
+        dsdt(P, y, torque, k2);   // :454
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k2[k];
+        dsdt(P, y, torque, k3);   // :455
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt * k3[k];
+        dsdt(P, y, torque, k4);   // :456
+        const double dt6 = dt / 6.0;
+        double ns[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ns[k] = y0[k] + dt6 * (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]);  // :463
+        s[0] = wrap(ns[0], -kPi, kPi);                       // :213
+        s[1] = wrap(ns[1], -kPi, kPi);                       // :214
+        s[2] = bound(ns[2], -P.get(8, 4 * kPi), P.get(8, 4 * kPi));  // :215
+        s[3] = bound(ns[3], -P.get(9, 9 * kPi), P.get(9, 9 * kPi));  // :216
+        double s0, c0, s1, c1;
+        sincos(s[0], &s0, &c0);
+        sincos(s[1], &s1, &c1);
+        const bool term = (-c0 - cos(s[1] + s[0])) > 1.0;  // :235
+        reward = (!term) ? -1.0 : 0.0;                     // :219
+        obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
+        obs[4] = (float)s[2]; obs[5] = (float)s[3];
+        return term;
+    }
+    // np_random.uniform(low, high, size=(4,)).astype(np.float32) :188-190
+    __device__ __forceinline__ static void reset(U4 w, double b0, double b1, double *s) {
+        s[0] = (double)(float)(b0 + (b1 - b0) * u01(w.x));
+        s[1] = (double)(float)(b0 + (b1 - b0) * u01(w.y));
+        s[2] = (double)(float)(b0 + (b1 - b0) * u01(w.z));
+        s[3] = (double)(float)(b0 + (b1 - b0) * u01(w.w));
+    }
+};
+
+// ---- MountainCar: gym/envs/classic_control/mountain_car.py:127-148 ------------------------
+template <>
+struct Env<MXV_MOUNTAINCAR> {
+    static constexpr int S = 2, O = 2, NA = 3;
+    __device__ __forceinline__ static void observe(const double *s, float *obs) {
+        obs[0] = (float)s[0]; obs[1] = (float)s[1];
+    }
+    template <bool DEF>
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
+                                                float *obs) {
+        const double min_position = P.get(0, -1.2), max_position = P.get(1, 0.6), max_speed = P.get(2, 0.07);
+        const double goal_position = P.get(3, 0.5), goal_velocity = P.get(4, 0.0);
+        const double force = P.get(5, 0.001), gravity = P.get(6, 0.0025);
+        double position = s[0], velocity = s[1];
+        velocity = velocity + ((double)(ai - 1) * force + cos(3 * position) * (-gravity));  // :133
+        if (velocity < -max_speed) velocity = -max_speed;                                  // np.clip :134
+        if (velocity > max_speed) velocity = max_speed;
+        position = position + velocity;                                                    // :135
+        if (position < min_position) position = min_position;                              // np.clip :136
+        if (position > max_position) position = max_position;
+        if (position == min_position && velocity < 0) velocity = 0;                        // :137-138
+        s[0] = position; s[1] = velocity;
+        reward = -1.0;                                                                     // :143
+        observe(s, obs);
+        return position >= goal_position && velocity >= goal_velocity;                     // :140-142
+    }
+    // np.array([np_random.uniform(low, high), 0]) :160
+    __device__ __forceinline__ static void reset(U4 w, double b0, double b1, double *s) {
+        s[0] = b0 + (b1 - b0) * u01(w.x);
+        s[1] = 0.0;
+    }
+};
+
+// ---- MountainCarContinuous: gym/envs/classic_control/continuous_mountain_car.py:142-175 ----
+// NumPy-2 semantics: float32 state/update after the first step, float64 on the first step after
+// reset (`fresh`), force term always float32 arithmetic on the float32 action unless clipped.
+template <>
+struct Env<MXV_MOUNTAINCAR_CONT> {
+    static constexpr int S = 2, O = 2, NA = 0;
+    __device__ __forceinline__ static void observe(const double *s, float *obs) {
+        obs[0] = (float)s[0]; obs[1] = (float)s[1];
+    }
+    template <bool DEF>
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool fresh, int, float a0,
+                                                double &reward, float *obs) {
+        const double min_action = P.get(0, -1.0), max_action = P.get(1, 1.0);
+        const double min_position = P.get(2, -1.2), max_position = P.get(3, 0.6), max_speed = P.get(4, 0.07);
+        const double goal_position = P.get(5, 0.45), goal_velocity = P.get(6, 0.0), power = P.get(7, 0.0015);
+        // force = min(max(action[0], min_action), max_action) :146 (python max/min)
+        const bool clipped_lo = min_action > (double)a0;
+        const double tmp = clipped_lo ? min_action : (double)a0;
+        const bool clipped_hi = max_action < tmp;
+        const bool clipped = clipped_lo || clipped_hi;
+        const double force_py = clipped_hi ? max_action : min_action;
+        const float fp = a0 * (float)power;  // np.float32 * python float -> float32
+        bool term;
+        if (fresh) {
+            double position = s[0], velocity = s[1];
+            const double g = 0.0025 * cos(3 * position);  // :148
+            const double inc = clipped ? (force_py * power - g) : (double)(fp - (float)g);
+            velocity = velocity + inc;
+            if (velocity > max_speed) velocity = max_speed;    // :149-152
+            if (velocity < -max_speed) velocity = -max_speed;
+            position = position + velocity;                    // :153
+            if (position > max_position) position = max_position;  // :154-157
+            if (position < min_position) position = min_position;
+            if (position == min_position && velocity < 0) velocity = 0;  // :158-159
+            term = position >= goal_position && velocity >= goal_velocity;  // :162-164
+            s[0] = (double)(float)position;  // :171 dtype=np.float32
+            s[1] = (double)(float)velocity;
+        } else {
+            float position = (float)s[0], velocity = (float)s[1];
+            const float three_p = 3.0f * position;            // int * np.float32 -> float32
+            const double g = 0.0025 * cos((double)three_p);
+            const float inc = clipped ? (float)(force_py * power - g) : (fp - (float)g);
+            velocity = velocity + inc;
+            if (velocity > (float)max_speed) velocity = (float)max_speed;
+            if (velocity < (float)(-max_speed)) velocity = (float)(-max_speed);
+            position = position + velocity;
+            if (position > (float)max_position) position = (float)max_position;
+            if (position < (float)min_position) position = (float)min_position;
+            if (position == (float)min_position && velocity < 0) velocity = 0;
+            term = position >= (float)goal_position && velocity >= (float)goal_velocity;
+            s[0] = (double)position;
+            s[1] = (double)velocity;
+        }
+        double rew = term ? 100.0 : 0.0;                // :166-168
+        rew = rew - ((double)a0 * (double)a0) * 0.1;    // math.pow(action[0], 2) * 0.1 :169
+        reward = rew;
+        observe(s, obs);                                // :175 returns self.state
+        return term;
+    }
+    __device__ __forceinline__ static void reset(U4 w, double b0, double b1, double *s) {  // :182
+        s[0] = b0 + (b1 - b0) * u01(w.x);
+        s[1] = 0.0;
+    }
+};
+
+// Action of one env from its stream word (see include/mxv.h, RNG contract).
+template <int ENV, bool DEF>
+__device__ __forceinline__ void action_from_word(const Par<DEF> &P, uint32_t w, int &ai, float &af) {
+    if constexpr (Env<ENV>::NA > 0) {
+        ai = (int)(((uint64_t)w * (uint32_t)Env<ENV>::NA) >> 32);
+        af = 0.0f;
+    } else if constexpr (ENV == MXV_PENDULUM) {
+        const double lo = -P.get(1, 2.0), hi = P.get(1, 2.0);  // Box(-max_torque, max_torque) pendulum.py:113-115
+        ai = 0;
+        af = (float)(lo + (hi - lo) * u01(w));
+    } else {
+        const double lo = P.get(0, -1.0), hi = P.get(1, 1.0);  // Box(min_action, max_action) continuous_mountain_car.py:132-134
+        ai = 0;
+        af = (float)(lo + (hi - lo) * u01(w));
+    }
+}
+
+}  // namespace mxv

@@ -1,0 +1,78 @@
+// mxv_kernels.hpp — launch interface between the C-ABI host code (mxv_api.cpp) and the
+// gfx950 kernels (mxv_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mxv_device.hpp"
+
+namespace mxv {
+
+struct StepArgs {
+    double *state;         // [S][N] fp64, struct-of-arrays
+    int32_t *elapsed;      // [N] TimeLimit counters
+    const void *actions;   // int64/int32/float32 [N]; nullptr -> draw from the Philox action stream
+    void *actions_out;     // optional record of the sampled actions
+    float *obs;            // [N][O]
+    void *reward;          // double[N] (float[N] with MXV_FLAG_REWARD_F32); may be nullptr
+    uint8_t *terminated;   // [N]; may be nullptr
+    uint8_t *truncated;    // [N]; may be nullptr
+    float *final_obs;      // [N][O], rows of finished envs only; may be nullptr
+    const uint64_t *seeds; // per-env seeds or nullptr (base_seed + global index)
+    const uint64_t *t_dev; // optional device-resident base step index (hipGraph replay)
+    int32_t *err;          // latched error word (bit 0: invalid discrete action)
+    int64_t n;             // local envs
+    uint64_t env0;         // global index of local env 0
+    uint64_t base_seed;
+    uint64_t action_seed;
+    uint64_t t;            // step index (added to *t_dev when t_dev != nullptr)
+    double b0, b1;         // reset bounds
+    int32_t max_steps;     // TimeLimit, <= 0 disables
+    int32_t flags;         // MXV_FLAG_*
+    EnvParams P;
+};
+
+struct ResetArgs {
+    double *state;
+    int32_t *elapsed;
+    float *obs;            // may be nullptr
+    const uint8_t *mask;   // may be nullptr (all)
+    const uint64_t *seeds; // may be nullptr
+    int64_t n;
+    uint64_t env0;
+    uint64_t base_seed;
+    uint64_t t;
+    uint32_t r;
+    double b0, b1;
+};
+
+struct SampleArgs {
+    void *actions_out;
+    const uint64_t *t_dev;
+    int64_t n;
+    uint64_t env0;
+    uint64_t action_seed;
+    uint64_t t;
+    int32_t flags;
+    EnvParams P;
+};
+
+// Envs per lane of the step kernel (tile = E * 256 envs per workgroup).  Acrobot's RK4 keeps
+// ~60 live fp64 values per env, so it runs one env per lane; the others interleave 4 chains.
+#ifndef MXV_ENVS_PER_LANE
+#define MXV_ENVS_PER_LANE 4
+#endif
+#ifndef MXV_ENVS_PER_LANE_ACROBOT
+#define MXV_ENVS_PER_LANE_ACROBOT 1
+#endif
+constexpr int envs_per_lane(int env_id) {
+    return env_id == MXV_ACROBOT ? MXV_ENVS_PER_LANE_ACROBOT : MXV_ENVS_PER_LANE;
+}
+constexpr int kBlock = 256;
+
+hipError_t launch_step(int env_id, bool default_params, const StepArgs &a, hipStream_t stream);
+hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
+hipError_t launch_sample(int env_id, bool default_params, const SampleArgs &a, hipStream_t stream);
+hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);
+
+}  // namespace mxv

@@ -1,0 +1,117 @@
+"""ShardedRollout — one logical vector env partitioned over the GPUs of a node, one process per GPU.
+
+Partition rule: env instances never interact (gym/vector/vector_env.py:13-16), so rank r owns
+the contiguous global index range [r*N/G, (r+1)*N/G) and steps it with no data-path collective.  The engine's
+Philox streams are indexed by GLOBAL env index, hence a 1/2/4/8-way sharding produces bit-identical
+trajectories.  The only exchange is what SyncVectorEnv does with np.stack (gym/vector/utils/numpy_utils.py:50):
+concatenating the output tensors.  Per north_star that is one RCCL all-gather of the FINAL observation / reward /
+terminated / truncated tensors of a rollout chunk — never per step (inbound xGMI is ~7.5x slower than HBM) — and
+it is issued asynchronously on RCCL's stream from a snapshot of the outputs so the next chunk's kernels overlap it.
+torch.distributed is used for the process group only (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from contextlib import nullcontext
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def partition(total_envs: int, world_size: int, rank: int, align: int = 4):
+    """(offset, count) of rank's shard; shards are equal and aligned to the engine's env alignment."""
+    if total_envs % world_size != 0:
+        raise ValueError(f"num_envs={total_envs} must be divisible by the number of GPUs ({world_size})")
+    local = total_envs // world_size
+    if local % align != 0:
+        raise ValueError(f"per-GPU shard ({local} envs) must be a multiple of {align}")
+    return rank * local, local
+
+
+class ShardedRollout:
+    """engine_factory(id, num_envs, env_offset=..., seed=..., action_seed=..., **kw) must return an object with
+    .obs/.reward/.terminated/.truncated tensors, .reset(seed), .rollout(K, ...), .synchronize() and .stream
+    (a torch.cuda.Stream or None).  The default is the HIP engine (gym_amd.rollout.DeviceRollout)."""
+
+    def __init__(self, id: str, total_envs: int, *, rank: Optional[int] = None, world_size: Optional[int] = None,
+                 device: Optional[int] = None, seed: int = 0, action_seed: int = 0, group=None,
+                 engine_factory: Optional[Callable] = None, **engine_kwargs):
+        self.group = group
+        distributed = dist.is_available() and dist.is_initialized()
+        self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if distributed else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if distributed else 0)
+        self.total_envs = int(total_envs)
+        self.env_offset, self.local_envs = partition(self.total_envs, self.world_size, self.rank)
+        if engine_factory is None:
+            from .rollout import DeviceRollout
+
+            engine_factory = DeviceRollout
+            if device is None:
+                device = torch.cuda.current_device()
+            engine_kwargs["device"] = device
+        self.engine = engine_factory(id, self.local_envs, env_offset=self.env_offset, seed=seed,
+                                     action_seed=action_seed, **engine_kwargs)
+        self._pending = None
+        self._send = None
+        self._recv = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream_ctx(self):
+        s = getattr(self.engine, "stream", None)
+        return torch.cuda.stream(s) if s is not None else nullcontext()
+
+    def reset(self, seed: Optional[int] = None):
+        return self.engine.reset(seed=seed)
+
+    def rollout(self, K: int, **kw):
+        """K vector steps of the local shard (no communication)."""
+        return self.engine.rollout(K, **kw)
+
+    def _buffers(self):
+        if self._send is None:
+            e = self.engine
+            with self._stream_ctx():
+                self._send = [torch.empty_like(t) for t in (e.obs, e.reward, e.terminated, e.truncated)]
+                self._recv = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                                          device=t.device) for t in self._send]
+        return self._send, self._recv
+
+    def gather_async(self):
+        """Snapshot the current output tensors and start their all-gather; returns immediately."""
+        self.wait_gather()
+        e = self.engine
+        send, recv = self._buffers()
+        with self._stream_ctx():
+            for dst, src in zip(send, (e.obs, e.reward, e.terminated, e.truncated)):
+                dst.copy_(src, non_blocking=True)
+            if self.world_size == 1:
+                for r, s in zip(recv, send):
+                    r.copy_(s, non_blocking=True)
+                self._pending = []
+            else:
+                self._pending = [dist.all_gather_into_tensor(r, s, group=self.group, async_op=True)
+                                 for r, s in zip(recv, send)]
+
+    def wait_gather(self):
+        """Full (N_total, ...) obs / reward / terminated / truncated of the last gather_async, or None."""
+        if self._pending is None:
+            return None
+        with self._stream_ctx():
+            for w in self._pending:
+                w.wait()
+        self._pending = None
+        return tuple(self._recv)
+
+    def gather(self):
+        self.gather_async()
+        return self.wait_gather()
+
+    def synchronize(self):
+        self.wait_gather()
+        self.engine.synchronize()
+
+    def close(self):
+        self.wait_gather()
+        close = getattr(self.engine, "close", None)
+        if close:
+            close()

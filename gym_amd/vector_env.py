@@ -1,0 +1,345 @@
+"""HipVectorEnv — drop-in for gym.vector.SyncVectorEnv on the classic-control env ids.
+
+Host-side mirror of the reference's vector API: gym.vector.VectorEnv
+(gym/vector/vector_env.py:12-274) for attributes/method names, gym.vector.SyncVectorEnv
+(gym/vector/sync_vector_env.py:15-236) for behaviour (dtypes, autoreset, infos, errors).
+All arithmetic happens in the HIP engine behind include/mxv.h; this file only converts
+between the NumPy contract of the reference and the engine's buffers.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Iterable, List, Optional, Union
+
+import numpy as np
+
+from . import _native, error
+from .registration import (CTOR_KWARGS, ENUM_PARAMS, PARAM_NAMES, PENDULUM, single_spaces, spec as _spec)
+from .spaces import Box, Discrete, batch_space
+
+__all__ = ["VectorEnv", "HipVectorEnv", "make"]
+
+
+def _verify_number_and_cast(x) -> float:
+    """gym/envs/classic_control/utils.py:8-14."""
+    try:
+        return float(x)
+    except (ValueError, TypeError):
+        raise ValueError(f"An option ({x}) could not be converted to a float.")
+
+
+class _Pending:
+    __slots__ = ("build",)
+
+    def __init__(self, build):
+        self.build = build
+
+
+class LazyInfos(dict):
+    """infos dict whose `final_observation` / `final_info` object arrays (vector_env.py:208-258:
+    length-N object ndarrays with None holes, plus `_key` boolean masks) are materialised on first
+    access — building them eagerly is a Python loop over every finished env of every step."""
+
+    def _resolve(self, key):
+        v = dict.__getitem__(self, key)
+        if isinstance(v, _Pending):
+            v = v.build()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def __getitem__(self, key):
+        return self._resolve(key)
+
+    def get(self, key, default=None):
+        return self._resolve(key) if key in self else default
+
+    def items(self):
+        return [(k, self._resolve(k)) for k in self.keys()]
+
+    def values(self):
+        return [self._resolve(k) for k in self.keys()]
+
+    def __eq__(self, other):
+        return dict(self.items()) == (dict(other.items()) if isinstance(other, dict) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
+class VectorEnv:
+    """Attribute/method surface of gym.vector.VectorEnv (vector_env.py:25-206)."""
+
+    def __init__(self, num_envs: int, observation_space, action_space):
+        self.num_envs = num_envs
+        self.is_vector_env = True
+        self.observation_space = batch_space(observation_space, n=num_envs)
+        self.action_space = batch_space(action_space, n=num_envs)
+        self.closed = False
+        self.viewer = None
+        self.single_observation_space = observation_space
+        self.single_action_space = action_space
+
+    def reset_async(self, seed=None, options=None):
+        pass
+
+    def reset_wait(self, seed=None, options=None):
+        raise NotImplementedError("VectorEnv does not implement function")
+
+    def reset(self, *, seed: Optional[Union[int, List[int]]] = None, options: Optional[dict] = None):
+        self.reset_async(seed=seed, options=options)
+        return self.reset_wait(seed=seed, options=options)
+
+    def step_async(self, actions):
+        pass
+
+    def step_wait(self, **kwargs):
+        raise NotImplementedError()
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def call_async(self, name, *args, **kwargs):
+        pass
+
+    def call_wait(self, **kwargs):
+        pass
+
+    def call(self, name: str, *args, **kwargs):
+        self.call_async(name, *args, **kwargs)
+        return self.call_wait()
+
+    def get_attr(self, name: str):
+        return self.call(name)
+
+    def set_attr(self, name: str, values):
+        pass
+
+    def close_extras(self, **kwargs):
+        pass
+
+    def close(self, **kwargs):
+        if self.closed:
+            return
+        self.close_extras(**kwargs)
+        self.closed = True
+
+    def __del__(self):
+        if not getattr(self, "closed", True):
+            self.close()
+
+    def __repr__(self) -> str:
+        spec_ = getattr(self, "spec", None)
+        if spec_ is None:
+            return f"{self.__class__.__name__}({self.num_envs})"
+        return f"{self.__class__.__name__}({spec_.id}, {self.num_envs})"
+
+
+class HipVectorEnv(VectorEnv):
+    """`num_envs` copies of one classic-control env, resident on one MI355X.
+
+    Same call surface and return contract as SyncVectorEnv: observations float32 (N, O) (a fresh array
+    per call), rewards float64 (N,), terminated/truncated np.bool_ (N,), infos with `final_observation`
+    / `final_info` and their `_` masks when an env finished (sync_vector_env.py:152-169).
+
+    Differences that cannot be avoided: resets draw from the engine's Philox4x32-10 streams, not from
+    PCG64, so seeded initial states differ from the reference's; physics attributes
+    set through set_attr must be equal across sub-envs (they are broadcast kernel arguments).
+    """
+
+    metadata = {"render_modes": []}
+    render_mode = None
+
+    def __init__(self, id: str, num_envs: int = 1, *, device: int = 0, max_episode_steps: Optional[int] = None,
+                 env_offset: int = 0, copy: bool = True, **kwargs):
+        self.spec = _spec(id)
+        self.kind = self.spec.kind
+        observation_space, action_space = single_spaces(self.kind)
+        super().__init__(num_envs=num_envs, observation_space=observation_space, action_space=action_space)
+        self.copy = copy
+        limit = self.spec.max_episode_steps if max_episode_steps is None else max_episode_steps
+        self._max_episode_steps = -1 if limit is None else int(limit)
+        self._discrete = isinstance(action_space, Discrete)
+        entropy = int.from_bytes(os.urandom(8), "little")  # Env.reset(seed=None) = fresh OS entropy (seeding.py:24)
+        self._handle = _native.Handle(self.kind, num_envs, self._max_episode_steps, device=device,
+                                      env_offset=env_offset, seed=entropy, action_seed=entropy ^ 0x9E3779B97F4A7C15)
+        self._actions = None
+        self._was_reset = False
+        allowed = CTOR_KWARGS.get(self.kind, {})
+        for k, v in kwargs.items():
+            if k == "render_mode" and v is None:
+                continue
+            if k not in allowed:
+                raise TypeError(f"{id} got an unexpected keyword argument {k!r}")
+            self._set_param(allowed[k], v)
+
+    # -- parameters (get_attr / set_attr / call) ---------------------------------------------------
+    def _param_index(self, name: str) -> int:
+        try:
+            return PARAM_NAMES[self.kind].index(name)
+        except ValueError:
+            raise AttributeError(f"{self.spec.id} sub-environments have no attribute {name!r}") from None
+
+    def _decode(self, name, value):
+        enum = ENUM_PARAMS.get((self.kind, name))
+        return enum[int(value)] if enum else value
+
+    def _encode(self, name, value):
+        enum = ENUM_PARAMS.get((self.kind, name))
+        if enum:
+            if value not in enum:
+                raise ValueError(f"{name} must be one of {enum}, got {value!r}")
+            return float(enum.index(value))
+        return float(value)
+
+    def _set_param(self, name, value):
+        p = self._handle.get_params()
+        p[self._param_index(name)] = self._encode(name, value)
+        try:
+            self._handle.set_params(p)
+        except _native.MxvError as e:
+            if e.code == _native.ERR_UNSUPPORTED:
+                raise NotImplementedError(e.message) from None
+            raise
+
+    def call(self, name: str, *args, **kwargs) -> tuple:
+        """sync_vector_env.py:171-190: attribute value (or method result) of every sub-env, as a tuple."""
+        self._assert_is_running()
+        if args or kwargs:
+            raise NotImplementedError("sub-environment methods are not callable on the device engine")
+        value = self._decode(name, self._handle.get_params()[self._param_index(name)])
+        return (value,) * self.num_envs
+
+    def set_attr(self, name: str, values):
+        """sync_vector_env.py:192-214: list/tuple of per-env values or one broadcast value."""
+        self._assert_is_running()
+        if not isinstance(values, (list, tuple)):
+            values = [values for _ in range(self.num_envs)]
+        if len(values) != self.num_envs:
+            raise ValueError("Values must be a list or tuple with length equal to the number of environments. "
+                             f"Got `{len(values)}` values for {self.num_envs} environments.")
+        first = values[0]
+        if any(v != first for v in values):
+            raise NotImplementedError("per-env heterogeneous physics attributes are not supported: the engine "
+                                      "broadcasts one value to all sub-environments")
+        self._set_param(name, first)
+
+    # -- reset ---------------------------------------------------------------------------------------
+    def _reset_bounds(self, options: Optional[dict]):
+        if options is None:
+            return None
+        if self.kind == PENDULUM:  # pendulum.py:141-152
+            d = _native.default_reset_bounds(self.kind)
+            x = _verify_number_and_cast(options.get("x_init")) if "x_init" in options else d[0]
+            y = _verify_number_and_cast(options.get("y_init")) if "y_init" in options else d[1]
+            return np.array([x, y], dtype=np.float64)
+        d = _native.default_reset_bounds(self.kind)  # classic_control/utils.py:17-46
+        low = _verify_number_and_cast(options.get("low")) if "low" in options else d[0]
+        high = _verify_number_and_cast(options.get("high")) if "high" in options else d[1]
+        if low > high:
+            raise ValueError(f"Lower bound ({low}) must be lower than higher bound ({high}).")
+        return np.array([low, high], dtype=np.float64)
+
+    def reset_wait(self, seed: Optional[Union[int, List[int]]] = None, options: Optional[dict] = None):
+        """sync_vector_env.py:90-129."""
+        self._assert_is_running()
+        bounds = self._reset_bounds(options)
+        if seed is not None:
+            if isinstance(seed, (int, np.integer)):
+                if seed < 0:
+                    raise error.Error(f"Seed must be a non-negative integer or omitted, not {seed}")
+                self._handle.seed(int(seed) + 0, None)  # env i gets seed + i (sync_vector_env.py:106-107)
+            else:
+                seeds = list(seed)
+                assert len(seeds) == self.num_envs
+                for s in seeds:
+                    if not (isinstance(s, (int, np.integer)) and s >= 0):
+                        raise error.Error(f"Seed must be a non-negative integer or omitted, not {s}")
+                self._handle.seed(0, np.array(seeds, dtype=np.uint64))
+        obs = self._handle.reset_host(bounds=bounds)
+        self._was_reset = True
+        self._actions = None
+        return obs, {}
+
+    # -- step ----------------------------------------------------------------------------------------
+    def step_async(self, actions):
+        """sync_vector_env.py:131-133."""
+        self._assert_is_running()
+        if self._actions is not None:
+            raise error.AlreadyPendingCallError("Calling `step_async` while waiting for a pending call to `step` to "
+                                                "complete.", "step")
+        n = self.num_envs
+        a = np.asarray(actions)
+        if self._discrete:
+            if a.shape != (n,) or not np.issubdtype(a.dtype, np.integer):
+                # Discrete.contains (discrete.py:83-94) accepts integers only: the reference asserts
+                raise AssertionError(f"{actions!r} ({type(actions)}) invalid")
+            self._actions = np.ascontiguousarray(a, dtype=self._handle.action_dtype)
+        else:
+            if a.size != n:
+                raise AssertionError(f"expected {n} actions of shape (1,), got array of shape {a.shape}")
+            self._actions = np.ascontiguousarray(a, dtype=np.float32).reshape(n)
+
+    def step_wait(self):
+        """sync_vector_env.py:135-169."""
+        self._assert_is_running()
+        if self._actions is None:
+            raise error.NoAsyncCallError("Calling `step_wait` without any prior call to `step_async`.", "step")
+        actions, self._actions = self._actions, None
+        if not self._was_reset:
+            raise error.ResetNeeded("Cannot call env.step() before calling env.reset()")
+        try:
+            obs, rew, term, trunc, fin = self._handle.step_host(actions, want_final=True)
+        except _native.MxvError as e:
+            if e.code == _native.ERR_INVALID_ACTION:
+                raise AssertionError(f"{actions!r} ({type(actions)}) invalid") from None
+            if e.code == _native.ERR_RESET_NEEDED:
+                raise error.ResetNeeded("Cannot call env.step() before calling env.reset()") from None
+            raise
+        infos = LazyInfos()
+        done = term | trunc
+        if done.any():
+            n = self.num_envs
+            idx = np.flatnonzero(done)
+
+            def build_final_obs():
+                arr = np.full(n, None, dtype=object)
+                for i in idx:
+                    arr[i] = fin[i].copy()
+                return arr
+
+            def build_final_info():
+                arr = np.full(n, None, dtype=object)
+                for i in idx:
+                    arr[i] = {}
+                return arr
+
+            dict.__setitem__(infos, "final_observation", _Pending(build_final_obs))
+            dict.__setitem__(infos, "_final_observation", done.copy())
+            dict.__setitem__(infos, "final_info", _Pending(build_final_info))
+            dict.__setitem__(infos, "_final_info", done.copy())
+        return obs, rew, term, trunc, infos
+
+    # -- misc ----------------------------------------------------------------------------------------
+    def close_extras(self, **kwargs):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            h.close()
+
+    def _assert_is_running(self):
+        if self.closed:
+            raise error.ClosedEnvironmentError(f"Trying to operate on `{type(self).__name__}`, after a call to `close()`.")
+
+    # -- escape hatch for device-resident use ----------------------------------------------------------
+    @property
+    def handle(self) -> "_native.Handle":
+        """The engine handle (device-pointer API: see gym_amd.rollout.DeviceRollout)."""
+        return self._handle
+
+
+def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> HipVectorEnv:
+    """gym.vector.make (gym/vector/__init__.py:12-73) for the engine's ids.  `asynchronous` is accepted and
+    ignored: there are no sub-processes, all sub-envs step in one kernel launch."""
+    kwargs.pop("disable_env_checker", None)
+    kwargs.pop("wrappers", None)
+    return HipVectorEnv(id, num_envs, **kwargs)

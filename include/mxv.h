@@ -1,0 +1,182 @@
+/*
+ * mxv.h — C ABI of the MI355X-native vectorised classic-control environment engine.
+ *
+ * What this boundary replaces.  openai/gym 0.26.2 has no FFI: its hot path
+ * gym.vector.SyncVectorEnv.step()/reset() (gym/vector/sync_vector_env.py:90-169) is a serial
+ * Python loop over TimeLimit-wrapped sub-envs (gym/wrappers/time_limit.py:39-68) whose step()
+ * bodies are the classic-control dynamics (gym/envs/classic_control/{cartpole.py:130-188,
+ * pendulum.py:119-139, acrobot.py:196-277, mountain_car.py:127-148,
+ * continuous_mountain_car.py:142-175}).  The entry points below are what a ctypes binding
+ * behind a gym.vector.VectorEnv subclass (gym/vector/vector_env.py:12-274) binds; the
+ * reference-side stub is shown in INTEGRATION.md, the shipped one is gym_amd/_native.py.
+ *
+ * Conventions.  C linkage, plain pointers and sizes, no C++/torch types.  Every function
+ * returns an int status (MXV_OK or a negative MXV_ERR_*); mxv_last_error() gives the message.
+ * One handle = one HIP device + one HIP stream + the device-resident env state
+ * (struct-of-arrays fp64 state[S][N], int32 elapsed[N]).  The library owns state buffers;
+ * the CALLER owns every I/O buffer it passes.  Pointers suffixed _dev are device pointers
+ * valid on the handle's device; _host are host pointers.  Device-pointer calls are
+ * asynchronous on the handle's stream; *_host calls synchronise.  A handle is not
+ * thread-safe; distinct handles are independent.
+ *
+ * Output dtypes follow SyncVectorEnv (sync_vector_env.py:65-72): observations float32
+ * [N][O] row-major, rewards float64 [N] (float32 with MXV_FLAG_REWARD_F32), terminated /
+ * truncated uint8 [N] (numpy bool layout).  Discrete actions are int64 [N] (the dtype of
+ * batch_space(Discrete) = MultiDiscrete, gym/vector/utils/spaces.py:53-68) or int32 with
+ * MXV_FLAG_ACTION_I32; Box actions are float32 [N] (= [N][1]).
+ *
+ * RNG contract (Philox4x32-10, counter based, no RNG state in memory) — see DESIGN.md §RNG:
+ *   actions : key = action_seed, ctr = (g_lo, g_hi, t_lo, (t_hi & 0x0fffffff) | 1<<28),
+ *             g = global_env >> 2, word = out[global_env & 3];
+ *             Discrete(n): (word*n)>>32 ; Box(lo,hi): float32(lo + (hi-lo)*(word+0.5)*2^-32)
+ *   resets  : key = per-env seed (base_seed + global_env unless explicit), ctr = (t_lo, t_hi, r, 2<<28),
+ *             r = 0 for an autoreset inside vector step t, r>=1 = ordinal of explicit reset calls.
+ * t = index of the vector step since the last mxv_seed().
+ */
+#ifndef MXV_H
+#define MXV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mxv_handle mxv_handle;
+
+/* env kinds (gym ids: CartPole-v0/v1, Pendulum-v1, Acrobot-v1, MountainCar-v0, MountainCarContinuous-v0) */
+enum {
+    MXV_CARTPOLE = 0,
+    MXV_PENDULUM = 1,
+    MXV_ACROBOT = 2,
+    MXV_MOUNTAINCAR = 3,
+    MXV_MOUNTAINCAR_CONT = 4,
+    MXV_NUM_ENV_KINDS = 5
+};
+
+/* status codes */
+enum {
+    MXV_OK = 0,
+    MXV_ERR_INVALID_ARG = -1,    /* bad config / NULL pointer / bad reset bounds (ValueError, classic_control/utils.py:41-44) */
+    MXV_ERR_HIP = -2,            /* HIP runtime failure; message holds hipGetErrorString */
+    MXV_ERR_INVALID_ACTION = -3, /* discrete action outside [0,n): the reference's `assert action_space.contains(action)` (cartpole.py:131-132) */
+    MXV_ERR_RESET_NEEDED = -4,   /* step before reset: gym.error.ResetNeeded (gym/wrappers/order_enforcing.py:33-37) */
+    MXV_ERR_UNSUPPORTED = -5
+};
+
+/* config flags */
+enum {
+    MXV_FLAG_ACTION_I32 = 1,   /* discrete actions are int32 instead of int64 */
+    MXV_FLAG_REWARD_F32 = 2,   /* rewards are float32 instead of float64 */
+    MXV_FLAG_NO_AUTORESET = 4  /* dynamics + TimeLimit only; finished envs are NOT reset (single-env semantics) */
+};
+
+#define MXV_MAX_PARAMS 12
+#define MXV_ENV_ALIGN 4 /* env_offset must be a multiple of this (Philox action groups of 4 envs) */
+
+/*
+ * Physics parameter vector P[MXV_MAX_PARAMS] (fp64) = the attributes the reference's env objects hold
+ * (VectorEnv.set_attr/get_attr, sync_vector_env.py:192-214, e.g. "gravity"):
+ *  CartPole   : 0 gravity 1 masscart 2 masspole 3 total_mass 4 length 5 polemass_length 6 force_mag 7 tau
+ *               8 theta_threshold_radians 9 x_threshold 10 kinematics_integrator (0 euler, 1 semi-implicit)
+ *  Pendulum   : 0 max_speed 1 max_torque 2 dt 3 g 4 m 5 l
+ *  Acrobot    : 0 dt 1 LINK_LENGTH_1 2 LINK_LENGTH_2 3 LINK_MASS_1 4 LINK_MASS_2 5 LINK_COM_POS_1 6 LINK_COM_POS_2
+ *               7 LINK_MOI 8 MAX_VEL_1 9 MAX_VEL_2 10 torque_noise_max (must be 0) 11 book_or_nips (0 book, 1 nips)
+ *  MountainCar: 0 min_position 1 max_position 2 max_speed 3 goal_position 4 goal_velocity 5 force 6 gravity
+ *  MountainCarContinuous: 0 min_action 1 max_action 2 min_position 3 max_position 4 max_speed 5 goal_position
+ *               6 goal_velocity 7 power
+ */
+
+typedef struct mxv_config {
+    int32_t env_id;            /* MXV_CARTPOLE ... */
+    int32_t device;            /* HIP device ordinal */
+    int64_t num_envs;          /* envs held by THIS handle (a shard of the logical vector env) */
+    int64_t env_offset;        /* global index of local env 0; RNG streams use global indices so that
+                                  1/2/4/8-GPU shardings of one logical env draw identical numbers */
+    int32_t max_episode_steps; /* TimeLimit (gym/envs/__init__.py:11-50); <= 0 disables truncation */
+    int32_t flags;             /* MXV_FLAG_* */
+    uint64_t seed;             /* base seed: env i is seeded with seed + global_index (sync_vector_env.py:106-107) */
+    uint64_t action_seed;      /* seed of the action-sampling stream (VectorEnv.action_space.seed) */
+} mxv_config;
+
+/* -- static information ---------------------------------------------------------------------- */
+/* state dim S, observation dim O, number of discrete actions (0 for Box action spaces). */
+int mxv_env_dims(int32_t env_id, int32_t *state_dim, int32_t *obs_dim, int32_t *num_actions);
+/* default P[] (the values the reference's __init__ sets) and default reset bounds (low, high)
+ * (Pendulum: (x_init, y_init) = (pi, 1), pendulum.py:14-15,141-159). */
+int mxv_default_params(int32_t env_id, double *params_host);
+int mxv_default_reset_bounds(int32_t env_id, double *bounds2_host);
+const char *mxv_version(void);
+
+/* -- lifetime -------------------------------------------------------------------------------- */
+int mxv_create(const mxv_config *cfg, mxv_handle **out);
+int mxv_destroy(mxv_handle *h);
+/* h may be NULL: message of the last failed mxv_create on this thread. */
+const char *mxv_last_error(const mxv_handle *h);
+
+/* -- seeding (Env.reset(seed=...), gym/core.py:149-151; SyncVectorEnv seeds env i with seed+i) -- */
+/* per_env_seeds_host: NULL -> env i uses base_seed + env_offset + i; else N explicit 64-bit seeds.
+ * Restarts the step index t and the explicit-reset ordinal r at 0. */
+int mxv_seed(mxv_handle *h, uint64_t base_seed, const uint64_t *per_env_seeds_host);
+int mxv_seed_actions(mxv_handle *h, uint64_t action_seed);
+
+/* -- reset: SyncVectorEnv.reset_wait (sync_vector_env.py:90-129) + TimeLimit.reset ------------ */
+/* mask_dev: NULL = all envs, else uint8[N] (1 = reset this env).  bounds2_host: NULL = defaults,
+ * else (low, high) from reset(options={"low","high"}) (classic_control/utils.py:17-46; Pendulum:
+ * (x_init, y_init)); low > high -> MXV_ERR_INVALID_ARG.  obs_dev may be NULL. */
+int mxv_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds2_host, float *obs_dev);
+
+/* -- step: SyncVectorEnv.step_wait (sync_vector_env.py:135-169), TimeLimit + autoreset fused ---- */
+/* On terminated|truncated (and unless MXV_FLAG_NO_AUTORESET): obs row = post-reset observation,
+ * final_obs row = terminal observation (info["final_observation"]); rows of envs that did not
+ * finish are left untouched in final_obs.  final_obs_dev may be NULL.  The mask of finished envs
+ * is terminated|truncated.  An out-of-range discrete action leaves that env unstepped and latches
+ * MXV_ERR_INVALID_ACTION, reported by the next mxv_sync()/ *_host call. */
+int mxv_step(mxv_handle *h, const void *actions_dev, float *obs_dev, void *reward_dev,
+             uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev);
+/* Same, with actions drawn on device from the Philox action stream (action_space.sample(),
+ * gym/spaces/{discrete.py:81,multi_discrete.py:123,box.py:216-222}); actions_out_dev (may be
+ * NULL) receives the actions taken, in the action dtype. */
+int mxv_step_sampled(mxv_handle *h, void *actions_out_dev, float *obs_dev, void *reward_dev,
+                     uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev);
+/* K sampled steps back to back (the user loop of README.md:29-41 with a random policy).
+ * per_step != 0: every output pointer addresses [K][...] and step k writes slice k;
+ * per_step == 0: every output pointer addresses one step's buffers, overwritten K times
+ * (the "final tensors" of a rollout chunk).  Any output pointer may be NULL except obs_dev.
+ * use_graph != 0 replays the K launches from a cached hipGraph. */
+int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t use_graph, void *actions_out_dev,
+                float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev,
+                float *final_obs_dev);
+/* action_space.sample() for the NEXT step index without stepping. */
+int mxv_sample_actions(mxv_handle *h, void *actions_out_dev);
+
+/* -- host-buffer convenience (what a NumPy-returning gym.vector.VectorEnv adapter calls) -------- */
+/* Copies through library-owned staging buffers and synchronises.  final_obs_host may be NULL. */
+int mxv_reset_host(mxv_handle *h, const uint8_t *mask_host, const double *bounds2_host, float *obs_host);
+int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void *reward_host,
+                  uint8_t *terminated_host, uint8_t *truncated_host, float *final_obs_host);
+
+/* -- state access (parity hook + checkpoint/resume) ---------------------------------------------- */
+/* state_soa_host: double[S][N]; elapsed_host: int32[N]; either may be NULL.  Synchronises. */
+int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host);
+int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *elapsed_host);
+/* step index t / explicit-reset ordinal r (restore with mxv_set_counters when resuming). */
+int mxv_get_counters(mxv_handle *h, uint64_t *t, uint32_t *r);
+int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r);
+
+/* -- physics parameters (VectorEnv.get_attr/set_attr; broadcast values only) ------------------- */
+int mxv_get_params(mxv_handle *h, double *params_host);
+int mxv_set_params(mxv_handle *h, const double *params_host);
+
+/* -- stream / sync -------------------------------------------------------------------------------- */
+/* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last
+ * sync saw an out-of-range action (and clears the latch). */
+int mxv_sync(mxv_handle *h);
+/* The hipStream_t the handle launches on (created non-blocking by mxv_create) / adopt an external one. */
+int mxv_get_stream(mxv_handle *h, void **stream);
+int mxv_set_stream(mxv_handle *h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXV_H */

@@ -1,0 +1,147 @@
+"""Shared parity machinery: golden-vector replay and oracle-vs-engine comparison.
+
+An "engine" here is anything with
+    set_state(state[S,N] f64, elapsed[N] i32) / get_state() -> (state, elapsed)
+    step(actions) -> obs[N,O] f32, reward[N] f64, terminated[N] bool, truncated[N] bool, final_obs[N,O] f32
+The CPU oracle (oracle/oracle.py) and the HIP engine behind the C ABI (gym_amd._native.Handle) are both wrapped
+to that shape so the very same checks run against either.
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ENV_NAMES = ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous"]
+ENV_IDS = {n: i for i, n in enumerate(ENV_NAMES)}
+GYM_IDS = {"CartPole": "CartPole-v1", "Pendulum": "Pendulum-v1", "Acrobot": "Acrobot-v1",
+           "MountainCar": "MountainCar-v0", "MountainCarContinuous": "MountainCarContinuous-v0"}
+LIMITS = {"CartPole": 500, "Pendulum": 200, "Acrobot": 500, "MountainCar": 200, "MountainCarContinuous": 999}
+DISCRETE = {"CartPole": 2, "Pendulum": 0, "Acrobot": 3, "MountainCar": 3, "MountainCarContinuous": 0}
+
+
+def load_golden(name, kind):
+    return np.load(os.path.join(GOLDEN, f"{name}_{kind}.npz"))
+
+
+def ulps32(a, b):
+    """Distance in float32 units-in-the-last-place (0 = bit-identical up to the sign of zero)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+class OracleEngine:
+    def __init__(self, name, n, max_steps, autoreset=True, seed=0, action_seed=0, env_offset=0):
+        from oracle.oracle import OracleVecEnv
+
+        self.o = OracleVecEnv(ENV_IDS[name], n, max_steps, seed=seed, action_seed=action_seed, env_offset=env_offset,
+                              autoreset=autoreset)
+
+    def set_state(self, state, elapsed):
+        self.o.state[:] = state
+        self.o.elapsed[:] = elapsed
+
+    def get_state(self):
+        return self.o.state.copy(), self.o.elapsed.copy()
+
+    def step(self, actions):
+        obs, rew, term, trunc, fin, fmask = self.o.step(actions)
+        return obs, rew, term, trunc, fin
+
+
+class HipEngine:
+    """The product path: every call goes through the C ABI (ctypes -> libmxv.so -> HIP kernels)."""
+
+    def __init__(self, name, n, max_steps, autoreset=True, seed=0, action_seed=0, env_offset=0):
+        from gym_amd import _native
+
+        flags = 0 if autoreset else _native.FLAG_NO_AUTORESET
+        self.h = _native.Handle(ENV_IDS[name], n, max_steps, seed=seed, action_seed=action_seed,
+                                env_offset=env_offset, flags=flags)
+
+    def set_state(self, state, elapsed):
+        self.h.set_state(state, elapsed)
+
+    def get_state(self):
+        return self.h.get_state()
+
+    def step(self, actions):
+        return self.h.step_host(actions, want_final=True)
+
+
+# Tolerances of engine-vs-reference comparisons.  Integer/boolean outputs (terminated, truncated, elapsed,
+# final mask) are always exact.  strict=True is the oracle's bar (bit-exact against the reference).  The HIP engine
+# computes in fp64 like the reference but its sin/cos (ocml) and x*x (vs libm pow) may differ from glibc in the
+# last fp64 bit, so observations are held to north_star's rtol=1e-5 AND to <= MAX_OBS_ULPS float32 ulps.
+OBS_RTOL = 1e-5
+MAX_OBS_ULPS = 2
+STATE_RTOL, STATE_ATOL = 1e-12, 1e-13
+REWARD_RTOL = 1e-12
+
+
+def compare_step(tag, got, ref, done_ref, strict):
+    """got/ref: dicts with obs, reward, terminated, truncated, final_obs, state, elapsed (post-step)."""
+    nd = ~done_ref
+    assert np.array_equal(got["terminated"], ref["terminated"]), f"{tag}: terminated mask differs"
+    assert np.array_equal(got["truncated"], ref["truncated"]), f"{tag}: truncated mask differs"
+    assert np.array_equal(got["elapsed"][nd], ref["elapsed"][nd]), f"{tag}: elapsed differs"
+    assert np.all(got["elapsed"][done_ref] == 0), f"{tag}: elapsed not zeroed by autoreset"
+    pairs = [("obs", got["obs"][nd], ref["obs"][nd]), ("final_obs", got["final_obs"][done_ref], ref["final_obs"][done_ref])]
+    for what, g, r in pairs:
+        if strict:
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), f"{tag}: {what} not bit-exact"
+        else:
+            u = ulps32(g, r)
+            assert u.size == 0 or u.max() <= MAX_OBS_ULPS, f"{tag}: {what} off by {u.max()} float32 ulps"
+            np.testing.assert_allclose(g, r, rtol=OBS_RTOL, atol=1e-30, err_msg=f"{tag}: {what}")
+    if strict:
+        assert np.array_equal(got["reward"], ref["reward"]), f"{tag}: reward not bit-exact"
+        assert np.array_equal(got["state"][nd], ref["state"][nd]), f"{tag}: fp64 state not bit-exact"
+    else:
+        np.testing.assert_allclose(got["reward"], ref["reward"], rtol=REWARD_RTOL, atol=1e-300, err_msg=f"{tag}: reward")
+        np.testing.assert_allclose(got["state"][nd], ref["state"][nd], rtol=STATE_RTOL, atol=STATE_ATOL,
+                                   err_msg=f"{tag}: fp64 state")
+
+
+def run_p1(engine_cls, name, strict):
+    """Single raw-env steps from hand-set states (golden <env>_p1.npz)."""
+    g = load_golden(name, "p1")
+    n = len(g["action"])
+    eng = engine_cls(name, n, 0, autoreset=False)
+    elapsed = np.where(g["fresh"] == 1, 0, 5).astype(np.int32)
+    eng.set_state(g["state0"].T, elapsed)
+    obs, rew, term, trunc, fin = eng.step(g["action"])
+    st, el = eng.get_state()
+    done = np.zeros(n, dtype=bool)
+    got = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, final_obs=fin, state=st.T, elapsed=el)
+    ref = dict(obs=g["obs"], reward=g["reward"], terminated=g["terminated"].astype(bool),
+               truncated=np.zeros(n, dtype=bool), final_obs=g["obs"], state=g["state1"], elapsed=elapsed + 1)
+    compare_step(f"{name} P1", got, ref, done, strict)
+    return int(term.sum())
+
+
+def run_p2(engine_cls, name, tag, strict):
+    """Teacher-forced replay of a SyncVectorEnv trajectory (golden <env>_p2_<tag>.npz): before every step the
+    engine is given the reference's pre-step fp64 state and elapsed counters (so PCG64-vs-Philox resets cannot
+    desynchronise the two), then one vector step is compared output by output."""
+    g = load_golden(name, f"p2_{tag}")
+    T, N = g["action"].shape
+    eng = engine_cls(name, N, int(g["max_episode_steps"]), autoreset=True)
+    ndone = 0
+    for t in range(T):
+        eng.set_state(g["state_pre"][t].T, g["elapsed_pre"][t])
+        obs, rew, term, trunc, fin = eng.step(g["action"][t])
+        st, el = eng.get_state()
+        done = (g["terminated"][t] | g["truncated"][t]).astype(bool)
+        assert np.array_equal(done, g["final_mask"][t].astype(bool))
+        got = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, final_obs=fin, state=st.T, elapsed=el)
+        ref = dict(obs=g["obs"][t], reward=g["reward"][t], terminated=g["terminated"][t].astype(bool),
+                   truncated=g["truncated"][t].astype(bool), final_obs=g["final_obs"][t], state=g["state_post"][t],
+                   elapsed=g["elapsed_post"][t])
+        compare_step(f"{name} P2[{tag}] t={t}", got, ref, done, strict)
+        ndone += int(done.sum())
+    return ndone

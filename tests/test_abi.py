@@ -1,0 +1,83 @@
+"""The C-ABI library: loads, exports every symbol include/mxv.h declares, static tables agree with the oracle.
+No compute calls here (no GPU needed); the compute checks are the -m gpu parity tests."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HAS_GPU, ROOT
+from helpers import ENV_IDS, ENV_NAMES
+from oracle import oracle
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mxv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mxv_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from gym_amd import _native
+
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for sym in declared:
+        assert hasattr(lib, sym), f"libmxv.so does not export {sym}"
+    assert sorted(_native.EXPORTS) == declared, "gym_amd/_native.py binds a different symbol set than include/mxv.h declares"
+    assert b"gfx950" in _native.lib.mxv_version()
+
+
+def test_static_tables_match_oracle():
+    from gym_amd import _native
+
+    for name in ENV_NAMES:
+        k = ENV_IDS[name]
+        S, O, NA = _native.env_dims(k)
+        assert S == oracle.lib().orc_state_dim(k) and O == oracle.lib().orc_obs_dim(k)
+        assert NA == oracle.DISCRETE.get(k, 0)
+        assert np.array_equal(_native.default_params(k), oracle.default_params(k))
+        assert np.array_equal(_native.default_reset_bounds(k), oracle.default_reset_bounds(k))
+    with pytest.raises(_native.MxvError):
+        _native.env_dims(9)
+
+
+def test_config_struct_layout_matches_header():
+    from gym_amd import _native
+
+    assert ctypes.sizeof(_native.MxvConfig) == 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8
+    assert _native.MxvConfig.num_envs.offset == 8 and _native.MxvConfig.seed.offset == 32
+
+
+@pytest.mark.skipif(HAS_GPU, reason="only meaningful where no HIP device exists")
+def test_no_device_fails_loudly_no_cpu_fallback():
+    from gym_amd import _native
+
+    with pytest.raises(_native.MxvError) as ei:
+        _native.Handle(0, 8, 500)
+    assert ei.value.code in (_native.ERR_HIP, _native.ERR_INVALID_ARG)
+    import gym_amd
+    with pytest.raises(Exception):
+        gym_amd.make("CartPole-v1", 8)
+
+
+def test_bad_config_rejected_before_touching_a_device():
+    from gym_amd import _native
+
+    for kw in (dict(env_id=7, num_envs=8), dict(env_id=0, num_envs=0), dict(env_id=0, num_envs=8, env_offset=3)):
+        with pytest.raises(_native.MxvError) as ei:
+            _native.Handle(kw["env_id"], kw["num_envs"], 500, env_offset=kw.get("env_offset", 0))
+        assert ei.value.code == _native.ERR_INVALID_ARG
+
+
+def test_product_code_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under gym_amd/ may import, link or execute it."""
+    pkg = os.path.join(ROOT, "gym_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.lower().replace("# oracle-free", ""), f"{f} mentions the oracle"
+                assert "liborc" not in src

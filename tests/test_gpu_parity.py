@@ -1,0 +1,220 @@
+"""Parity of the HIP engine, called through the C ABI, against (a) the reference's golden vectors,
+(b) SURVEY App. B known answers, (c) the oracle on seeded random rollouts incl. Philox actions + autoreset,
+(d) size-independent properties at BASELINE.json's full sizes.
+
+Bars: terminated / truncated / elapsed / sampled discrete actions / reset states: bit-exact.
+Observations: north_star's fp32 rtol=1e-5 and additionally <= MAX_OBS_ULPS float32 ulps; fp64 state and reward
+within helpers.STATE_RTOL / REWARD_RTOL (device sin/cos and x*x may differ from glibc in the last fp64 bit)."""
+import numpy as np
+import pytest
+
+from helpers import (DISCRETE, ENV_IDS, ENV_NAMES, LIMITS, MAX_OBS_ULPS, OBS_RTOL, HipEngine, OracleEngine, run_p1,
+                     run_p2, ulps32)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_golden_single_steps(name):
+    run_p1(HipEngine, name, strict=False)
+
+
+@pytest.mark.parametrize("tag", ["default", "short"])
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_golden_trajectories(name, tag):
+    run_p2(HipEngine, name, tag, strict=False)
+
+
+def test_known_answers_survey_appendix_b():
+    from test_oracle_golden import kat_check
+
+    kat_check(HipEngine, strict_bits=False)
+
+
+def _rollout_compare(name, n, steps, seed, limit=None, env_offset=0, resync_every=1):
+    """Device vs oracle on the full engine semantics: Philox-sampled actions, TimeLimit, autoreset from the Philox
+    reset stream.  Both sides follow the same RNG contract, so actions and reset states are bit-identical and the
+    two trajectories stay aligned; every `resync_every` steps the device's fp64 state is copied into the oracle so
+    that last-bit libm differences cannot accumulate in the chaotic envs."""
+    import torch
+    from gym_amd import _native
+
+    limit = LIMITS[name] if limit is None else limit
+    h = _native.Handle(ENV_IDS[name], n, limit, seed=seed, action_seed=seed * 31 + 7, env_offset=env_offset)
+    ref = OracleEngine(name, n, limit, seed=seed, action_seed=seed * 31 + 7, env_offset=env_offset).o
+    obs0 = h.reset_host()
+    robs0 = ref.reset(seed=seed)
+    assert ulps32(obs0, robs0).max() <= MAX_OBS_ULPS
+    dt = torch.int64 if DISCRETE[name] else torch.float32
+    d_act = torch.zeros(n, dtype=dt, device="cuda")
+    d_obs = torch.zeros((n, h.O), dtype=torch.float32, device="cuda")
+    d_rew = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d_term = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    d_trunc = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    d_fin = torch.zeros((n, h.O), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ndone = 0
+    for t in range(steps):
+        st_pre, el_pre = h.get_state()
+        if t % resync_every == 0:
+            ref.state[:] = st_pre
+            ref.elapsed[:] = el_pre
+        want_a = ref.sample_actions()
+        d_fin.zero_()
+        torch.cuda.synchronize()
+        h.step_sampled(d_obs, d_rew, d_term, d_trunc, d_fin, d_act)
+        h.sync()
+        robs, rrew, rterm, rtrunc, rfin, rfmask = ref.step(want_a)
+        assert np.array_equal(d_act.cpu().numpy(), want_a), f"{name} t={t}: sampled actions differ"
+        term, trunc = d_term.cpu().numpy().astype(bool), d_trunc.cpu().numpy().astype(bool)
+        assert np.array_equal(term, rterm), f"{name} t={t}: terminated mask differs"
+        assert np.array_equal(trunc, rtrunc), f"{name} t={t}: truncated mask differs"
+        done = term | trunc
+        obs, fin = d_obs.cpu().numpy(), d_fin.cpu().numpy()
+        assert ulps32(obs, robs).max() <= MAX_OBS_ULPS, f"{name} t={t}: obs ulps {ulps32(obs, robs).max()}"
+        np.testing.assert_allclose(obs, robs, rtol=OBS_RTOL, atol=1e-30)
+        if done.any():
+            assert ulps32(fin[done], rfin[done]).max() <= MAX_OBS_ULPS
+            assert np.all(fin[~done] == 0), "final_obs rows of unfinished envs must stay untouched"
+        np.testing.assert_allclose(d_rew.cpu().numpy(), rrew, rtol=1e-12, atol=1e-300)
+        st, el = h.get_state()
+        assert np.array_equal(el, ref.elapsed)
+        assert np.array_equal(st[:, done], ref.state[:, done]), "post-reset states are pure Philox: must be bit-exact"
+        np.testing.assert_allclose(st, ref.state, rtol=1e-12, atol=1e-13)
+        ndone += int(done.sum())
+    return ndone
+
+
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_rollout_vs_oracle_default_limits(name):
+    ndone = _rollout_compare(name, n=3000, steps=260, seed=1234, env_offset=4096)
+    if name in ("CartPole", "Pendulum", "MountainCar"):
+        assert ndone > 0
+
+
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_rollout_vs_oracle_short_limit(name):
+    ndone = _rollout_compare(name, n=1025, steps=60, seed=99, limit=7)
+    assert ndone >= 1025 * 8
+
+
+def test_config1_cartpole_8_envs_1000_steps():
+    """BASELINE.json configs[0]: CartPole-v1, num_envs=8, random actions, 1000 steps (plumbing case)."""
+    ndone = _rollout_compare("CartPole", n=8, steps=1000, seed=0)
+    assert ndone > 100  # random-policy episodes last ~22 steps
+
+
+@pytest.mark.parametrize("name,n", [("CartPole", 1 << 20), ("Pendulum", 1 << 19), ("MountainCarContinuous", 1 << 19),
+                                    ("Acrobot", 1 << 19), ("MountainCar", 1 << 18)])
+def test_full_size_against_oracle_and_properties(name, n):
+    """BASELINE.json sizes: 16 steps of the whole batch against the oracle, then invariants over a longer run."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    steps = 12 if name == "Acrobot" else 16
+    _rollout_compare(name, n=n, steps=steps, seed=5, resync_every=1)
+
+    def run(env_offset, count, graph):
+        r = DeviceRollout(GYM_IDS[name], count, env_offset=env_offset, seed=77, action_seed=78)
+        r.reset(seed=77)
+        with torch.cuda.stream(r.stream):
+            acc = torch.zeros(count, dtype=torch.float64, device="cuda")
+            dones = torch.zeros(count, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            r.rollout(20, use_graph=graph)
+            with torch.cuda.stream(r.stream):
+                acc += r.reward
+                dones += (r.terminated | r.truncated).to(torch.int64)
+        r.synchronize()
+        st, el = r.handle.get_state()
+        out = (r.obs.cpu().numpy().copy(), acc.cpu().numpy(), dones.cpu().numpy(), st, el)
+        r.close()
+        return out
+
+    whole = run(0, n, False)
+    again = run(0, n, True)  # determinism + hipGraph replay == eager launches
+    for a, b in zip(whole, again):
+        assert np.array_equal(a, b)
+    lo, hi = run(0, n // 2, False), run(n // 2, n // 2, False)  # shard-invariance (multi-GPU partition rule)
+    assert np.array_equal(whole[0], np.concatenate([lo[0], hi[0]]))
+    assert np.array_equal(whole[3], np.concatenate([lo[3], hi[3]], axis=1))
+    assert np.array_equal(whole[4], np.concatenate([lo[4], hi[4]]))
+    obs, _, _, st, el = whole
+    assert np.all(np.isfinite(obs)) and np.all(np.isfinite(st))
+    assert el.min() >= 0 and el.max() < LIMITS[name]
+    from gym_amd.registration import single_spaces, spec
+    space, _ = single_spaces(spec(GYM_IDS[name]).kind)
+    assert np.all(obs >= space.low - 1e-6) and np.all(obs <= space.high + 1e-6)
+
+
+def test_invalid_action_is_latched_and_reported():
+    from gym_amd import _native
+
+    h = _native.Handle(ENV_IDS["CartPole"], 64, 500, seed=1)
+    h.reset_host()
+    st0, el0 = h.get_state()
+    bad = np.zeros(64, dtype=np.int64)
+    bad[17] = 2
+    with pytest.raises(_native.MxvError) as ei:
+        h.step_host(bad)
+    assert ei.value.code == _native.ERR_INVALID_ACTION
+    st1, el1 = h.get_state()
+    assert np.array_equal(st0[:, 17], st1[:, 17]) and el1[17] == el0[17]  # the offending env was not stepped
+    h.step_host(np.zeros(64, dtype=np.int64))  # latch cleared, engine usable again
+
+
+def test_step_before_reset_is_refused():
+    from gym_amd import _native
+
+    h = _native.Handle(ENV_IDS["Pendulum"], 16, 200)
+    with pytest.raises(_native.MxvError) as ei:
+        h.step_host(np.zeros(16, dtype=np.float32))
+    assert ei.value.code == _native.ERR_RESET_NEEDED
+
+
+def test_non_default_params_match_oracle():
+    """set_attr path: the runtime-parameter kernels against the oracle with the same parameter vector."""
+    from gym_amd import _native
+
+    rng = np.random.default_rng(0)
+    tweaks = {"CartPole": {0: 11.0, 6: 12.5, 10: 1.0}, "Pendulum": {3: 9.81, 1: 1.5}, "Acrobot": {11: 1.0, 3: 1.2},
+              "MountainCar": {4: 0.01, 5: 0.0012}, "MountainCarContinuous": {7: 0.002, 6: 0.005}}
+    for name in ENV_NAMES:
+        g = np.load(f"{__import__('helpers').GOLDEN}/{name}_p1.npz")
+        n = 2048
+        eng = HipEngine(name, n, 0, autoreset=False)
+        orc = OracleEngine(name, n, 0, autoreset=False)
+        p = eng.h.get_params()
+        for k, v in tweaks[name].items():
+            p[k] = v
+        eng.h.set_params(p)
+        orc.o.P[:] = p
+        el = np.where(g["fresh"][:n] == 1, 0, 3).astype(np.int32)
+        eng.set_state(g["state0"][:n].T, el)
+        orc.set_state(g["state0"][:n].T, el)
+        a = g["action"][:n]
+        o1, r1, t1, _, _ = eng.step(a)
+        o2, r2, t2, _, _ = orc.step(a)
+        assert np.array_equal(t1, t2), name
+        assert ulps32(o1, o2).max() <= MAX_OBS_ULPS, name
+        np.testing.assert_allclose(r1, r2, rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(eng.get_state()[0], orc.get_state()[0], rtol=1e-12, atol=1e-13)
+
+
+def test_reward_f32_and_action_i32_flags():
+    import torch
+    from gym_amd import _native
+
+    n = 4096
+    h = _native.Handle(ENV_IDS["Acrobot"], n, 500, seed=3, action_seed=4,
+                       flags=_native.FLAG_REWARD_F32 | _native.FLAG_ACTION_I32)
+    h2 = _native.Handle(ENV_IDS["Acrobot"], n, 500, seed=3, action_seed=4)
+    h.reset_host(), h2.reset_host()
+    a64 = torch.zeros(n, dtype=torch.int64, device="cuda")
+    h2.sample_actions(a64)
+    h2.sync()
+    a = a64.cpu().numpy()
+    o1, r1, t1, tr1, _ = h.step_host(a.astype(np.int32))
+    o2, r2, t2, tr2, _ = h2.step_host(a)
+    assert r1.dtype == np.float32 and np.array_equal(o1, o2) and np.array_equal(r1, r2.astype(np.float32))
