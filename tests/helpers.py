@@ -80,7 +80,13 @@ class HipEngine:
 OBS_RTOL = 1e-5
 MAX_OBS_ULPS = 2
 STATE_RTOL, STATE_ATOL = 1e-12, 1e-13
-REWARD_RTOL = 1e-12
+# Rewards are fp64.  Pendulum's cost holds one float32 term, 0.001*(u**2) (pendulum.py:129): the reference gets u**2
+# from libm powf (<= 0.82 ulp, not correctly rounded) while the engine multiplies u*u (correctly rounded), so that
+# term (<= 0.004) may differ by one float32 ulp = 2^-31 absolute (measured: libm powf(u,2) != u*u for 0.08 % of
+# random u): Pendulum rewards get atol 1e-9 on top of rtol 1e-13; every other env rtol 1e-13 only.
+REWARD_RTOL = 1e-13
+REWARD_ATOL = {"Pendulum": 1e-9}
+REWARD_ATOL_DEFAULT = 1e-300
 
 
 def compare_step(tag, got, ref, done_ref, strict):
@@ -102,7 +108,8 @@ def compare_step(tag, got, ref, done_ref, strict):
         assert np.array_equal(got["reward"], ref["reward"]), f"{tag}: reward not bit-exact"
         assert np.array_equal(got["state"][nd], ref["state"][nd]), f"{tag}: fp64 state not bit-exact"
     else:
-        np.testing.assert_allclose(got["reward"], ref["reward"], rtol=REWARD_RTOL, atol=1e-300, err_msg=f"{tag}: reward")
+        ra = REWARD_ATOL.get(tag.split()[0], REWARD_ATOL_DEFAULT)
+        np.testing.assert_allclose(got["reward"], ref["reward"], rtol=REWARD_RTOL, atol=ra, err_msg=f"{tag}: reward")
         np.testing.assert_allclose(got["state"][nd], ref["state"][nd], rtol=STATE_RTOL, atol=STATE_ATOL,
                                    err_msg=f"{tag}: fp64 state")
 

@@ -66,6 +66,7 @@ def test_device_action_stream_matches_twin(name):
     h.set_counters(12345678901, 0)
     dt = torch.int64 if DISCRETE[name] else torch.float32
     out = torch.zeros(n, dtype=dt, device="cuda")
+    torch.cuda.synchronize()  # the handle launches on its own non-blocking stream
     h.sample_actions(out)
     h.sync()
     ref = oracle.OracleVecEnv(ENV_IDS[name], n, LIMITS[name], action_seed=0xDEADBEEFCAFE, env_offset=1024)
