@@ -6,14 +6,17 @@
         bench.py --gpus N --steps K --warmup W
 
 Workload = BASELINE.json configs[1]: CartPole-v1, num_envs = 2^20 PER GPU (weak scaling), on-device autoreset,
-Philox-sampled actions, inputs/state resident in HBM.  A "step" is one vector step of every env of the job =
-one launch of the step kernel per GPU.  At N > 1 every rank steps its shard of the 2^20*N logical envs with no
-data-path collective; the final obs/reward/terminated/truncated tensors of each chunk of --chunk steps are
+Philox-sampled actions, inputs/state resident in HBM.  A "step" is one vector step (SyncVectorEnv.step_wait) of
+every env of the job; EVERY step writes its observations, rewards, terminated/truncated flags and the sampled
+actions to its own slice of [chunk][N] trajectory tensors in HBM (nothing is skipped or overwritten in cache).
+--mode fused (default) runs a chunk of --chunk steps as ONE kernel launch with the env state in registers;
+--mode graph / eager launch the same kernel once per step.  At N > 1 every rank steps its shard of the 2^20*N
+logical envs with no data-path collective; the final obs/reward/terminated/truncated tensors of each chunk are
 all-gathered over RCCL asynchronously (north_star: all-gather only for the final tensors).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the step kernel against HBM: achieved = algorithmic bytes per
-launch (66 B per CartPole env-step) / average launch duration measured with HIP events on the
-engine's stream over the timed region.  `cpu_baseline` (N=1 only) times the C port of the reference
+launch (see algorithmic_bytes_per_env_step) / average launch duration measured with HIP events on
+the engine's stream over the timed region.  `cpu_baseline` (N=1 only) times the C port of the reference
 (oracle/, kind "port") on one host core over a bounded sample of the same workload.
 """
 import argparse
@@ -27,8 +30,18 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 1 << 20
 ENV_ID = "CartPole-v1"
-ALGO_BYTES_PER_ENV_STEP = 66  # 8*S + 4*O + 4 + 4 + 2 + 8 with S=4, O=4
-HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+S_DIM, O_DIM = 4, 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(mode: str, chunk: int) -> float:
+    """SURVEY.md §8(d).  One launch per step (eager/graph): read {state, action, counter} + write {state, obs,
+    reward, 2 flags, counter} at the fp32 contract = 8*S + 4*O + 4 + 4 + 2 + 8 = 66 B for CartPole.  Fused chunk of
+    K steps with the state resident in registers: outputs only, 4*O + 4 + 4 + 2, plus the state round trip
+    amortised over the chunk, 16*S/K."""
+    if mode == "fused":
+        return 4 * O_DIM + 4 + 4 + 2 + 16.0 * S_DIM / chunk
+    return 8 * S_DIM + 4 * O_DIM + 4 + 4 + 2 + 8
 
 
 def cpu_baseline(sample_steps: int):
@@ -53,17 +66,19 @@ def cpu_baseline(sample_steps: int):
     }
 
 
-def read_traffic():
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic_*.json), or None."""
+def read_traffic(mode: str, chunk: int):
+    """HBM bytes per launch of the SAME launch shape from the committed PMC passes (profiles/traffic_*.json,
+    written by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs), or None."""
     pdir = os.path.join(ROOT, "profiles")
     try:
-        names = sorted(f for f in os.listdir(pdir) if f.startswith("traffic_") and f.endswith(".json"))
-        if not names:
-            return None
-        with open(os.path.join(pdir, names[-1])) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+        for name in sorted((f for f in os.listdir(pdir) if f.startswith("traffic_") and f.endswith(".json")), reverse=True):
+            with open(os.path.join(pdir, name)) as f:
+                j = json.load(f)
+            if j.get("mode", "eager") == mode and (mode != "fused" or int(j.get("chunk", 0)) == chunk):
+                return float(j["hbm_bytes_per_launch"])
     except Exception:
-        return None
+        pass
+    return None
 
 
 def main():
@@ -72,7 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--chunk", type=int, default=100, help="steps per launch batch / per all-gather")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--mode", default="fused", choices=["fused", "graph", "eager"],
+                    help="fused: one launch per chunk, env state in registers; graph/eager: one launch per step")
+    ap.add_argument("--no-graph", action="store_true", help="alias of --mode eager")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -101,14 +118,17 @@ def main():
     sr = ShardedRollout(ENV_ID, total_envs, rank=rank, world_size=world, device=local_rank, seed=0, action_seed=1,
                         reward_f32=False)
     eng = sr.engine
-    use_graph = not args.no_graph
+    mode = "eager" if args.no_graph else args.mode
     sr.reset(seed=0)
+    traj = eng.trajectory_buffers(args.chunk)  # [chunk][N] obs / reward / flags / actions, reused every chunk
+    launches = [0]
 
     def run(steps):
         done = 0
         while done < steps:
             k = min(args.chunk, steps - done)
-            sr.rollout(k, use_graph=use_graph)
+            sr.rollout_per_step(k, mode=mode, out=traj, record_actions=True)
+            launches[0] += 1 if mode == "fused" else k
             if world > 1:
                 sr.gather_async()
             done += k
@@ -122,7 +142,7 @@ def main():
     # warmup (also instantiates the hipGraph(s) and RCCL communicators used in the timed region)
     run(args.warmup)
     if args.steps % args.chunk:
-        sr.rollout(args.steps % args.chunk, use_graph=use_graph)
+        run(args.steps % args.chunk)
     if world > 1:
         sr.gather()
     fence()
@@ -130,6 +150,7 @@ def main():
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     fence()
+    launches[0] = 0
     t0 = time.perf_counter()
     ev0.record(eng.stream)
     run(args.steps)
@@ -137,7 +158,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg step-kernel launch duration on the engine's stream
+    launch_ms = ev0.elapsed_time(ev1) / launches[0]  # avg step-kernel launch duration on the engine's stream
+    steps_per_launch = args.steps / launches[0]
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -145,8 +167,9 @@ def main():
 
     if rank == 0:
         value = total_envs * args.steps / elapsed
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * ENVS_PER_GPU
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        b_env_step = algorithmic_bytes_per_env_step(mode, args.chunk)
+        algo_bytes = b_env_step * ENVS_PER_GPU * steps_per_launch
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec at num_envs=2^20 per GPU, CartPole-v1",
             "value": value,
@@ -164,7 +187,9 @@ def main():
                 "workload": f"{ENV_ID}, num_envs=2^20 per GPU ({total_envs} total), on-device autoreset + "
                             "Philox4x32-10 sampled actions, fp64 state (BASELINE.json configs[1])",
                 "num_envs_per_gpu": ENVS_PER_GPU,
-                "launch": "hipGraph" if use_graph else "eager",
+                "launch": {"fused": f"fused: 1 launch per {args.chunk}-step chunk, env state in registers",
+                           "graph": "1 launch per step, hipGraph replay", "eager": "1 launch per step, eager"}[mode],
+                "outputs": "per-step obs/reward/terminated/truncated/actions written to [chunk][N] trajectory tensors",
                 "chunk": args.chunk,
                 "parallelism": f"env-shard x{world}" + (", async RCCL all-gather of final tensors per chunk" if world > 1 else ""),
             },
@@ -175,9 +200,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": read_traffic(),
+                "traffic": read_traffic(mode, args.chunk),
+                "algorithmic_bytes_per_env_step": b_env_step,
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_launch_us": kernel_ms * 1e3,
+                "env_steps_per_launch": ENVS_PER_GPU * steps_per_launch,
+                "avg_launch_us": launch_ms * 1e3,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

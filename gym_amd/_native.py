@@ -28,11 +28,12 @@ ERR_RESET_NEEDED = -4
 ERR_UNSUPPORTED = -5
 MAX_PARAMS = 12
 ENV_ALIGN = 4
+ROLLOUT_EAGER, ROLLOUT_GRAPH, ROLLOUT_FUSED = 0, 1, 2
 
 EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
-    "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
+    "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
 )
 
@@ -79,6 +80,7 @@ def _load():
         "mxv_step": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_step_sampled": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_rollout": ([vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "mxv_rollout_tape": ([vp, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_sample_actions": ([vp, vp], C.c_int),
         "mxv_reset_host": ([vp, vp, vp, vp], C.c_int),
         "mxv_step_host": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
@@ -215,10 +217,16 @@ class Handle:
                                          _ptr(terminated_dev), _ptr(truncated_dev), _ptr(final_obs_dev)))
 
     def rollout(self, K, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None,
-                actions_out_dev=None, per_step=False, use_graph=False):
-        self._check(lib.mxv_rollout(self._h, int(K), int(per_step), int(use_graph), _ptr(actions_out_dev),
+                actions_out_dev=None, per_step=False, mode=ROLLOUT_FUSED):
+        self._check(lib.mxv_rollout(self._h, int(K), int(per_step), int(mode), _ptr(actions_out_dev),
                                     _ptr(obs_dev), _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev),
                                     _ptr(final_obs_dev)))
+
+    def rollout_tape(self, K, actions_tape_dev, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None,
+                     final_obs_dev=None, per_step=False):
+        self._check(lib.mxv_rollout_tape(self._h, int(K), int(per_step), _ptr(actions_tape_dev), _ptr(obs_dev),
+                                         _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev),
+                                         _ptr(final_obs_dev)))
 
     def sample_actions(self, actions_out_dev):
         self._check(lib.mxv_sample_actions(self._h, _ptr(actions_out_dev)))

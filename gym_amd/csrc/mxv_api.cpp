@@ -152,6 +152,9 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.b1 = h->bounds[1];
     a.max_steps = h->cfg.max_episode_steps;
     a.flags = h->cfg.flags;
+    a.K = 1;
+    a.slice = 0;
+    a.act_slice = 0;
     a.P = h->P;
 }
 
@@ -371,14 +374,50 @@ int mxv_step_sampled(mxv_handle *h, void *actions_out_dev, float *obs_dev, void 
     return do_step(h, nullptr, actions_out_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, final_obs_dev);
 }
 
-int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t use_graph, void *actions_out_dev, float *obs_dev,
-                void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev) {
-    MXV_CHECK_HANDLE(h);
+}  // extern "C" (re-opened below)
+
+namespace {
+
+int rollout_checks(mxv_handle *h, int32_t K, const float *obs_dev) {
     if (K <= 0) return fail(h, MXV_ERR_INVALID_ARG, "K must be positive");
     if (!h->was_reset)
         return fail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
     if (!obs_dev) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
-    if (int rc = use_device(h)) return rc;
+    return use_device(h);
+}
+
+// One launch, K steps, env state in registers between steps.
+int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions_tape, void *actions_out, float *obs,
+                 void *reward, uint8_t *term, uint8_t *trunc, float *final_obs) {
+    StepArgs a{};
+    fill_step_args(h, a);
+    a.K = K;
+    a.slice = per_step ? h->cfg.num_envs : 0;
+    a.act_slice = actions_tape ? h->cfg.num_envs : 0;
+    a.actions = actions_tape;
+    a.actions_out = actions_out;
+    a.obs = obs;
+    a.reward = reward;
+    a.terminated = term;
+    a.truncated = trunc;
+    a.final_obs = final_obs;
+    MXV_HIP(h, launch_step(h->cfg.env_id, h->default_params, a, h->stream));
+    h->t += (uint64_t)K;
+    return MXV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *actions_out_dev, float *obs_dev,
+                void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = rollout_checks(h, K, obs_dev)) return rc;
+    if (mode == MXV_ROLLOUT_FUSED)
+        return fused_launch(h, K, per_step, nullptr, actions_out_dev, obs_dev, reward_dev, terminated_dev,
+                            truncated_dev, final_obs_dev);
+    if (mode != MXV_ROLLOUT_EAGER && mode != MXV_ROLLOUT_GRAPH) return fail(h, MXV_ERR_INVALID_ARG, "unknown rollout mode %d", mode);
     const size_t n = (size_t)h->cfg.num_envs;
     auto slice = [&](void *p, size_t elem_bytes, int k) -> void * {
         if (!p) return nullptr;
@@ -398,7 +437,7 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t use_graph, v
         a.final_obs = (float *)slice(final_obs_dev, h->O * sizeof(float), k);
         return launch_step(h->cfg.env_id, h->default_params, a, h->stream);
     };
-    if (!use_graph) {
+    if (mode == MXV_ROLLOUT_EAGER) {
         for (int k = 0; k < K; ++k) MXV_HIP(h, launch_k(k, nullptr, h->t + (uint64_t)k));
     } else {
         // The captured launches read the base step index from device memory (t_dev) and add their
@@ -425,6 +464,15 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t use_graph, v
     }
     h->t += (uint64_t)K;
     return MXV_OK;
+}
+
+int mxv_rollout_tape(mxv_handle *h, int32_t K, int32_t per_step, const void *actions_tape_dev, float *obs_dev,
+                     void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (!actions_tape_dev) return fail(h, MXV_ERR_INVALID_ARG, "actions tape pointer is NULL");
+    if (int rc = rollout_checks(h, K, obs_dev)) return rc;
+    return fused_launch(h, K, per_step, actions_tape_dev, nullptr, obs_dev, reward_dev, terminated_dev, truncated_dev,
+                        final_obs_dev);
 }
 
 int mxv_sample_actions(mxv_handle *h, void *actions_out_dev) {

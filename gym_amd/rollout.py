@@ -17,6 +17,9 @@ from . import _native
 from .registration import spec as _spec
 
 
+MODES = {"eager": _native.ROLLOUT_EAGER, "graph": _native.ROLLOUT_GRAPH, "fused": _native.ROLLOUT_FUSED}
+
+
 class DeviceRollout:
     def __init__(self, id: str, num_envs: int, *, device: int = 0, env_offset: int = 0, seed: int = 0,
                  action_seed: int = 0, max_episode_steps: Optional[int] = None, reward_f32: bool = False,
@@ -51,6 +54,7 @@ class DeviceRollout:
             self.final_obs = torch.zeros((n, self.O), dtype=torch.float32, device=self.device)
             self.actions = torch.zeros(n, dtype=self.action_dtype, device=self.device)
         self.stream.synchronize()
+        self._last = (self.obs, self.reward, self.terminated, self.truncated)
 
     # -- reference-shaped calls ------------------------------------------------------------------
     def seed(self, seed: int, action_seed: Optional[int] = None):
@@ -70,32 +74,58 @@ class DeviceRollout:
         assert actions.is_contiguous()
         self.handle.step(actions, self.obs, self.reward, self.terminated, self.truncated,
                          self.final_obs if want_final else None)
-        return self.obs, self.reward, self.terminated, self.truncated
+        self._last = (self.obs, self.reward, self.terminated, self.truncated)
+        return self._last
 
     def step_sampled(self, want_final: bool = False, record_actions: bool = True):
         """One vector step with actions drawn on device (action_space.sample())."""
         self.handle.step_sampled(self.obs, self.reward, self.terminated, self.truncated,
                                  self.final_obs if want_final else None, self.actions if record_actions else None)
-        return self.obs, self.reward, self.terminated, self.truncated
+        self._last = (self.obs, self.reward, self.terminated, self.truncated)
+        return self._last
 
-    def rollout(self, K: int, *, use_graph: bool = False, record_actions: bool = False, want_final: bool = False):
-        """K sampled steps back to back; outputs hold the last step ("final tensors" of the chunk)."""
+    def rollout(self, K: int, *, mode: str = "fused", record_actions: bool = False, want_final: bool = False):
+        """K sampled steps back to back; the output tensors hold the last step ("final tensors" of the chunk).
+        mode: "fused" (one launch, state in registers), "graph" (K launches from a hipGraph) or "eager"."""
         self.handle.rollout(K, self.obs, self.reward, self.terminated, self.truncated,
                             self.final_obs if want_final else None, self.actions if record_actions else None,
-                            per_step=False, use_graph=use_graph)
-        return self.obs, self.reward, self.terminated, self.truncated
+                            per_step=False, mode=MODES[mode])
+        self._last = (self.obs, self.reward, self.terminated, self.truncated)
+        return self._last
 
-    def rollout_per_step(self, K: int, *, use_graph: bool = False):
-        """K sampled steps, every step's outputs kept: returns [K, ...] tensors (trajectory buffers)."""
+    def trajectory_buffers(self, K: int):
+        """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk)."""
         n, dev = self.num_envs, self.device
         with torch.cuda.stream(self.stream):
-            obs = torch.empty((K, n, self.O), dtype=torch.float32, device=dev)
-            rew = torch.empty((K, n), dtype=self.reward_dtype, device=dev)
-            term = torch.empty((K, n), dtype=torch.uint8, device=dev)
-            trunc = torch.empty((K, n), dtype=torch.uint8, device=dev)
-            act = torch.empty((K, n), dtype=self.action_dtype, device=dev)
-        self.handle.rollout(K, obs, rew, term, trunc, None, act, per_step=True, use_graph=use_graph)
-        return obs, rew, term, trunc, act
+            return dict(obs=torch.empty((K, n, self.O), dtype=torch.float32, device=dev),
+                        reward=torch.empty((K, n), dtype=self.reward_dtype, device=dev),
+                        terminated=torch.empty((K, n), dtype=torch.uint8, device=dev),
+                        truncated=torch.empty((K, n), dtype=torch.uint8, device=dev),
+                        actions=torch.empty((K, n), dtype=self.action_dtype, device=dev))
+
+    def rollout_per_step(self, K: int, *, mode: str = "fused", out: Optional[dict] = None, record_actions: bool = True):
+        """K sampled steps, every step's outputs kept in [K, N, ...] trajectory tensors (returned as a dict)."""
+        out = self.trajectory_buffers(K) if out is None else out
+        assert out["obs"].shape[0] >= K
+        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], None,
+                            out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
+        self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
+        return out
+
+    def rollout_tape(self, actions: torch.Tensor, *, out: Optional[dict] = None):
+        """One fused launch driven by an action tape actions[K, N] (the engine's action dtype)."""
+        K = actions.shape[0]
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self.action_dtype
+        assert actions.numel() == K * self.num_envs
+        out = self.trajectory_buffers(K) if out is None else out
+        self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"], None,
+                                 per_step=True)
+        self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
+        return out
+
+    def final_tensors(self):
+        """(obs, reward, terminated, truncated) of the most recent vector step (views, valid until the next call)."""
+        return self._last
 
     def sample_actions(self) -> torch.Tensor:
         self.handle.sample_actions(self.actions)

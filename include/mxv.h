@@ -140,13 +140,22 @@ int mxv_step(mxv_handle *h, const void *actions_dev, float *obs_dev, void *rewar
 int mxv_step_sampled(mxv_handle *h, void *actions_out_dev, float *obs_dev, void *reward_dev,
                      uint8_t *terminated_dev, uint8_t *truncated_dev, float *final_obs_dev);
 /* K sampled steps back to back (the user loop of README.md:29-41 with a random policy).
- * per_step != 0: every output pointer addresses [K][...] and step k writes slice k;
- * per_step == 0: every output pointer addresses one step's buffers, overwritten K times
+ * per_step != 0: every output pointer addresses [K][...] and step k writes slice k (trajectory
+ * buffers); per_step == 0: every output pointer addresses one step's buffers, overwritten K times
  * (the "final tensors" of a rollout chunk).  Any output pointer may be NULL except obs_dev.
- * use_graph != 0 replays the K launches from a cached hipGraph. */
-int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t use_graph, void *actions_out_dev,
+ * mode: MXV_ROLLOUT_EAGER = K launches of the step kernel; MXV_ROLLOUT_GRAPH = the same K launches
+ * replayed from a cached hipGraph; MXV_ROLLOUT_FUSED = ONE launch that keeps every env's state in
+ * registers across the K steps (state/elapsed touch HBM once per chunk instead of once per step).
+ * All three produce bit-identical results. */
+enum { MXV_ROLLOUT_EAGER = 0, MXV_ROLLOUT_GRAPH = 1, MXV_ROLLOUT_FUSED = 2 };
+int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *actions_out_dev,
                 float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev,
                 float *final_obs_dev);
+/* K steps in one fused launch driven by an action tape actions_tape_dev[K][N] (action dtype of the
+ * handle) instead of the Philox action stream: scripted / policy-chunk rollouts. */
+int mxv_rollout_tape(mxv_handle *h, int32_t K, int32_t per_step, const void *actions_tape_dev,
+                     float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev,
+                     float *final_obs_dev);
 /* action_space.sample() for the NEXT step index without stepping. */
 int mxv_sample_actions(mxv_handle *h, void *actions_out_dev);
 

@@ -23,44 +23,53 @@ def main():
     ap.add_argument("--envs", default="CartPole-v1")
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--modes", default="graph,eager,given,f32")
+    ap.add_argument("--modes", default="fused,graph,given,fused-final,fusedf32")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--chunk", type=int, default=64)
     args = ap.parse_args()
     if args.lib:
         os.environ["MXV_LIB_PATH"] = os.path.abspath(args.lib)
     import torch
     from gym_amd.rollout import DeviceRollout
 
+    K = args.chunk
     for env in args.envs.split(","):
         for mode in args.modes.split(","):
-            r = DeviceRollout(env, args.n, seed=0, action_seed=1, reward_f32=(mode == "f32"),
-                              action_i32=(mode == "f32"))
+            f32 = mode.endswith("f32")
+            base = mode[:-3] if f32 else mode
+            r = DeviceRollout(env, args.n, seed=0, action_seed=1, reward_f32=f32, action_i32=f32)
             r.reset(seed=0)
-            graph = mode in ("graph", "f32")
-            if mode == "given":
+            if base == "given":      # one launch per step, caller-provided actions, outputs overwritten
                 acts = r.sample_actions().clone()
 
                 def go(k):
                     for _ in range(k):
                         r.step(acts, want_final=False)
-            else:
-                def go(k):
-                    r.rollout(k, use_graph=graph)
-            go(100)
-            go(args.steps)
+            elif base.endswith("-final"):  # outputs of every step overwrite one buffer ("final tensors" mode)
+                def go(k, m=base[:-6]):
+                    for _ in range(k // K):
+                        r.rollout(K, mode=m)
+            else:                    # trajectory mode: every step writes its own [k][N] slice
+                traj = r.trajectory_buffers(K)
+
+                def go(k, m=base):
+                    for _ in range(k // K):
+                        r.rollout_per_step(K, mode=m, out=traj)
+            steps = (args.steps // K) * K
+            go(K * 2)
+            go(steps)
             r.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             best = 1e9
             for _ in range(3):
                 ev0.record(r.stream)
-                go(args.steps)
+                go(steps)
                 ev1.record(r.stream)
                 r.synchronize()
-                best = min(best, ev0.elapsed_time(ev1) / args.steps * 1e3)
-            gbs = ALGO_B[env] * args.n / (best * 1e-6) / 1e9
-            print(json.dumps({"tag": args.tag, "env": env, "n": args.n, "mode": mode, "us_per_launch": round(best, 3),
-                              "env_steps_per_s": args.n / (best * 1e-6), "algo_GBs": round(gbs, 1),
-                              "frac_of_8TBs": round(gbs / 8000, 4)}), flush=True)
+                best = min(best, ev0.elapsed_time(ev1) / steps * 1e3)
+            print(json.dumps({"tag": args.tag, "env": env, "n": args.n, "mode": mode, "chunk": K,
+                              "us_per_step": round(best, 3), "env_steps_per_s": float(f"{args.n / (best * 1e-6):.4g}"),
+                              "GBs_at_66B": round(ALGO_B[env] * args.n / (best * 1e-6) / 1e9, 1)}), flush=True)
             r.close()
 
 
