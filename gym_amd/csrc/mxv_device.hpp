@@ -37,9 +37,12 @@ struct U4 {
     uint32_t x, y, z, w;
 };
 
+#ifndef MXV_EXP_PHILOX_ROUNDS  // tuning experiments only (tools/build_variants.sh); the product is always 10 rounds
+#define MXV_EXP_PHILOX_ROUNDS 10
+#endif
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MXV_EXP_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;  // one v_mad_u64_u32 yields hi and lo
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;

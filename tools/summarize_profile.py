@@ -21,6 +21,11 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
+try:  # "<mode> <chunk> trace:<steps>/<warmup> pmc:<steps>/<warmup>" written by tools/gpu_profile.sh
+    META = open(os.path.join(src, "meta.txt")).read().split()
+except OSError:
+    META = ["eager", "100", "trace:1000/100", "pmc:40/10"]
+MODE, CHUNK = META[0], int(META[1])
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 CALIB_BYTES = 64 << 20
@@ -84,6 +89,9 @@ corr_w = step_w * 1024 / ratios["copy8"]["write_ratio"]
 step_stat = next(r for r in stats if "step_kernel" in r["Name"] or "rollout_kernel" in r["Name"])
 traffic = {
     "round": R,
+    "mode": MODE,
+    "chunk": CHUNK,
+    "env_steps_per_launch": (CHUNK if MODE == "fused" else 1) << 20,
     "kernel": short(step_stat["Name"]),
     "avg_launch_ns_rocprof": float(step_stat["AverageNs"]),
     "calls": int(step_stat["Calls"]),
@@ -99,9 +107,12 @@ json.dump(traffic, open(os.path.join(dst, f"traffic_{R}.json"), "w"), indent=1)
 
 with open(os.path.join(dst, f"{R}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary, round {R}\n\n")
-    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --steps 1000 "
-            "--warmup 100` (tools/gpu_profile.sh); PMC passes: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs "
-            "(`--steps 40 --warmup 10 --no-graph`), plus the same passes over tools/calib.\n\n")
+    ts, tw = META[2].split(":")[1].split("/")
+    ps, pw = META[3].split(":")[1].split("/")
+    f.write(f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --mode {MODE} "
+            f"--chunk {CHUNK} --steps {ts} --warmup {tw}` (tools/gpu_profile.sh {R} {MODE} {CHUNK}); PMC passes: `--pmc FETCH_SIZE` "
+            f"and `--pmc WRITE_SIZE` in separate runs of the same command with `--steps {ps} --warmup {pw}`, plus the same "
+            "passes over tools/calib (known 64 MiB copies).\n\n")
     f.write("## Kernel stats (top rows)\n\n| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
     for r in stats[:6]:
         f.write(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |\n")
