@@ -1,0 +1,61 @@
+"""CPU stand-in for gym_amd.rollout.DeviceRollout, backed by the oracle, for the world_size-2 gloo tests.
+
+Lives under tests/ on purpose: the oracle is test infrastructure and may not be imported by gym_amd/.  It has the
+engine protocol ShardedRollout documents (reset / rollout / rollout_per_step / final_tensors / synchronize / stream)
+with CPU torch tensors, so the partition rule, the Philox global-index contract and the all-gather plumbing of
+gym_amd.distributed / gym_amd.mixed run unchanged over `gloo`."""
+import numpy as np
+import torch
+
+from gym_amd.registration import spec as _spec
+from oracle.oracle import OracleVecEnv
+
+
+class OracleRollout:
+    stream = None
+
+    def __init__(self, id, num_envs, *, env_offset=0, seed=0, action_seed=0, **_):
+        self.spec = _spec(id)
+        limit = self.spec.max_episode_steps
+        self.o = OracleVecEnv(self.spec.kind, num_envs, -1 if limit is None else limit, seed=seed,
+                              action_seed=action_seed, env_offset=env_offset)
+        self.num_envs = num_envs
+        self._last = None
+
+    def reset(self, seed=None):
+        obs = torch.from_numpy(self.o.reset(seed=seed))
+        n = self.num_envs
+        self._last = (obs, torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.uint8),
+                      torch.zeros(n, dtype=torch.uint8))
+        return obs
+
+    def _step(self):
+        a = self.o.sample_actions()
+        obs, rew, term, trunc, _, _ = self.o.step(a)
+        self._last = (torch.from_numpy(obs), torch.from_numpy(rew), torch.from_numpy(term.astype(np.uint8)),
+                      torch.from_numpy(trunc.astype(np.uint8)))
+        return a
+
+    def rollout(self, K, **_):
+        for _i in range(K):
+            self._step()
+        return self._last
+
+    def rollout_per_step(self, K, out=None, **_):
+        keys = ("obs", "reward", "terminated", "truncated")
+        acc = {k: [] for k in keys + ("actions",)}
+        for _i in range(K):
+            a = self._step()
+            for k, t in zip(keys, self._last):
+                acc[k].append(t)
+            acc["actions"].append(torch.from_numpy(np.asarray(a)))
+        return {k: torch.stack(v) for k, v in acc.items()}
+
+    def final_tensors(self):
+        return self._last
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass

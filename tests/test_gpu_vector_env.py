@@ -1,0 +1,229 @@
+"""HipVectorEnv (the gym.vector.SyncVectorEnv drop-in) on a real MI355X: the reference's own vector-env tests,
+restated for this adapter — return contract (tests/vector/test_sync_vector_env.py:24-76), get/set_attr on "gravity"
+(79-112), final_observation / final_info layout (tests/vector/test_vector_env_info.py:14-56,
+tests/vector/test_vector_env.py:75-125), TimeLimit truncation (tests/wrappers/test_time_limit.py:17-57), determinism
+under the same seed and actions (tests/envs/test_envs.py:63-115), reset bounds (tests/envs/test_env_implementation.py:
+150-215), error behaviour — plus numeric parity of every returned value against the oracle."""
+import numpy as np
+import pytest
+
+from helpers import ENV_IDS, GYM_IDS, LIMITS, MAX_OBS_ULPS, ulps32
+
+pytestmark = pytest.mark.gpu
+
+ALL_IDS = ["CartPole-v1", "CartPole-v0", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0"]
+
+
+def _make(env_id, n, **kw):
+    import gym_amd
+
+    return gym_amd.make(env_id, num_envs=n, asynchronous=False, **kw)
+
+
+@pytest.mark.parametrize("env_id", ALL_IDS)
+def test_reset_and_step_contract(env_id):
+    from gym_amd.spaces import Box, Discrete, MultiDiscrete
+
+    n = 8
+    env = _make(env_id, n)
+    obs, infos = env.reset(seed=0)
+    assert isinstance(env.observation_space, Box) and isinstance(obs, np.ndarray) and infos == {}
+    assert obs.dtype == env.observation_space.dtype == np.float32
+    assert obs.shape == (n,) + env.single_observation_space.shape == env.observation_space.shape
+    assert env.observation_space.contains(obs)
+    if isinstance(env.single_action_space, Discrete):
+        assert isinstance(env.action_space, MultiDiscrete)
+        actions = [env.single_action_space.sample() for _ in range(n)]  # list of python ints, like the reference's test
+    else:
+        actions = env.action_space.sample()
+        assert actions.shape == (n, 1) and actions.dtype == np.float32
+    obs2, rew, term, trunc, infos = env.step(actions)
+    assert obs2.dtype == np.float32 and obs2.shape == obs.shape and obs2 is not obs
+    assert isinstance(rew, np.ndarray) and rew.dtype == np.float64 and rew.shape == (n,)
+    assert term.dtype == np.bool_ and term.shape == (n,) and trunc.dtype == np.bool_ and trunc.shape == (n,)
+    assert isinstance(infos, dict)
+    env.close()
+    assert env.closed
+    from gym_amd import error
+    with pytest.raises(error.ClosedEnvironmentError):
+        env.reset()
+
+
+def test_call_get_attr_set_attr_gravity():
+    env = _make("CartPole-v1", 4)
+    env.reset(seed=1)
+    g = env.call("gravity")
+    assert isinstance(g, tuple) and len(g) == 4 and all(isinstance(x, float) and x == 9.8 for x in g)
+    env.set_attr("gravity", 3.72)
+    assert env.get_attr("gravity") == (3.72,) * 4
+    env.set_attr("gravity", [9.81] * 4)
+    assert env.get_attr("gravity") == (9.81,) * 4
+    with pytest.raises(ValueError):
+        env.set_attr("gravity", [9.81, 1.62])  # wrong length (sync_vector_env.py:206-211)
+    with pytest.raises(AttributeError):
+        env.get_attr("no_such_attribute")
+    assert env.get_attr("kinematics_integrator") == ("euler",) * 4
+    # the new gravity is what the kernel integrates with
+    from oracle.oracle import OracleVecEnv
+
+    st, el = env.handle.get_state()
+    o = OracleVecEnv(0, 4, 500)
+    o.P[0] = 9.81
+    o.state[:], o.elapsed[:] = st, el
+    a = np.array([1, 0, 1, 1])
+    obs, *_ = env.step(a)
+    robs, *_ = o.step(a)
+    assert ulps32(obs, robs).max() <= MAX_OBS_ULPS
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous"])
+def test_adapter_rollout_matches_oracle_with_final_observation(name):
+    """Every value HipVectorEnv returns over a rollout with many episode ends (short TimeLimit), against the oracle
+    stepping from the engine's own pre-step state with the same actions."""
+    from oracle.oracle import OracleVecEnv
+
+    n, limit, steps = 64, 9, 40
+    env = _make(GYM_IDS[name], n, max_episode_steps=limit)
+    env.reset(seed=3)
+    env.action_space.seed(3)
+    o = OracleVecEnv(ENV_IDS[name], n, limit)
+    saw_final = 0
+    for t in range(steps):
+        st, el = env.handle.get_state()
+        o.state[:], o.elapsed[:] = st, el
+        a = env.action_space.sample()
+        if name == "Pendulum" and t % 3 == 0:
+            a = a * 2  # out-of-bounds torques are clipped by the env, not rejected (tests/envs/test_action_dim_check.py:90-136)
+        obs, rew, term, trunc, infos = env.step(a)
+        robs, rrew, rterm, rtrunc, rfin, rmask = o.step(a.reshape(n) if a.ndim == 2 else a)
+        assert np.array_equal(term, rterm) and np.array_equal(trunc, rtrunc)
+        np.testing.assert_allclose(rew, rrew, rtol=1e-13, atol=1e-9)
+        done = term | trunc
+        assert ulps32(obs[~done], robs[~done]).max(initial=0) <= MAX_OBS_ULPS
+        assert np.all(trunc == (el + 1 >= limit))
+        if done.any():
+            # layout of vector_env.py:208-258: object arrays with None holes + boolean masks
+            assert set(infos) == {"final_observation", "_final_observation", "final_info", "_final_info"}
+            assert np.array_equal(infos["_final_observation"], done) and np.array_equal(infos["_final_info"], done)
+            fo, fi = infos["final_observation"], infos["final_info"]
+            assert fo.dtype == object and fo.shape == (n,) and fi.dtype == object
+            for i in range(n):
+                if done[i]:
+                    assert fo[i].dtype == np.float32 and ulps32(fo[i], rfin[i]).max() <= MAX_OBS_ULPS and fi[i] == {}
+                    assert env.single_observation_space.contains(obs[i])  # the returned row is the post-reset obs
+                else:
+                    assert fo[i] is None and fi[i] is None
+            saw_final += int(done.sum())
+        else:
+            assert "final_observation" not in infos
+    assert saw_final >= n * (steps // limit)
+    env.close()
+
+
+def test_time_limit_truncation_and_coinciding_termination():
+    env = _make("CartPole-v1", 16, max_episode_steps=3)
+    env.reset(seed=0)
+    for k in range(1, 7):
+        _, _, term, trunc, _ = env.step(np.zeros(16, dtype=np.int64))
+        assert np.all(trunc == (k % 3 == 0))
+    # terminated and truncated can coincide (tests/wrappers/test_time_limit.py:38-57)
+    st, el = env.handle.get_state()
+    st[0, :] = 2.399
+    st[1, :] = 5.0
+    el[:] = 2
+    env.handle.set_state(st, el)
+    _, _, term, trunc, infos = env.step(np.ones(16, dtype=np.int64))
+    assert term.all() and trunc.all() and infos["_final_observation"].all()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1", "MountainCarContinuous-v0"])
+def test_determinism_same_seed_same_actions(env_id):
+    n = 32
+    a, b = _make(env_id, n), _make(env_id, n)
+    oa, _ = a.reset(seed=42)
+    ob, _ = b.reset(seed=42)
+    assert np.array_equal(oa, ob)
+    a.action_space.seed(42), b.action_space.seed(42)
+    for _ in range(60):
+        ra = a.step(a.action_space.sample())
+        rb = b.step(b.action_space.sample())
+        for x, y in zip(ra[:4], rb[:4]):
+            assert np.array_equal(x, y)
+    oc, _ = a.reset(seed=[7] * n)   # list of seeds: identical seeds give identical envs (sync_vector_env.py:102-110)
+    assert np.all(oc == oc[0])
+    od, _ = a.reset(seed=43)
+    assert not np.array_equal(od, oa) and len(np.unique(od[:, 0])) == n
+    a.close(), b.close()
+
+
+def test_reset_options_bounds():
+    env = _make("CartPole-v1", 256)
+    obs, _ = env.reset(seed=1)
+    assert np.all(np.abs(obs) <= 0.05)
+    obs, _ = env.reset(seed=1, options={"low": -0.02, "high": 0.01})
+    assert obs.min() >= -0.02 and obs.max() <= 0.01 and obs.min() < -0.015 and obs.max() > 0.005
+    with pytest.raises(ValueError):
+        env.reset(options={"low": 0.1, "high": -0.1})      # classic_control/utils.py:41-44
+    with pytest.raises(ValueError):
+        env.reset(options={"low": "abc"})                   # classic_control/utils.py:8-14
+    env.close()
+    env = _make("Pendulum-v1", 256)
+    obs, _ = env.reset(seed=1, options={"x_init": 0.1, "y_init": 0.2})
+    th = np.arctan2(obs[:, 1], obs[:, 0])
+    assert np.all(np.abs(th) <= 0.1 + 1e-6) and np.all(np.abs(obs[:, 2]) <= 0.2 + 1e-6)
+    env.close()
+    env = _make("MountainCar-v0", 256)
+    obs, _ = env.reset(seed=1)
+    assert np.all((obs[:, 0] >= -0.6) & (obs[:, 0] <= -0.4)) and np.all(obs[:, 1] == 0)
+    env.close()
+    env = _make("Acrobot-v1", 64)
+    obs, _ = env.reset(seed=1)
+    st, _ = env.handle.get_state()
+    assert np.array_equal(st, st.astype(np.float32).astype(np.float64)) and np.all(np.abs(st) <= 0.1 + 1e-7)  # acrobot.py:188-190
+    env.close()
+
+
+def test_error_behaviour():
+    from gym_amd import error
+
+    env = _make("CartPole-v1", 8)
+    with pytest.raises(error.ResetNeeded):
+        env.step(np.zeros(8, dtype=np.int64))        # order_enforcing.py:33-37
+    with pytest.raises(error.Error):
+        env.reset(seed=-1)                           # seeding.py:21-22
+    env.reset(seed=0)
+    with pytest.raises(AssertionError):
+        env.step(np.full(8, 2, dtype=np.int64))      # cartpole.py:131-132
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(8, dtype=np.float32))      # Discrete.contains rejects floats
+    with pytest.raises(error.NoAsyncCallError):
+        env.step_wait()
+    env.step_async(np.zeros(8, dtype=np.int64))
+    with pytest.raises(error.AlreadyPendingCallError):
+        env.step_async(np.zeros(8, dtype=np.int64))
+    env.step_wait()
+    env.step(np.ones(8, dtype=np.int64))             # still usable after the errors
+    env.close()
+    with pytest.raises(error.UnregisteredEnv):
+        _make("FrozenLake-v1", 8)
+    with pytest.raises(TypeError):
+        _make("CartPole-v1", 8, g=1.0)               # not a CartPole kwarg
+    env = _make("Pendulum-v1", 4, g=9.81)            # pendulum.py:91
+    assert env.get_attr("g") == (9.81,) * 4
+    env.close()
+
+
+def test_random_policy_episode_length_cartpole():
+    """P3 distributional check: mean random-policy CartPole episode ~22 steps."""
+    env = _make("CartPole-v1", 4096)
+    env.reset(seed=9)
+    env.action_space.seed(9)
+    done_count, steps = 0, 120
+    for _ in range(steps):
+        _, _, term, trunc, _ = env.step(env.action_space.sample())
+        done_count += int((term | trunc).sum())
+    mean_len = 4096 * steps / done_count
+    assert 19.0 < mean_len < 25.5, mean_len
+    env.close()

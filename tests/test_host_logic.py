@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference interface (no GPU): spaces, batch_space, registry, seeding rules, LazyInfos.
+When /root/reference is present (build container) the same checks also run against the live reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from gym_amd import error
+from gym_amd.registration import PARAM_NAMES, registry, single_spaces, spec
+from gym_amd.spaces import Box, Discrete, MultiDiscrete, batch_space, np_random
+
+REF = "/root/reference"
+
+
+def _ref_gym():
+    if not os.path.isdir(os.path.join(REF, "gym")):
+        pytest.skip("live reference not available")
+    for name, val in (("bool8", np.bool_), ("float_", np.float64), ("alltrue", np.all)):
+        if not hasattr(np, name):
+            setattr(np, name, val)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import gym
+
+    gym.logger.set_level(gym.logger.ERROR)
+    return gym
+
+
+def test_registry_matches_reference_ids_and_limits():
+    want = {"CartPole-v0": 200, "CartPole-v1": 500, "MountainCar-v0": 200, "MountainCarContinuous-v0": 999,
+            "Pendulum-v1": 200, "Acrobot-v1": 500}  # gym/envs/__init__.py:11-50
+    assert {k: v.max_episode_steps for k, v in registry.items()} == want
+    with pytest.raises(error.UnregisteredEnv):
+        spec("LunarLander-v2")
+
+
+def test_registry_against_live_reference():
+    gym = _ref_gym()
+    for env_id, s in registry.items():
+        rs = gym.spec(env_id)
+        assert rs.max_episode_steps == s.max_episode_steps and rs.reward_threshold == s.reward_threshold
+        env = gym.make(env_id, disable_env_checker=True)
+        obs_space, act_space = single_spaces(s.kind)
+        assert obs_space.shape == env.observation_space.shape and obs_space.dtype == env.observation_space.dtype
+        assert np.array_equal(obs_space.low, env.observation_space.low)
+        assert np.array_equal(obs_space.high, env.observation_space.high)
+        if isinstance(act_space, Discrete):
+            assert act_space.n == env.action_space.n
+        else:
+            assert np.array_equal(act_space.low, env.action_space.low) and act_space.shape == env.action_space.shape
+        for name in PARAM_NAMES[s.kind]:  # every attribute the engine exposes exists on the reference env object
+            assert hasattr(env.unwrapped, name), (env_id, name)
+
+
+def test_spaces_sample_like_the_reference():
+    gym = _ref_gym()
+    from gym import spaces as rs
+    from gym.vector.utils import batch_space as ref_batch
+
+    for mine, ref in ((Discrete(3), rs.Discrete(3)), (Box(-2.0, 2.0, (1,), np.float32), rs.Box(-2.0, 2.0, (1,), np.float32)),
+                      (MultiDiscrete([2] * 5), rs.MultiDiscrete([2] * 5))):
+        mine.seed(123), ref.seed(123)
+        for _ in range(5):
+            assert np.array_equal(np.asarray(mine.sample()), np.asarray(ref.sample()))
+    # batch_space: same class, bounds, dtype and the same RNG stream (deepcopy of the single space's generator)
+    for mine, ref in ((Discrete(2), rs.Discrete(2)), (Box(-1.0, 1.0, (1,), np.float32), rs.Box(-1.0, 1.0, (1,), np.float32))):
+        mine.seed(7), ref.seed(7)
+        bm, br = batch_space(mine, 6), ref_batch(ref, 6)
+        assert type(bm).__name__ == type(br).__name__ and bm.shape == br.shape and bm.dtype == br.dtype
+        assert np.array_equal(bm.sample(), br.sample())
+
+
+def test_batch_space_shapes_and_dtypes():
+    b = batch_space(Discrete(3), 8)
+    assert isinstance(b, MultiDiscrete) and b.shape == (8,) and b.dtype == np.int64 and np.all(b.nvec == 3)
+    bb = batch_space(Box(-2.0, 2.0, (1,), np.float32), 8)
+    assert isinstance(bb, Box) and bb.shape == (8, 1) and bb.dtype == np.float32
+    obs, _ = single_spaces(spec("CartPole-v1").kind)
+    bo = batch_space(obs, 4)
+    assert bo.shape == (4, 4) and np.array_equal(bo.high[2], obs.high)
+    assert b.contains(np.array([0, 1, 2, 0, 1, 2, 0, 1])) and not b.contains(np.array([0, 1, 3, 0, 1, 2, 0, 1]))
+    assert Discrete(2).contains(1) and not Discrete(2).contains(2) and not Discrete(2).contains(1.0)
+
+
+def test_seeding_rules():
+    rng, s = np_random(5)
+    assert s == 5 and rng.integers(10) == np.random.Generator(np.random.PCG64(np.random.SeedSequence(5))).integers(10)
+    for bad in (-1, 1.5, "x"):
+        with pytest.raises(error.Error):  # gym/utils/seeding.py:21-22
+            np_random(bad)
+
+
+def test_lazy_infos_materialise_on_access():
+    from gym_amd.vector_env import LazyInfos, _Pending
+
+    calls = []
+
+    def build():
+        calls.append(1)
+        return np.array([None, 3], dtype=object)
+
+    d = LazyInfos()
+    dict.__setitem__(d, "final_observation", _Pending(build))
+    dict.__setitem__(d, "_final_observation", np.array([False, True]))
+    assert "final_observation" in d and not calls
+    assert d["final_observation"][1] == 3 and d.get("final_observation")[0] is None and len(calls) == 1
+    assert d.get("missing", 9) == 9
+    assert dict(d.items())["_final_observation"][1]
+
+
+def test_vector_env_base_surface():
+    """Names of gym.vector.VectorEnv (vector_env.py:25-206) exist with the same call shapes."""
+    from gym_amd.vector_env import HipVectorEnv, VectorEnv
+
+    for name in ("reset_async", "reset_wait", "reset", "step_async", "step_wait", "step", "call_async", "call_wait",
+                 "call", "get_attr", "set_attr", "close_extras", "close"):
+        assert callable(getattr(VectorEnv, name)) and callable(getattr(HipVectorEnv, name))
+    obs, act = single_spaces(spec("Pendulum-v1").kind)
+    v = VectorEnv(5, obs, act)
+    assert v.num_envs == 5 and v.is_vector_env and v.observation_space.shape == (5, 3) and v.action_space.shape == (5, 1)
+    assert v.single_observation_space is obs and not v.closed
+    v.close()
+    assert v.closed
