@@ -84,12 +84,15 @@ def read_traffic(mode: str, chunk: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--chunk", type=int, default=100, help="steps per launch batch / per all-gather")
     ap.add_argument("--mode", default="fused", choices=["fused", "graph", "eager"],
                     help="fused: one launch per chunk, env state in registers; graph/eager: one launch per step")
     ap.add_argument("--no-graph", action="store_true", help="alias of --mode eager")
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="untimed device spin-up before the W warmup steps (DVFS: the GPU needs tens of ms of load to "
+                         "reach its sustained clocks; a 2000-step run is 13 ms); 0 disables; reported in config")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -139,7 +142,15 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # warmup (also instantiates the hipGraph(s) and RCCL communicators used in the timed region)
+    # device spin-up: same workload, untimed, until --spinup-ms of wall time has passed; then W warmup steps
+    # (which also instantiate the hipGraph(s) and RCCL communicators used in the timed region)
+    spin_steps = 0
+    if args.spinup_ms > 0:
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            run(args.chunk)
+            sr.synchronize()
+            spin_steps += args.chunk
     run(args.warmup)
     if args.steps % args.chunk:
         run(args.steps % args.chunk)
@@ -191,11 +202,12 @@ def main():
                            "graph": "1 launch per step, hipGraph replay", "eager": "1 launch per step, eager"}[mode],
                 "outputs": "per-step obs/reward/terminated/truncated/actions written to [chunk][N] trajectory tensors",
                 "chunk": args.chunk,
+                "spinup": f"{spin_steps} untimed steps ({args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps (clock ramp)",
                 "parallelism": f"env-shard x{world}" + (", async RCCL all-gather of final tensors per chunk" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "step_kernel<CartPole>",
+                "kernel": "rollout_kernel<CartPole>" if mode == "fused" else "step_kernel<CartPole>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -75,6 +75,7 @@ struct mxv_handle {
     uint64_t t = 0;
     uint32_t r = 0;
     bool was_reset = false;
+    bool state_injected = false;  // set by mxv_set_state, consumed by the next step launch
     EnvParams P{};
     bool default_params = true;
     double bounds[2] = {0, 0};
@@ -153,6 +154,7 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.max_steps = h->cfg.max_episode_steps;
     a.flags = h->cfg.flags;
     a.K = 1;
+    a.state_injected = h->state_injected ? 1 : 0;
     a.slice = 0;
     a.act_slice = 0;
     a.P = h->P;
@@ -174,6 +176,7 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     a.truncated = trunc;
     a.final_obs = final_obs;
     MXV_HIP(h, launch_step(h->cfg.env_id, h->default_params, a, h->stream));
+    h->state_injected = false;
     h->t += 1;
     return MXV_OK;
 }
@@ -402,6 +405,7 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     a.truncated = trunc;
     a.final_obs = final_obs;
     MXV_HIP(h, launch_step(h->cfg.env_id, h->default_params, a, h->stream));
+    h->state_injected = false;
     h->t += (uint64_t)K;
     return MXV_OK;
 }
@@ -462,6 +466,7 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
         MXV_HIP(h, hipGraphLaunch(it->second, h->stream));
     }
+    h->state_injected = false;
     h->t += (uint64_t)K;
     return MXV_OK;
 }
@@ -554,6 +559,7 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
         MXV_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     h->was_reset = true;  // an injected state stands in for reset() (parity harness, checkpoint restore)
+    if (state_soa_host) h->state_injected = true;
     return MXV_OK;
 }
 

@@ -107,25 +107,31 @@ __device__ __forceinline__ double div_par(double x, double c) {
         return x / c;
 }
 
-// sin and cos of |x| <= pi/4 without argument reduction: the classic fdlibm/msun kernel polynomials
-// (Sun Microsystems 1993; error < 1 ulp), evaluated without FMA contraction.  CartPole's pole angle never
-// leaves (-0.42, 0.42) on an autoresetting trajectory, so its sin/cos need no reduction at all; callers fall
-// back to the general sincos() outside the interval.
+// sin and cos of |x| <= pi/4 without argument reduction: the fdlibm/msun kernel polynomials (Sun Microsystems
+// 1993; error < 1 ulp, the same bound glibc documents for its own sin/cos), evaluated in Horner form with explicit
+// FMAs.  The no-contraction rule of this file protects the REFERENCE's arithmetic (every Python operator rounds
+// once); what happens inside a libm call is the library's business, and FMA Horner steps are both more accurate and
+// half the instructions of separate multiply/add.  CartPole's pole angle never leaves (-0.42, 0.42) on an
+// autoresetting trajectory, so its sin/cos need no reduction at all; callers fall back to the general sincos()
+// outside the interval.
 __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) {
     const double z = x * x;
-    const double w = z * z;
-    // sin: x + x^3 * (S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6)))))
-    const double rs = 8.33333333332248946124e-03 +
-                      z * (-1.98412698298579493134e-04 + z * 2.75573137070700676789e-06) +
-                      z * w * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10);
-    const double v = z * x;
-    *sn = x + v * (-1.66666666666666324348e-01 + z * rs);
-    // cos: 1 - z/2 + z^2 * (C1 + z*(C2 + ... z*C6)), summed so that the 1 - z/2 rounding error is recovered
-    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
-                      (w * w) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+    // sin: x + x*z*(S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6)))))
+    double r = __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    r = __fma_rn(z, r, 2.75573137070700676789e-06);
+    r = __fma_rn(z, r, -1.98412698298579493134e-04);
+    r = __fma_rn(z, r, 8.33333333332248946124e-03);
+    r = __fma_rn(z, r, -1.66666666666666324348e-01);
+    *sn = __fma_rn(x * z, r, x);
+    // cos: 1 - z/2 + z*z*(C1 + z*(C2 + ... z*C6)), summed so that the rounding error of 1 - z/2 is recovered
+    double c = __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    c = __fma_rn(z, c, -2.75573143513906633035e-07);
+    c = __fma_rn(z, c, 2.48015872894767294178e-05);
+    c = __fma_rn(z, c, -1.38888888888741095749e-03);
+    c = __fma_rn(z, c, 4.16666666666666019037e-02);
     const double hz = 0.5 * z;
     const double t = 1.0 - hz;
-    *cs = t + (((1.0 - t) - hz) + z * rc);
+    *cs = t + __fma_rn(z, z * c, (1.0 - t) - hz);
 }
 
 __device__ __forceinline__ void sincos_small_or_general(double x, double *sn, double *cs) {
@@ -148,7 +154,10 @@ struct Env;
 template <>
 struct Env<MXV_CARTPOLE> {
     static constexpr int S = 4, O = 4, NA = 2;
-    template <bool DEF>
+    // SAFE = false (rollout fast path, default parameters only): the caller guarantees |theta| <= pi/4 on entry, which
+    // holds inductively after reset() under autoreset (an env leaves (-0.2095, 0.2095) only in the step that ends it);
+    // mxv_set_state() breaks the induction, so the launch after it uses the SAFE instantiation (see mxv_api.cpp).
+    template <bool DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double gravity = P.get(0, 9.8), masspole = P.get(2, 0.1), total_mass = P.get(3, 0.1 + 1.0);
@@ -158,7 +167,10 @@ struct Env<MXV_CARTPOLE> {
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = (ai == 1) ? force_mag : -force_mag;  // :135
         double sintheta, costheta;
-        sincos_small_or_general(theta, &sintheta, &costheta);     // :136-137
+        if constexpr (DEF && !SAFE)
+            sincos_kernel(theta, &sintheta, &costheta);
+        else
+            sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
         const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
         const double thetaacc = (gravity * sintheta - costheta * temp) /
                                 (length * (4.0 / 3.0 - div_par<DEF>(masspole * (costheta * costheta), total_mass)));  // :144-146
@@ -212,7 +224,7 @@ struct Env<MXV_PENDULUM> {
         sincos(s[0], &sn, &cs);
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
     }
-    template <bool DEF>
+    template <bool DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int, float a0, double &reward,
                                                 float *obs) {
         const double max_speed = P.get(0, 8.0), max_torque = P.get(1, 2.0), dt = P.get(2, 0.05);
@@ -289,7 +301,7 @@ struct Env<MXV_ACROBOT> {
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
     }
-    template <bool DEF>
+    template <bool DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
@@ -340,7 +352,7 @@ struct Env<MXV_MOUNTAINCAR> {
     __device__ __forceinline__ static void observe(const double *s, float *obs) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
-    template <bool DEF>
+    template <bool DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double min_position = P.get(0, -1.2), max_position = P.get(1, 0.6), max_speed = P.get(2, 0.07);
@@ -375,7 +387,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
     __device__ __forceinline__ static void observe(const double *s, float *obs) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
-    template <bool DEF>
+    template <bool DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool fresh, int, float a0,
                                                 double &reward, float *obs) {
         const double min_action = P.get(0, -1.0), max_action = P.get(1, 1.0);

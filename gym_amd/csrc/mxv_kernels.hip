@@ -37,6 +37,23 @@ __device__ __forceinline__ void store_obs(float *base, int64_t e, const float *o
     }
 }
 
+// XCD-aware workgroup -> tile map.  The hardware deals workgroup ids round-robin over the 8 XCDs (id % 8), each with
+// its own L2.  Handing out tiles in id order makes every XCD write 4-8 KiB crumbs interleaved with the other seven
+// all over each output row; giving XCD x the x-th contiguous eighth of the tiles instead lets each L2 stream long
+// contiguous runs to its memory channels.  Measured on the rollout's store pattern with the physics removed
+// (tools/wbench, profiles/r01_wbench.txt): 4.7 -> 5.7 TB/s.  Works for any tile count (remainder tiles go to the
+// low XCDs, matching how many ids of each residue exist).
+constexpr unsigned kXcds = 8;
+__device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned ntiles) {
+#if MXV_XCD_MAP
+    const unsigned x = bid % kXcds, idx = bid / kXcds;
+    const unsigned base = ntiles / kXcds, rem = ntiles % kXcds;
+    return x * base + (x < rem ? x : rem) + idx;
+#else
+    return bid;
+#endif
+}
+
 // Word `idx` (0..3, runtime) of a Philox result.
 __device__ __forceinline__ uint32_t pick_word(const U4 &w, uint32_t idx) {
     return idx == 0 ? w.x : (idx == 1 ? w.y : (idx == 2 ? w.z : w.w));
@@ -56,7 +73,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     constexpr int TILE = E * kBlock;
     static_assert(!CONSEC || E == 1 || E == 2 || E % 4 == 0, "CONSEC needs E in {1, 2, 4k}");
     const int tid = threadIdx.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    const int64_t tile0 = (int64_t)xcd_contiguous_tile(blockIdx.x, gridDim.x) * TILE;
     const int64_t n = a.n;
     const Par<DEF> P(a.P);
     const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
@@ -226,6 +243,227 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// rollout_kernel<ENV, DEF, E>: the sampled-action + autoreset fast path (mxv_step_sampled, mxv_rollout FUSED/GRAPH/
+// EAGER), a.K vector steps per launch with the env state in registers.
+//
+// Workgroup = ONE wave64 owning a tile of E*64 consecutive envs (lane L owns envs tile0 + j*64 + L): no s_barrier
+// anywhere, cross-lane traffic goes through a few hundred bytes of LDS that only this wave touches (LDS operations
+// of one wave execute in order).  All Philox work of a vector step is folded into ONE masked call per wave:
+//   lanes [0, 16E)   draw the action words of step t+1 (one call = 4 consecutive envs),
+//   lanes [16E, 64)  draw the reset state of the envs that finished step t.  Finished envs are compacted onto
+//                    those lanes with ballot/mbcnt (about 6 of 128 CartPole envs finish per step), and the lane that
+//                    draws also builds the new fp64 state AND its float32 observation, so the owner only copies them
+//                    back: the reset arithmetic (Pendulum: a full-range sincos) is paid once per wave-step, not
+//                    once per env chain.
+// More finished envs than free lanes (e.g. every Pendulum env truncating at step 200) are handled by extra passes
+// of all 64 lanes.  Output addressing: the per-step base of every array is a scalar; lanes add a 32-bit byte offset
+// fixed for the whole launch, so the loop holds no 64-bit vector address arithmetic.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kWave = 64;
+
+template <int S, int O>
+struct alignas(16) ResetEntry {
+    double s[S];
+    float o[O];
+};
+
+template <int ENV, bool DEF, int E, bool SAFE>
+__global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
+    using EV = Env<ENV>;
+    constexpr int S = EV::S, O = EV::O, NA = EV::NA;
+    constexpr int TILE = E * kWave;
+    constexpr int NACT = TILE / 4;        // lanes drawing action words
+    constexpr int NRST = kWave - NACT;    // lanes free for resets in the merged call
+    static_assert(NACT < kWave, "E must be < 4: the merged call needs free lanes");
+    using Entry = ResetEntry<S, O>;
+    __shared__ uint32_t lds_act[TILE];    // action words of the tile for the coming step
+    __shared__ uint32_t lds_q[TILE];      // compacted list of finished envs (tile-local index)
+    __shared__ Entry lds_res[TILE];       // their new state + observation
+
+    const int lane = threadIdx.x;
+    const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int64_t tile0 = (int64_t)tile * TILE;
+    const int64_t n = a.n;
+    const Par<DEF> P(a.P);
+    const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
+    const bool act_i32 = (a.flags & MXV_FLAG_ACTION_I32) != 0;
+    const bool rew_f32 = (a.flags & MXV_FLAG_REWARD_F32) != 0;
+    const uint64_t group0 = (a.env0 + (uint64_t)tile0) >> 2;
+
+    double s[E][S];
+    int32_t el[E];
+    bool valid[E];
+    uint32_t le[E];  // env index inside the shard (fits 32 bits: mxv_create caps num_envs)
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t e = tile0 + j * kWave + lane;
+        valid[j] = e < n;
+        le[j] = (uint32_t)(valid[j] ? e : 0);
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
+        el[j] = a.elapsed[le[j]];
+    }
+
+    // action words of the first step
+    if (lane < NACT) {
+        const U4 w = action_words(a.action_seed, t0, group0 + (uint64_t)lane);
+        reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    // per-step output bases (scalars)
+    char *p_obs = reinterpret_cast<char *>(a.obs);
+    char *p_rew = reinterpret_cast<char *>(a.reward);
+    char *p_act = reinterpret_cast<char *>(a.actions_out);
+    char *p_term = reinterpret_cast<char *>(a.terminated);
+    char *p_trunc = reinterpret_cast<char *>(a.truncated);
+    char *p_fin = reinterpret_cast<char *>(a.final_obs);
+    const int64_t slice = a.slice;
+    const uint32_t rew_b = rew_f32 ? 4u : 8u;
+    const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
+
+    for (int step = 0; step < a.K; ++step) {
+        const uint64_t t = t0 + (uint64_t)step;
+
+        // ---- this step's actions ----
+        int ai[E];
+        float af[E];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, lds_act[j * kWave + lane], ai[j], af[j]);
+        if (p_act != nullptr) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if (!valid[j]) continue;
+                char *q = p_act + le[j] * act_b;
+                if constexpr (NA > 0) {
+                    if (act_i32)
+                        *reinterpret_cast<int32_t *>(q) = ai[j];
+                    else
+                        *reinterpret_cast<int64_t *>(q) = (int64_t)ai[j];
+                } else {
+                    *reinterpret_cast<float *>(q) = af[j];
+                }
+            }
+        }
+
+        // ---- dynamics + TimeLimit, E independent chains ----
+        float obs[E][O];
+        double rew[E];
+        bool term[E], trunc[E], pend[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            term[j] = EV::template step<DEF, SAFE>(P, s[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            el[j] += 1;                                              // time_limit.py:51
+            trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
+            pend[j] = valid[j] && (term[j] || trunc[j]);
+        }
+
+        // ---- compact the finished envs of the wave (sync_vector_env.py:152-156) ----
+        uint32_t slot[E];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint64_t m = __ballot(pend[j]);
+            slot[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            total += (uint32_t)__popcll(m);
+            if (pend[j]) {
+                lds_q[slot[j]] = (uint32_t)(j * kWave + lane);
+                if (p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);  // info["final_observation"]
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        // ---- ONE masked Philox call: next step's action words + this step's reset draws ----
+        const bool more = step + 1 < a.K;
+        auto draw_reset = [&](uint32_t i, const U4 &w) {
+            Entry r;
+            EV::reset(w, a.b0, a.b1, r.s);
+            EV::observe(r.s, r.o);
+            lds_res[i] = r;
+        };
+        auto reset_key = [&](uint32_t i) -> uint64_t {
+            const uint32_t q = lds_q[i];
+            const uint32_t e = (uint32_t)tile0 + q;
+            return a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
+        };
+        {
+            const bool is_act = lane < NACT;
+            const uint32_t i = (uint32_t)(lane - NACT);
+            const bool active = is_act ? more : (i < total);
+            if (active) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                U4 c;
+                uint64_t key;
+                if (is_act) {
+                    const uint64_t g = group0 + (uint64_t)lane, tn = t + 1;
+                    c.x = (uint32_t)g; c.y = (uint32_t)(g >> 32); c.z = (uint32_t)tn;
+                    c.w = ((uint32_t)(tn >> 32) & 0x0fffffffu) | (kStreamAction << 28);
+                    key = a.action_seed;
+                } else {
+                    c.x = (uint32_t)t; c.y = (uint32_t)(t >> 32); c.z = 0u; c.w = (kStreamReset << 28);
+                    key = reset_key(i);
+                }
+                const U4 w = philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+                if (is_act)
+                    reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
+                else
+                    draw_reset(i, w);
+            }
+        }
+        for (uint32_t base = NRST; base < total; base += kWave) {  // rare: more finished envs than free lanes
+            const uint32_t i = base + (uint32_t)lane;
+            if (i < total) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                draw_reset(i, reset_words(reset_key(i), t, 0u));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        // ---- owners take the new state + observation; this step's outputs ----
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (pend[j]) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const Entry r = lds_res[slot[j]];
+#pragma unroll
+                for (int k = 0; k < S; ++k) s[j][k] = r.s[k];
+#pragma unroll
+                for (int k = 0; k < O; ++k) obs[j][k] = r.o[k];
+                el[j] = 0;  // time_limit.py:67
+            }
+            if (!valid[j]) continue;
+            store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
+            if (p_rew != nullptr) {
+                char *q = p_rew + le[j] * rew_b;
+                if (rew_f32)
+                    *reinterpret_cast<float *>(q) = (float)rew[j];
+                else
+                    *reinterpret_cast<double *>(q) = rew[j];
+            }
+            if (p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
+            if (p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
+        }
+
+        // ---- advance the scalar output bases to the next trajectory slice ----
+        p_obs += slice * (int64_t)(O * sizeof(float));
+        if (p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
+        if (p_act != nullptr) p_act += slice * (int64_t)act_b;
+        if (p_term != nullptr) p_term += slice;
+        if (p_trunc != nullptr) p_trunc += slice;
+        if (p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
+    }
+
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (!valid[j]) continue;
+#pragma unroll
+        for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
+        a.elapsed[le[j]] = el[j];
+    }
+}
+
 // Explicit reset (SyncVectorEnv.reset_wait, sync_vector_env.py:90-129): one env per lane.
 template <int ENV>
 __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
@@ -280,6 +518,20 @@ __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
 template <int ENV>
 hipError_t launch_step_env(bool def, const StepArgs &a, hipStream_t stream) {
+    // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
+    // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
+    if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1) {
+        constexpr int ER = rollout_envs_per_lane(ENV);
+        const int64_t rtile = (int64_t)ER * kWave;
+        const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);
+        if (!def)
+            hipLaunchKernelGGL((rollout_kernel<ENV, false, ER, true>), dim3(rgrid), dim3(kWave), 0, stream, a);
+        else if (ENV == MXV_CARTPOLE && !a.state_injected)
+            hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, false>), dim3(rgrid), dim3(kWave), 0, stream, a);
+        else
+            hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, true>), dim3(rgrid), dim3(kWave), 0, stream, a);
+        return hipGetLastError();
+    }
     constexpr int E = envs_per_lane(ENV);
     constexpr bool C = MXV_CONSEC != 0;
     const int64_t tile = (int64_t)E * kBlock;

@@ -30,6 +30,7 @@ struct StepArgs {
     int32_t max_steps;     // TimeLimit, <= 0 disables
     int32_t flags;         // MXV_FLAG_*
     int32_t K;             // vector steps fused into this launch (>= 1)
+    int32_t state_injected; // mxv_set_state() ran since the last launch: no invariant on the state may be assumed
     int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
     int64_t act_slice;     // action tape advance per step (envs) or 0
     EnvParams P;
@@ -76,6 +77,20 @@ constexpr int envs_per_lane(int env_id) {
     return env_id == MXV_ACROBOT ? MXV_ENVS_PER_LANE_ACROBOT
                                  : (env_id == MXV_PENDULUM ? MXV_ENVS_PER_LANE_PENDULUM : MXV_ENVS_PER_LANE);
 }
+// Envs per lane of rollout_kernel (one wave64 per workgroup, tile = E * 64 envs; E <= 3).
+#ifndef MXV_ROLLOUT_E
+#define MXV_ROLLOUT_E 2
+#endif
+#ifndef MXV_ROLLOUT_E_PENDULUM
+#define MXV_ROLLOUT_E_PENDULUM 1
+#endif
+#ifndef MXV_ROLLOUT_E_ACROBOT
+#define MXV_ROLLOUT_E_ACROBOT 1
+#endif
+constexpr int rollout_envs_per_lane(int env_id) {
+    return env_id == MXV_ACROBOT ? MXV_ROLLOUT_E_ACROBOT
+                                 : (env_id == MXV_PENDULUM ? MXV_ROLLOUT_E_PENDULUM : MXV_ROLLOUT_E);
+}
 // 1: a lane owns E consecutive envs (lane-private Philox action group); 0: wave-dense striding + LDS exchange.
 #ifndef MXV_CONSEC
 #define MXV_CONSEC 0
@@ -84,6 +99,10 @@ constexpr int envs_per_lane(int env_id) {
 // per lane is exactly 4 waves per SIMD, all of which must be co-resident to run in one round.
 #ifndef MXV_MIN_WAVES
 #define MXV_MIN_WAVES 1
+#endif
+// 1: XCD-aware workgroup -> tile map (see xcd_contiguous_tile in mxv_kernels.hip); 0: tiles in workgroup-id order.
+#ifndef MXV_XCD_MAP
+#define MXV_XCD_MAP 1
 #endif
 constexpr int kBlock = 256;
 

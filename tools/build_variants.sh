@@ -3,7 +3,7 @@
 set -uo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 out="$root/gym_amd/_lib/variants"
-mkdir -p "$out"; rm -f "$out"/*.so
+mkdir -p "$out"
 for s in "$@"; do
   IFS=: read -r name e ea c mw extra <<<"$s"
   (

@@ -20,13 +20,17 @@ __device__ __forceinline__ void st(float4 *p, float4 v, bool nt) {
     if (nt) __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p)); else *p = v;
 }
 
-template <int E, int BLOCK, typename RT, typename AT, bool NT, int FLAGMODE>
-__global__ void __launch_bounds__(BLOCK) traj_write(float4 *obs, RT *rew, AT *act, uint8_t *term, uint8_t *trunc, int64_t n, int K) {
+template <int E, int BLOCK, typename RT, typename AT, bool NT, int FLAGMODE, int MAP = 0>
+__global__ void __launch_bounds__(BLOCK) traj_write(float4 *obs, RT *rew, AT *act, uint8_t *term, uint8_t *trunc, int64_t n, int K, int k0 = 0, int k1 = -1) {
     const int tid = threadIdx.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * (E * BLOCK);
+    int64_t tile = blockIdx.x;
+    if (MAP == 1) tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD x owns a contiguous eighth
+    const int64_t tile0 = tile * (E * BLOCK);
     float x = (float)tid;
-    for (int k = 0; k < K; ++k) {
-        const int64_t so = (int64_t)k * n;
+    if (k1 < 0) k1 = K;
+    for (int kk = k0; kk < k1; ++kk) {
+        const int k = MAP == 2 ? (int)((kk + blockIdx.x * 37) % K) : kk;
+        const int64_t so = MAP == 3 ? (tile0 * K + (int64_t)k * (E * BLOCK) - tile0) : (int64_t)k * n;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int64_t e = so + tile0 + (int64_t)j * BLOCK + tid;
@@ -113,6 +117,27 @@ int main() {
                bytes / n / K);                                                                                        \
     }
     RUN(2, 256, double, int64_t, false, 0, "E2 B256 f64/i64 bytes");
+#define RUNM(E, BLOCK, MAP, label)                                                                                    \
+    {                                                                                                                 \
+        const unsigned grid = (unsigned)(n / (E * BLOCK));                                                            \
+        float ms = time_ms([&] {                                                                                      \
+            traj_write<E, BLOCK, double, int64_t, false, 0, MAP><<<grid, BLOCK>>>(obs, rew, act, term, trunc, n, K);  \
+        });                                                                                                           \
+        printf("%-44s %6.2f us/step  %6.1f GB/s\n", label, ms * 1e3 / K, 34.0 * n * K / ms / 1e6);                    \
+    }
+    RUNM(2, 256, 1, "E2 B256 XCD-contiguous tiles");
+    RUNM(2, 256, 2, "E2 B256 staggered steps (diagnostic)");
+    RUNM(2, 256, 3, "E2 B256 tile-major layout [N/T][K][T]");
+    RUNM(4, 256, 1, "E4 B256 XCD-contiguous tiles");
+    RUNM(4, 256, 3, "E4 B256 tile-major layout");
+    {
+        const unsigned grid = (unsigned)(n / (2 * 256));
+        float ms = time_ms([&] {
+            for (int k = 0; k < K; ++k)
+                traj_write<2, 256, double, int64_t, false, 0, 0><<<grid, 256>>>(obs, rew, act, term, trunc, n, K, k, k + 1);
+        });
+        printf("%-44s %6.2f us/step  %6.1f GB/s\n", "E2 B256 one launch per step (K launches)", ms * 1e3 / K, 34.0 * n * K / ms / 1e6);
+    }
     RUN(2, 256, double, int64_t, true, 0, "E2 B256 f64/i64 bytes nontemporal");
     RUN(2, 256, double, int64_t, false, 1, "E2 B256 f64/i64 packed-flag dwords");
     RUN(2, 256, double, int64_t, true, 1, "E2 B256 f64/i64 packed-flag dwords nt");
