@@ -134,12 +134,38 @@ __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) 
     *cs = t + __fma_rn(z, z * c, (1.0 - t) - hz);
 }
 
+// General-range sin/cos = ocml's sincos (Cody-Waite below 2^21-ish, Payne-Hanek above; documented <= 2 ulp).  A
+// hand-written fdlibm-style medium-range reduction with FMA tails (< 0.78 ulp, validated against mpmath) was built
+// and measured in round 1: it was 5-15 % SLOWER than ocml inside the Acrobot and MountainCar kernels (its quadrant
+// selects and cancellation branch cost more than ocml's), so it was dropped; profiles/r01_trig_ab.txt keeps the A/B.
+__device__ __forceinline__ void mx_sincos(double x, double *sn, double *cs) { sincos(x, sn, cs); }
+__device__ __forceinline__ double mx_cos(double x) { return cos(x); }
+__device__ __forceinline__ double mx_sin(double x) {
+    double s, c;
+    sincos(x, &s, &c);  // the sine of sincos, so that a cached sine (Pendulum aux) and a fresh one are the same bits
+    return s;
+}
+
 __device__ __forceinline__ void sincos_small_or_general(double x, double *sn, double *cs) {
     if (fabs(x) <= 0.78539816339744830962) {
         sincos_kernel(x, sn, cs);
     } else {
-        sincos(x, sn, cs);
+        mx_sincos(x, sn, cs);
     }
+}
+
+// C fmod(a, b) for a compile-time b > 0 and |a| < 2^20 * b in ~8 instructions.  fmod is exact by definition, so any
+// exact algorithm returns identical bits: q = trunc(|a| * (1/b)) is the true quotient or off by one, |a| - q*b is
+// then exactly representable (a multiple of ulp(b) below 2b), so the FMA computes it without rounding and one
+// conditional +-b repairs the off-by-one.  Larger |a| (never produced by these dynamics) goes to ocml's fmod.
+__device__ __forceinline__ double fmod_const(double a, double b, double inv_b) {
+    const double aa = fabs(a);
+    if (!(aa < 1048576.0 * b)) return fmod(a, b);
+    const double q = trunc(aa * inv_b);
+    double r = __fma_rn(-q, b, aa);
+    if (r < 0.0) r += b;
+    else if (r >= b) r -= b;
+    return copysign(r, a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -154,11 +180,13 @@ struct Env;
 template <>
 struct Env<MXV_CARTPOLE> {
     static constexpr int S = 4, O = 4, NA = 2;
+    static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    __device__ __forceinline__ static void prime(const double *s, double *aux) {}
     // SAFE = false (rollout fast path, default parameters only): the caller guarantees |theta| <= pi/4 on entry, which
     // holds inductively after reset() under autoreset (an env leaves (-0.2095, 0.2095) only in the step that ends it);
     // mxv_set_state() breaks the induction, so the launch after it uses the SAFE instantiation (see mxv_api.cpp).
     template <bool DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double gravity = P.get(0, 9.8), masspole = P.get(2, 0.1), total_mass = P.get(3, 0.1 + 1.0);
         const double length = P.get(4, 0.5), polemass_length = P.get(5, 0.1 * 0.5), force_mag = P.get(6, 10.0);
@@ -191,7 +219,7 @@ struct Env<MXV_CARTPOLE> {
         obs[0] = (float)x; obs[1] = (float)x_dot; obs[2] = (float)theta; obs[3] = (float)theta_dot;  // :188
         return (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);          // :162-167
     }
-    __device__ __forceinline__ static void observe(const double *s, float *obs) {  // :207
+    __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {  // :207
         obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
     }
     // np_random.uniform(low, high, size=(4,)) :202
@@ -205,8 +233,8 @@ struct Env<MXV_CARTPOLE> {
 
 // ---- Pendulum: gym/envs/classic_control/pendulum.py:119-139,161-163,270-271 ---------------
 // state fp64, action fp32; python-float (op) np.float32 stays float32 under NumPy-2 promotion.
-__device__ __forceinline__ double np_remainder(double a, double b) {  // numpy float64 `%`
-    double mod = fmod(a, b);
+__device__ __forceinline__ double np_remainder(double a, double b) {  // numpy float64 `%` (npy_divmod); b is a literal
+    double mod = fmod_const(a, b, 1.0 / b);
     if (b == 0.0) return mod;
     if (mod != 0.0) {
         if ((b < 0) != (mod < 0)) mod += b;
@@ -219,14 +247,18 @@ __device__ __forceinline__ double np_remainder(double a, double b) {  // numpy f
 template <>
 struct Env<MXV_PENDULUM> {
     static constexpr int S = 2, O = 3, NA = 0;
-    __device__ __forceinline__ static void observe(const double *s, float *obs) {  // :161-163
+    static constexpr int AUX = 1;  // fp64 values derived from the state that a fused rollout carries across steps
+    __device__ __forceinline__ static void prime(const double *s, double *aux) { aux[0] = mx_sin(s[0]); }
+    // aux[0] = sin(theta): `sin(th)` of step t+1 (:131) is the sine _get_obs took at the end of step t (:162)
+    __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux) {  // :161-163
         double sn, cs;
-        sincos(s[0], &sn, &cs);
+        mx_sincos(s[0], &sn, &cs);
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
+        aux[0] = sn;
     }
     template <bool DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int, float a0, double &reward,
-                                                float *obs) {
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int, float a0,
+                                                double &reward, float *obs) {
         const double max_speed = P.get(0, 8.0), max_torque = P.get(1, 2.0), dt = P.get(2, 0.05);
         const double g = P.get(3, 10.0), m = P.get(4, 1.0), l = P.get(5, 1.0);
         const double th = s[0], thdot = s[1];
@@ -240,13 +272,13 @@ struct Env<MXV_PENDULUM> {
         const double A = 3 * g / (2 * l);                                  // python floats :131
         const float B = (float)(3.0 / (m * (l * l)));
         const float Bu = B * u;                                            // python float * np.float32 -> f32
-        double newthdot = thdot + (A * sin(th) + (double)Bu) * dt;
+        double newthdot = thdot + (A * aux[0] + (double)Bu) * dt;         // aux[0] = sin(th)
         if (newthdot < -max_speed) newthdot = -max_speed;                  // np.clip :132
         if (newthdot > max_speed) newthdot = max_speed;
         const double newth = th + newthdot * dt;                           // :133
         s[0] = newth; s[1] = newthdot;
         reward = -costs;                                                   // :139
-        observe(s, obs);
+        observe(s, obs, aux);
         return false;
     }
     // high = (x_init, y_init), low = -high; np_random.uniform(low, high) :141-154
@@ -260,6 +292,8 @@ struct Env<MXV_PENDULUM> {
 template <>
 struct Env<MXV_ACROBOT> {
     static constexpr int S = 4, O = 6, NA = 3;
+    static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    __device__ __forceinline__ static void prime(const double *s, double *aux) {}
     template <bool DEF>
     __device__ __forceinline__ static void dsdt(const Par<DEF> &P, const double *sa, double a, double *out) {
         const double m1 = P.get(3, 1.0), m2 = P.get(4, 1.0), l1 = P.get(1, 1.0);
@@ -268,12 +302,12 @@ struct Env<MXV_ACROBOT> {
         const double g = 9.8;  // :245
         const double theta1 = sa[0], theta2 = sa[1], dtheta1 = sa[2], dtheta2 = sa[3];
         double s2, c2;
-        sincos(theta2, &s2, &c2);
+        mx_sincos(theta2, &s2, &c2);
         const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;  // :252-257
         const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;                                          // :258
-        const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - kPi / 2.0);                                // :259
+        const double phi2 = m2 * lc2 * g * mx_cos(theta1 + theta2 - kPi / 2.0);                                // :259
         const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
-                            (m1 * lc1 + m2 * l1) * g * cos(theta1 - kPi / 2) + phi2;                        // :260-265
+                            (m1 * lc1 + m2 * l1) * g * mx_cos(theta1 - kPi / 2) + phi2;                        // :260-265
         double ddtheta2;
         if (nips) {  // :266-269
             ddtheta2 = (a + d2 / d1 * phi1 - phi2) / (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
@@ -294,15 +328,15 @@ struct Env<MXV_ACROBOT> {
         const double t = (m > x) ? m : x;
         return (M < t) ? M : t;
     }
-    __device__ __forceinline__ static void observe(const double *s, float *obs) {  // :225-230
+    __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {  // :225-230
         double s0, c0, s1, c1;
-        sincos(s[0], &s0, &c0);
-        sincos(s[1], &s1, &c1);
+        mx_sincos(s[0], &s0, &c0);
+        mx_sincos(s[1], &s1, &c1);
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
     }
     template <bool DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
         const double dt = P.get(0, 0.2) - 0;    // t[i+1] - this, t = [0, self.dt] :210,449
@@ -328,9 +362,9 @@ struct Env<MXV_ACROBOT> {
         s[2] = bound(ns[2], -P.get(8, 4 * kPi), P.get(8, 4 * kPi));  // :215
         s[3] = bound(ns[3], -P.get(9, 9 * kPi), P.get(9, 9 * kPi));  // :216
         double s0, c0, s1, c1;
-        sincos(s[0], &s0, &c0);
-        sincos(s[1], &s1, &c1);
-        const bool term = (-c0 - cos(s[1] + s[0])) > 1.0;  // :235
+        mx_sincos(s[0], &s0, &c0);
+        mx_sincos(s[1], &s1, &c1);
+        const bool term = (-c0 - mx_cos(s[1] + s[0])) > 1.0;  // :235
         reward = (!term) ? -1.0 : 0.0;                     // :219
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
@@ -349,17 +383,19 @@ struct Env<MXV_ACROBOT> {
 template <>
 struct Env<MXV_MOUNTAINCAR> {
     static constexpr int S = 2, O = 2, NA = 3;
-    __device__ __forceinline__ static void observe(const double *s, float *obs) {
+    static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    __device__ __forceinline__ static void prime(const double *s, double *aux) {}
+    __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
     template <bool DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool, int ai, float, double &reward,
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double min_position = P.get(0, -1.2), max_position = P.get(1, 0.6), max_speed = P.get(2, 0.07);
         const double goal_position = P.get(3, 0.5), goal_velocity = P.get(4, 0.0);
         const double force = P.get(5, 0.001), gravity = P.get(6, 0.0025);
         double position = s[0], velocity = s[1];
-        velocity = velocity + ((double)(ai - 1) * force + cos(3 * position) * (-gravity));  // :133
+        velocity = velocity + ((double)(ai - 1) * force + mx_cos(3 * position) * (-gravity));  // :133
         if (velocity < -max_speed) velocity = -max_speed;                                  // np.clip :134
         if (velocity > max_speed) velocity = max_speed;
         position = position + velocity;                                                    // :135
@@ -384,11 +420,13 @@ struct Env<MXV_MOUNTAINCAR> {
 template <>
 struct Env<MXV_MOUNTAINCAR_CONT> {
     static constexpr int S = 2, O = 2, NA = 0;
-    __device__ __forceinline__ static void observe(const double *s, float *obs) {
+    static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    __device__ __forceinline__ static void prime(const double *s, double *aux) {}
+    __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
     template <bool DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, bool fresh, int, float a0,
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool fresh, int, float a0,
                                                 double &reward, float *obs) {
         const double min_action = P.get(0, -1.0), max_action = P.get(1, 1.0);
         const double min_position = P.get(2, -1.2), max_position = P.get(3, 0.6), max_speed = P.get(4, 0.07);
@@ -403,7 +441,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
         bool term;
         if (fresh) {
             double position = s[0], velocity = s[1];
-            const double g = 0.0025 * cos(3 * position);  // :148
+            const double g = 0.0025 * mx_cos(3 * position);  // :148
             const double inc = clipped ? (force_py * power - g) : (double)(fp - (float)g);
             velocity = velocity + inc;
             if (velocity > max_speed) velocity = max_speed;    // :149-152
@@ -418,7 +456,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
         } else {
             float position = (float)s[0], velocity = (float)s[1];
             const float three_p = 3.0f * position;            // int * np.float32 -> float32
-            const double g = 0.0025 * cos((double)three_p);
+            const double g = 0.0025 * mx_cos((double)three_p);
             const float inc = clipped ? (float)(force_py * power - g) : (fp - (float)g);
             velocity = velocity + inc;
             if (velocity > (float)max_speed) velocity = (float)max_speed;

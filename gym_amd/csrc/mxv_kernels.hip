@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     auto env_of = [&](int j) -> int64_t { return CONSEC ? tile0 + (int64_t)tid * E + j : tile0 + (int64_t)j * kBlock + tid; };
 
     // ---- entry: state + elapsed of the lane's E envs ----
-    double s[E][S];
+    constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
+    double s[E][S], aux[E][AUXN];
     int32_t el[E];
     bool valid[E];
 #pragma unroll
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + ec];
         el[j] = a.elapsed[ec];
+        EV::prime(s[j], aux[j]);
     }
     __shared__ uint32_t sw[CONSEC ? 4 : TILE];
 
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         bool term[E], trunc[E], pend[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            term[j] = EV::template step<DEF>(P, s[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            term[j] = EV::template step<DEF>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = autoreset && (term[j] || trunc[j]);
@@ -198,13 +200,15 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                 if (a.final_obs != nullptr && v) store_obs<O>(a.final_obs, so + e, cur);  // info["final_observation"]
                 const uint64_t seed = a.seeds ? a.seeds[v ? e : 0] : a.base_seed + a.env0 + (uint64_t)e;
                 const U4 w = reset_words(seed, t, 0u);
-                double ns[S];
+                double ns[S], naux[AUXN];
                 float nobs[O];
                 EV::reset(w, a.b0, a.b1, ns);
-                EV::observe(ns, nobs);
+                EV::observe(ns, nobs, naux);
 #pragma unroll
                 for (int j = 0; j < E; ++j)
                     if (j == jsel) {
+#pragma unroll
+                        for (int k = 0; k < EV::AUX; ++k) aux[j][k] = naux[k];
 #pragma unroll
                         for (int k = 0; k < S; ++k) s[j][k] = ns[k];
 #pragma unroll
@@ -248,23 +252,25 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 // EAGER), a.K vector steps per launch with the env state in registers.
 //
 // Workgroup = ONE wave64 owning a tile of E*64 consecutive envs (lane L owns envs tile0 + j*64 + L): no s_barrier
-// anywhere, cross-lane traffic goes through a few hundred bytes of LDS that only this wave touches (LDS operations
-// of one wave execute in order).  All Philox work of a vector step is folded into ONE masked call per wave:
-//   lanes [0, 16E)   draw the action words of step t+1 (one call = 4 consecutive envs),
-//   lanes [16E, 64)  draw the reset state of the envs that finished step t.  Finished envs are compacted onto
-//                    those lanes with ballot/mbcnt (about 6 of 128 CartPole envs finish per step), and the lane that
-//                    draws also builds the new fp64 state AND its float32 observation, so the owner only copies them
-//                    back: the reset arithmetic (Pendulum: a full-range sincos) is paid once per wave-step, not
-//                    once per env chain.
+// anywhere, cross-lane traffic goes through a few KiB of LDS that only this wave touches (LDS operations of one
+// wave execute in order).  All Philox work is scheduled onto the 64 lanes of AT MOST ONE masked call per wave-step:
+//   * the envs that finished step t are compacted with ballot/mbcnt (about 6 of 128 CartPole envs per step) and their
+//     reset draws take the top lanes; the lane that draws also builds the new fp64 state AND its float32 observation,
+//     so the owner only copies them back: the reset arithmetic (Pendulum: a full-range sincos) is paid once per
+//     wave-step, not once per env chain;
+//   * every remaining block of 16E lanes draws the action words of one FUTURE step (one call = 4 consecutive envs)
+//     into a ring of 64/(16E) steps.  With nothing to reset (Pendulum, Acrobot, MountainCar between truncations) a
+//     wave therefore runs Philox once every 64/(16E) steps with all 64 lanes busy, and skips the call otherwise.
 // More finished envs than free lanes (e.g. every Pendulum env truncating at step 200) are handled by extra passes
 // of all 64 lanes.  Output addressing: the per-step base of every array is a scalar; lanes add a 32-bit byte offset
 // fixed for the whole launch, so the loop holds no 64-bit vector address arithmetic.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kWave = 64;
 
-template <int S, int O>
+template <int S, int O, int AUXN>
 struct alignas(16) ResetEntry {
     double s[S];
+    double x[AUXN];  // Env::AUX values (sized 1 when the env has none; never read then)
     float o[O];
 };
 
@@ -273,11 +279,12 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     constexpr int TILE = E * kWave;
-    constexpr int NACT = TILE / 4;        // lanes drawing action words
-    constexpr int NRST = kWave - NACT;    // lanes free for resets in the merged call
+    constexpr int NACT = TILE / 4;        // lanes that draw the action words of ONE step
+    constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
     static_assert(NACT < kWave, "E must be < 4: the merged call needs free lanes");
-    using Entry = ResetEntry<S, O>;
-    __shared__ uint32_t lds_act[TILE];    // action words of the tile for the coming step
+    constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
+    using Entry = ResetEntry<S, O, AUXN>;
+    __shared__ uint32_t lds_act[H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
     __shared__ uint32_t lds_q[TILE];      // compacted list of finished envs (tile-local index)
     __shared__ Entry lds_res[TILE];       // their new state + observation
 
@@ -291,7 +298,7 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
     const bool rew_f32 = (a.flags & MXV_FLAG_REWARD_F32) != 0;
     const uint64_t group0 = (a.env0 + (uint64_t)tile0) >> 2;
 
-    double s[E][S];
+    double s[E][S], aux[E][AUXN];
     int32_t el[E];
     bool valid[E];
     uint32_t le[E];  // env index inside the shard (fits 32 bits: mxv_create caps num_envs)
@@ -303,11 +310,13 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
         el[j] = a.elapsed[le[j]];
+        EV::prime(s[j], aux[j]);
     }
 
-    // action words of the first step
-    if (lane < NACT) {
-        const U4 w = action_words(a.action_seed, t0, group0 + (uint64_t)lane);
+    // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
+    int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
+    if (lane < filled * NACT) {
+        const U4 w = action_words(a.action_seed, t0 + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT));
         reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -331,7 +340,8 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
         float af[E];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, lds_act[j * kWave + lane], ai[j], af[j]);
+        for (int j = 0; j < E; ++j)
+            action_from_word<ENV, DEF>(P, lds_act[(step % H) * TILE + j * kWave + lane], ai[j], af[j]);
         if (p_act != nullptr) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -354,7 +364,7 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
         bool term[E], trunc[E], pend[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            term[j] = EV::template step<DEF, SAFE>(P, s[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            term[j] = EV::template step<DEF, SAFE>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = valid[j] && (term[j] || trunc[j]);
@@ -375,12 +385,11 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-        // ---- ONE masked Philox call: next step's action words + this step's reset draws ----
-        const bool more = step + 1 < a.K;
+        // ---- at most ONE masked Philox call: this step's reset draws + action words of future steps ----
         auto draw_reset = [&](uint32_t i, const U4 &w) {
             Entry r;
             EV::reset(w, a.b0, a.b1, r.s);
-            EV::observe(r.s, r.o);
+            EV::observe(r.s, r.o, r.x);
             lds_res[i] = r;
         };
         auto reset_key = [&](uint32_t i) -> uint64_t {
@@ -388,31 +397,41 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
             const uint32_t e = (uint32_t)tile0 + q;
             return a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
         };
-        {
-            const bool is_act = lane < NACT;
-            const uint32_t i = (uint32_t)(lane - NACT);
-            const bool active = is_act ? more : (i < total);
-            if (active) {
+        // wave-uniform schedule.  Ring capacity: step's own slot was consumed above, so steps (step, step + H] fit.
+        const int horizon = (a.K < step + 1 + H) ? a.K : step + 1 + H;
+        const int room = horizon - filled;                               // steps that may be drawn now
+        const bool must = (filled == step + 1) && (step + 1 < a.K);      // the next step has no action words yet
+        const int keep = must ? NACT : 0;
+        const int rlanes = (int)total < kWave - keep ? (int)total : kWave - keep;  // reset draws in this call
+        int nfit = (kWave - rlanes) / NACT;                              // future steps that fit beside them
+        nfit = nfit < room ? nfit : room;
+        if (rlanes == 0 && !must) nfit = 0;                              // nothing forces a call: skip it
+        if (rlanes > 0 || nfit > 0) {
+            const bool is_act = lane < nfit * NACT;
+            const int i = lane - (kWave - rlanes);                       // reset slot of the top lanes
+            if (is_act || i >= 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 U4 c;
                 uint64_t key;
+                const int q = filled + lane / NACT;                      // launch-relative step drawn by an action lane
                 if (is_act) {
-                    const uint64_t g = group0 + (uint64_t)lane, tn = t + 1;
-                    c.x = (uint32_t)g; c.y = (uint32_t)(g >> 32); c.z = (uint32_t)tn;
-                    c.w = ((uint32_t)(tn >> 32) & 0x0fffffffu) | (kStreamAction << 28);
+                    const uint64_t g = group0 + (uint64_t)(lane % NACT), tq = t0 + (uint64_t)q;
+                    c.x = (uint32_t)g; c.y = (uint32_t)(g >> 32); c.z = (uint32_t)tq;
+                    c.w = ((uint32_t)(tq >> 32) & 0x0fffffffu) | (kStreamAction << 28);
                     key = a.action_seed;
                 } else {
                     c.x = (uint32_t)t; c.y = (uint32_t)(t >> 32); c.z = 0u; c.w = (kStreamReset << 28);
-                    key = reset_key(i);
+                    key = reset_key((uint32_t)i);
                 }
                 const U4 w = philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
                 if (is_act)
-                    reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
+                    reinterpret_cast<uint4 *>(lds_act)[(q % H) * NACT + lane % NACT] = make_uint4(w.x, w.y, w.z, w.w);
                 else
-                    draw_reset(i, w);
+                    draw_reset((uint32_t)i, w);
             }
+            filled += nfit;
         }
-        for (uint32_t base = NRST; base < total; base += kWave) {  // rare: more finished envs than free lanes
+        for (uint32_t base = (uint32_t)rlanes; base < total; base += kWave) {  // rare: more finished envs than lanes
             const uint32_t i = base + (uint32_t)lane;
             if (i < total) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -429,6 +448,8 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
                 const Entry r = lds_res[slot[j]];
 #pragma unroll
                 for (int k = 0; k < S; ++k) s[j][k] = r.s[k];
+#pragma unroll
+                for (int k = 0; k < EV::AUX; ++k) aux[j][k] = r.x[k];
 #pragma unroll
                 for (int k = 0; k < O; ++k) obs[j][k] = r.o[k];
                 el[j] = 0;  // time_limit.py:67
@@ -481,7 +502,8 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
     a.elapsed[e] = 0;  // time_limit.py:67
     if (a.obs != nullptr) {
         float o[O];
-        EV::observe(s, o);
+        double aux_unused[EV::AUX > 0 ? EV::AUX : 1];
+        EV::observe(s, o, aux_unused);
         store_obs<O>(a.obs, e, o);
     }
 }
@@ -524,12 +546,16 @@ hipError_t launch_step_env(bool def, const StepArgs &a, hipStream_t stream) {
         constexpr int ER = rollout_envs_per_lane(ENV);
         const int64_t rtile = (int64_t)ER * kWave;
         const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);
-        if (!def)
+        bool fast = false;
+        if constexpr (ENV == MXV_CARTPOLE) fast = def && !a.state_injected;  // see Env<MXV_CARTPOLE>::step, SAFE
+        if (!def) {
             hipLaunchKernelGGL((rollout_kernel<ENV, false, ER, true>), dim3(rgrid), dim3(kWave), 0, stream, a);
-        else if (ENV == MXV_CARTPOLE && !a.state_injected)
-            hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, false>), dim3(rgrid), dim3(kWave), 0, stream, a);
-        else
+        } else if (fast) {
+            if constexpr (ENV == MXV_CARTPOLE)
+                hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, false>), dim3(rgrid), dim3(kWave), 0, stream, a);
+        } else {
             hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, true>), dim3(rgrid), dim3(kWave), 0, stream, a);
+        }
         return hipGetLastError();
     }
     constexpr int E = envs_per_lane(ENV);
