@@ -34,7 +34,7 @@ EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
-    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
 )
 
 
@@ -90,6 +90,8 @@ def _load():
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_get_params": ([vp, vp], C.c_int),
         "mxv_set_params": ([vp, vp], C.c_int),
+        "mxv_set_params_per_env": ([vp, vp], C.c_int),
+        "mxv_get_params_per_env": ([vp, vp], C.c_int),
         "mxv_sync": ([vp], C.c_int),
         "mxv_get_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_set_stream": ([vp, vp], C.c_int),
@@ -282,6 +284,17 @@ class Handle:
         p = np.ascontiguousarray(params, dtype=np.float64)
         assert p.shape == (MAX_PARAMS,)
         self._check(lib.mxv_set_params(self._h, p.ctypes.data))
+
+    def get_params_per_env(self) -> np.ndarray:
+        """[MAX_PARAMS, N] attribute-major table (broadcast values are expanded)."""
+        p = np.zeros((MAX_PARAMS, self.num_envs), dtype=np.float64)
+        self._check(lib.mxv_get_params_per_env(self._h, p.ctypes.data))
+        return p
+
+    def set_params_per_env(self, table):
+        p = np.ascontiguousarray(table, dtype=np.float64)
+        assert p.shape == (MAX_PARAMS, self.num_envs), p.shape
+        self._check(lib.mxv_set_params_per_env(self._h, p.ctypes.data))
 
     def sync(self):
         self._check(lib.mxv_sync(self._h))

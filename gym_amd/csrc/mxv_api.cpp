@@ -78,6 +78,8 @@ struct mxv_handle {
     bool state_injected = false;  // set by mxv_set_state, consumed by the next step launch
     EnvParams P{};
     bool default_params = true;
+    double *params_pe = nullptr;  // [MXV_MAX_PARAMS][N] when per-env physics parameters are active
+    int param_mode() const { return params_pe ? PM_PER_ENV : (default_params ? PM_DEFAULT : PM_BROADCAST); }
     double bounds[2] = {0, 0};
     // staging for *_host calls
     void *st_actions = nullptr;
@@ -157,6 +159,7 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.state_injected = h->state_injected ? 1 : 0;
     a.slice = 0;
     a.act_slice = 0;
+    a.params_pe = h->params_pe;
     a.P = h->P;
 }
 
@@ -175,7 +178,7 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
-    MXV_HIP(h, launch_step(h->cfg.env_id, h->default_params, a, h->stream));
+    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream));
     h->state_injected = false;
     h->t += 1;
     return MXV_OK;
@@ -320,7 +323,7 @@ int mxv_destroy(mxv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graphs(h);
-    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->st_actions, h->st_obs, h->st_final,
+    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->params_pe, h->st_actions, h->st_obs, h->st_final,
                     h->st_reward, h->st_term, h->st_trunc, h->st_mask};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -404,7 +407,7 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
-    MXV_HIP(h, launch_step(h->cfg.env_id, h->default_params, a, h->stream));
+    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream));
     h->state_injected = false;
     h->t += (uint64_t)K;
     return MXV_OK;
@@ -439,7 +442,7 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         a.terminated = (uint8_t *)slice(terminated_dev, 1, k);
         a.truncated = (uint8_t *)slice(truncated_dev, 1, k);
         a.final_obs = (float *)slice(final_obs_dev, h->O * sizeof(float), k);
-        return launch_step(h->cfg.env_id, h->default_params, a, h->stream);
+        return launch_step(h->cfg.env_id, h->param_mode(), a, h->stream);
     };
     if (mode == MXV_ROLLOUT_EAGER) {
         for (int k = 0; k < K; ++k) MXV_HIP(h, launch_k(k, nullptr, h->t + (uint64_t)k));
@@ -492,8 +495,9 @@ int mxv_sample_actions(mxv_handle *h, void *actions_out_dev) {
     a.action_seed = h->action_seed;
     a.t = h->t;
     a.flags = h->cfg.flags;
+    a.params_pe = h->params_pe;
     a.P = h->P;
-    MXV_HIP(h, launch_sample(h->cfg.env_id, h->default_params, a, h->stream));
+    MXV_HIP(h, launch_sample(h->cfg.env_id, h->param_mode(), a, h->stream));
     return MXV_OK;
 }
 
@@ -596,6 +600,44 @@ int mxv_set_params(mxv_handle *h, const double *params_host) {
     if (int rc = use_device(h)) return rc;
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     free_graphs(h);  // captured kernel arguments hold the old parameters
+    if (h->params_pe) {  // one value for all sub-envs again
+        MXV_HIP(h, hipFree(h->params_pe));
+        h->params_pe = nullptr;
+    }
+    return MXV_OK;
+}
+
+int mxv_set_params_per_env(mxv_handle *h, const double *params_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!params_host) return fail(h, MXV_ERR_INVALID_ARG, "params pointer is NULL");
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (h->cfg.env_id == MXV_ACROBOT)
+        for (size_t i = 0; i < n; ++i)
+            if (params_host[10 * n + i] != 0.0)
+                return fail(h, MXV_ERR_UNSUPPORTED, "Acrobot torque_noise_max != 0 is not supported");
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);
+    const size_t bytes = n * MXV_MAX_PARAMS * sizeof(double);
+    if (!h->params_pe) MXV_HIP(h, hipMalloc((void **)&h->params_pe, bytes));
+    MXV_HIP(h, hipMemcpyAsync(h->params_pe, params_host, bytes, hipMemcpyHostToDevice, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < MXV_MAX_PARAMS; ++k) h->P.p[k] = params_host[(size_t)k * n];  // env 0's values for mxv_get_params
+    return MXV_OK;
+}
+
+int mxv_get_params_per_env(mxv_handle *h, double *params_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!params_host) return fail(h, MXV_ERR_INVALID_ARG, "params pointer is NULL");
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (!h->params_pe) {
+        for (int k = 0; k < MXV_MAX_PARAMS; ++k)
+            for (size_t i = 0; i < n; ++i) params_host[(size_t)k * n + i] = h->P.p[k];
+        return MXV_OK;
+    }
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipMemcpyAsync(params_host, h->params_pe, n * MXV_MAX_PARAMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
     return MXV_OK;
 }
 

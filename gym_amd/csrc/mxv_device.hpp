@@ -18,14 +18,27 @@ struct EnvParams {
     double p[MXV_MAX_PARAMS];
 };
 
-// Parameter access policy: DEF = true folds the reference's default attribute values into the
-// instruction stream as constants; DEF = false reads the broadcast values set through
-// mxv_set_params() (VectorEnv.set_attr) from the kernel argument segment (SGPRs).
-template <bool DEF>
+// Parameter access policy (template argument DEF of everything below):
+//   PM_DEFAULT   (1, `true`)  folds the reference's default attribute values into the instruction stream;
+//   PM_BROADCAST (0, `false`) reads the values set through mxv_set_params() (VectorEnv.set_attr with one value for
+//                             all sub-envs) from the kernel argument segment (SGPRs);
+//   PM_PER_ENV   (2)          reads this env's own values from a [MXV_MAX_PARAMS][N] device array
+//                             (mxv_set_params_per_env: set_attr with a list of differing values,
+//                             gym/vector/sync_vector_env.py:192-214).
+enum { PM_BROADCAST = 0, PM_DEFAULT = 1, PM_PER_ENV = 2 };
+template <int DEF>
 struct Par {
     const EnvParams &P;
-    __device__ __forceinline__ explicit Par(const EnvParams &p) : P(p) {}
-    __device__ __forceinline__ double get(int i, double dflt) const { return DEF ? dflt : P.p[i]; }
+    const double *pe;  // per-env table or nullptr
+    int64_t n, e;
+    __device__ __forceinline__ explicit Par(const EnvParams &p, const double *per_env = nullptr, int64_t n_ = 0, int64_t e_ = 0)
+        : P(p), pe(per_env), n(n_), e(e_) {}
+    __device__ __forceinline__ Par at(int64_t env) const { return Par(P, pe, n, env); }  // bind to one env (PM_PER_ENV)
+    __device__ __forceinline__ double get(int i, double dflt) const {
+        if constexpr (DEF == PM_DEFAULT) return dflt;
+        else if constexpr (DEF == PM_BROADCAST) return P.p[i];
+        else return pe[(int64_t)i * n + e];
+    }
 };
 
 constexpr double kPi = 3.141592653589793;
@@ -99,9 +112,9 @@ __device__ __forceinline__ double div_by_const(double x, double c, double rc) {
     const double r = __fma_rn(-c, q0, x);
     return __fma_rn(r, rc, q0);
 }
-template <bool DEF>
+template <int DEF>
 __device__ __forceinline__ double div_par(double x, double c) {
-    if constexpr (DEF)
+    if constexpr (DEF == PM_DEFAULT)
         return div_by_const(x, c, 1.0 / c);  // c is a literal on this path: 1.0 / c folds at compile time
     else
         return x / c;
@@ -185,7 +198,7 @@ struct Env<MXV_CARTPOLE> {
     // SAFE = false (rollout fast path, default parameters only): the caller guarantees |theta| <= pi/4 on entry, which
     // holds inductively after reset() under autoreset (an env leaves (-0.2095, 0.2095) only in the step that ends it);
     // mxv_set_state() breaks the induction, so the launch after it uses the SAFE instantiation (see mxv_api.cpp).
-    template <bool DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double gravity = P.get(0, 9.8), masspole = P.get(2, 0.1), total_mass = P.get(3, 0.1 + 1.0);
@@ -195,7 +208,7 @@ struct Env<MXV_CARTPOLE> {
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = (ai == 1) ? force_mag : -force_mag;  // :135
         double sintheta, costheta;
-        if constexpr (DEF && !SAFE)
+        if constexpr (DEF == PM_DEFAULT && !SAFE)
             sincos_kernel(theta, &sintheta, &costheta);
         else
             sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
@@ -256,7 +269,7 @@ struct Env<MXV_PENDULUM> {
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
         aux[0] = sn;
     }
-    template <bool DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int, float a0,
                                                 double &reward, float *obs) {
         const double max_speed = P.get(0, 8.0), max_torque = P.get(1, 2.0), dt = P.get(2, 0.05);
@@ -294,7 +307,7 @@ struct Env<MXV_ACROBOT> {
     static constexpr int S = 4, O = 6, NA = 3;
     static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
     __device__ __forceinline__ static void prime(const double *s, double *aux) {}
-    template <bool DEF>
+    template <int DEF>
     __device__ __forceinline__ static void dsdt(const Par<DEF> &P, const double *sa, double a, double *out) {
         const double m1 = P.get(3, 1.0), m2 = P.get(4, 1.0), l1 = P.get(1, 1.0);
         const double lc1 = P.get(5, 0.5), lc2 = P.get(6, 0.5), I1 = P.get(7, 1.0), I2 = P.get(7, 1.0);
@@ -335,7 +348,7 @@ struct Env<MXV_ACROBOT> {
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
     }
-    template <bool DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
@@ -388,7 +401,7 @@ struct Env<MXV_MOUNTAINCAR> {
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
-    template <bool DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double min_position = P.get(0, -1.2), max_position = P.get(1, 0.6), max_speed = P.get(2, 0.07);
@@ -425,7 +438,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
-    template <bool DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true>
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool fresh, int, float a0,
                                                 double &reward, float *obs) {
         const double min_action = P.get(0, -1.0), max_action = P.get(1, 1.0);
@@ -482,7 +495,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
 };
 
 // Action of one env from its stream word (see include/mxv.h, RNG contract).
-template <int ENV, bool DEF>
+template <int ENV, int DEF>
 __device__ __forceinline__ void action_from_word(const Par<DEF> &P, uint32_t w, int &ai, float &af) {
     if constexpr (Env<ENV>::NA > 0) {
         ai = (int)(((uint64_t)w * (uint32_t)Env<ENV>::NA) >> 32);

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t pick_word(const U4 &w, uint32_t idx) {
 //                   Philox action words are transposed through LDS (one call = 4 consecutive envs).
 //   CONSEC = true : lane owns the E consecutive envs tile0 + tid*E + j: a Philox action group is
 //                   lane-private (no LDS, no barrier) and the flag bytes of a lane are contiguous.
-template <int ENV, bool DEF, int E, bool CONSEC, bool MULTI>
+template <int ENV, int DEF, int E, bool CONSEC, bool MULTI>
 __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     const int tid = threadIdx.x;
     const int64_t tile0 = (int64_t)xcd_contiguous_tile(blockIdx.x, gridDim.x) * TILE;
     const int64_t n = a.n;
-    const Par<DEF> P(a.P);
+    const Par<DEF> P(a.P, a.params_pe, a.n);
     const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
     const bool autoreset = !(a.flags & MXV_FLAG_NO_AUTORESET);
     const bool sampled = a.actions == nullptr;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                     const U4 w = action_words(a.action_seed, t, ge >> 2);
 #pragma unroll
                     for (int q = 0; q < 4 && j0 + q < E; ++q)
-                        action_from_word<ENV, DEF>(P, pick_word(w, (uint32_t)((ge + q) & 3)), ai[j0 + q], af[j0 + q]);
+                        action_from_word<ENV, DEF>(P.at(valid[j0 + q] ? env_of(j0 + q) : 0), pick_word(w, (uint32_t)((ge + q) & 3)), ai[j0 + q], af[j0 + q]);
                 }
             } else {
                 // thread c computes the 4 words of group (env0 + tile0)/4 + c; LDS hands them to the owning lanes
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                 }
                 __syncthreads();
 #pragma unroll
-                for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, sw[j * kBlock + tid], ai[j], af[j]);
+                for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P.at(valid[j] ? env_of(j) : 0), sw[j * kBlock + tid], ai[j], af[j]);
             }
             if (a.actions_out != nullptr) {
 #pragma unroll
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         bool term[E], trunc[E], pend[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            term[j] = EV::template step<DEF>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            term[j] = EV::template step<DEF>(P.at(valid[j] ? env_of(j) : 0), s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = autoreset && (term[j] || trunc[j]);
@@ -509,12 +509,12 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
 }
 
 // action_space.sample() without stepping: one Philox call (4 envs) per lane.
-template <int ENV, bool DEF>
+template <int ENV, int DEF>
 __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
     constexpr int NA = Env<ENV>::NA;
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // local group index
     if (c * 4 >= a.n) return;
-    const Par<DEF> P(a.P);
+    const Par<DEF> P(a.P, a.params_pe, a.n);
     const uint64_t t = a.t + (a.t_dev ? *a.t_dev : 0);
     const U4 w = action_words(a.action_seed, t, (a.env0 >> 2) + (uint64_t)c);
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
         if (e >= a.n) break;
         int ai;
         float af;
-        action_from_word<ENV, DEF>(P, ws[q], ai, af);
+        action_from_word<ENV, DEF>(P.at(e), ws[q], ai, af);
         if constexpr (NA > 0) {
             if (a.flags & MXV_FLAG_ACTION_I32)
                 static_cast<int32_t *>(a.actions_out)[e] = ai;
@@ -539,10 +539,11 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
 __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
 template <int ENV>
-hipError_t launch_step_env(bool def, const StepArgs &a, hipStream_t stream) {
+hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
+    const bool def = pm == PM_DEFAULT;
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
-    if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1) {
+    if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV) {
         constexpr int ER = rollout_envs_per_lane(ENV);
         const int64_t rtile = (int64_t)ER * kWave;
         const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);
@@ -563,33 +564,39 @@ hipError_t launch_step_env(bool def, const StepArgs &a, hipStream_t stream) {
     const int64_t tile = (int64_t)E * kBlock;
     const unsigned grid = (unsigned)((a.n + tile - 1) / tile);
     if (a.K > 1) {
-        if (def)
-            hipLaunchKernelGGL((step_kernel<ENV, true, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+        if (pm == PM_DEFAULT)
+            hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+        else if (pm == PM_BROADCAST)
+            hipLaunchKernelGGL((step_kernel<ENV, PM_BROADCAST, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
         else
-            hipLaunchKernelGGL((step_kernel<ENV, false, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<ENV, PM_PER_ENV, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
     } else {
-        if (def)
-            hipLaunchKernelGGL((step_kernel<ENV, true, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+        if (pm == PM_DEFAULT)
+            hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+        else if (pm == PM_BROADCAST)
+            hipLaunchKernelGGL((step_kernel<ENV, PM_BROADCAST, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
         else
-            hipLaunchKernelGGL((step_kernel<ENV, false, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<ENV, PM_PER_ENV, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
     }
     return hipGetLastError();
 }
 
 template <int ENV>
-hipError_t launch_sample_env(bool def, const SampleArgs &a, hipStream_t stream) {
+hipError_t launch_sample_env(int pm, const SampleArgs &a, hipStream_t stream) {
     const int64_t groups = (a.n + 3) / 4;
     const unsigned grid = (unsigned)((groups + kBlock - 1) / kBlock);
-    if (def)
-        hipLaunchKernelGGL((sample_kernel<ENV, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+    if (pm == PM_DEFAULT)
+        hipLaunchKernelGGL((sample_kernel<ENV, PM_DEFAULT>), dim3(grid), dim3(kBlock), 0, stream, a);
+    else if (pm == PM_BROADCAST)
+        hipLaunchKernelGGL((sample_kernel<ENV, PM_BROADCAST>), dim3(grid), dim3(kBlock), 0, stream, a);
     else
-        hipLaunchKernelGGL((sample_kernel<ENV, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL((sample_kernel<ENV, PM_PER_ENV>), dim3(grid), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_step(int env_id, bool default_params, const StepArgs &a, hipStream_t stream) {
+hipError_t launch_step(int env_id, int default_params, const StepArgs &a, hipStream_t stream) {
     switch (env_id) {
         case MXV_CARTPOLE: return launch_step_env<MXV_CARTPOLE>(default_params, a, stream);
         case MXV_PENDULUM: return launch_step_env<MXV_PENDULUM>(default_params, a, stream);
@@ -615,7 +622,7 @@ hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_sample(int env_id, bool default_params, const SampleArgs &a, hipStream_t stream) {
+hipError_t launch_sample(int env_id, int default_params, const SampleArgs &a, hipStream_t stream) {
     switch (env_id) {
         case MXV_CARTPOLE: return launch_sample_env<MXV_CARTPOLE>(default_params, a, stream);
         case MXV_PENDULUM: return launch_sample_env<MXV_PENDULUM>(default_params, a, stream);

@@ -33,6 +33,7 @@ struct StepArgs {
     int32_t state_injected; // mxv_set_state() ran since the last launch: no invariant on the state may be assumed
     int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
     int64_t act_slice;     // action tape advance per step (envs) or 0
+    const double *params_pe; // [MXV_MAX_PARAMS][N] per-env physics parameters (PM_PER_ENV launches) or nullptr
     EnvParams P;
 };
 
@@ -58,6 +59,7 @@ struct SampleArgs {
     uint64_t action_seed;
     uint64_t t;
     int32_t flags;
+    const double *params_pe;
     EnvParams P;
 };
 
@@ -106,9 +108,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #endif
 constexpr int kBlock = 256;
 
-hipError_t launch_step(int env_id, bool default_params, const StepArgs &a, hipStream_t stream);
+// param_mode: PM_DEFAULT / PM_BROADCAST / PM_PER_ENV (mxv_device.hpp)
+hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream);
 hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
-hipError_t launch_sample(int env_id, bool default_params, const SampleArgs &a, hipStream_t stream);
+hipError_t launch_sample(int env_id, int param_mode, const SampleArgs &a, hipStream_t stream);
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);
 
 }  // namespace mxv

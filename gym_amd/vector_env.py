@@ -142,9 +142,8 @@ class HipVectorEnv(VectorEnv):
     per call), rewards float64 (N,), terminated/truncated np.bool_ (N,), infos with `final_observation`
     / `final_info` and their `_` masks when an env finished (sync_vector_env.py:152-169).
 
-    Differences that cannot be avoided: resets draw from the engine's Philox4x32-10 streams, not from
-    PCG64, so seeded initial states differ from the reference's; physics attributes
-    set through set_attr must be equal across sub-envs (they are broadcast kernel arguments).
+    Difference that cannot be avoided: resets draw from the engine's Philox4x32-10 streams, not from
+    PCG64, so seeded initial states differ from the reference's (RNG).
     """
 
     metadata = {"render_modes": []}
@@ -165,6 +164,7 @@ class HipVectorEnv(VectorEnv):
                                       env_offset=env_offset, seed=entropy, action_seed=entropy ^ 0x9E3779B97F4A7C15)
         self._actions = None
         self._was_reset = False
+        self._per_env = False  # True while sub-envs hold differing physics attributes (set_attr with a list)
         allowed = CTOR_KWARGS.get(self.kind, {})
         for k, v in kwargs.items():
             if k == "render_mode" and v is None:
@@ -207,7 +207,10 @@ class HipVectorEnv(VectorEnv):
         self._assert_is_running()
         if args or kwargs:
             raise NotImplementedError("sub-environment methods are not callable on the device engine")
-        value = self._decode(name, self._handle.get_params()[self._param_index(name)])
+        idx = self._param_index(name)
+        if self._per_env:
+            return tuple(self._decode(name, v) for v in self._handle.get_params_per_env()[idx].tolist())
+        value = self._decode(name, self._handle.get_params()[idx])
         return (value,) * self.num_envs
 
     def set_attr(self, name: str, values):
@@ -219,10 +222,24 @@ class HipVectorEnv(VectorEnv):
             raise ValueError("Values must be a list or tuple with length equal to the number of environments. "
                              f"Got `{len(values)}` values for {self.num_envs} environments.")
         first = values[0]
-        if any(v != first for v in values):
-            raise NotImplementedError("per-env heterogeneous physics attributes are not supported: the engine "
-                                      "broadcasts one value to all sub-environments")
-        self._set_param(name, first)
+        if not self._per_env and all(v == first for v in values):
+            self._set_param(name, first)   # one value for all: constants stay kernel arguments
+            return
+        # differing values (tests/vector/test_sync_vector_env.py:101-110): per-env parameter table on the device
+        idx = self._param_index(name)
+        table = self._handle.get_params_per_env()
+        table[idx] = [self._encode(name, v) for v in values]
+        if all(np.all(row == row[0]) for row in table):  # back to common values: leave per-env mode
+            self._handle.set_params(table[:, 0].copy())
+            self._per_env = False
+            return
+        try:
+            self._handle.set_params_per_env(table)
+        except _native.MxvError as e:
+            if e.code == _native.ERR_UNSUPPORTED:
+                raise NotImplementedError(e.message) from None
+            raise
+        self._per_env = True
 
     # -- reset ---------------------------------------------------------------------------------------
     def _reset_bounds(self, options: Optional[dict]):

@@ -173,9 +173,17 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
 int mxv_get_counters(mxv_handle *h, uint64_t *t, uint32_t *r);
 int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r);
 
-/* -- physics parameters (VectorEnv.get_attr/set_attr; broadcast values only) ------------------- */
+/* -- physics parameters (VectorEnv.get_attr/set_attr/call, sync_vector_env.py:171-214) ----------- */
+/* One value per attribute for all sub-envs (set_attr with a scalar or a list of equal values).  Default values run
+ * the kernels with the constants folded in; any other value switches the handle to the runtime-parameter kernels. */
 int mxv_get_params(mxv_handle *h, double *params_host);
 int mxv_set_params(mxv_handle *h, const double *params_host);
+/* A value per sub-env (set_attr with a list of differing values, e.g. env.set_attr("gravity", [9.81, 3.72, 8.87, 1.62]),
+ * tests/vector/test_sync_vector_env.py:101-110): params_host is double[MXV_MAX_PARAMS][N] (attribute-major).  The
+ * handle then steps with the per-env-parameter kernels (one launch per step; the fused fast path needs equal
+ * attributes) until mxv_set_params() sets common values again.  mxv_get_params_per_env always fills [MXV_MAX_PARAMS][N]. */
+int mxv_set_params_per_env(mxv_handle *h, const double *params_host);
+int mxv_get_params_per_env(mxv_handle *h, double *params_host);
 
 /* -- stream / sync -------------------------------------------------------------------------------- */
 /* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last

@@ -227,3 +227,47 @@ def test_random_policy_episode_length_cartpole():
     mean_len = 4096 * steps / done_count
     assert 19.0 < mean_len < 25.5, mean_len
     env.close()
+
+
+def test_set_attr_per_env_values_like_the_reference_test():
+    """tests/vector/test_sync_vector_env.py:101-110: set_attr("gravity", [9.81, 3.72, 8.87, 1.62]) gives every sub-env
+    its own value; every sub-env then integrates with ITS gravity (checked against one oracle per distinct value)."""
+    from oracle.oracle import OracleVecEnv
+
+    env = _make("CartPole-v1", 4)
+    env.reset(seed=5)
+    env.set_attr("gravity", [9.81, 3.72, 8.87, 1.62])
+    assert env.get_attr("gravity") == (9.81, 3.72, 8.87, 1.62)
+    assert env.get_attr("force_mag") == (10.0,) * 4
+    env.set_attr("kinematics_integrator", ["euler", "semi-implicit", "euler", "semi-implicit"])
+    assert env.call("kinematics_integrator") == ("euler", "semi-implicit", "euler", "semi-implicit")
+    for _ in range(25):
+        st, el = env.handle.get_state()
+        a = env.action_space.sample()
+        obs, rew, term, trunc, _ = env.step(a)
+        for i, (g, ki) in enumerate(zip((9.81, 3.72, 8.87, 1.62), (0.0, 1.0, 0.0, 1.0))):
+            o = OracleVecEnv(0, 1, 500)
+            o.P[0], o.P[10] = g, ki
+            o.state[:, 0], o.elapsed[:] = st[:, i], el[i]
+            robs, _, rterm, rtrunc, _, _ = o.step(a[i:i + 1])
+            assert rterm[0] == term[i] and rtrunc[0] == trunc[i]
+            if not (term[i] or trunc[i]):
+                assert ulps32(obs[i], robs[0]).max() <= MAX_OBS_ULPS, (i, obs[i], robs[0])
+    # equal values again -> broadcast mode, fast kernels
+    env.set_attr("gravity", [9.8] * 4)
+    env.set_attr("kinematics_integrator", "euler")
+    assert env.get_attr("gravity") == (9.8,) * 4 and not env._per_env
+    env.step(env.action_space.sample())
+    env.close()
+    # sampled fused rollouts keep working while attributes differ (they take the per-step kernel)
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout("Pendulum-v1", 64, seed=1, action_seed=2)
+    tbl = r.handle.get_params_per_env()
+    tbl[3] = np.linspace(9.0, 11.0, 64)  # g
+    r.handle.set_params_per_env(tbl)
+    r.reset(seed=1)
+    out = r.rollout_per_step(10, mode="fused")
+    r.synchronize()
+    assert np.isfinite(out["obs"].cpu().numpy()).all()
+    r.close()
