@@ -15,6 +15,8 @@ _LAZY = {
     "DeviceRollout": ("gym_amd.rollout", "DeviceRollout"),
     "ShardedRollout": ("gym_amd.distributed", "ShardedRollout"),
     "MixedRollout": ("gym_amd.mixed", "MixedRollout"),
+    "RecordEpisodeStatistics": ("gym_amd.wrappers", "RecordEpisodeStatistics"),
+    "VectorListInfo": ("gym_amd.wrappers", "VectorListInfo"),
 }
 
 

@@ -34,7 +34,7 @@ EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
-    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
 )
 
 
@@ -92,6 +92,9 @@ def _load():
         "mxv_set_params": ([vp, vp], C.c_int),
         "mxv_set_params_per_env": ([vp, vp], C.c_int),
         "mxv_get_params_per_env": ([vp, vp], C.c_int),
+        "mxv_episode_stats": ([vp, i32], C.c_int),
+        "mxv_set_episode_outputs": ([vp, vp, vp], C.c_int),
+        "mxv_episode_stats_host": ([vp, vp, vp, vp], C.c_int),
         "mxv_sync": ([vp], C.c_int),
         "mxv_get_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_set_stream": ([vp, vp], C.c_int),
@@ -295,6 +298,20 @@ class Handle:
         p = np.ascontiguousarray(table, dtype=np.float64)
         assert p.shape == (MAX_PARAMS, self.num_envs), p.shape
         self._check(lib.mxv_set_params_per_env(self._h, p.ctypes.data))
+
+    def episode_stats(self, enable: bool = True):
+        self._check(lib.mxv_episode_stats(self._h, 1 if enable else 0))
+
+    def set_episode_outputs(self, ep_return_dev=None, ep_length_dev=None):
+        self._check(lib.mxv_set_episode_outputs(self._h, _ptr(ep_return_dev), _ptr(ep_length_dev)))
+
+    def episode_stats_host(self, want_running: bool = False):
+        """(returns, lengths[, running_returns]) of the last step_host call; valid where terminated | truncated."""
+        r = np.zeros(self.num_envs, dtype=np.float32)
+        l = np.zeros(self.num_envs, dtype=np.int32)
+        run = np.zeros(self.num_envs, dtype=np.float32) if want_running else None
+        self._check(lib.mxv_episode_stats_host(self._h, r.ctypes.data, l.ctypes.data, _ptr(run)))
+        return (r, l, run) if want_running else (r, l)
 
     def sync(self):
         self._check(lib.mxv_sync(self._h))

@@ -78,6 +78,11 @@ struct mxv_handle {
     bool state_injected = false;  // set by mxv_set_state, consumed by the next step launch
     EnvParams P{};
     bool default_params = true;
+    float *ep_acc = nullptr;        // running episode returns when episode statistics are enabled
+    float *ep_return_out = nullptr; // caller-attached outputs of the statistics (device)
+    int32_t *ep_length_out = nullptr;
+    float *st_ep_r = nullptr;       // staging for mxv_step_host / mxv_episode_stats_host
+    int32_t *st_ep_l = nullptr;
     double *params_pe = nullptr;  // [MXV_MAX_PARAMS][N] when per-env physics parameters are active
     int param_mode() const { return params_pe ? PM_PER_ENV : (default_params ? PM_DEFAULT : PM_BROADCAST); }
     double bounds[2] = {0, 0};
@@ -160,6 +165,9 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.slice = 0;
     a.act_slice = 0;
     a.params_pe = h->params_pe;
+    a.ep_acc = h->ep_acc;
+    a.ep_return_out = h->ep_acc ? h->ep_return_out : nullptr;
+    a.ep_length_out = h->ep_acc ? h->ep_length_out : nullptr;
     a.P = h->P;
 }
 
@@ -208,6 +216,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     a.obs = obs_dev;
     a.mask = mask_dev;
     a.seeds = h->seeds;
+    a.ep_acc = h->ep_acc;
     a.n = h->cfg.num_envs;
     a.env0 = (uint64_t)h->cfg.env_offset;
     a.base_seed = h->base_seed;
@@ -323,7 +332,7 @@ int mxv_destroy(mxv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graphs(h);
-    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->params_pe, h->st_actions, h->st_obs, h->st_final,
+    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->st_actions, h->st_obs, h->st_final,
                     h->st_reward, h->st_term, h->st_trunc, h->st_mask};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -442,6 +451,8 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         a.terminated = (uint8_t *)slice(terminated_dev, 1, k);
         a.truncated = (uint8_t *)slice(truncated_dev, 1, k);
         a.final_obs = (float *)slice(final_obs_dev, h->O * sizeof(float), k);
+        a.ep_return_out = (float *)slice(a.ep_return_out, sizeof(float), k);
+        a.ep_length_out = (int32_t *)slice(a.ep_length_out, sizeof(int32_t), k);
         return launch_step(h->cfg.env_id, h->param_mode(), a, h->stream);
     };
     if (mode == MXV_ROLLOUT_EAGER) {
@@ -522,6 +533,16 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     if (int rc = ensure_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
     MXV_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * h->action_bytes(), hipMemcpyHostToDevice, h->stream));
+    float *keep_r = h->ep_return_out;
+    int32_t *keep_l = h->ep_length_out;
+    if (h->ep_acc) {  // host callers read the statistics of this step with mxv_episode_stats_host()
+        h->ep_return_out = h->st_ep_r;
+        h->ep_length_out = h->st_ep_l;
+    }
+    struct Restore {
+        mxv_handle *h; float *r; int32_t *l;
+        ~Restore() { h->ep_return_out = r; h->ep_length_out = l; }
+    } restore{h, keep_r, keep_l};
     if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, reward_host ? h->st_reward : nullptr,
                          terminated_host ? h->st_term : nullptr, truncated_host ? h->st_trunc : nullptr,
                          final_obs_host ? h->st_final : nullptr))
@@ -637,6 +658,58 @@ int mxv_get_params_per_env(mxv_handle *h, double *params_host) {
     }
     if (int rc = use_device(h)) return rc;
     MXV_HIP(h, hipMemcpyAsync(params_host, h->params_pe, n * MXV_MAX_PARAMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_episode_stats(mxv_handle *h, int32_t enable) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (enable && !h->ep_acc) {
+        if (h->cfg.flags & MXV_FLAG_NO_AUTORESET)
+            return fail(h, MXV_ERR_UNSUPPORTED, "episode statistics need autoreset (episode length is the TimeLimit counter)");
+        MXV_HIP(h, hipMalloc((void **)&h->ep_acc, n * sizeof(float)));
+        MXV_HIP(h, hipMalloc((void **)&h->st_ep_r, n * sizeof(float)));
+        MXV_HIP(h, hipMalloc((void **)&h->st_ep_l, n * sizeof(int32_t)));
+        MXV_HIP(h, hipMemsetAsync(h->ep_acc, 0, n * sizeof(float), h->stream));
+        MXV_HIP(h, hipMemsetAsync(h->st_ep_r, 0, n * sizeof(float), h->stream));
+        MXV_HIP(h, hipMemsetAsync(h->st_ep_l, 0, n * sizeof(int32_t), h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+    } else if (!enable && h->ep_acc) {
+        MXV_HIP(h, hipFree(h->ep_acc));
+        MXV_HIP(h, hipFree(h->st_ep_r));
+        MXV_HIP(h, hipFree(h->st_ep_l));
+        h->ep_acc = nullptr;
+        h->st_ep_r = nullptr;
+        h->st_ep_l = nullptr;
+    }
+    return MXV_OK;
+}
+
+int mxv_set_episode_outputs(mxv_handle *h, float *ep_return_dev, int32_t *ep_length_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    free_graphs(h);  // captured kernel arguments hold the old pointers
+    h->ep_return_out = ep_return_dev;
+    h->ep_length_out = ep_length_dev;
+    return MXV_OK;
+}
+
+int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->ep_acc) return fail(h, MXV_ERR_INVALID_ARG, "episode statistics are not enabled (mxv_episode_stats)");
+    if (int rc = use_device(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (ep_return_host)
+        MXV_HIP(h, hipMemcpyAsync(ep_return_host, h->st_ep_r, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (ep_length_host)
+        MXV_HIP(h, hipMemcpyAsync(ep_length_host, h->st_ep_l, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (running_return_host)
+        MXV_HIP(h, hipMemcpyAsync(running_return_host, h->ep_acc, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     return MXV_OK;
 }

@@ -96,6 +96,9 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         el[j] = a.elapsed[ec];
         EV::prime(s[j], aux[j]);
     }
+    float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
+#pragma unroll
+    for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[valid[j] ? env_of(j) : 0] : 0.0f;
     __shared__ uint32_t sw[CONSEC ? 4 : TILE];
 
     const int nsteps = MULTI ? a.K : 1;  // MULTI = false: the plain step() launch, no loop-carried bookkeeping
@@ -177,6 +180,17 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = autoreset && (term[j] || trunc[j]);
         }
+        if (a.ep_acc != nullptr) {  // record_episode_statistics.py:119-143
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
+                if (valid[j] && (term[j] || trunc[j])) {
+                    if (a.ep_return_out) a.ep_return_out[so + env_of(j)] = er[j];
+                    if (a.ep_length_out) a.ep_length_out[so + env_of(j)] = el[j];
+                    er[j] = 0.0f;
+                }
+            }
+        }
 
         // ---- autoreset (sync_vector_env.py:152-156), compacted: every pass each lane resets its first
         // pending env, so a wave spends max-over-lanes(#finished) Philox calls, not E ----
@@ -244,6 +258,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + e] = s[j][k];
         a.elapsed[e] = el[j];
+        if (a.ep_acc) a.ep_acc[e] = er[j];
     }
 }
 
@@ -312,6 +327,11 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
         el[j] = a.elapsed[le[j]];
         EV::prime(s[j], aux[j]);
     }
+    float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
+#pragma unroll
+    for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[le[j]] : 0.0f;
+    float *p_epr = a.ep_return_out;
+    int32_t *p_epl = a.ep_length_out;
 
     // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
     int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
@@ -368,6 +388,17 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = valid[j] && (term[j] || trunc[j]);
+        }
+        if (a.ep_acc != nullptr) {  // record_episode_statistics.py:119-143
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
+                if (pend[j]) {
+                    if (p_epr) p_epr[le[j]] = er[j];
+                    if (p_epl) p_epl[le[j]] = el[j];
+                    er[j] = 0.0f;
+                }
+            }
         }
 
         // ---- compact the finished envs of the wave (sync_vector_env.py:152-156) ----
@@ -474,6 +505,8 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
         if (p_term != nullptr) p_term += slice;
         if (p_trunc != nullptr) p_trunc += slice;
         if (p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
+        if (p_epr != nullptr) p_epr += slice;
+        if (p_epl != nullptr) p_epl += slice;
     }
 
 #pragma unroll
@@ -482,6 +515,7 @@ __global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
         a.elapsed[le[j]] = el[j];
+        if (a.ep_acc) a.ep_acc[le[j]] = er[j];
     }
 }
 
@@ -500,6 +534,7 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
 #pragma unroll
     for (int k = 0; k < S; ++k) a.state[(int64_t)k * a.n + e] = s[k];
     a.elapsed[e] = 0;  // time_limit.py:67
+    if (a.ep_acc != nullptr) a.ep_acc[e] = 0.0f;  // record_episode_statistics.py:91-94
     if (a.obs != nullptr) {
         float o[O];
         double aux_unused[EV::AUX > 0 ? EV::AUX : 1];

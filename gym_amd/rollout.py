@@ -72,6 +72,7 @@ class DeviceRollout:
         """One vector step with caller-provided actions (device tensor of the engine's action dtype)."""
         assert actions.is_cuda and actions.dtype == self.action_dtype and actions.numel() == self.num_envs
         assert actions.is_contiguous()
+        self._attach_episode_outputs(None)
         self.handle.step(actions, self.obs, self.reward, self.terminated, self.truncated,
                          self.final_obs if want_final else None)
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
@@ -79,6 +80,7 @@ class DeviceRollout:
 
     def step_sampled(self, want_final: bool = False, record_actions: bool = True):
         """One vector step with actions drawn on device (action_space.sample())."""
+        self._attach_episode_outputs(None)
         self.handle.step_sampled(self.obs, self.reward, self.terminated, self.truncated,
                                  self.final_obs if want_final else None, self.actions if record_actions else None)
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
@@ -87,17 +89,40 @@ class DeviceRollout:
     def rollout(self, K: int, *, mode: str = "fused", record_actions: bool = False, want_final: bool = False):
         """K sampled steps back to back; the output tensors hold the last step ("final tensors" of the chunk).
         mode: "fused" (one launch, state in registers), "graph" (K launches from a hipGraph) or "eager"."""
+        self._attach_episode_outputs(None)
         self.handle.rollout(K, self.obs, self.reward, self.terminated, self.truncated,
                             self.final_obs if want_final else None, self.actions if record_actions else None,
                             per_step=False, mode=MODES[mode])
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
         return self._last
 
+    def enable_episode_stats(self):
+        """RecordEpisodeStatistics fused into the step kernels: `ep_return` (float32) / `ep_length` (int32) hold, where
+        terminated | truncated of a step is set, the return and length of the episode that ended there."""
+        self.handle.episode_stats(True)
+        self.episode_stats = True
+        with torch.cuda.stream(self.stream):
+            self.ep_return = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+            self.ep_length = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.stream.synchronize()
+        self.handle.set_episode_outputs(self.ep_return, self.ep_length)
+
+    def _attach_episode_outputs(self, out):
+        if getattr(self, "episode_stats", False):
+            tgt = (out["ep_return"], out["ep_length"]) if out is not None else (self.ep_return, self.ep_length)
+            if getattr(self, "_ep_attached", None) is not tgt[0]:
+                self.handle.set_episode_outputs(*tgt)
+                self._ep_attached = tgt[0]
+
     def trajectory_buffers(self, K: int):
         """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk)."""
         n, dev = self.num_envs, self.device
         with torch.cuda.stream(self.stream):
-            return dict(obs=torch.empty((K, n, self.O), dtype=torch.float32, device=dev),
+            extra = {}
+            if getattr(self, "episode_stats", False):
+                extra = dict(ep_return=torch.zeros((K, n), dtype=torch.float32, device=dev),
+                             ep_length=torch.zeros((K, n), dtype=torch.int32, device=dev))
+            return dict(**extra, obs=torch.empty((K, n, self.O), dtype=torch.float32, device=dev),
                         reward=torch.empty((K, n), dtype=self.reward_dtype, device=dev),
                         terminated=torch.empty((K, n), dtype=torch.uint8, device=dev),
                         truncated=torch.empty((K, n), dtype=torch.uint8, device=dev),
@@ -107,6 +132,7 @@ class DeviceRollout:
         """K sampled steps, every step's outputs kept in [K, N, ...] trajectory tensors (returned as a dict)."""
         out = self.trajectory_buffers(K) if out is None else out
         assert out["obs"].shape[0] >= K
+        self._attach_episode_outputs(out)
         self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], None,
                             out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
@@ -118,6 +144,7 @@ class DeviceRollout:
         assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self.action_dtype
         assert actions.numel() == K * self.num_envs
         out = self.trajectory_buffers(K) if out is None else out
+        self._attach_episode_outputs(out)
         self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"], None,
                                  per_step=True)
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])

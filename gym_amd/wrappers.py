@@ -1,0 +1,137 @@
+"""Vector-env wrappers of the reference that sit directly on the hot path, backed by the engine.
+
+`RecordEpisodeStatistics` mirrors gym.wrappers.RecordEpisodeStatistics (gym/wrappers/record_episode_statistics.py:40-151)
+for a HipVectorEnv: same attributes (`return_queue`, `length_queue`, `episode_count`, `episode_returns`,
+`episode_lengths`, `t0`) and the same `infos["episode"]` / `infos["_episode"]` layout (:10-37), but the cumulative
+returns and lengths are accumulated inside the step kernel (float32 returns exactly like the reference's np.float32
+accumulator; the length is the TimeLimit counter), so no Python loop over the N sub-envs runs per step.
+`VectorListInfo` mirrors gym.wrappers.VectorListInfo (gym/wrappers/vector_list_info.py:43-111).
+"""
+from __future__ import annotations
+
+import time
+from collections import deque
+from typing import List
+
+import numpy as np
+
+from .vector_env import HipVectorEnv, LazyInfos
+
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo"]
+
+
+class _VectorWrapper:
+    """gym.Wrapper surface for a vector env: attribute access falls through to the wrapped env (gym/core.py:227-243)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(f"accessing private attribute '{name}' is prohibited")
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return getattr(self.env, "unwrapped", self.env)
+
+    def step(self, actions):
+        return self.env.step(actions)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def close(self):
+        return self.env.close()
+
+    def __repr__(self):
+        return f"<{type(self).__name__}{self.env}>"
+
+
+class RecordEpisodeStatistics(_VectorWrapper):
+    def __init__(self, env: HipVectorEnv, deque_size: int = 100):
+        if not isinstance(env, HipVectorEnv):
+            raise TypeError("gym_amd.wrappers.RecordEpisodeStatistics wraps a HipVectorEnv (the statistics are "
+                            "accumulated by its engine)")
+        super().__init__(env)
+        self.num_envs = env.num_envs
+        self.is_vector_env = True
+        self.t0 = time.perf_counter()
+        self.episode_count = 0
+        self.return_queue = deque(maxlen=deque_size)
+        self.length_queue = deque(maxlen=deque_size)
+        self._enabled = False
+
+    # episode_returns / episode_lengths are None before the first reset (record_episode_statistics.py:89-90)
+    @property
+    def episode_returns(self):
+        if not self._enabled:
+            return None
+        return self.env.handle.episode_stats_host(want_running=True)[2]
+
+    @property
+    def episode_lengths(self):
+        if not self._enabled:
+            return None
+        return self.env.handle.get_state()[1].astype(np.int32)
+
+    def reset(self, **kwargs):
+        if not self._enabled:
+            self.env.handle.episode_stats(True)
+            self._enabled = True
+        return self.env.reset(**kwargs)  # the engine zeroes the accumulators of every env it resets (:91-94)
+
+    def step(self, action):
+        observations, rewards, terminateds, truncateds, infos = self.env.step(action)
+        assert isinstance(infos, dict), (f"`info` dtype is {type(infos)} while supported dtype is `dict`. This may be "
+                                         "due to usage of other wrappers in the wrong order.")
+        done = terminateds | truncateds
+        if done.any():
+            r, l = self.env.handle.episode_stats_host()
+            t = round(time.perf_counter() - self.t0, 6)
+            # add_vector_episode_statistics (:10-37): float64 arrays of length N, zero where no episode ended
+            episode = {"r": np.where(done, r, 0).astype(np.float64), "l": np.where(done, l, 0).astype(np.float64),
+                       "t": np.where(done, t, 0.0)}
+            if isinstance(infos, LazyInfos):
+                dict.__setitem__(infos, "episode", episode)
+                dict.__setitem__(infos, "_episode", done.copy())
+            else:
+                infos["episode"], infos["_episode"] = episode, done.copy()
+            idx = np.flatnonzero(done)
+            self.return_queue.extend(r[idx].tolist())
+            self.length_queue.extend(l[idx].tolist())
+            self.episode_count += int(idx.size)
+        return observations, rewards, terminateds, truncateds, infos
+
+
+class VectorListInfo(_VectorWrapper):
+    """Converts the dict-of-arrays infos of a vector env into a list of per-env dicts (vector_list_info.py:43-111)."""
+
+    def __init__(self, env):
+        assert getattr(env, "is_vector_env", False), "This wrapper can only be used in vectorized environments."
+        super().__init__(env)
+        self.num_envs = env.num_envs
+        self.is_vector_env = True
+
+    def step(self, action):
+        observation, reward, terminated, truncated, infos = self.env.step(action)
+        return observation, reward, terminated, truncated, self._convert_info_to_list(infos)
+
+    def reset(self, **kwargs):
+        obs, infos = self.env.reset(**kwargs)
+        return obs, self._convert_info_to_list(infos)
+
+    def _convert_info_to_list(self, infos: dict) -> List[dict]:
+        infos = dict(infos.items())
+        list_info = [{} for _ in range(self.num_envs)]
+        episode = infos.pop("episode", False)
+        if episode:
+            mask = infos.pop("_episode")
+            for i in np.flatnonzero(mask):
+                list_info[i]["episode"] = {k: episode[k][i] for k in ("r", "l", "t")}
+        for k in infos:
+            if k.startswith("_"):
+                continue
+            for i in np.flatnonzero(infos[f"_{k}"]):
+                list_info[i][k] = infos[k][i]
+        return list_info

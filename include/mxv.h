@@ -185,6 +185,21 @@ int mxv_set_params(mxv_handle *h, const double *params_host);
 int mxv_set_params_per_env(mxv_handle *h, const double *params_host);
 int mxv_get_params_per_env(mxv_handle *h, double *params_host);
 
+/* -- episode statistics: gym.wrappers.RecordEpisodeStatistics (gym/wrappers/record_episode_statistics.py:96-151) fused
+ *    into the step kernels: no extra pass over the step outputs ------------------------------------ */
+/* enable != 0: allocate the per-env running-return accumulators (float32, like the reference's np.float32 array;
+ * episode length is the TimeLimit counter) and zero them; they are zeroed again for every env an explicit reset
+ * touches (:91-94).  Needs autoreset.  enable == 0 frees them. */
+int mxv_episode_stats(mxv_handle *h, int32_t enable);
+/* Attach device output buffers used by every following mxv_step* / mxv_rollout* call: float32 returns and int32
+ * lengths, [N] (or [K][N] when the call is made with per_step != 0).  Entries are WRITTEN ONLY where
+ * terminated | truncated of that step is set (that flag pair is the "_episode" mask, :33-35); other entries keep
+ * their previous content.  Either pointer may be NULL. */
+int mxv_set_episode_outputs(mxv_handle *h, float *ep_return_dev, int32_t *ep_length_dev);
+/* Host view after mxv_step_host: returns / lengths of the episodes that ended in that step (valid where its
+ * terminated | truncated is set) and the running returns of all envs (episode_returns).  Any pointer may be NULL. */
+int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host);
+
 /* -- stream / sync -------------------------------------------------------------------------------- */
 /* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last
  * sync saw an out-of-range action (and clears the latch). */

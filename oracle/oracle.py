@@ -166,3 +166,28 @@ class OracleVecEnv:
                           _p(ai), _p(af), _p(obs), _p(reward), _p(term), _p(trunc), C.byref(sr), C.byref(nd))
         self.t += int(K)
         return sr.value, nd.value, obs, reward, term.astype(bool), trunc.astype(bool)
+
+
+class EpisodeStats:
+    """gym.wrappers.RecordEpisodeStatistics restated for a batched stream (gym/wrappers/record_episode_statistics.py:
+    89-151): float32 cumulative returns (`episode_returns += rewards` casts the float64 sum back to float32), int32
+    lengths, both zeroed where an episode ended.  Checked against the reference's own wrapper in tests/golden."""
+
+    def __init__(self, n: int):
+        self.returns = np.zeros(n, dtype=np.float32)   # :92
+        self.lengths = np.zeros(n, dtype=np.int32)     # :93
+
+    def reset(self):
+        self.returns[:] = 0
+        self.lengths[:] = 0
+
+    def step(self, rewards, terminated, truncated):
+        """-> (ep_return f32[N], ep_length i32[N], mask bool[N]); entries outside the mask are 0."""
+        self.returns += rewards                         # :119
+        self.lengths += 1                               # :120
+        done = np.asarray(terminated, dtype=bool) | np.asarray(truncated, dtype=bool)
+        r = np.where(done, self.returns, 0).astype(np.float32)
+        l = np.where(done, self.lengths, 0).astype(np.int32)
+        self.returns[done] = 0                          # :142
+        self.lengths[done] = 0                          # :143
+        return r, l, done

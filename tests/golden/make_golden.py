@@ -152,7 +152,9 @@ def make_p2(name, tag, T, max_episode_steps=None, num_envs=8, seed=123):
     venv = gym.vector.make(gid, num_envs=num_envs, asynchronous=False, **kwargs)
     limit = venv.envs[0]._max_episode_steps
     venv.action_space.seed(seed + 1)
-    obs0, _ = venv.reset(seed=seed)
+    # the reference's RecordEpisodeStatistics rides along (it does not alter the stream)
+    stats = gym.wrappers.RecordEpisodeStatistics(venv)
+    obs0, _ = stats.reset(seed=seed)
     N = num_envs
     rec = dict(
         state_pre=np.zeros((T, N, S)), elapsed_pre=np.zeros((T, N), np.int32),
@@ -161,6 +163,8 @@ def make_p2(name, tag, T, max_episode_steps=None, num_envs=8, seed=123):
         truncated=np.zeros((T, N), np.uint8), final_obs=np.zeros((T, N, O), np.float32),
         final_mask=np.zeros((T, N), np.uint8), state_post=np.zeros((T, N, S)),
         elapsed_post=np.zeros((T, N), np.int32),
+        ep_return=np.zeros((T, N), np.float32), ep_length=np.zeros((T, N), np.int32), ep_mask=np.zeros((T, N), np.uint8),
+        ep_running_return=np.zeros((T, N), np.float32),
     )
     for t in range(T):
         for i, e in enumerate(venv.envs):
@@ -169,7 +173,14 @@ def make_p2(name, tag, T, max_episode_steps=None, num_envs=8, seed=123):
         a = venv.action_space.sample()
         if not nd and t % 7 == 3:  # exercise the clip path inside real trajectories too
             a = (a * 2.5).astype(np.float32)
-        o, r, te, tr, infos = venv.step(a)
+        o, r, te, tr, infos = stats.step(a)
+        te, tr = np.asarray(te, dtype=bool), np.asarray(tr, dtype=bool)
+        if "episode" in infos:
+            rec["ep_mask"][t] = infos["_episode"]
+            rec["ep_return"][t] = infos["episode"]["r"]
+            rec["ep_length"][t] = infos["episode"]["l"]
+        assert np.array_equal(rec["ep_mask"][t].astype(bool), te | tr)
+        rec["ep_running_return"][t] = stats.episode_returns
         rec["action"][t] = a.reshape(N)
         rec["obs"][t], rec["reward"][t], rec["terminated"][t], rec["truncated"][t] = o, r, te, tr
         if "final_observation" in infos:
