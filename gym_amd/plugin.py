@@ -1,0 +1,52 @@
+"""Registration of the engine with the reference's registry (SURVEY.md §8b extension points (ii)-(iv), §8f-3).
+
+Three ways in, none of which touches the reference tree:
+
+  * explicit:      `import gym_amd.plugin; gym_amd.plugin.register_envs()`  then  `gym.make("hip/CartPole-v1", num_envs=4096)`
+  * import hook:   `gym.make("gym_amd.plugin:hip/CartPole-v1", num_envs=4096)` — gym imports this module first
+                   (gym/envs/registration.py:537-545) and importing it registers the ids
+  * entry point:   an installed distribution declares  [project.entry-points."gym.envs"]  hip = "gym_amd.plugin:register_envs"
+                   (pyproject.toml) and gym loads it at import (registration.py:266-309, gym/envs/__init__.py:5)
+
+The registered ids are `hip/<reference id>` for every id of gym_amd.registration.registry.  Their entry point returns
+a HipVectorEnv — a *vector* env — so the specs switch off everything gym.make would wrap around a single env:
+`order_enforce=False`, `disable_env_checker=True`, `max_episode_steps=None` (TimeLimit lives inside the kernels; pass
+`time_limit=` to change it, not gym.make's own `max_episode_steps=` which would add the single-env wrapper).
+"""
+from __future__ import annotations
+
+from .registration import registry
+
+NAMESPACE = "hip"
+
+
+def make_vector(id: str, num_envs: int = 1, time_limit=None, **kwargs):
+    """Entry point of the registered specs."""
+    from .vector_env import HipVectorEnv
+
+    if time_limit is not None:
+        kwargs["max_episode_steps"] = time_limit
+    return HipVectorEnv(id, num_envs, **kwargs)
+
+
+def register_envs(gym_module=None) -> list:
+    """Register `hip/<id>` for every supported id; returns the registered ids.  Safe to call twice."""
+    if gym_module is None:
+        import gym as gym_module  # the reference (or its successor) must be importable for this entry point
+    done = []
+    for env_id, spec in registry.items():
+        full = f"{NAMESPACE}/{env_id}"
+        if full not in gym_module.envs.registry:
+            gym_module.register(id=full, entry_point="gym_amd.plugin:make_vector", reward_threshold=spec.reward_threshold,
+                                max_episode_steps=None, order_enforce=False, disable_env_checker=True,
+                                kwargs={"id": env_id})
+        done.append(full)
+    return done
+
+
+try:  # the import hook path: importing this module is enough
+    import gym as _gym
+
+    register_envs(_gym)
+except Exception:  # gym not importable (the engine works without it)
+    pass

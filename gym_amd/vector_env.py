@@ -347,6 +347,11 @@ class HipVectorEnv(VectorEnv):
         if self.closed:
             raise error.ClosedEnvironmentError(f"Trying to operate on `{type(self).__name__}`, after a call to `close()`.")
 
+    @property
+    def unwrapped(self):
+        """gym.Env surface used by gym.make (`env.unwrapped.spec = ...`, gym/envs/registration.py:656)."""
+        return self
+
     # -- escape hatch for device-resident use ----------------------------------------------------------
     @property
     def handle(self) -> "_native.Handle":

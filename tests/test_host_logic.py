@@ -122,3 +122,23 @@ def test_vector_env_base_surface():
     assert v.single_observation_space is obs and not v.closed
     v.close()
     assert v.closed
+
+
+def test_plugin_registers_with_the_live_reference_registry():
+    """gym.register / import hook route gym.make to the engine's entry point."""
+    gym = _ref_gym()
+    from conftest import HAS_GPU
+    import gym_amd.plugin as plugin
+
+    ids = plugin.register_envs(gym)
+    assert "hip/CartPole-v1" in ids and len(ids) == len(registry)
+    s = gym.spec("hip/Pendulum-v1")
+    assert s.max_episode_steps is None and s.order_enforce is False and s.disable_env_checker is True
+    assert s.kwargs == {"id": "Pendulum-v1"} and s.namespace == "hip"
+    assert plugin.register_envs(gym) == ids  # idempotent
+    if not HAS_GPU:
+        from gym_amd import _native
+        for env_id in ("hip/CartPole-v1", "gym_amd.plugin:hip/Acrobot-v1"):  # plain id and module:id import hook
+            with pytest.raises(_native.MxvError) as ei:   # reached mxv_create: no device here, and no CPU fallback
+                gym.make(env_id, num_envs=8)
+            assert "no HIP device" in str(ei.value) or ei.value.code == _native.ERR_HIP
