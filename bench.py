@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="untimed device spin-up before the W warmup steps (DVFS: the GPU needs tens of ms of load to "
                          "reach its sustained clocks; a 2000-step run is 13 ms); 0 disables; reported in config")
+    ap.add_argument("--compact-outputs", action="store_true",
+                    help="float32 rewards + int32 actions (MXV_FLAG_REWARD_F32|ACTION_I32: 26 real bytes per env-step "
+                         "instead of 34); off by default: the headline keeps the reference's float64 / int64 dtypes")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -119,7 +122,7 @@ def main():
 
     total_envs = ENVS_PER_GPU * world
     sr = ShardedRollout(ENV_ID, total_envs, rank=rank, world_size=world, device=local_rank, seed=0, action_seed=1,
-                        reward_f32=False)
+                        reward_f32=args.compact_outputs, action_i32=args.compact_outputs)
     eng = sr.engine
     mode = "eager" if args.no_graph else args.mode
     sr.reset(seed=0)
@@ -200,7 +203,9 @@ def main():
                 "num_envs_per_gpu": ENVS_PER_GPU,
                 "launch": {"fused": f"fused: 1 launch per {args.chunk}-step chunk, env state in registers",
                            "graph": "1 launch per step, hipGraph replay", "eager": "1 launch per step, eager"}[mode],
-                "outputs": "per-step obs/reward/terminated/truncated/actions written to [chunk][N] trajectory tensors",
+                "outputs": "per-step obs/reward/terminated/truncated/actions written to [chunk][N] trajectory tensors"
+                           + (" (float32 rewards, int32 actions)" if args.compact_outputs else
+                              " (float64 rewards, int64 actions: the reference's dtypes)"),
                 "chunk": args.chunk,
                 "spinup": f"{spin_steps} untimed steps ({args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps (clock ramp)",
                 "parallelism": f"env-shard x{world}" + (", async RCCL all-gather of final tensors per chunk" if world > 1 else ""),
@@ -212,7 +217,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": read_traffic(mode, args.chunk),
+                "traffic": None if args.compact_outputs else read_traffic(mode, args.chunk),
                 "algorithmic_bytes_per_env_step": b_env_step,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "env_steps_per_launch": ENVS_PER_GPU * steps_per_launch,

@@ -138,6 +138,23 @@ int main() {
         });
         printf("%-44s %6.2f us/step  %6.1f GB/s\n", "E2 B256 one launch per step (K launches)", ms * 1e3 / K, 34.0 * n * K / ms / 1e6);
     }
+    {   // row pitch / base offset experiment (partition camping?): XCD-contiguous tiles, 1-wave workgroups like rollout_kernel
+        const unsigned grid = (unsigned)(n / (2 * 64));
+        for (int64_t padenv : {0ll, 64ll, 1024ll, 4096ll + 64, 65536ll + 1024}) {
+            for (int stagger = 0; stagger < 2; ++stagger) {
+                const int64_t pitch = n + padenv;
+                // pitch-aware variant: reuse traj_write with n := pitch for the row stride (tiles still cover n envs)
+                float4 *o = obs + (stagger ? 3 * 4096 / 16 : 0);
+                double *r = rew + (stagger ? 5 * 4096 / 8 + 17 * 64 : 0);
+                int64_t *a = act + (stagger ? 9 * 4096 / 8 + 33 * 64 : 0);
+                uint8_t *te = term + (stagger ? 13 * 4096 + 49 * 512 : 0), *tr = trunc + (stagger ? 21 * 4096 + 77 * 512 : 0);
+                const int Kp = 56;  // fewer rows so that padded rows still fit the allocations
+                float ms = time_ms([&] { traj_write<2, 64, double, int64_t, false, 0, 1><<<grid, 64>>>(o, r, a, te, tr, pitch, Kp); });
+                printf("E2 B64 XCD pitch=N+%-6lld stagger=%d          %6.2f us/step  %6.1f GB/s\n", (long long)padenv, stagger,
+                       ms * 1e3 / Kp, 34.0 * n * Kp / ms / 1e6);
+            }
+        }
+    }
     RUN(2, 256, double, int64_t, true, 0, "E2 B256 f64/i64 bytes nontemporal");
     RUN(2, 256, double, int64_t, false, 1, "E2 B256 f64/i64 packed-flag dwords");
     RUN(2, 256, double, int64_t, true, 1, "E2 B256 f64/i64 packed-flag dwords nt");
