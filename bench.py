@@ -84,9 +84,11 @@ def read_traffic(mode: str, chunk: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--chunk", type=int, default=100, help="steps per launch batch / per all-gather")
+    ap.add_argument("--steps", type=int, default=20480)
+    ap.add_argument("--warmup", type=int, default=2048)
+    ap.add_argument("--chunk", type=int, default=256,
+                    help="steps per fused launch = rollout length between all-gathers of the final tensors (a typical "
+                         "on-policy horizon; 9.3 GB of trajectory tensors at 2^20 envs)")
     ap.add_argument("--mode", default="fused", choices=["fused", "graph", "eager"],
                     help="fused: one launch per chunk, env state in registers; graph/eager: one launch per step")
     ap.add_argument("--no-graph", action="store_true", help="alias of --mode eager")

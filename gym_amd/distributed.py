@@ -28,6 +28,44 @@ def partition(total_envs: int, world_size: int, rank: int, align: int = 4):
     return rank * local, local
 
 
+class GatheredOutputs:
+    """Result of one packed all-gather.  `shards(i)` are zero-copy views into the receive buffer (one per rank, in
+    rank = global-env-index order); `obs / reward / terminated / truncated` (and tuple unpacking) concatenate them
+    into the full (N_total, ...) tensors that np.stack yields in the reference — an HBM-local copy made on first
+    use only.  Valid until the owner's next gather_async()."""
+
+    names = ("obs", "reward", "terminated", "truncated")
+
+    def __init__(self, owner: "ShardedRollout"):
+        self._o = owner
+        self._full = {}
+
+    def shards(self, i: int):
+        o = self._o
+        off, nb, dt, shape = o._layout[i]
+        return [o._recv[r, off:off + nb].view(dt).view(shape) for r in range(o.world_size)]
+
+    def full(self, i: int) -> torch.Tensor:
+        if i not in self._full:
+            with self._o._stream_ctx():
+                self._full[i] = torch.cat(self.shards(i), dim=0)
+        return self._full[i]
+
+    obs = property(lambda self: self.full(0))
+    reward = property(lambda self: self.full(1))
+    terminated = property(lambda self: self.full(2))
+    truncated = property(lambda self: self.full(3))
+
+    def __iter__(self):
+        return iter(self.full(i) for i in range(4))
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return self.full(range(4)[i])
+
+
 class ShardedRollout:
     """engine_factory(id, num_envs, env_offset=..., seed=..., action_seed=..., **kw) must return an object with
     .reset(seed), .rollout(K, ...), .rollout_per_step(K, ...), .final_tensors() -> (obs, reward, terminated,
@@ -73,11 +111,23 @@ class ShardedRollout:
         return self.engine.rollout_per_step(K, **kw)
 
     def _buffers(self):
+        """One packed send buffer (this rank's snapshot of obs | reward | terminated | truncated, every section
+        aligned to 256 B) and one [world][bytes] receive buffer: the four logical gathers travel as ONE RCCL
+        all-gather (one launch, one large message per peer instead of four, two of them tiny)."""
         if self._send is None:
+            finals = self.engine.final_tensors()
+            self._layout = []
+            off = 0
+            for t in finals:
+                nbytes = t.numel() * t.element_size()
+                self._layout.append((off, nbytes, t.dtype, tuple(t.shape)))
+                off = (off + nbytes + 255) // 256 * 256
+            self._shard_bytes = off
             with self._stream_ctx():
-                self._send = [torch.empty_like(t) for t in self.engine.final_tensors()]
-                self._recv = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
-                                          device=t.device) for t in self._send]
+                dev = finals[0].device
+                self._send = torch.empty(off, dtype=torch.uint8, device=dev)
+                self._recv = torch.empty((self.world_size, off), dtype=torch.uint8, device=dev)
+            self._send_views = [self._send[o:o + nb].view(dt).view(shape) for o, nb, dt, shape in self._layout]
         return self._send, self._recv
 
     def gather_async(self):
@@ -85,25 +135,24 @@ class ShardedRollout:
         self.wait_gather()
         send, recv = self._buffers()
         with self._stream_ctx():
-            for dst, src in zip(send, self.engine.final_tensors()):
+            for dst, src in zip(self._send_views, self.engine.final_tensors()):
                 dst.copy_(src, non_blocking=True)
             if self.world_size == 1:
-                for r, s in zip(recv, send):
-                    r.copy_(s, non_blocking=True)
+                recv.view(-1).copy_(send, non_blocking=True)
                 self._pending = []
             else:
-                self._pending = [dist.all_gather_into_tensor(r, s, group=self.group, async_op=True)
-                                 for r, s in zip(recv, send)]
+                self._pending = [dist.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)]
 
     def wait_gather(self):
-        """Full (N_total, ...) obs / reward / terminated / truncated of the last gather_async, or None."""
+        """GatheredOutputs of the last gather_async (unpacks to the full (N_total, ...) obs / reward / terminated /
+        truncated), or None."""
         if self._pending is None:
             return None
         with self._stream_ctx():
             for w in self._pending:
                 w.wait()
         self._pending = None
-        return tuple(self._recv)
+        return GatheredOutputs(self)
 
     def gather(self):
         self.gather_async()
