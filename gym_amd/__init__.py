@@ -17,6 +17,9 @@ _LAZY = {
     "MixedRollout": ("gym_amd.mixed", "MixedRollout"),
     "RecordEpisodeStatistics": ("gym_amd.wrappers", "RecordEpisodeStatistics"),
     "VectorListInfo": ("gym_amd.wrappers", "VectorListInfo"),
+    "NormalizeObservation": ("gym_amd.wrappers", "NormalizeObservation"),
+    "NormalizeReward": ("gym_amd.wrappers", "NormalizeReward"),
+    "RunningNormalizer": ("gym_amd.normalize", "RunningNormalizer"),
 }
 
 

@@ -35,6 +35,9 @@ EXPORTS = (
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
+    "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
+    "mxv_norm_reward_sums", "mxv_norm_reward_apply",
 )
 
 
@@ -98,6 +101,18 @@ def _load():
         "mxv_sync": ([vp], C.c_int),
         "mxv_get_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_set_stream": ([vp, vp], C.c_int),
+        "mxv_norm_create": ([i32, i32, i64, vp, C.POINTER(vp)], C.c_int),
+        "mxv_norm_destroy": ([vp], C.c_int),
+        "mxv_norm_last_error": ([vp], C.c_char_p),
+        "mxv_norm_set_stream": ([vp, vp], C.c_int),
+        "mxv_norm_get_state": ([vp, vp, vp, vp, vp], C.c_int),
+        "mxv_norm_set_state": ([vp, vp, vp, C.c_double, vp], C.c_int),
+        "mxv_norm_observations": ([vp, i32, vp, vp, i32, C.c_double], C.c_int),
+        "mxv_norm_rewards": ([vp, i32, vp, i32, vp, vp, vp, C.c_double, C.c_double], C.c_int),
+        "mxv_norm_obs_sums": ([vp, i32, vp, vp], C.c_int),
+        "mxv_norm_obs_apply": ([vp, i32, vp, vp, i32, C.c_double, vp, i32, i64], C.c_int),
+        "mxv_norm_reward_sums": ([vp, i32, vp, i32, vp, vp, C.c_double, vp], C.c_int),
+        "mxv_norm_reward_apply": ([vp, i32, vp, i32, vp, C.c_double, vp, i32, i64], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the .so does not export a declared symbol
@@ -324,3 +339,70 @@ class Handle:
 
     def set_stream(self, stream_ptr: int):
         self._check(lib.mxv_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+
+class Norm:
+    """One mxv_norm = one device-resident RunningMeanStd (+ NormalizeReward's return accumulators); see include/mxv.h."""
+
+    def __init__(self, dim: int, num_envs: int, *, device: int = 0, stream: int = 0):
+        self.dim, self.num_envs, self.device = int(dim), int(num_envs), int(device)
+        h = C.c_void_p()
+        rc = lib.mxv_norm_create(self.device, self.dim, self.num_envs, C.c_void_p(stream or None), C.byref(h))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_norm_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_norm_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.mxv_norm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        self._check(lib.mxv_norm_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def get_state(self, want_returns: bool = False):
+        """(mean[dim], var[dim], count[, returns[num_envs]]) as float64 host values."""
+        mean = np.zeros(self.dim, np.float64)
+        var = np.zeros(self.dim, np.float64)
+        count = C.c_double()
+        ret = np.zeros(self.num_envs, np.float64) if want_returns else None
+        self._check(lib.mxv_norm_get_state(self._h, mean.ctypes.data, var.ctypes.data, C.addressof(count), _ptr(ret)))
+        return (mean, var, count.value, ret) if want_returns else (mean, var, count.value)
+
+    def set_state(self, mean, var, count: float, returns=None):
+        m = np.ascontiguousarray(mean, dtype=np.float64).reshape(self.dim)
+        v = np.ascontiguousarray(var, dtype=np.float64).reshape(self.dim)
+        r = None if returns is None else np.ascontiguousarray(returns, dtype=np.float64).reshape(self.num_envs)
+        self._check(lib.mxv_norm_set_state(self._h, m.ctypes.data, v.ctypes.data, float(count), _ptr(r)))
+
+    def observations(self, K, x_dev, y_dev, out_f32: bool, epsilon: float):
+        self._check(lib.mxv_norm_observations(self._h, int(K), _ptr(x_dev), _ptr(y_dev), int(out_f32), float(epsilon)))
+
+    def rewards(self, K, reward_dev, reward_f32: bool, terminated_dev, truncated_dev, out_dev, gamma: float, epsilon: float):
+        self._check(lib.mxv_norm_rewards(self._h, int(K), _ptr(reward_dev), int(reward_f32), _ptr(terminated_dev),
+                                         _ptr(truncated_dev), _ptr(out_dev), float(gamma), float(epsilon)))
+
+    def obs_sums(self, K, x_dev, sums_dev):
+        self._check(lib.mxv_norm_obs_sums(self._h, int(K), _ptr(x_dev), _ptr(sums_dev)))
+
+    def obs_apply(self, K, x_dev, y_dev, out_f32: bool, epsilon: float, all_sums_dev, world: int, total_rows: int):
+        self._check(lib.mxv_norm_obs_apply(self._h, int(K), _ptr(x_dev), _ptr(y_dev), int(out_f32), float(epsilon),
+                                           _ptr(all_sums_dev), int(world), int(total_rows)))
+
+    def reward_sums(self, K, reward_dev, reward_f32: bool, terminated_dev, truncated_dev, gamma: float, sums_dev):
+        self._check(lib.mxv_norm_reward_sums(self._h, int(K), _ptr(reward_dev), int(reward_f32), _ptr(terminated_dev),
+                                             _ptr(truncated_dev), float(gamma), _ptr(sums_dev)))
+
+    def reward_apply(self, K, reward_dev, reward_f32: bool, out_dev, epsilon: float, all_sums_dev, world: int, total_rows: int):
+        self._check(lib.mxv_norm_reward_apply(self._h, int(K), _ptr(reward_dev), int(reward_f32), _ptr(out_dev),
+                                              float(epsilon), _ptr(all_sums_dev), int(world), int(total_rows)))

@@ -9,6 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result ${MXV_EXTRA_FLAGS:-})
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_kernels.hip" -o "$out/mxv_kernels.o" &
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_api.cpp" -o "$out/mxv_api.o" &
+"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_norm.hip" -o "$out/mxv_norm.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o" "$out/mxv_norm.o"
 echo "built $out/libmxv.so"

@@ -1,0 +1,566 @@
+// mxv_norm.hip — SURVEY.md §8(f)-2: gym.wrappers.NormalizeObservation / NormalizeReward
+// (gym/wrappers/normalize.py:8-145) for a vector env, as gfx950 kernels behind the mxv_norm_* C ABI (include/mxv.h).
+//
+// The reference normalises one batch per step() call: RunningMeanStd.update(batch) (:17-29, a Chan/Welford merge of
+// the batch mean/var into the running mean/var, :32-47) followed by an element-wise affine map (:90-93, :143-145).
+// The batch moments are the only cross-env reduction on the whole hot path.  Here a chunk of K consecutive batches
+// ([K][N][O] trajectory tensors written by mxv_rollout) is processed by four launches, all HBM-streaming:
+//
+//   1. *_sums_kernel     per step k and per leaf (4096 rows of observations / 256 envs of returns): fp64 sum and sum of
+//                        squares of every column.  NormalizeReward's discounted-return recurrence (:132,:136) runs here
+//                        too, one env per lane, K steps sequentially, so the returns never touch HBM.
+//   2. tree_kernel       fixed binary tree over the leaves (by leaf index) -> per-step sums of this shard.  A fixed tree
+//                        makes the result independent of scheduling AND of how a logical vector env is sharded over
+//                        1/2/4/8 GPUs (power-of-two shards of >= 4096 rows are complete subtrees of the same tree).
+//   3. scan_kernel       one thread per column walks the K steps: combines the shards' sums (tree over ranks), forms the
+//                        batch mean/var IN THE REFERENCE'S MOMENT DTYPE (float32 for observations — np.mean/np.var of a
+//                        float32 array — float64 for returns), applies update_mean_var_count_from_moments in source
+//                        order, and emits (mean_k, sqrt(var_k + epsilon)) per step.
+//   4. *_apply_kernel    y = (x - mean_k) / denom_k  resp.  r / denom_k, IEEE fp64 subtraction and division as in the
+//                        reference (float32 - float64 -> float64).
+//
+// Numerics: sums are exact-order fp64 (no atomics), so results are bit-reproducible; they differ from the reference only
+// by the float32 accumulation error the reference's own np.mean/np.var carry (the test suite's CPU restatement has both
+// arithmetics: the reference's, pinned bit-exact by goldens generated from the live wrappers, and this definition).
+// Built with -ffp-contract=off like the rest of the engine: explicit __fma_rn only where the product is exact anyway.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mxv.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kObsLeafRows = 4096;  // rows of observations per leaf of the sum tree
+constexpr int kRewLeafEnvs = 256;   // envs per leaf of the return-sum tree (one wave64, 4 envs per lane)
+constexpr int kTreeFan = 1024;      // leaves folded per workgroup per tree level (a complete 10-level subtree)
+constexpr int kMaxWorld = 64;
+
+__device__ __forceinline__ double wave_tree_sum(double v) {
+    // xor butterfly = the binary tree over lane index (addition is commutative, so every lane holds the tree's value)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int O>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, float (&f)[O]) {
+    if constexpr (O == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else if constexpr (O == 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(p);
+        f[0] = v.x; f[1] = v.y;
+    } else if constexpr (O == 6) {
+        const float2 a = reinterpret_cast<const float2 *>(p)[0], b = reinterpret_cast<const float2 *>(p)[1],
+                     c = reinterpret_cast<const float2 *>(p)[2];
+        f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < O; ++j) f[j] = p[j];
+    }
+}
+
+// ---- 1a. observations: per-(step, leaf) column sums ---------------------------------------------------------------
+// grid (leaves, K); partials [K][leaves][2*O] = (sum_0..sum_{O-1}, sumsq_0..sumsq_{O-1}).
+template <int O>
+__global__ void __launch_bounds__(kThreads) obs_sums_kernel(const float *__restrict__ x, int64_t n, int64_t leaves,
+                                                            double *__restrict__ partials) {
+    const int tid = threadIdx.x;
+    const int64_t k = blockIdx.y, leaf = blockIdx.x;
+    const int64_t row0 = leaf * kObsLeafRows;
+    const int rows = (int)((n - row0) < kObsLeafRows ? (n - row0) : kObsLeafRows);
+    const float *__restrict__ base = x + (k * n + row0) * O;
+    double s[O], q[O];
+#pragma unroll
+    for (int j = 0; j < O; ++j) s[j] = q[j] = 0.0;
+    // a lane's rows are tid, tid+256, ...: every wave load is a dense burst (64 rows x 4*O bytes)
+#pragma unroll 4
+    for (int r = tid; r < rows; r += kThreads) {
+        float f[O];
+        load_row<O>(base + (int64_t)r * O, f);
+#pragma unroll
+        for (int j = 0; j < O; ++j) {
+            const double v = (double)f[j];
+            s[j] += v;
+            q[j] = __fma_rn(v, v, q[j]);  // v*v is exact in fp64 (24-bit significands): one rounding, as mul+add would give
+        }
+    }
+    __shared__ double sm[kThreads / 64][2 * O];
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < O; ++j) {
+        const double a = wave_tree_sum(s[j]), b = wave_tree_sum(q[j]);
+        if (lane == 0) {
+            sm[wave][j] = a;
+            sm[wave][O + j] = b;
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * O)
+        partials[(k * leaves + leaf) * (2 * O) + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+}
+
+// ---- 1b. rewards: discounted-return recurrence + per-(step, leaf) sums ----------------------------------------------
+// One wave per workgroup, leaf = 256 consecutive envs, lane L owns envs leaf*256 + j*64 + L (j < 4): dense 512-B
+// bursts of rewards, 64-B bursts of flags.  partials [K][leaves][2] = (sum, sumsq) of the returns AFTER the update of
+// step k and BEFORE the zeroing of finished envs (normalize.py:132-136).
+template <typename RT>
+__global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__ rew, const uint8_t *__restrict__ term,
+                                                          const uint8_t *__restrict__ trunc, double *__restrict__ returns,
+                                                          int64_t n, int K, double gamma, int64_t leaves,
+                                                          double *__restrict__ partials) {
+    const int lane = threadIdx.x;
+    const int64_t leaf = blockIdx.x;
+    int64_t e[4];
+    bool live[4];
+    double ret[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        e[j] = leaf * kRewLeafEnvs + j * 64 + lane;
+        live[j] = e[j] < n;
+        ret[j] = live[j] ? returns[e[j]] : 0.0;
+    }
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        const int64_t off = (int64_t)k * n;
+        double s = 0.0, q = 0.0;
+        bool done[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double r = 0.0;
+            done[j] = false;
+            if (live[j]) {
+                r = (double)rew[off + e[j]];
+                done[j] = (term[off + e[j]] | trunc[off + e[j]]) != 0;
+                ret[j] = ret[j] * gamma + r;  // :132 (two roundings; contraction is off)
+                s += ret[j];
+                q = __fma_rn(ret[j], ret[j], q);
+            }
+        }
+        s = wave_tree_sum(s);
+        q = wave_tree_sum(q);
+        if (lane == 0) {
+            partials[((int64_t)k * leaves + leaf) * 2 + 0] = s;
+            partials[((int64_t)k * leaves + leaf) * 2 + 1] = q;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (done[j]) ret[j] = 0.0;  // :135-136
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (live[j]) returns[e[j]] = ret[j];
+}
+
+// ---- 2. one level of the fixed binary tree: in [K][leaves][V] -> out [K][ceil(leaves/1024)][V] ------------------------
+// Missing leaves count as +0.0 (x + 0.0 == x): an odd leftover passes through unchanged, as a pairwise tree does.
+__global__ void __launch_bounds__(kThreads) tree_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                        int64_t leaves, int V) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t k = blockIdx.y, group = blockIdx.x, groups = gridDim.x;
+    const int64_t l0 = group * kTreeFan + (int64_t)tid * 4;
+    __shared__ double sm[kThreads / 64];
+    for (int v = 0; v < V; ++v) {
+        double a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = (l0 + i < leaves) ? in[(k * leaves + l0 + i) * V + v] : 0.0;
+        double t = wave_tree_sum((a[0] + a[1]) + (a[2] + a[3]));
+        if (lane == 0) sm[wave] = t;
+        __syncthreads();
+        if (tid == 0) out[(k * groups + group) * V + v] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        __syncthreads();
+    }
+}
+
+// ---- 3. the running update, sequential over the K steps (normalize.py:17-47) ------------------------------------------
+// all_sums [W][K][2*O]; stat = mean[O], var[O], count; coef [K][O][2] = (mean_k, sqrt(var_k + epsilon)).
+__global__ void scan_kernel(const double *__restrict__ all_sums, int W, int K, int O, double total_rows, double epsilon,
+                            int obs_dtype_f32, double *__restrict__ stat, double *__restrict__ coef) {
+    const int j = threadIdx.x;
+    if (j >= O) return;
+    double mean = stat[j], var = stat[O + j], count = stat[2 * O];
+    const double N = total_rows;
+    for (int k = 0; k < K; ++k) {
+        double bs[kMaxWorld], bq[kMaxWorld];
+        for (int w = 0; w < W; ++w) {
+            bs[w] = all_sums[((int64_t)w * K + k) * (2 * O) + j];
+            bq[w] = all_sums[((int64_t)w * K + k) * (2 * O) + O + j];
+        }
+        for (int stride = 1; stride < W; stride <<= 1)  // binary tree over the rank index
+            for (int w = 0; w + stride < W; w += 2 * stride) {
+                bs[w] += bs[w + stride];
+                bq[w] += bq[w + stride];
+            }
+        const double S = bs[0], Q = bq[0];
+        double batch_mean, m_b;
+        if (obs_dtype_f32) {
+            // np.mean / np.var of a float32 array are float32 (the division itself runs in double: _methods.py _mean/_var);
+            // var = mean((x - mean32)^2) expanded over the exact sums
+            const float mean32 = (float)(S / N);
+            const double m = (double)mean32;
+            double v = ((Q - 2.0 * m * S) + N * m * m) / N;
+            v = v > 0.0 ? v : 0.0;
+            const float var32 = (float)v;
+            batch_mean = m;
+            m_b = (double)__fmul_rn(var32, (float)N);  // float32 array * python int stays float32 (:41)
+        } else {
+            batch_mean = S / N;
+            double v = Q / N - batch_mean * batch_mean;
+            v = v > 0.0 ? v : 0.0;
+            m_b = v * N;
+        }
+        const double delta = batch_mean - mean;                                  // :36
+        const double tot = count + N;                                            // :37
+        const double new_mean = mean + delta * N / tot;                          // :39
+        const double m_a = var * count;                                          // :40
+        const double M2 = m_a + m_b + delta * delta * count * N / tot;           // :42
+        mean = new_mean;
+        var = M2 / tot;                                                          // :43
+        count = tot;                                                             // :44
+        coef[((int64_t)k * O + j) * 2 + 0] = mean;
+        coef[((int64_t)k * O + j) * 2 + 1] = sqrt(var + epsilon);                // np.sqrt(var + epsilon), :93 / :145
+    }
+    stat[j] = mean;
+    stat[O + j] = var;
+    if (j == 0) stat[2 * O] = count;
+}
+
+// ---- 4a. (obs - mean) / sqrt(var + epsilon): one row per lane, grid (ceil(N/256), K) -----------------------------------
+template <int O, typename OUT>
+__global__ void __launch_bounds__(kThreads) obs_apply_kernel(const float *__restrict__ x, OUT *__restrict__ y,
+                                                             const double *__restrict__ coef, int64_t n) {
+    const int64_t k = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (row >= n) return;
+    const double *__restrict__ c = coef + k * O * 2;  // uniform per workgroup: scalar loads
+    float f[O];
+    load_row<O>(x + (k * n + row) * O, f);
+    OUT o[O];
+#pragma unroll
+    for (int j = 0; j < O; ++j) o[j] = (OUT)(((double)f[j] - c[2 * j]) / c[2 * j + 1]);
+    OUT *__restrict__ dst = y + (k * n + row) * O;
+    if constexpr (O == 4 && sizeof(OUT) == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (O % 2 == 0 && sizeof(OUT) == 8) {
+#pragma unroll
+        for (int j = 0; j < O; j += 2) reinterpret_cast<double2 *>(dst)[j / 2] = make_double2(o[j], o[j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < O; ++j) dst[j] = o[j];
+    }
+}
+
+// ---- 4b. rews / sqrt(var + epsilon) -------------------------------------------------------------------------------------
+template <typename RT>
+__global__ void __launch_bounds__(kThreads) reward_apply_kernel(const RT *__restrict__ rew, RT *__restrict__ out,
+                                                                const double *__restrict__ coef, int64_t n) {
+    const int64_t k = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    out[k * n + i] = (RT)((double)rew[k * n + i] / coef[k * 2 + 1]);
+}
+
+}  // namespace
+
+struct mxv_norm {
+    int device = 0, dim = 0;
+    int64_t n = 0;
+    hipStream_t stream = nullptr;
+    double *stat = nullptr;     // mean[dim], var[dim], count
+    double *returns = nullptr;  // [n] discounted returns of NormalizeReward (zeros until used)
+    double *part_a = nullptr, *part_b = nullptr;  // ping-pong scratch of the sum tree
+    size_t part_cap = 0;        // doubles per scratch buffer
+    double *sums = nullptr;     // [K][2*dim] sums of this shard
+    double *coef = nullptr;     // [K][dim][2]
+    size_t k_cap = 0;
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_norm_create_error;
+
+int nfail(mxv_norm *nm, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (nm)
+        nm->error = buf;
+    else
+        g_norm_create_error = buf;
+    return code;
+}
+
+#define NRM_HIP(nm, expr)                                                                               \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return nfail((nm), MXV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+bool dim_supported(int d) { return d == 1 || d == 2 || d == 3 || d == 4 || d == 6; }
+
+int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int ensure_capacity(mxv_norm *nm, int K, int64_t leaves, int V) {
+    const size_t need = (size_t)K * (size_t)leaves * (size_t)V;
+    if (need > nm->part_cap) {
+        NRM_HIP(nm, hipStreamSynchronize(nm->stream));
+        if (nm->part_a) NRM_HIP(nm, hipFree(nm->part_a));
+        if (nm->part_b) NRM_HIP(nm, hipFree(nm->part_b));
+        nm->part_a = nm->part_b = nullptr;
+        NRM_HIP(nm, hipMalloc((void **)&nm->part_a, need * sizeof(double)));
+        NRM_HIP(nm, hipMalloc((void **)&nm->part_b, need * sizeof(double)));
+        nm->part_cap = need;
+    }
+    if ((size_t)K > nm->k_cap) {
+        NRM_HIP(nm, hipStreamSynchronize(nm->stream));
+        if (nm->sums) NRM_HIP(nm, hipFree(nm->sums));
+        if (nm->coef) NRM_HIP(nm, hipFree(nm->coef));
+        nm->sums = nm->coef = nullptr;
+        NRM_HIP(nm, hipMalloc((void **)&nm->sums, (size_t)K * 2 * nm->dim * sizeof(double)));
+        NRM_HIP(nm, hipMalloc((void **)&nm->coef, (size_t)K * 2 * nm->dim * sizeof(double)));
+        nm->k_cap = (size_t)K;
+    }
+    return MXV_OK;
+}
+
+// folds partials [K][leaves][V] (in part_a) down to [K][V] written to dst (device)
+int run_tree(mxv_norm *nm, int K, int64_t leaves, int V, double *dst) {
+    double *in = nm->part_a, *out = nm->part_b;
+    while (true) {
+        const int64_t groups = ceil_div(leaves, kTreeFan);
+        double *target = groups == 1 ? dst : out;
+        hipLaunchKernelGGL(tree_kernel, dim3((unsigned)groups, (unsigned)K), dim3(kThreads), 0, nm->stream, in, target, leaves, V);
+        NRM_HIP(nm, hipGetLastError());
+        if (groups == 1) break;
+        leaves = groups;
+        double *t = in;
+        in = out;
+        out = t;
+    }
+    return MXV_OK;
+}
+
+template <int O>
+int launch_obs_sums(mxv_norm *nm, int K, const float *x, int64_t leaves) {
+    hipLaunchKernelGGL(obs_sums_kernel<O>, dim3((unsigned)leaves, (unsigned)K), dim3(kThreads), 0, nm->stream, x, nm->n,
+                       leaves, nm->part_a);
+    NRM_HIP(nm, hipGetLastError());
+    return MXV_OK;
+}
+
+template <int O>
+int launch_obs_apply(mxv_norm *nm, int K, const float *x, void *y, int out_f32) {
+    const dim3 grid((unsigned)ceil_div(nm->n, kThreads), (unsigned)K);
+    if (out_f32)
+        hipLaunchKernelGGL((obs_apply_kernel<O, float>), grid, dim3(kThreads), 0, nm->stream, x, (float *)y, nm->coef, nm->n);
+    else
+        hipLaunchKernelGGL((obs_apply_kernel<O, double>), grid, dim3(kThreads), 0, nm->stream, x, (double *)y, nm->coef, nm->n);
+    NRM_HIP(nm, hipGetLastError());
+    return MXV_OK;
+}
+
+#define DISPATCH_DIM(nm, fn, ...)                                                   \
+    switch ((nm)->dim) {                                                            \
+        case 1: return fn<1>(__VA_ARGS__);                                          \
+        case 2: return fn<2>(__VA_ARGS__);                                          \
+        case 3: return fn<3>(__VA_ARGS__);                                          \
+        case 4: return fn<4>(__VA_ARGS__);                                          \
+        case 6: return fn<6>(__VA_ARGS__);                                          \
+        default: return nfail((nm), MXV_ERR_UNSUPPORTED, "dim %d", (nm)->dim);      \
+    }
+
+int dispatch_obs_sums(mxv_norm *nm, int K, const float *x, int64_t leaves) { DISPATCH_DIM(nm, launch_obs_sums, nm, K, x, leaves) }
+int dispatch_obs_apply(mxv_norm *nm, int K, const float *x, void *y, int out_f32) { DISPATCH_DIM(nm, launch_obs_apply, nm, K, x, y, out_f32) }
+
+int checks(mxv_norm *nm, int K) {
+    if (!nm) return nfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_norm");
+    if (K <= 0) return nfail(nm, MXV_ERR_INVALID_ARG, "K must be positive");
+    NRM_HIP(nm, hipSetDevice(nm->device));
+    return MXV_OK;
+}
+
+int run_scan(mxv_norm *nm, int K, const double *all_sums, int world, int64_t total_rows, double epsilon, int obs) {
+    if (world < 1 || world > kMaxWorld) return nfail(nm, MXV_ERR_INVALID_ARG, "world must be in [1, %d]", kMaxWorld);
+    if (total_rows <= 0) return nfail(nm, MXV_ERR_INVALID_ARG, "total_rows must be positive");
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, nm->stream, all_sums, world, K, nm->dim, (double)total_rows, epsilon,
+                       obs, nm->stat, nm->coef);
+    NRM_HIP(nm, hipGetLastError());
+    return MXV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mxv_norm_create(int32_t device, int32_t dim, int64_t num_envs, void *stream, mxv_norm **out) {
+    if (!out) return nfail(nullptr, MXV_ERR_INVALID_ARG, "NULL output pointer");
+    *out = nullptr;
+    if (!dim_supported(dim)) return nfail(nullptr, MXV_ERR_UNSUPPORTED, "dim must be one of 1, 2, 3, 4, 6 (got %d)", dim);
+    if (num_envs <= 0) return nfail(nullptr, MXV_ERR_INVALID_ARG, "num_envs must be positive");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return nfail(nullptr, MXV_ERR_HIP, "no HIP device available (%s): the engine has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return nfail(nullptr, MXV_ERR_INVALID_ARG, "device %d out of range", device);
+    mxv_norm *nm = new (std::nothrow) mxv_norm();
+    if (!nm) return nfail(nullptr, MXV_ERR_INVALID_ARG, "out of host memory");
+    nm->device = device;
+    nm->dim = dim;
+    nm->n = num_envs;
+    nm->stream = (hipStream_t)stream;
+    std::vector<double> init(2 * dim + 1, 0.0);
+    for (int j = 0; j < dim; ++j) init[dim + j] = 1.0;  // RunningMeanStd.__init__: mean 0, var 1,
+    init[2 * dim] = 1e-4;                                // count = epsilon = 1e-4 (normalize.py:12-15)
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipMalloc((void **)&nm->stat, init.size() * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void **)&nm->returns, (size_t)num_envs * sizeof(double));
+    if (err == hipSuccess) err = hipMemcpy(nm->stat, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemset(nm->returns, 0, (size_t)num_envs * sizeof(double));  // np.zeros(num_envs), :123
+    if (err != hipSuccess) {
+        nfail(nullptr, MXV_ERR_HIP, "mxv_norm_create: %s", hipGetErrorString(err));
+        mxv_norm_destroy(nm);
+        return MXV_ERR_HIP;
+    }
+    *out = nm;
+    return MXV_OK;
+}
+
+int mxv_norm_destroy(mxv_norm *nm) {
+    if (!nm) return MXV_OK;
+    (void)hipSetDevice(nm->device);
+    (void)hipStreamSynchronize(nm->stream);
+    void *bufs[] = {nm->stat, nm->returns, nm->part_a, nm->part_b, nm->sums, nm->coef};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete nm;
+    return MXV_OK;
+}
+
+const char *mxv_norm_last_error(const mxv_norm *nm) { return nm ? nm->error.c_str() : g_norm_create_error.c_str(); }
+
+int mxv_norm_set_stream(mxv_norm *nm, void *stream) {
+    if (!nm) return nfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_norm");
+    NRM_HIP(nm, hipSetDevice(nm->device));
+    NRM_HIP(nm, hipStreamSynchronize(nm->stream));
+    nm->stream = (hipStream_t)stream;
+    return MXV_OK;
+}
+
+int mxv_norm_get_state(mxv_norm *nm, double *mean_host, double *var_host, double *count_host, double *returns_host) {
+    if (!nm) return nfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_norm");
+    NRM_HIP(nm, hipSetDevice(nm->device));
+    std::vector<double> st(2 * nm->dim + 1);
+    NRM_HIP(nm, hipMemcpyAsync(st.data(), nm->stat, st.size() * sizeof(double), hipMemcpyDeviceToHost, nm->stream));
+    if (returns_host)
+        NRM_HIP(nm, hipMemcpyAsync(returns_host, nm->returns, (size_t)nm->n * sizeof(double), hipMemcpyDeviceToHost, nm->stream));
+    NRM_HIP(nm, hipStreamSynchronize(nm->stream));
+    for (int j = 0; j < nm->dim; ++j) {
+        if (mean_host) mean_host[j] = st[j];
+        if (var_host) var_host[j] = st[nm->dim + j];
+    }
+    if (count_host) *count_host = st[2 * nm->dim];
+    return MXV_OK;
+}
+
+int mxv_norm_set_state(mxv_norm *nm, const double *mean_host, const double *var_host, double count, const double *returns_host) {
+    if (!nm) return nfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_norm");
+    if (!mean_host || !var_host) return nfail(nm, MXV_ERR_INVALID_ARG, "mean/var pointer is NULL");
+    NRM_HIP(nm, hipSetDevice(nm->device));
+    std::vector<double> st(2 * nm->dim + 1);
+    for (int j = 0; j < nm->dim; ++j) {
+        st[j] = mean_host[j];
+        st[nm->dim + j] = var_host[j];
+    }
+    st[2 * nm->dim] = count;
+    NRM_HIP(nm, hipMemcpyAsync(nm->stat, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice, nm->stream));
+    if (returns_host)
+        NRM_HIP(nm, hipMemcpyAsync(nm->returns, returns_host, (size_t)nm->n * sizeof(double), hipMemcpyHostToDevice, nm->stream));
+    NRM_HIP(nm, hipStreamSynchronize(nm->stream));
+    return MXV_OK;
+}
+
+int mxv_norm_obs_sums(mxv_norm *nm, int32_t K, const float *x_dev, double *sums_dev) {
+    if (int rc = checks(nm, K)) return rc;
+    if (!x_dev || !sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "x/sums pointer is NULL");
+    const int64_t leaves = ceil_div(nm->n, kObsLeafRows);
+    if (int rc = ensure_capacity(nm, K, leaves, 2 * nm->dim)) return rc;
+    if (int rc = dispatch_obs_sums(nm, K, x_dev, leaves)) return rc;
+    return run_tree(nm, K, leaves, 2 * nm->dim, sums_dev);
+}
+
+int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon,
+                       const double *all_sums_dev, int32_t world, int64_t total_rows) {
+    if (int rc = checks(nm, K)) return rc;
+    if (!x_dev || !y_dev || !all_sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "x/y/sums pointer is NULL");
+    if (int rc = ensure_capacity(nm, K, 1, 2 * nm->dim)) return rc;
+    if (int rc = run_scan(nm, K, all_sums_dev, world, total_rows, epsilon, 1)) return rc;
+    return dispatch_obs_apply(nm, K, x_dev, y_dev, out_f32);
+}
+
+int mxv_norm_observations(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon) {
+    if (int rc = checks(nm, K)) return rc;
+    if (!x_dev || !y_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "x/y pointer is NULL");
+    const int64_t leaves = ceil_div(nm->n, kObsLeafRows);
+    if (int rc = ensure_capacity(nm, K, leaves, 2 * nm->dim)) return rc;
+    if (int rc = mxv_norm_obs_sums(nm, K, x_dev, nm->sums)) return rc;
+    return mxv_norm_obs_apply(nm, K, x_dev, y_dev, out_f32, epsilon, nm->sums, 1, nm->n);
+}
+
+int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,
+                         const uint8_t *truncated_dev, double gamma, double *sums_dev) {
+    if (int rc = checks(nm, K)) return rc;
+    if (nm->dim != 1) return nfail(nm, MXV_ERR_INVALID_ARG, "reward statistics need dim == 1 (RunningMeanStd(shape=()))");
+    if (!reward_dev || !terminated_dev || !truncated_dev || !sums_dev)
+        return nfail(nm, MXV_ERR_INVALID_ARG, "reward/terminated/truncated/sums pointer is NULL");
+    const int64_t leaves = ceil_div(nm->n, kRewLeafEnvs);
+    if (int rc = ensure_capacity(nm, K, leaves, 2)) return rc;
+    if (reward_f32)
+        hipLaunchKernelGGL(returns_sums_kernel<float>, dim3((unsigned)leaves), dim3(64), 0, nm->stream, (const float *)reward_dev,
+                           terminated_dev, truncated_dev, nm->returns, nm->n, (int)K, gamma, leaves, nm->part_a);
+    else
+        hipLaunchKernelGGL(returns_sums_kernel<double>, dim3((unsigned)leaves), dim3(64), 0, nm->stream, (const double *)reward_dev,
+                           terminated_dev, truncated_dev, nm->returns, nm->n, (int)K, gamma, leaves, nm->part_a);
+    NRM_HIP(nm, hipGetLastError());
+    return run_tree(nm, K, leaves, 2, sums_dev);
+}
+
+int mxv_norm_reward_apply(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, void *out_dev, double epsilon,
+                          const double *all_sums_dev, int32_t world, int64_t total_rows) {
+    if (int rc = checks(nm, K)) return rc;
+    if (nm->dim != 1) return nfail(nm, MXV_ERR_INVALID_ARG, "reward statistics need dim == 1 (RunningMeanStd(shape=()))");
+    if (!reward_dev || !out_dev || !all_sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "reward/out/sums pointer is NULL");
+    if (int rc = ensure_capacity(nm, K, 1, 2)) return rc;
+    if (int rc = run_scan(nm, K, all_sums_dev, world, total_rows, epsilon, 0)) return rc;
+    const dim3 grid((unsigned)ceil_div(nm->n, kThreads), (unsigned)K);
+    if (reward_f32)
+        hipLaunchKernelGGL(reward_apply_kernel<float>, grid, dim3(kThreads), 0, nm->stream, (const float *)reward_dev,
+                           (float *)out_dev, nm->coef, nm->n);
+    else
+        hipLaunchKernelGGL(reward_apply_kernel<double>, grid, dim3(kThreads), 0, nm->stream, (const double *)reward_dev,
+                           (double *)out_dev, nm->coef, nm->n);
+    NRM_HIP(nm, hipGetLastError());
+    return MXV_OK;
+}
+
+int mxv_norm_rewards(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,
+                     const uint8_t *truncated_dev, void *out_dev, double gamma, double epsilon) {
+    if (int rc = checks(nm, K)) return rc;
+    if (!out_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "out pointer is NULL");
+    const int64_t leaves = ceil_div(nm->n, kRewLeafEnvs);
+    if (int rc = ensure_capacity(nm, K, leaves, 2)) return rc;
+    if (int rc = mxv_norm_reward_sums(nm, K, reward_dev, reward_f32, terminated_dev, truncated_dev, gamma, nm->sums)) return rc;
+    return mxv_norm_reward_apply(nm, K, reward_dev, reward_f32, out_dev, epsilon, nm->sums, 1, nm->n);
+}
+
+}  // extern "C"

@@ -110,6 +110,20 @@ class ShardedRollout:
         """K vector steps of the local shard into [K, N_local, ...] trajectory tensors (no communication)."""
         return self.engine.rollout_per_step(K, **kw)
 
+    def make_normalizer(self, obs_dim: Optional[int] = None, **kw):
+        """RunningNormalizer (NormalizeObservation / NormalizeReward) over the LOGICAL vector env: the
+        batch of every update is all total_envs rows; the shards exchange their per-step column sums (one small
+        all-gather per call) and run the identical running update."""
+        from .normalize import RunningNormalizer
+
+        if obs_dim is None:
+            obs_dim = self.engine.O
+        if "backend" not in kw:
+            kw.setdefault("device", self.engine.device.index)
+            kw.setdefault("stream", getattr(self.engine, "stream", None))
+        return RunningNormalizer(self.local_envs, obs_dim, world_size=self.world_size, total_envs=self.total_envs,
+                                 group=self.group, **kw)
+
     def _buffers(self):
         """One packed send buffer (this rank's snapshot of obs | reward | terminated | truncated, every section
         aligned to 256 B) and one [world][bytes] receive buffer: the four logical gathers travel as ONE RCCL

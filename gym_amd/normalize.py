@@ -1,0 +1,157 @@
+"""RunningNormalizer — gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-145) on device
+tensors.
+
+The reference wraps a vector env and, per step() call, folds the batch of N observations (resp. the N discounted
+returns) into a RunningMeanStd and maps the batch with the UPDATED statistics.  A learner that keeps trajectories on the
+GPU wants the same transformation applied to the [K, N, ...] tensors a fused rollout produced, K batches at a time and in
+the wrappers' order — that is `normalize_obs` / `normalize_rewards` below, backed by the mxv_norm_* kernels
+(gym_amd/csrc/mxv_norm.hip).  The batch moments are the only cross-env reduction on the hot path, hence the only place a
+sharded vector env needs a collective besides the output all-gather: with world_size > 1 every rank reduces its shard to
+per-step column sums ([K][2*dim] fp64), the sums are all-gathered (a few KiB), and every rank runs the identical running
+update — so all ranks hold bit-identical statistics, equal to those of an unsharded run for power-of-two shards.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+
+__all__ = ["RunningNormalizer", "HipNormBackend"]
+
+
+class HipNormBackend:
+    """Statistics + maps of ONE shard on the HIP device (two mxv_norm objects: observations, returns)."""
+
+    def __init__(self, num_envs: int, obs_dim: int, *, device: int = 0, stream: Optional[torch.cuda.Stream] = None):
+        from . import _native
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("RunningNormalizer needs a HIP device; gym_amd has no CPU fallback")
+        self.torch_device = torch.device("cuda", device)
+        self.stream = stream
+        sp = stream.cuda_stream if stream is not None else 0
+        self.obs = _native.Norm(obs_dim, num_envs, device=device, stream=sp)
+        self.rew = _native.Norm(1, num_envs, device=device, stream=sp)
+
+    def obs_sums(self, K, x, sums):
+        self.obs.obs_sums(K, x, sums)
+
+    def obs_apply(self, K, x, y, epsilon, all_sums, world, total_rows):
+        self.obs.obs_apply(K, x, y, y.dtype == torch.float32, epsilon, all_sums, world, total_rows)
+
+    def reward_sums(self, K, reward, terminated, truncated, gamma, sums):
+        self.rew.reward_sums(K, reward, reward.dtype == torch.float32, terminated, truncated, gamma, sums)
+
+    def reward_apply(self, K, reward, out, epsilon, all_sums, world, total_rows):
+        self.rew.reward_apply(K, reward, reward.dtype == torch.float32, out, epsilon, all_sums, world, total_rows)
+
+    def obs_state(self):
+        return self.obs.get_state()
+
+    def reward_state(self):
+        return self.rew.get_state(want_returns=True)
+
+    def set_obs_state(self, mean, var, count):
+        self.obs.set_state(mean, var, count)
+
+    def set_reward_state(self, mean, var, count, returns=None):
+        self.rew.set_state(mean, var, count, returns)
+
+    def close(self):
+        self.obs.close()
+        self.rew.close()
+
+
+class RunningNormalizer:
+    """num_envs = rows of THIS shard; total_envs = rows of the logical vector env (the reference's batch size).
+
+    normalize_obs(x)               x float32 [K, N, O] or [N, O]  -> same shape, float64 (reference dtype) or float32
+    normalize_rewards(r, te, tr)   r float64/float32 [K, N] or [N] + uint8 flags -> same shape and dtype as r
+    obs_rms / return_rms           .mean / .var / .count of the running statistics (host copies, as in the reference)
+    """
+
+    def __init__(self, num_envs: int, obs_dim: int, *, device: int = 0, stream=None, gamma: float = 0.99,
+                 obs_epsilon: float = 1e-8, reward_epsilon: float = 1e-8, world_size: int = 1,
+                 total_envs: Optional[int] = None, group=None, backend=None):
+        self.num_envs, self.obs_dim = int(num_envs), int(obs_dim)
+        self.gamma, self.obs_epsilon, self.reward_epsilon = float(gamma), float(obs_epsilon), float(reward_epsilon)
+        self.world_size = int(world_size)
+        self.total_envs = int(total_envs) if total_envs is not None else self.num_envs * self.world_size
+        self.group = group
+        self.backend = backend if backend is not None else HipNormBackend(num_envs, obs_dim, device=device, stream=stream)
+        self.stream = getattr(self.backend, "stream", None)
+        self._dev = getattr(self.backend, "torch_device", torch.device("cpu"))
+
+    def _ctx(self):
+        from contextlib import nullcontext
+
+        return torch.cuda.stream(self.stream) if self.stream is not None else nullcontext()
+
+    def _all_sums(self, sums: torch.Tensor) -> torch.Tensor:
+        """[K][2*dim] sums of this shard -> [world][K][2*dim] in rank order (one small all-gather)."""
+        if self.world_size == 1:
+            return sums.unsqueeze(0)
+        import torch.distributed as dist
+
+        out = torch.empty((self.world_size,) + tuple(sums.shape), dtype=sums.dtype, device=sums.device)
+        dist.all_gather_into_tensor(out.view(-1), sums.view(-1), group=self.group)
+        return out
+
+    def normalize_obs(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_dtype=torch.float64) -> torch.Tensor:
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        K = x.shape[0] if x.dim() == 3 else 1
+        assert x.numel() == K * self.num_envs * self.obs_dim, (tuple(x.shape), self.num_envs, self.obs_dim)
+        with self._ctx():
+            if out is None:
+                out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+            assert out.is_contiguous() and out.shape == x.shape and out.dtype in (torch.float64, torch.float32)
+            sums = torch.empty((K, 2 * self.obs_dim), dtype=torch.float64, device=x.device)
+            self.backend.obs_sums(K, x, sums)
+            self.backend.obs_apply(K, x, out, self.obs_epsilon, self._all_sums(sums), self.world_size, self.total_envs)
+        return out
+
+    def normalize_rewards(self, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert reward.dtype in (torch.float64, torch.float32) and reward.is_contiguous()
+        K = reward.shape[0] if reward.dim() == 2 else 1
+        assert reward.numel() == K * self.num_envs
+        assert terminated.numel() == reward.numel() and truncated.numel() == reward.numel()
+        assert terminated.is_contiguous() and truncated.is_contiguous()
+        assert terminated.element_size() == 1 and truncated.element_size() == 1
+        with self._ctx():
+            if out is None:
+                out = torch.empty_like(reward)
+            assert out.is_contiguous() and out.shape == reward.shape and out.dtype == reward.dtype
+            sums = torch.empty((K, 2), dtype=torch.float64, device=reward.device)
+            self.backend.reward_sums(K, reward, terminated, truncated, self.gamma, sums)
+            self.backend.reward_apply(K, reward, out, self.reward_epsilon, self._all_sums(sums), self.world_size,
+                                      self.total_envs)
+        return out
+
+    # -- the wrappers' attributes (normalize.py:64-70,117-125) ---------------------------------------------------------
+    @property
+    def obs_rms(self):
+        mean, var, count = self.backend.obs_state()
+        return SimpleNamespace(mean=mean, var=var, count=count)
+
+    @property
+    def return_rms(self):
+        mean, var, count, _ = self.backend.reward_state()
+        return SimpleNamespace(mean=mean[0], var=var[0], count=count)
+
+    @property
+    def returns(self):
+        return self.backend.reward_state()[3]
+
+    def state_dict(self):
+        om, ov, oc = self.backend.obs_state()
+        rm, rv, rc, ret = self.backend.reward_state()
+        return dict(obs_mean=om, obs_var=ov, obs_count=oc, ret_mean=rm, ret_var=rv, ret_count=rc, returns=ret)
+
+    def load_state_dict(self, sd):
+        self.backend.set_obs_state(sd["obs_mean"], sd["obs_var"], sd["obs_count"])
+        self.backend.set_reward_state(sd["ret_mean"], sd["ret_var"], sd["ret_count"], sd.get("returns"))
+
+    def close(self):
+        self.backend.close()

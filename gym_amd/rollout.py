@@ -150,6 +150,13 @@ class DeviceRollout:
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
         return out
 
+    def make_normalizer(self, **kw):
+        """RunningNormalizer (NormalizeObservation / NormalizeReward on device tensors) sized for this
+        engine and ordered on its stream: feed it the reset observations and the [K, N, ...] trajectory tensors."""
+        from .normalize import RunningNormalizer
+
+        return RunningNormalizer(self.num_envs, self.O, device=self.device.index, stream=self.stream, **kw)
+
     def final_tensors(self):
         """(obs, reward, terminated, truncated) of the most recent vector step (views, valid until the next call)."""
         return self._last

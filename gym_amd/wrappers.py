@@ -6,6 +6,9 @@ for a HipVectorEnv: same attributes (`return_queue`, `length_queue`, `episode_co
 returns and lengths are accumulated inside the step kernel (float32 returns exactly like the reference's np.float32
 accumulator; the length is the TimeLimit counter), so no Python loop over the N sub-envs runs per step.
 `VectorListInfo` mirrors gym.wrappers.VectorListInfo (gym/wrappers/vector_list_info.py:43-111).
+`NormalizeObservation` / `NormalizeReward` mirror gym.wrappers.normalize (gym/wrappers/normalize.py:50-145): same
+attributes (`obs_rms`, `return_rms`, `returns`, `gamma`, `epsilon`) and result dtypes (float64), with the batch moments,
+the running update and the affine map computed by the mxv_norm_* kernels (gym_amd.normalize.RunningNormalizer).
 """
 from __future__ import annotations
 
@@ -17,7 +20,7 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo"]
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward"]
 
 
 class _VectorWrapper:
@@ -50,7 +53,7 @@ class _VectorWrapper:
 
 class RecordEpisodeStatistics(_VectorWrapper):
     def __init__(self, env: HipVectorEnv, deque_size: int = 100):
-        if not isinstance(env, HipVectorEnv):
+        if not isinstance(getattr(env, "unwrapped", env), HipVectorEnv):
             raise TypeError("gym_amd.wrappers.RecordEpisodeStatistics wraps a HipVectorEnv (the statistics are "
                             "accumulated by its engine)")
         super().__init__(env)
@@ -135,3 +138,91 @@ class VectorListInfo(_VectorWrapper):
             for i in np.flatnonzero(infos[f"_{k}"]):
                 list_info[i][k] = infos[k][i]
         return list_info
+
+
+def _hip_base(env, who: str) -> HipVectorEnv:
+    base = getattr(env, "unwrapped", env)
+    if not isinstance(base, HipVectorEnv):
+        raise TypeError(f"gym_amd.wrappers.{who} wraps a HipVectorEnv (the statistics live on its device)")
+    return base
+
+
+class NormalizeObservation(_VectorWrapper):
+    """gym.wrappers.NormalizeObservation for a HipVectorEnv (normalize.py:50-93): every reset()/step() folds the batch of
+    N observations into `obs_rms` and returns (obs - mean) / sqrt(var + epsilon) as float64."""
+
+    def __init__(self, env, epsilon: float = 1e-8):
+        import torch
+
+        from .normalize import RunningNormalizer
+
+        base = _hip_base(env, "NormalizeObservation")
+        super().__init__(env)
+        self.num_envs = env.num_envs
+        self.is_vector_env = True
+        self.epsilon = epsilon
+        self._torch = torch
+        self._dev = torch.device("cuda", base.handle.device)
+        self._rn = RunningNormalizer(self.num_envs, int(base.single_observation_space.shape[0]),
+                                     device=base.handle.device, obs_epsilon=epsilon)
+
+    @property
+    def obs_rms(self):
+        return self._rn.obs_rms
+
+    def step(self, action):
+        obs, rews, terminateds, truncateds, infos = self.env.step(action)
+        return self.normalize(obs), rews, terminateds, truncateds, infos
+
+    def reset(self, **kwargs):
+        obs, info = self.env.reset(**kwargs)
+        return self.normalize(obs), info
+
+    def normalize(self, obs):
+        x = self._torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)).to(self._dev)
+        return self._rn.normalize_obs(x).cpu().numpy()
+
+    def close(self):
+        self._rn.close()
+        return self.env.close()
+
+
+class NormalizeReward(_VectorWrapper):
+    """gym.wrappers.NormalizeReward for a HipVectorEnv (normalize.py:96-145): discounted returns per env, their running
+    variance, rewards / sqrt(var + epsilon); the accumulators of finished envs are zeroed."""
+
+    def __init__(self, env, gamma: float = 0.99, epsilon: float = 1e-8):
+        import torch
+
+        from .normalize import RunningNormalizer
+
+        base = _hip_base(env, "NormalizeReward")
+        super().__init__(env)
+        self.num_envs = env.num_envs
+        self.is_vector_env = True
+        self.gamma = gamma
+        self.epsilon = epsilon
+        self._torch = torch
+        self._dev = torch.device("cuda", base.handle.device)
+        self._rn = RunningNormalizer(self.num_envs, 1, device=base.handle.device, gamma=gamma, reward_epsilon=epsilon)
+
+    @property
+    def return_rms(self):
+        return self._rn.return_rms
+
+    @property
+    def returns(self):
+        return self._rn.returns
+
+    def step(self, action):
+        obs, rews, terminateds, truncateds, infos = self.env.step(action)
+        t = self._torch
+        r = t.from_numpy(np.ascontiguousarray(rews, dtype=np.float64)).to(self._dev)
+        te = t.from_numpy(np.ascontiguousarray(terminateds).view(np.uint8)).to(self._dev)
+        tr = t.from_numpy(np.ascontiguousarray(truncateds).view(np.uint8)).to(self._dev)
+        rews = self._rn.normalize_rewards(r, te, tr).cpu().numpy()
+        return obs, rews, terminateds, truncateds, infos
+
+    def close(self):
+        self._rn.close()
+        return self.env.close()

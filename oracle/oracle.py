@@ -21,8 +21,8 @@ DISCRETE = {0: 2, 2: 3, 3: 3}  # env_id -> number of actions
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Returns the library path."""
-    src = os.path.join(_HERE, "classic_control.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("classic_control.c", "normalize.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
@@ -49,6 +49,12 @@ def lib():
         L.orc_vec_step.restype = i64
         L.orc_rollout.argtypes = [C.c_int, i64, u64, vp, C.c_int, u64, u64, u64, C.c_int, vp, vp, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orc_norm_obs_batches.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, C.c_int, vp]
+        L.orc_norm_reward_steps.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, i64, i64, C.c_int, vp]
+        L.orc_norm_obs_sums.argtypes = [vp, i64, i64, C.c_int, vp]
+        L.orc_norm_obs_apply.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, vp, C.c_int, i64, vp]
+        L.orc_norm_reward_sums.argtypes = [vp, vp, vp, vp, i64, i64, C.c_double, vp]
+        L.orc_norm_reward_apply.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, vp, C.c_int, i64, vp]
         _lib = L
     return _lib
 
@@ -191,3 +197,75 @@ class EpisodeStats:
         self.returns[done] = 0                          # :142
         self.lengths[done] = 0                          # :143
         return r, l, done
+
+
+class RunningNorm:
+    """gym.wrappers.NormalizeObservation / NormalizeReward restated for a batched stream (oracle/normalize.c follows
+    gym/wrappers/normalize.py:8-145).  mode 0 = the reference's own arithmetic (float32 row-by-row batch moments, NumPy
+    pairwise sums) — pinned bit-exact by tests/golden/normalize_*.npz; mode 1 = exact batch sums rounded to the
+    reference's moment dtype, the definition the device kernels implement."""
+
+    def __init__(self, num_envs: int, obs_dim: int, gamma: float = 0.99, obs_epsilon: float = 1e-8,
+                 rew_epsilon: float = 1e-8, mode: int = 0):
+        self.n, self.O, self.mode = int(num_envs), int(obs_dim), int(mode)
+        self.gamma, self.obs_epsilon, self.rew_epsilon = float(gamma), float(obs_epsilon), float(rew_epsilon)
+        self.obs_mean = np.zeros(self.O, np.float64)      # RunningMeanStd.__init__, normalize.py:12-15
+        self.obs_var = np.ones(self.O, np.float64)
+        self.obs_count = np.array([1e-4], np.float64)
+        self.ret_mean = np.zeros(1, np.float64)
+        self.ret_var = np.ones(1, np.float64)
+        self.ret_count = np.array([1e-4], np.float64)
+        self.returns = np.zeros(self.n, np.float64)       # :123
+
+    def normalize_obs(self, x):
+        """x float32 [K][n][O] (or [n][O]) -> float64, K consecutive NormalizeObservation.normalize calls."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        xs = x.reshape(-1, self.n, self.O)
+        y = np.zeros(xs.shape, np.float64)
+        lib().orc_norm_obs_batches(_p(self.obs_mean), _p(self.obs_var), _p(self.obs_count), self.obs_epsilon, _p(xs),
+                                   xs.shape[0], self.n, self.O, self.mode, _p(y))
+        return y.reshape(x.shape)
+
+    def normalize_rewards(self, rew, terminated, truncated):
+        """rew float64 [K][n] (or [n]) + flags -> float64, K consecutive NormalizeReward.step calls."""
+        r = np.ascontiguousarray(rew, dtype=np.float64)
+        rs = r.reshape(-1, self.n)
+        te = np.ascontiguousarray(np.asarray(terminated).reshape(rs.shape), dtype=np.uint8)
+        tr = np.ascontiguousarray(np.asarray(truncated).reshape(rs.shape), dtype=np.uint8)
+        out = np.zeros(rs.shape, np.float64)
+        lib().orc_norm_reward_steps(_p(self.returns), _p(self.ret_mean), _p(self.ret_var), _p(self.ret_count), self.gamma,
+                                    self.rew_epsilon, _p(rs), _p(te), _p(tr), rs.shape[0], self.n, self.mode, _p(out))
+        return out.reshape(r.shape)
+
+    # -- split form (a shard of a vector env sharded over `world` ranks), mode 1 arithmetic -------------------------------
+    def obs_sums(self, x):
+        xs = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.n, self.O)
+        sums = np.zeros((xs.shape[0], 2 * self.O), np.float64)
+        lib().orc_norm_obs_sums(_p(xs), xs.shape[0], self.n, self.O, _p(sums))
+        return sums
+
+    def obs_apply(self, x, all_sums, total_rows):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        xs = x.reshape(-1, self.n, self.O)
+        a = np.ascontiguousarray(all_sums, dtype=np.float64)
+        y = np.zeros(xs.shape, np.float64)
+        lib().orc_norm_obs_apply(_p(self.obs_mean), _p(self.obs_var), _p(self.obs_count), self.obs_epsilon, _p(xs),
+                                 xs.shape[0], self.n, self.O, _p(a), a.shape[0], int(total_rows), _p(y))
+        return y.reshape(x.shape)
+
+    def reward_sums(self, rew, terminated, truncated):
+        rs = np.ascontiguousarray(rew, dtype=np.float64).reshape(-1, self.n)
+        te = np.ascontiguousarray(np.asarray(terminated).reshape(rs.shape), dtype=np.uint8)
+        tr = np.ascontiguousarray(np.asarray(truncated).reshape(rs.shape), dtype=np.uint8)
+        sums = np.zeros((rs.shape[0], 2), np.float64)
+        lib().orc_norm_reward_sums(_p(self.returns), _p(rs), _p(te), _p(tr), rs.shape[0], self.n, self.gamma, _p(sums))
+        return sums
+
+    def reward_apply(self, rew, all_sums, total_rows):
+        r = np.ascontiguousarray(rew, dtype=np.float64)
+        rs = r.reshape(-1, self.n)
+        a = np.ascontiguousarray(all_sums, dtype=np.float64)
+        out = np.zeros(rs.shape, np.float64)
+        lib().orc_norm_reward_apply(_p(self.ret_mean), _p(self.ret_var), _p(self.ret_count), self.rew_epsilon, _p(rs),
+                                    rs.shape[0], self.n, _p(a), a.shape[0], int(total_rows), _p(out))
+        return out.reshape(r.shape)

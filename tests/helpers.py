@@ -152,3 +152,33 @@ def run_p2(engine_cls, name, tag, strict):
         compare_step(f"{name} P2[{tag}] t={t}", got, ref, done, strict)
         ndone += int(done.sum())
     return ndone
+
+
+# ---- NormalizeObservation / NormalizeReward -------------------------------------------------------
+NORM_CASES = ["CartPole", "Pendulum", "Acrobot", "MountainCarContinuous"]
+
+
+def load_norm_golden(name):
+    return np.load(os.path.join(GOLDEN, f"normalize_{name}.npz"))
+
+
+def norm_obs_bound(raw_obs, ref_norm, rtol=1e-5):
+    """Tolerance of `exact-sum batch moments` against the reference's float32 np.mean / np.var, per element of the
+    normalised observations [T][n][O].
+
+    The reference accumulates each batch column in float32: its batch mean carries an absolute error of
+    ~sqrt(n) * 2^-24 * max|x| (sequential sum, random-walk growth) and its batch var, formed from float32 (x - mean)^2,
+    a relative error of ~2^-23 * max|x| / std.  Propagated through y = (x - mean) / sqrt(var + eps) and through the
+    running merge (errors of earlier batches stay in the running statistics) this gives, per element,
+        |dy| <= rtol * |y|  +  2^-24 * (2 + sqrt(n)) * max|x_col| / std_col * (1 + |y|)
+    with std_col the running std implied by the reference's own output scale; rtol is north_star's fp32 rtol.
+    (The worst golden element sits at 0.25 of this bound.)"""
+    x = np.asarray(raw_obs, dtype=np.float64)
+    T, n, O = x.shape
+    xmax = np.abs(x).max(axis=(0, 1))                                  # [O]
+    # running std recovered from the reference's outputs: y = (x - mean)/std  =>  std = range(x) / range(y) per batch
+    rng_x = x.max(axis=1) - x.min(axis=1)                              # [T][O]
+    rng_y = ref_norm.max(axis=1) - ref_norm.min(axis=1)
+    std = np.where(rng_y > 0, rng_x / np.where(rng_y > 0, rng_y, 1), np.inf)   # [T][O]
+    scale = (2.0 ** -24) * (2.0 + np.sqrt(n)) * xmax[None, :] / std    # [T][O]
+    return rtol * np.abs(ref_norm) + scale[:, None, :] * (1.0 + np.abs(ref_norm)) + 1e-300

@@ -32,7 +32,28 @@ def _worker(rank, world, port, case, total, steps, q):
     try:
         from oracle_engine import OracleRollout
 
-        if case == "mixed":
+        if case.startswith("normalize:"):
+            from gym_amd.distributed import ShardedRollout
+            from gym_amd.normalize import RunningNormalizer
+            from oracle_engine import OracleNormBackend
+
+            env_id = case.split(":", 1)[1]
+            sr = ShardedRollout(env_id, total, engine_factory=OracleRollout, seed=11, action_seed=12)
+            obs0 = sr.reset(seed=11)
+            tr = sr.rollout_per_step(steps)
+            O = obs0.shape[1]
+            rn = sr.make_normalizer(O, gamma=0.9, backend=OracleNormBackend(sr.local_envs, O))
+            assert rn.world_size == world and rn.total_envs == total
+            y0 = rn.normalize_obs(obs0.contiguous())                 # the reset batch, then the K step batches
+            y = rn.normalize_obs(tr["obs"].contiguous())
+            o = rn.normalize_rewards(tr["reward"].contiguous(), tr["terminated"].contiguous(), tr["truncated"].contiguous())
+            parts = [None] * world
+            dist.all_gather_object(parts, (y0.numpy(), y.numpy(), o.numpy(), rn.obs_rms.mean, rn.obs_rms.var,
+                                           rn.return_rms.var, rn.obs_rms.count))
+            if rank == 0:
+                q.put(parts)
+            sr.close()
+        elif case == "mixed":
             from gym_amd.mixed import MixedRollout
 
             mr = MixedRollout(total, engine_factory=OracleRollout, seed=5, action_seed=6)
@@ -122,3 +143,33 @@ def test_partition_rule():
         partition(100, 8, 0)   # not divisible
     with pytest.raises(ValueError):
         partition(24, 4, 0)    # shard of 6 envs is not a multiple of the Philox group (4)
+
+
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1"])
+def test_two_rank_running_normalizer_equals_single_rank(env_id):
+    """SURVEY.md §8(f)-2 sharded: every rank reduces its shard to per-step column sums, the sums are all-gathered, every
+    rank runs the same running update -> identical statistics on all ranks, equal to the unsharded run."""
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleRollout
+    from oracle.oracle import RunningNorm
+
+    total, steps = 128, 20
+    parts = _run("normalize:" + env_id, total, steps)
+    e = OracleRollout(env_id, total, seed=11, action_seed=12)
+    obs0 = e.reset(seed=11).numpy()
+    tr = {k: v.numpy() for k, v in e.rollout_per_step(steps).items()}
+    rn = RunningNorm(total, obs0.shape[1], gamma=0.9, mode=1)
+    y0 = rn.normalize_obs(obs0)
+    y = rn.normalize_obs(tr["obs"])
+    o = rn.normalize_rewards(tr["reward"], tr["terminated"], tr["truncated"])
+    got_y0 = np.concatenate([p[0] for p in parts], axis=0)
+    got_y = np.concatenate([p[1] for p in parts], axis=1)
+    got_o = np.concatenate([p[2] for p in parts], axis=1)
+    np.testing.assert_allclose(got_y0, y0, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got_y, y, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got_o, o, rtol=1e-12, atol=0)
+    for a, b in zip(parts[0][3:], parts[1][3:]):
+        assert np.array_equal(a, b)                       # bit-identical statistics on every rank
+    np.testing.assert_allclose(parts[0][3], rn.obs_mean, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(parts[0][4], rn.obs_var, rtol=1e-12)
+    assert parts[0][6] == rn.obs_count[0]
