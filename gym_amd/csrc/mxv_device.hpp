@@ -112,6 +112,23 @@ __device__ __forceinline__ double div_by_const(double x, double c, double rc) {
     const double r = __fma_rn(-c, q0, x);
     return __fma_rn(r, rc, q0);
 }
+// Several quotients by the SAME runtime divisor d (Acrobot divides three times by d1 per RK4 stage): the compiler's IEEE
+// fp64 division is v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal, q0 = x*r, rem = fma(-d, q0, x),
+// v_div_fmas (= fma(rem, r, q0)), v_div_fixup.  For operands that need no scaling or fix-up (normal, exponents far from
+// the limits, x != -0: true for the default-parameter dynamics) the scale factors are 1 and the fix-up is the identity,
+// so running the reciprocal part once and the 3-instruction tail per dividend reproduces `/` bit for bit
+// (tools/divcheck.hip: 0 mismatches against `/` on 4e9 random operand pairs on the MI355X).
+__device__ __forceinline__ double refined_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __fma_rn(-d, r, 1.0);
+    r = __fma_rn(r, e, r);
+    e = __fma_rn(-d, r, 1.0);
+    return __fma_rn(r, e, r);
+}
+__device__ __forceinline__ double div_with_rcp(double x, double d, double r) {
+    const double q0 = x * r;
+    return __fma_rn(__fma_rn(-d, q0, x), r, q0);
+}
 template <int DEF>
 __device__ __forceinline__ double div_par(double x, double c) {
     if constexpr (DEF == PM_DEFAULT)
@@ -302,33 +319,73 @@ struct Env<MXV_PENDULUM> {
 };
 
 // ---- Acrobot: gym/envs/classic_control/acrobot.py:196-277 (step, _dsdt), 378-465 (wrap, bound, rk4) ----
+// Trig budget.  The reference evaluates, per RK4 stage, sin/cos(theta2), cos(theta1 + theta2 - pi/2) and cos(theta1 - pi/2)
+// (:252-265), and after the step cos/sin of both angles (:225-230) plus cos(theta1), cos(theta2 + theta1) (:235): 6 sincos +
+// 9 cos per step, each ~70 fp64 instructions, i.e. ~3/4 of this VALU-bound kernel.  Every one of those values is a function
+// of sin/cos of the two stage angles, so each stage takes ONE sincos per angle and rebuilds the shifted / summed cosines by
+// angle addition, carrying the argument roundings of the reference explicitly:
+//     cos(fl(x - p)),  p = fl(pi/2) = pi/2 - delta:   fl(x - p) = x - pi/2 + (delta - e),  e = exact residual of the subtraction
+//                                                      => cos = sin(x + (delta - e)) = sin x + (delta - e) cos x   (+ O(1e-32))
+//     cos(fl(fl(t1 + t2) - p)) = sin(t1 + t2 + eps)  = S12 + eps C12,   S12 = s1 c2 + c1 s2,  C12 = c1 c2 - s1 s2,
+//                                                      eps = delta - e_add - e_sub
+//     cos(fl(t2 + t1))         = cos(t1 + t2 - e_add) = C12 + e_add S12
+// (TwoSum residuals; FMAs only inside these libm-like helpers, as in sincos_kernel).  The results agree with direct
+// evaluation to ~2 ulp of 1.0 — the same size as ocml-vs-glibc differences of the direct calls — and the sin/cos of the
+// post-step angles (the observation) ARE the stage-1 values of the next step, so a fused rollout carries them in
+// registers: 8 sincos per step instead of 6 sincos + 9 cos.
+__device__ __forceinline__ double two_sum_residual(double a, double b, double sum) {  // a + b == sum + residual exactly
+    const double bb = sum - a;
+    return (a - (sum - bb)) + (b - bb);
+}
+constexpr double kHalfPiTail = 6.123233995736766036e-17;  // pi/2 - fl(pi/2)
+
 template <>
 struct Env<MXV_ACROBOT> {
     static constexpr int S = 4, O = 6, NA = 3;
-    static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
-    __device__ __forceinline__ static void prime(const double *s, double *aux) {}
+    static constexpr int AUX = 4;  // sin(theta1), cos(theta1), sin(theta2), cos(theta2) of the current state
+    __device__ __forceinline__ static void prime(const double *s, double *aux) {
+        mx_sincos(s[0], &aux[0], &aux[1]);
+        mx_sincos(s[1], &aux[2], &aux[3]);
+    }
+    // sc = sin/cos of sa[0], sa[1]
     template <int DEF>
-    __device__ __forceinline__ static void dsdt(const Par<DEF> &P, const double *sa, double a, double *out) {
+    __device__ __forceinline__ static void dsdt(const Par<DEF> &P, const double *sa, const double *sc, double a, double *out) {
         const double m1 = P.get(3, 1.0), m2 = P.get(4, 1.0), l1 = P.get(1, 1.0);
         const double lc1 = P.get(5, 0.5), lc2 = P.get(6, 0.5), I1 = P.get(7, 1.0), I2 = P.get(7, 1.0);
         const bool nips = P.get(11, 0.0) != 0.0;
         const double g = 9.8;  // :245
         const double theta1 = sa[0], theta2 = sa[1], dtheta1 = sa[2], dtheta2 = sa[3];
-        double s2, c2;
-        mx_sincos(theta2, &s2, &c2);
+        const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
+        const double halfpi = kPi / 2.0;
+        // cos(theta1 + theta2 - pi / 2.0) :259
+        const double t12 = theta1 + theta2;
+        const double a12 = t12 - halfpi;
+        const double eps12 = kHalfPiTail - two_sum_residual(theta1, theta2, t12) - two_sum_residual(t12, -halfpi, a12);
+        const double S12 = __fma_rn(s1, c2, c1 * s2), C12 = __fma_rn(c1, c2, -(s1 * s2));
+        const double cos_t12_shift = __fma_rn(eps12, C12, S12);
+        // cos(theta1 - pi / 2) :264
+        const double a1 = theta1 - halfpi;
+        const double cos_t1_shift = __fma_rn(kHalfPiTail - two_sum_residual(theta1, -halfpi, a1), c1, s1);
         const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;  // :252-257
         const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;                                          // :258
-        const double phi2 = m2 * lc2 * g * mx_cos(theta1 + theta2 - kPi / 2.0);                                // :259
+        const double phi2 = m2 * lc2 * g * cos_t12_shift;                                                   // :259
         const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
-                            (m1 * lc1 + m2 * l1) * g * mx_cos(theta1 - kPi / 2) + phi2;                        // :260-265
-        double ddtheta2;
-        if (nips) {  // :266-269
-            ddtheta2 = (a + d2 / d1 * phi1 - phi2) / (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
-        } else {  // "book" :270-275
-            ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
-                       (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+                            (m1 * lc1 + m2 * l1) * g * cos_t1_shift + phi2;                                 // :260-265
+        double ddtheta2, ddtheta1;
+        if constexpr (DEF == PM_DEFAULT) {  // "book" dynamics, three quotients by d1 share one reciprocal (same bits as `/`)
+            const double r1 = refined_rcp(d1);
+            ddtheta2 = (a + div_with_rcp(d2, d1, r1) * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                       (m2 * (lc2 * lc2) + I2 - div_with_rcp(d2 * d2, d1, r1));  // :270-275
+            ddtheta1 = div_with_rcp(-(d2 * ddtheta2 + phi1), d1, r1);              // :276
+        } else {
+            if (nips) {  // :266-269
+                ddtheta2 = (a + d2 / d1 * phi1 - phi2) / (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+            } else {  // "book" :270-275
+                ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                           (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+            }
+            ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;  // :276
         }
-        const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;  // :276
         out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2;  // :277 (5th component is 0.0)
     }
     __device__ __forceinline__ static double wrap(double x, double m, double M) {  // :378-396
@@ -341,31 +398,38 @@ struct Env<MXV_ACROBOT> {
         const double t = (m > x) ? m : x;
         return (M < t) ? M : t;
     }
-    __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {  // :225-230
+    __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux = nullptr) {  // :225-230
         double s0, c0, s1, c1;
         mx_sincos(s[0], &s0, &c0);
         mx_sincos(s[1], &s1, &c1);
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
+        if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
     }
     template <int DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
         const double dt = P.get(0, 0.2) - 0;    // t[i+1] - this, t = [0, self.dt] :210,449
         const double dt2 = dt / 2.0;            // :450
         const double y0[4] = {s[0], s[1], s[2], s[3]};
-        double k1[4], k2[4], k3[4], k4[4], y[4];
-        dsdt(P, y0, torque, k1);  // :453  (the augmented torque component has derivative 0.0: it stays `torque`)
+        double k1[4], k2[4], k3[4], k4[4], y[4], sc[4];
+        dsdt(P, y0, aux, torque, k1);  // :453  (the augmented torque component has derivative 0.0: it stays `torque`)
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k1[k];
-        dsdt(P, y, torque, k2);   // :454
+        mx_sincos(y[0], &sc[0], &sc[1]);
+        mx_sincos(y[1], &sc[2], &sc[3]);
+        dsdt(P, y, sc, torque, k2);   // :454
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k2[k];
-        dsdt(P, y, torque, k3);   // :455
+        mx_sincos(y[0], &sc[0], &sc[1]);
+        mx_sincos(y[1], &sc[2], &sc[3]);
+        dsdt(P, y, sc, torque, k3);   // :455
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt * k3[k];
-        dsdt(P, y, torque, k4);   // :456
+        mx_sincos(y[0], &sc[0], &sc[1]);
+        mx_sincos(y[1], &sc[2], &sc[3]);
+        dsdt(P, y, sc, torque, k4);   // :456
         const double dt6 = dt / 6.0;
         double ns[4];
 #pragma unroll
@@ -377,10 +441,14 @@ struct Env<MXV_ACROBOT> {
         double s0, c0, s1, c1;
         mx_sincos(s[0], &s0, &c0);
         mx_sincos(s[1], &s1, &c1);
-        const bool term = (-c0 - mx_cos(s[1] + s[0])) > 1.0;  // :235
+        // cos(s[1] + s[0]) :235 from the same four values
+        const double t21 = s[1] + s[0];
+        const double cos21 = __fma_rn(two_sum_residual(s[1], s[0], t21), __fma_rn(s0, c1, c0 * s1), __fma_rn(c0, c1, -(s0 * s1)));
+        const bool term = (-c0 - cos21) > 1.0;               // :235
         reward = (!term) ? -1.0 : 0.0;                     // :219
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
+        aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1;  // stage-1 values of the next step
         return term;
     }
     // np_random.uniform(low, high, size=(4,)).astype(np.float32) :188-190
