@@ -127,19 +127,36 @@ __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__
         live[j] = e[j] < n;
         ret[j] = live[j] ? returns[e[j]] : 0.0;
     }
-#pragma unroll 4
+    // software pipeline: the loads of step k+1 are in flight while step k is reduced (the recurrence itself is a few
+    // instructions per step; without the prefetch every step would wait a full HBM round trip)
+    RT r_next[4];
+    uint8_t f_next[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r_next[j] = live[j] ? rew[e[j]] : (RT)0;
+        f_next[j] = live[j] ? (uint8_t)(term[e[j]] | trunc[e[j]]) : (uint8_t)0;
+    }
     for (int k = 0; k < K; ++k) {
-        const int64_t off = (int64_t)k * n;
-        double s = 0.0, q = 0.0;
-        bool done[4];
+        RT r_cur[4];
+        uint8_t f_cur[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            double r = 0.0;
-            done[j] = false;
+            r_cur[j] = r_next[j];
+            f_cur[j] = f_next[j];
+        }
+        if (k + 1 < K) {
+            const int64_t off = (int64_t)(k + 1) * n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r_next[j] = live[j] ? rew[off + e[j]] : (RT)0;
+                f_next[j] = live[j] ? (uint8_t)(term[off + e[j]] | trunc[off + e[j]]) : (uint8_t)0;
+            }
+        }
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             if (live[j]) {
-                r = (double)rew[off + e[j]];
-                done[j] = (term[off + e[j]] | trunc[off + e[j]]) != 0;
-                ret[j] = ret[j] * gamma + r;  // :132 (two roundings; contraction is off)
+                ret[j] = ret[j] * gamma + (double)r_cur[j];  // :132 (two roundings; contraction is off)
                 s += ret[j];
                 q = __fma_rn(ret[j], ret[j], q);
             }
@@ -152,7 +169,7 @@ __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (done[j]) ret[j] = 0.0;  // :135-136
+            if (f_cur[j]) ret[j] = 0.0;  // :135-136
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
