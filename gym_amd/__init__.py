@@ -20,6 +20,8 @@ _LAZY = {
     "NormalizeObservation": ("gym_amd.wrappers", "NormalizeObservation"),
     "NormalizeReward": ("gym_amd.wrappers", "NormalizeReward"),
     "RunningNormalizer": ("gym_amd.normalize", "RunningNormalizer"),
+    "HipTabularVectorEnv": ("gym_amd.toy_text", "HipTabularVectorEnv"),
+    "TabularRollout": ("gym_amd.toy_text", "TabularRollout"),
 }
 
 

@@ -38,6 +38,9 @@ EXPORTS = (
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
+    "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
+    "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
+    "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_set_stream",
 )
 
 
@@ -45,6 +48,21 @@ class MxvConfig(C.Structure):
     _fields_ = [
         ("env_id", C.c_int32),
         ("device", C.c_int32),
+        ("num_envs", C.c_int64),
+        ("env_offset", C.c_int64),
+        ("max_episode_steps", C.c_int32),
+        ("flags", C.c_int32),
+        ("seed", C.c_uint64),
+        ("action_seed", C.c_uint64),
+    ]
+
+
+class MxvTabConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("num_states", C.c_int32),
+        ("num_actions", C.c_int32),
+        ("max_transitions", C.c_int32),
         ("num_envs", C.c_int64),
         ("env_offset", C.c_int64),
         ("max_episode_steps", C.c_int32),
@@ -113,6 +131,23 @@ def _load():
         "mxv_norm_obs_apply": ([vp, i32, vp, vp, i32, C.c_double, vp, i32, i64], C.c_int),
         "mxv_norm_reward_sums": ([vp, i32, vp, i32, vp, vp, C.c_double, vp], C.c_int),
         "mxv_norm_reward_apply": ([vp, i32, vp, i32, vp, C.c_double, vp, i32, i64], C.c_int),
+        "mxv_tab_create": ([C.POINTER(MxvTabConfig), vp, vp, vp, vp, vp, vp, C.POINTER(vp)], C.c_int),
+        "mxv_tab_destroy": ([vp], C.c_int),
+        "mxv_tab_last_error": ([vp], C.c_char_p),
+        "mxv_tab_seed": ([vp, u64, vp], C.c_int),
+        "mxv_tab_seed_actions": ([vp, u64], C.c_int),
+        "mxv_tab_reset": ([vp, vp, vp], C.c_int),
+        "mxv_tab_step": ([vp] * 10, C.c_int),
+        "mxv_tab_rollout": ([vp, i32, i32] + [vp] * 8, C.c_int),
+        "mxv_tab_rollout_tape": ([vp, i32, i32] + [vp] * 8, C.c_int),
+        "mxv_tab_reset_host": ([vp, vp, vp], C.c_int),
+        "mxv_tab_step_host": ([vp] * 10, C.c_int),
+        "mxv_tab_get_state": ([vp, vp, vp], C.c_int),
+        "mxv_tab_set_state": ([vp, vp, vp], C.c_int),
+        "mxv_tab_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
+        "mxv_tab_set_counters": ([vp, u64, u32], C.c_int),
+        "mxv_tab_sync": ([vp], C.c_int),
+        "mxv_tab_set_stream": ([vp, vp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the .so does not export a declared symbol
@@ -406,3 +441,123 @@ class Norm:
     def reward_apply(self, K, reward_dev, reward_f32: bool, out_dev, epsilon: float, all_sums_dev, world: int, total_rows: int):
         self._check(lib.mxv_norm_reward_apply(self._h, int(K), _ptr(reward_dev), int(reward_f32), _ptr(out_dev),
                                               float(epsilon), _ptr(all_sums_dev), int(world), int(total_rows)))
+
+
+class Tab:
+    """One mxv_tab handle = one device + one stream + N device-resident copies of a tabular MDP (see include/mxv.h)."""
+
+    def __init__(self, num_states, num_actions, cum_prob, prob, next_state, reward, terminated, initial_cum, num_envs,
+                 max_episode_steps, *, device=0, env_offset=0, seed=0, action_seed=0):
+        S, A = int(num_states), int(num_actions)
+        cum = np.ascontiguousarray(cum_prob, dtype=np.float64)
+        assert cum.ndim == 3 and cum.shape[:2] == (S, A), cum.shape
+        M = cum.shape[2]
+        pr = np.ascontiguousarray(prob, dtype=np.float64).reshape(S, A, M)
+        nx = np.ascontiguousarray(next_state, dtype=np.int32).reshape(S, A, M)
+        rw = np.ascontiguousarray(reward, dtype=np.float64).reshape(S, A, M)
+        te = np.ascontiguousarray(terminated, dtype=np.uint8).reshape(S, A, M)
+        ic = np.ascontiguousarray(initial_cum, dtype=np.float64).reshape(S)
+        self.S, self.A, self.M, self.num_envs, self.device = S, A, M, int(num_envs), int(device)
+        cfg = MxvTabConfig(self.device, S, A, M, self.num_envs, int(env_offset), int(max_episode_steps), 0,
+                           int(seed) & (2**64 - 1), int(action_seed) & (2**64 - 1))
+        h = C.c_void_p()
+        rc = lib.mxv_tab_create(C.byref(cfg), cum.ctypes.data, pr.ctypes.data, nx.ctypes.data, rw.ctypes.data,
+                                te.ctypes.data, ic.ctypes.data, C.byref(h))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_tab_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_tab_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.mxv_tab_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seed(self, base_seed: int, per_env_seeds=None):
+        p = None
+        if per_env_seeds is not None:
+            per_env_seeds = np.ascontiguousarray(per_env_seeds, dtype=np.uint64)
+            assert per_env_seeds.shape == (self.num_envs,)
+            p = per_env_seeds.ctypes.data
+        self._check(lib.mxv_tab_seed(self._h, int(base_seed) & (2**64 - 1), p))
+
+    def seed_actions(self, action_seed: int):
+        self._check(lib.mxv_tab_seed_actions(self._h, int(action_seed) & (2**64 - 1)))
+
+    def reset(self, obs_dev=None, mask_dev=None):
+        self._check(lib.mxv_tab_reset(self._h, _ptr(mask_dev), _ptr(obs_dev)))
+
+    def step(self, actions_dev, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, prob_dev=None,
+             final_obs_dev=None, final_prob_dev=None, uniforms_dev=None):
+        self._check(lib.mxv_tab_step(self._h, _ptr(actions_dev), _ptr(uniforms_dev), _ptr(obs_dev), _ptr(reward_dev),
+                                     _ptr(terminated_dev), _ptr(truncated_dev), _ptr(prob_dev), _ptr(final_obs_dev),
+                                     _ptr(final_prob_dev)))
+
+    def rollout(self, K, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, prob_dev=None,
+                final_obs_dev=None, final_prob_dev=None, actions_out_dev=None, per_step=False):
+        self._check(lib.mxv_tab_rollout(self._h, int(K), int(per_step), _ptr(actions_out_dev), _ptr(obs_dev),
+                                        _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev), _ptr(prob_dev),
+                                        _ptr(final_obs_dev), _ptr(final_prob_dev)))
+
+    def rollout_tape(self, K, actions_tape_dev, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None,
+                     prob_dev=None, final_obs_dev=None, final_prob_dev=None, per_step=False):
+        self._check(lib.mxv_tab_rollout_tape(self._h, int(K), int(per_step), _ptr(actions_tape_dev), _ptr(obs_dev),
+                                             _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev), _ptr(prob_dev),
+                                             _ptr(final_obs_dev), _ptr(final_prob_dev)))
+
+    def reset_host(self, mask=None) -> np.ndarray:
+        obs = np.empty(self.num_envs, dtype=np.int64)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(lib.mxv_tab_reset_host(self._h, _ptr(m), obs.ctypes.data))
+        return obs
+
+    def step_host(self, actions, uniforms=None):
+        """-> obs i64[N], reward f64[N], terminated bool[N], truncated bool[N], prob f64[N], final_obs i64[N], final_prob f64[N]
+        (final_* valid where terminated | truncated).  uniforms: None or float64 [2][N] (transition, autoreset)."""
+        n = self.num_envs
+        a = np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
+        u = None if uniforms is None else np.ascontiguousarray(uniforms, dtype=np.float64).reshape(2, n)
+        obs = np.empty(n, np.int64)
+        rew = np.empty(n, np.float64)
+        term = np.empty(n, np.uint8)
+        trunc = np.empty(n, np.uint8)
+        prob = np.empty(n, np.float64)
+        fin = np.zeros(n, np.int64)
+        fprob = np.zeros(n, np.float64)
+        self._check(lib.mxv_tab_step_host(self._h, a.ctypes.data, _ptr(u), obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+                                          trunc.ctypes.data, prob.ctypes.data, fin.ctypes.data, fprob.ctypes.data))
+        return obs, rew, term.view(np.bool_), trunc.view(np.bool_), prob, fin, fprob
+
+    def get_state(self):
+        st = np.empty(self.num_envs, dtype=np.int32)
+        el = np.empty(self.num_envs, dtype=np.int32)
+        self._check(lib.mxv_tab_get_state(self._h, st.ctypes.data, el.ctypes.data))
+        return st, el
+
+    def set_state(self, state=None, elapsed=None):
+        st = None if state is None else np.ascontiguousarray(state, dtype=np.int32).reshape(self.num_envs)
+        el = None if elapsed is None else np.ascontiguousarray(elapsed, dtype=np.int32).reshape(self.num_envs)
+        self._check(lib.mxv_tab_set_state(self._h, _ptr(st), _ptr(el)))
+
+    def get_counters(self):
+        t, r = C.c_uint64(), C.c_uint32()
+        self._check(lib.mxv_tab_get_counters(self._h, C.byref(t), C.byref(r)))
+        return t.value, r.value
+
+    def set_counters(self, t: int, r: int):
+        self._check(lib.mxv_tab_set_counters(self._h, int(t), int(r)))
+
+    def sync(self):
+        self._check(lib.mxv_tab_sync(self._h))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(lib.mxv_tab_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -10,6 +10,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_kernels.hip" -o "$out/mxv_kernels.o" &
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_api.cpp" -o "$out/mxv_api.o" &
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_norm.hip" -o "$out/mxv_norm.o" &
+"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_tab.hip" -o "$out/mxv_tab.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o" "$out/mxv_norm.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o" "$out/mxv_norm.o" "$out/mxv_tab.o"
 echo "built $out/libmxv.so"

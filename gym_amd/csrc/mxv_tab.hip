@@ -1,0 +1,614 @@
+// mxv_tab.hip — SURVEY.md §8(f)-4: the reference's tabular toy_text environments (FrozenLake-v1, FrozenLake8x8-v1,
+// Taxi-v3, CliffWalking-v0) as ONE table-driven gfx950 engine behind the mxv_tab_* C ABI (include/mxv.h).
+//
+// All three reference classes share one step() (gym/envs/toy_text/frozen_lake.py:247-256, taxi.py:254-263,
+// cliffwalking.py:148-157):   transitions = P[s][a];  i = categorical_sample([t[0] for t in transitions], np_random)
+//                             p, s, r, t = transitions[i];  return int(s), r, t, False, {"prob": p}
+// and one reset() (frozen_lake.py:258-270, taxi.py:265-278, cliffwalking.py:159-166):
+//                             s = categorical_sample(initial_state_distrib, np_random)
+// with categorical_sample = argmax(cumsum(prob_n) > np_random.random()) (toy_text/utils.py:4-8).  The MDP itself is the
+// table P, which the HOST builds (gym_amd/toy_text.py restates the three __init__ constructions) and hands over as
+// dense arrays [S][A][M] (M = the longest transition list; shorter lists are padded with cum_prob = -1, which never
+// compares greater than a uniform in [0,1), so "first index whose cumulative probability exceeds u, 0 if none" is
+// preserved).  TimeLimit (gym/wrappers/time_limit.py:39-68) and SyncVectorEnv's autoreset + final_observation
+// (gym/vector/sync_vector_env.py:135-169) are fused exactly as in the classic-control kernels.
+//
+// Kernel: one env per lane, the whole table staged in LDS once per workgroup (FrozenLake8x8: 24 KiB, Taxi: 40 KiB);
+// per env-step: one Philox4x32-10 call for the env's transition/reset uniforms, one (shared by 4 envs) for the action,
+// <= M + 3 LDS reads, and the outputs — obs int64, reward f64, 2 flag bytes, prob f64, action int64: 34 B — which is
+// what bounds it (HBM).  K steps per launch keep state + elapsed in registers (mxv_tab_rollout).
+//
+// RNG contract (Philox4x32-10, counter based): actions as in the classic engine (key = action_seed, ctr = (g, t, stream 1));
+// transition stream: key = per-env seed, ctr = (b_lo, b_hi, 0, 3 << 28) with b = t >> 1: words (x, y) serve the even step
+// 2b, (z, w) the odd step 2b+1 — first word: the step's uniform, second: the uniform of an autoreset inside that step (one
+// Philox call per env per TWO steps); explicit reset: the classic reset stream (ctr = (t_lo, t_hi, r, 2 << 28)),
+// word x.  uniform = (word + 0.5) * 2^-32.  A caller may instead inject the uniforms (mxv_tab_step, `uniforms_dev`):
+// that is how the parity tests replay the reference's own PCG64 draws bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mxv_device.hpp"
+
+using namespace mxv;
+
+namespace {
+
+constexpr int kTabBlock = 256;
+constexpr uint32_t kStreamTransition = 3u;
+constexpr unsigned kTabXcds = 8;
+
+struct TabArgs {
+    int32_t *state;          // [N] current state index
+    int32_t *elapsed;        // [N] TimeLimit counters
+    const uint64_t *seeds;   // per-env seeds or nullptr
+    // the MDP (global copies; staged into LDS when they fit)
+    const double *cum;       // [S*A*M] cumulative transition probabilities (padding = -1) or nullptr when M == 1
+    const double *prob;      // [S*A*M] transition probabilities or nullptr when every probability is 1.0
+    const double *reward;    // [S*A*M]
+    const int32_t *nt;       // [S*A*M] next_state | terminated << 31
+    const double *init_cum;  // [S] cumulative initial-state distribution
+    int32_t S, A, M, log2S;
+    // step I/O
+    const int64_t *actions;  // [N] (or [K][N] tape) or nullptr -> Philox action stream
+    int64_t *actions_out;    // optional
+    const double *uniforms;  // optional [2][N]: (transition uniform, autoreset uniform) per env; nullptr -> Philox
+    int64_t *obs;            // [N] / [K][N]
+    double *reward_out;      // may be nullptr
+    uint8_t *terminated, *truncated;  // may be nullptr
+    double *prob_out;        // may be nullptr: info["prob"] (1.0 for envs that were reset in this step)
+    int64_t *final_obs;      // may be nullptr: terminal state of finished envs (untouched elsewhere)
+    double *final_prob;      // may be nullptr: info["final_info"]["prob"] of finished envs
+    int32_t *err;
+    int64_t n;
+    uint64_t env0, base_seed, action_seed, t;
+    int32_t max_steps, K;
+    int64_t slice;           // 0 or N (per-step trajectory outputs)
+    int64_t act_slice;       // 0 or N (action tape)
+};
+
+__device__ __forceinline__ unsigned tab_tile(unsigned bid, unsigned ntiles) {  // XCD x owns the x-th contiguous eighth
+    const unsigned x = bid % kTabXcds, idx = bid / kTabXcds;
+    const unsigned base = ntiles / kTabXcds, rem = ntiles % kTabXcds;
+    return x * base + (x < rem ? x : rem) + idx;
+}
+
+__device__ __forceinline__ U4 transition_words(uint64_t seed, uint64_t b) {  // b = t >> 1
+    U4 c;
+    c.x = (uint32_t)b;
+    c.y = (uint32_t)(b >> 32);
+    c.z = 0;
+    c.w = (kStreamTransition << 28);
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// categorical_sample(initial_state_distrib): first index whose cumulative probability exceeds u, 0 if none.
+__device__ __forceinline__ int32_t sample_initial(const double *init_cum, int32_t S, int32_t log2S, double u) {
+    int32_t lo = 0, hi = S;
+    for (int it = 0; it <= log2S; ++it) {
+        if (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (init_cum[mid] > u) hi = mid;
+            else lo = mid + 1;
+        }
+    }
+    return lo < S ? lo : 0;
+}
+
+template <bool LDS_TABLE>
+__global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const int entries = a.S * a.A * a.M;
+    const double *cum = a.cum, *prob = a.prob, *reward = a.reward, *init_cum = a.init_cum;
+    const int32_t *nt = a.nt;
+    if (LDS_TABLE) {
+        double *p = smem;
+        double *l_cum = nullptr, *l_prob = nullptr;
+        if (a.cum) { l_cum = p; p += entries; }
+        if (a.prob) { l_prob = p; p += entries; }
+        double *l_rew = p; p += entries;
+        double *l_init = p; p += a.S;
+        int32_t *l_nt = reinterpret_cast<int32_t *>(p);
+        for (int i = tid; i < entries; i += kTabBlock) {
+            if (l_cum) l_cum[i] = a.cum[i];
+            if (l_prob) l_prob[i] = a.prob[i];
+            l_rew[i] = a.reward[i];
+            l_nt[i] = a.nt[i];
+        }
+        for (int i = tid; i < a.S; i += kTabBlock) l_init[i] = a.init_cum[i];
+        __syncthreads();
+        cum = l_cum; prob = l_prob; reward = l_rew; init_cum = l_init; nt = l_nt;
+    }
+    const int64_t e = (int64_t)tab_tile(blockIdx.x, gridDim.x) * kTabBlock + tid;
+    const bool valid = e < a.n;  // lanes past the end stay in the loop: their quad partners need their action words
+    const uint64_t ge = a.env0 + (uint64_t)e;
+    const uint64_t seed = (a.seeds && valid) ? a.seeds[e] : a.base_seed + ge;
+    int32_t s = valid ? a.state[e] : 0, el = valid ? a.elapsed[e] : 0;
+    // Philox caches.  Actions: one call yields the words of the 4 envs of group g = env >> 2 at ONE step, so the four
+    // lanes of a quad (= one group) each evaluate a different step of the aligned block 4*(t >> 2) .. +3 and trade words
+    // through quad shuffles: one call per lane per four steps.  Transitions: one call per two steps (see the contract).
+    const uint32_t q = (uint32_t)(ge & 3);
+    uint64_t act_block = ~0ull, tr_block = ~0ull;
+    uint32_t act_word[4] = {0, 0, 0, 0};
+    U4 tw{0, 0, 0, 0};
+    for (int k = 0; k < a.K; ++k) {
+        const uint64_t t = a.t + (uint64_t)k;
+        const int64_t o = (int64_t)k * a.slice + e;
+        // ---- action: caller's, or Discrete(A).sample() from the Philox action stream ----
+        int64_t act;
+        if (a.actions) {
+            if (!valid) continue;
+            act = a.actions[(int64_t)k * a.act_slice + e];
+            if (act < 0 || act >= a.A) {  // `assert self.action_space.contains(a)`-class error: latch, leave the env unstepped
+                atomicOr(a.err, 1);
+                continue;
+            }
+        } else {
+            if ((t >> 2) != act_block) {  // uniform across the launch: every lane refills its cache at the same step
+                act_block = t >> 2;
+                const U4 w = action_words(a.action_seed, (act_block << 2) + q, ge >> 2);
+                const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r) {
+                    // lane q sends the word of env (q ^ r); it receives, from lane q ^ r (which evaluated step q ^ r of
+                    // the block), the word of env (q ^ r) ^ r = q: its own word for step q ^ r
+                    const uint32_t i = q ^ r;
+                    const uint32_t send = i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
+                    const uint32_t recv = r == 0 ? send : (uint32_t)__shfl_xor((int)send, (int)r, 64);
+                    act_word[0] = i == 0 ? recv : act_word[0];
+                    act_word[1] = i == 1 ? recv : act_word[1];
+                    act_word[2] = i == 2 ? recv : act_word[2];
+                    act_word[3] = i == 3 ? recv : act_word[3];
+                }
+            }
+            const uint32_t j = (uint32_t)(t & 3);
+            const uint32_t word = j == 0 ? act_word[0] : (j == 1 ? act_word[1] : (j == 2 ? act_word[2] : act_word[3]));
+            act = (int64_t)(((uint64_t)word * (uint64_t)a.A) >> 32);
+            if (!valid) continue;
+            if (a.actions_out) a.actions_out[o] = act;
+        }
+        // ---- the step's uniforms ----
+        double u_step, u_reset;
+        if (a.uniforms) {
+            u_step = a.uniforms[e];
+            u_reset = a.uniforms[a.n + e];
+        } else {
+            if ((t >> 1) != tr_block) {
+                tr_block = t >> 1;
+                tw = transition_words(seed, tr_block);
+            }
+            u_step = u01((t & 1) ? tw.z : tw.x);
+            u_reset = u01((t & 1) ? tw.w : tw.y);
+        }
+        // ---- categorical_sample over P[s][act] (toy_text/utils.py:4-8) ----
+        const int base = (s * a.A + (int)act) * a.M;
+        int idx = 0;
+        if (cum) {
+            bool found = false;
+            for (int i = 0; i < a.M; ++i) {
+                const bool hit = !found && cum[base + i] > u_step;
+                idx = hit ? i : idx;
+                found = found || hit;
+            }
+        }
+        const int j = base + idx;
+        const int32_t packed = nt[j];
+        const int32_t ns = packed & 0x7fffffff;
+        const bool term = packed < 0;
+        double p = prob ? prob[j] : 1.0;
+        const double rew = reward[j];
+        el += 1;                                                   // TimeLimit.step, time_limit.py:50-53
+        const bool trunc = a.max_steps > 0 && el >= a.max_steps;
+        s = ns;
+        if (term || trunc) {  // sync_vector_env.py:152-156: the returned observation/info are the reset's
+            if (a.final_obs) a.final_obs[o] = (int64_t)ns;
+            if (a.final_prob) a.final_prob[o] = p;
+            s = sample_initial(init_cum, a.S, a.log2S, u_reset);
+            el = 0;
+            p = 1.0;                                               // reset() returns {"prob": 1}
+        }
+        a.obs[o] = (int64_t)s;
+        if (a.reward_out) a.reward_out[o] = rew;
+        if (a.terminated) a.terminated[o] = term ? 1 : 0;
+        if (a.truncated) a.truncated[o] = trunc ? 1 : 0;
+        if (a.prob_out) a.prob_out[o] = p;
+    }
+    if (valid) {
+        a.state[e] = s;
+        a.elapsed[e] = el;
+    }
+}
+
+struct TabResetArgs {
+    int32_t *state, *elapsed;
+    const uint64_t *seeds;
+    const uint8_t *mask;
+    const double *init_cum;
+    int64_t *obs;
+    int32_t S, log2S;
+    int64_t n;
+    uint64_t env0, base_seed, t;
+    uint32_t r;
+};
+
+__global__ void __launch_bounds__(kTabBlock) tab_reset_kernel(TabResetArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * kTabBlock + threadIdx.x;
+    if (e >= a.n) return;
+    if (a.mask && !a.mask[e]) {
+        if (a.obs) a.obs[e] = (int64_t)a.state[e];
+        return;
+    }
+    const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
+    const U4 w = reset_words(seed, a.t, a.r);
+    const int32_t s = sample_initial(a.init_cum, a.S, a.log2S, u01(w.x));
+    a.state[e] = s;
+    a.elapsed[e] = 0;
+    if (a.obs) a.obs[e] = (int64_t)s;
+}
+
+}  // namespace
+
+struct mxv_tab {
+    mxv_tab_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int32_t *state = nullptr, *elapsed = nullptr, *err = nullptr, *nt = nullptr;
+    uint64_t *seeds = nullptr;
+    double *cum = nullptr, *prob = nullptr, *reward = nullptr, *init_cum = nullptr;
+    size_t lds_bytes = 0;
+    bool lds_table = false;
+    int log2S = 0;
+    uint64_t base_seed = 0, action_seed = 0, t = 0;
+    uint32_t r = 0;
+    bool was_reset = false;
+    // staging for *_host calls
+    int64_t *st_actions = nullptr, *st_obs = nullptr, *st_final = nullptr;
+    double *st_reward = nullptr, *st_prob = nullptr, *st_fprob = nullptr, *st_uniforms = nullptr;
+    uint8_t *st_term = nullptr, *st_trunc = nullptr, *st_mask = nullptr;
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_tab_create_error;
+
+int tfail(mxv_tab *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h)
+        h->error = buf;
+    else
+        g_tab_create_error = buf;
+    return code;
+}
+
+#define TAB_HIP(h, expr)                                                                             \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return tfail((h), MXV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define TAB_CHECK(h) \
+    if (!(h)) return tfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_tab")
+
+int tab_check_latched(mxv_tab *h) {
+    int32_t e = 0;
+    TAB_HIP(h, hipMemcpyAsync(&e, h->err, sizeof e, hipMemcpyDeviceToHost, h->stream));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    if (e != 0) {
+        TAB_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+        return tfail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains)", h->cfg.num_actions);
+    }
+    return MXV_OK;
+}
+
+int tab_launch(mxv_tab *h, int K, int64_t slice, const int64_t *actions, int64_t act_slice, int64_t *actions_out,
+               const double *uniforms, int64_t *obs, double *reward, uint8_t *term, uint8_t *trunc, double *prob,
+               int64_t *final_obs, double *final_prob) {
+    if (!h->was_reset)
+        return tfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
+    if (!obs) return tfail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
+    if (K <= 0) return tfail(h, MXV_ERR_INVALID_ARG, "K must be positive");
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    TabArgs a{};
+    a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds;
+    a.cum = h->cum; a.prob = h->prob; a.reward = h->reward; a.nt = h->nt; a.init_cum = h->init_cum;
+    a.S = h->cfg.num_states; a.A = h->cfg.num_actions; a.M = h->cfg.max_transitions; a.log2S = h->log2S;
+    a.actions = actions; a.actions_out = actions_out; a.uniforms = uniforms;
+    a.obs = obs; a.reward_out = reward; a.terminated = term; a.truncated = trunc; a.prob_out = prob;
+    a.final_obs = final_obs; a.final_prob = final_prob;
+    a.err = h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset;
+    a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->t;
+    a.max_steps = h->cfg.max_episode_steps; a.K = K; a.slice = slice; a.act_slice = act_slice;
+    const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
+    if (h->lds_table)
+        hipLaunchKernelGGL(tab_step_kernel<true>, dim3(blocks), dim3(kTabBlock), h->lds_bytes, h->stream, a);
+    else
+        hipLaunchKernelGGL(tab_step_kernel<false>, dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
+    TAB_HIP(h, hipGetLastError());
+    h->t += (uint64_t)K;
+    return MXV_OK;
+}
+
+int tab_do_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    h->r += 1;
+    TabResetArgs a{};
+    a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.mask = mask_dev; a.init_cum = h->init_cum;
+    a.obs = obs_dev; a.S = h->cfg.num_states; a.log2S = h->log2S; a.n = h->cfg.num_envs;
+    a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->t; a.r = h->r;
+    const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
+    hipLaunchKernelGGL(tab_reset_kernel, dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
+    TAB_HIP(h, hipGetLastError());
+    h->was_reset = true;
+    return MXV_OK;
+}
+
+int tab_ensure_staging(mxv_tab *h) {
+    if (h->st_obs) return MXV_OK;
+    const size_t n = (size_t)h->cfg.num_envs;
+    TAB_HIP(h, hipMalloc((void **)&h->st_actions, n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_obs, n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_final, n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_reward, n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_prob, n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_fprob, n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_uniforms, 2 * n * 8));
+    TAB_HIP(h, hipMalloc((void **)&h->st_term, n));
+    TAB_HIP(h, hipMalloc((void **)&h->st_trunc, n));
+    TAB_HIP(h, hipMalloc((void **)&h->st_mask, n));
+    return MXV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const double *prob_host,
+                   const int32_t *next_state_host, const double *reward_host, const uint8_t *terminated_host,
+                   const double *initial_cum_host, mxv_tab **out) {
+    if (!cfg || !out) return tfail(nullptr, MXV_ERR_INVALID_ARG, "NULL config or output pointer");
+    *out = nullptr;
+    if (!cum_prob_host || !prob_host || !next_state_host || !reward_host || !terminated_host || !initial_cum_host)
+        return tfail(nullptr, MXV_ERR_INVALID_ARG, "NULL table pointer");
+    const int S = cfg->num_states, A = cfg->num_actions, M = cfg->max_transitions;
+    if (S <= 0 || A <= 0 || M <= 0 || (int64_t)S * A * M > (1 << 26))
+        return tfail(nullptr, MXV_ERR_INVALID_ARG, "bad table dimensions S=%d A=%d M=%d", S, A, M);
+    if (cfg->num_envs <= 0) return tfail(nullptr, MXV_ERR_INVALID_ARG, "num_envs must be positive");
+    if (cfg->env_offset < 0 || cfg->env_offset % MXV_ENV_ALIGN != 0)
+        return tfail(nullptr, MXV_ERR_INVALID_ARG, "env_offset must be a non-negative multiple of %d", MXV_ENV_ALIGN);
+    const size_t entries = (size_t)S * A * M;
+    for (size_t i = 0; i < entries; ++i)
+        if (next_state_host[i] < 0 || next_state_host[i] >= S)
+            return tfail(nullptr, MXV_ERR_INVALID_ARG, "next_state[%zu] = %d outside [0, %d)", i, next_state_host[i], S);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return tfail(nullptr, MXV_ERR_HIP, "no HIP device available (%s): the engine has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (cfg->device < 0 || cfg->device >= ndev) return tfail(nullptr, MXV_ERR_INVALID_ARG, "device %d out of range", cfg->device);
+    mxv_tab *h = new (std::nothrow) mxv_tab();
+    if (!h) return tfail(nullptr, MXV_ERR_INVALID_ARG, "out of host memory");
+    h->cfg = *cfg;
+    h->base_seed = cfg->seed;
+    h->action_seed = cfg->action_seed;
+    while ((1 << h->log2S) < S) h->log2S += 1;
+    bool all_one = true;
+    for (size_t i = 0; i < entries; ++i)
+        if (cum_prob_host[i] >= 0.0 && prob_host[i] != 1.0) all_one = false;
+    const bool need_cum = M > 1;
+    std::vector<int32_t> packed(entries);
+    for (size_t i = 0; i < entries; ++i) packed[i] = next_state_host[i] | (terminated_host[i] ? (int32_t)0x80000000 : 0);
+    const size_t n = (size_t)cfg->num_envs;
+#define TAB_CREATE_HIP(expr)                                                     \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            tfail(nullptr, MXV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+            mxv_tab_destroy(h);                                                  \
+            return MXV_ERR_HIP;                                                  \
+        }                                                                        \
+    } while (0)
+    TAB_CREATE_HIP(hipSetDevice(cfg->device));
+    TAB_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    TAB_CREATE_HIP(hipMalloc((void **)&h->state, n * sizeof(int32_t)));
+    TAB_CREATE_HIP(hipMalloc((void **)&h->elapsed, n * sizeof(int32_t)));
+    TAB_CREATE_HIP(hipMalloc((void **)&h->err, sizeof(int32_t)));
+    TAB_CREATE_HIP(hipMalloc((void **)&h->reward, entries * sizeof(double)));
+    TAB_CREATE_HIP(hipMalloc((void **)&h->nt, entries * sizeof(int32_t)));
+    TAB_CREATE_HIP(hipMalloc((void **)&h->init_cum, (size_t)S * sizeof(double)));
+    if (need_cum) TAB_CREATE_HIP(hipMalloc((void **)&h->cum, entries * sizeof(double)));
+    if (!all_one) TAB_CREATE_HIP(hipMalloc((void **)&h->prob, entries * sizeof(double)));
+    TAB_CREATE_HIP(hipMemsetAsync(h->state, 0, n * sizeof(int32_t), h->stream));
+    TAB_CREATE_HIP(hipMemsetAsync(h->elapsed, 0, n * sizeof(int32_t), h->stream));
+    TAB_CREATE_HIP(hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+    TAB_CREATE_HIP(hipMemcpyAsync(h->reward, reward_host, entries * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    TAB_CREATE_HIP(hipMemcpyAsync(h->nt, packed.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    TAB_CREATE_HIP(hipMemcpyAsync(h->init_cum, initial_cum_host, (size_t)S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (need_cum) TAB_CREATE_HIP(hipMemcpyAsync(h->cum, cum_prob_host, entries * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!all_one) TAB_CREATE_HIP(hipMemcpyAsync(h->prob, prob_host, entries * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    TAB_CREATE_HIP(hipStreamSynchronize(h->stream));
+#undef TAB_CREATE_HIP
+    h->lds_bytes = entries * (sizeof(double) * (1 + (need_cum ? 1 : 0) + (all_one ? 0 : 1)) + sizeof(int32_t)) + (size_t)S * sizeof(double);
+    h->lds_table = h->lds_bytes <= 64 * 1024;  // larger MDPs (custom maps) read the table through L2 instead
+    *out = h;
+    return MXV_OK;
+}
+
+int mxv_tab_destroy(mxv_tab *h) {
+    if (!h) return MXV_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->st_actions,
+                    h->st_obs, h->st_final, h->st_reward, h->st_prob, h->st_fprob, h->st_uniforms, h->st_term, h->st_trunc, h->st_mask};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MXV_OK;
+}
+
+const char *mxv_tab_last_error(const mxv_tab *h) { return h ? h->error.c_str() : g_tab_create_error.c_str(); }
+
+int mxv_tab_seed(mxv_tab *h, uint64_t base_seed, const uint64_t *per_env_seeds_host) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    h->base_seed = base_seed;
+    h->t = 0;
+    h->r = 0;
+    if (per_env_seeds_host) {
+        const size_t bytes = (size_t)h->cfg.num_envs * sizeof(uint64_t);
+        if (!h->seeds) TAB_HIP(h, hipMalloc((void **)&h->seeds, bytes));
+        TAB_HIP(h, hipMemcpyAsync(h->seeds, per_env_seeds_host, bytes, hipMemcpyHostToDevice, h->stream));
+        TAB_HIP(h, hipStreamSynchronize(h->stream));
+    } else if (h->seeds) {
+        TAB_HIP(h, hipFree(h->seeds));
+        h->seeds = nullptr;
+    }
+    return MXV_OK;
+}
+
+int mxv_tab_seed_actions(mxv_tab *h, uint64_t action_seed) {
+    TAB_CHECK(h);
+    h->action_seed = action_seed;
+    return MXV_OK;
+}
+
+int mxv_tab_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
+    TAB_CHECK(h);
+    return tab_do_reset(h, mask_dev, obs_dev);
+}
+
+int mxv_tab_step(mxv_tab *h, const int64_t *actions_dev, const double *uniforms_dev, int64_t *obs_dev, double *reward_dev,
+                 uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
+                 double *final_prob_dev) {
+    TAB_CHECK(h);
+    if (!actions_dev) return tfail(h, MXV_ERR_INVALID_ARG, "actions pointer is NULL (use mxv_tab_rollout for sampled actions)");
+    return tab_launch(h, 1, 0, actions_dev, 0, nullptr, uniforms_dev, obs_dev, reward_dev, terminated_dev, truncated_dev,
+                      prob_dev, final_obs_dev, final_prob_dev);
+}
+
+int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, int64_t *actions_out_dev, int64_t *obs_dev, double *reward_dev,
+                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
+                    double *final_prob_dev) {
+    TAB_CHECK(h);
+    return tab_launch(h, K, per_step ? h->cfg.num_envs : 0, nullptr, 0, actions_out_dev, nullptr, obs_dev, reward_dev,
+                      terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev);
+}
+
+int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *obs_dev,
+                         double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev,
+                         int64_t *final_obs_dev, double *final_prob_dev) {
+    TAB_CHECK(h);
+    if (!actions_tape_dev) return tfail(h, MXV_ERR_INVALID_ARG, "actions tape pointer is NULL");
+    return tab_launch(h, K, per_step ? h->cfg.num_envs : 0, actions_tape_dev, h->cfg.num_envs, nullptr, nullptr, obs_dev,
+                      reward_dev, terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev);
+}
+
+int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    if (int rc = tab_ensure_staging(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (mask_host) TAB_HIP(h, hipMemcpyAsync(h->st_mask, mask_host, n, hipMemcpyHostToDevice, h->stream));
+    if (int rc = tab_do_reset(h, mask_host ? h->st_mask : nullptr, obs_host ? h->st_obs : nullptr)) return rc;
+    if (obs_host) TAB_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * 8, hipMemcpyDeviceToHost, h->stream));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uniforms_host, int64_t *obs_host,
+                      double *reward_host, uint8_t *terminated_host, uint8_t *truncated_host, double *prob_host,
+                      int64_t *final_obs_host, double *final_prob_host) {
+    TAB_CHECK(h);
+    if (!actions_host || !obs_host) return tfail(h, MXV_ERR_INVALID_ARG, "actions/obs pointer is NULL");
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    if (int rc = tab_ensure_staging(h)) return rc;
+    const size_t n = (size_t)h->cfg.num_envs;
+    TAB_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (uniforms_host) TAB_HIP(h, hipMemcpyAsync(h->st_uniforms, uniforms_host, 2 * n * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = tab_launch(h, 1, 0, h->st_actions, 0, nullptr, uniforms_host ? h->st_uniforms : nullptr, h->st_obs,
+                            reward_host ? h->st_reward : nullptr, terminated_host ? h->st_term : nullptr,
+                            truncated_host ? h->st_trunc : nullptr, prob_host ? h->st_prob : nullptr,
+                            final_obs_host ? h->st_final : nullptr, final_prob_host ? h->st_fprob : nullptr))
+        return rc;
+    TAB_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (reward_host) TAB_HIP(h, hipMemcpyAsync(reward_host, h->st_reward, n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (terminated_host) TAB_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
+    if (truncated_host) TAB_HIP(h, hipMemcpyAsync(truncated_host, h->st_trunc, n, hipMemcpyDeviceToHost, h->stream));
+    if (prob_host) TAB_HIP(h, hipMemcpyAsync(prob_host, h->st_prob, n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (final_obs_host) TAB_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (final_prob_host) TAB_HIP(h, hipMemcpyAsync(final_prob_host, h->st_fprob, n * 8, hipMemcpyDeviceToHost, h->stream));
+    int rc = tab_check_latched(h);
+    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;
+    return rc;
+}
+
+int mxv_tab_get_state(mxv_tab *h, int32_t *state_host, int32_t *elapsed_host) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (state_host) TAB_HIP(h, hipMemcpyAsync(state_host, h->state, n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (elapsed_host) TAB_HIP(h, hipMemcpyAsync(elapsed_host, h->elapsed, n * 4, hipMemcpyDeviceToHost, h->stream));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elapsed_host) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (state_host) {
+        for (size_t i = 0; i < n; ++i)
+            if (state_host[i] < 0 || state_host[i] >= h->cfg.num_states)
+                return tfail(h, MXV_ERR_INVALID_ARG, "state[%zu] = %d outside [0, %d)", i, state_host[i], h->cfg.num_states);
+        TAB_HIP(h, hipMemcpyAsync(h->state, state_host, n * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (elapsed_host) TAB_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * 4, hipMemcpyHostToDevice, h->stream));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    h->was_reset = true;
+    return MXV_OK;
+}
+
+int mxv_tab_get_counters(mxv_tab *h, uint64_t *t, uint32_t *r) {
+    TAB_CHECK(h);
+    if (t) *t = h->t;
+    if (r) *r = h->r;
+    return MXV_OK;
+}
+
+int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r) {
+    TAB_CHECK(h);
+    h->t = t;
+    h->r = r;
+    return MXV_OK;
+}
+
+int mxv_tab_sync(mxv_tab *h) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    return tab_check_latched(h);
+}
+
+int mxv_tab_set_stream(mxv_tab *h, void *stream) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    if (h->stream) TAB_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) TAB_HIP(h, hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return MXV_OK;
+}
+
+}  // extern "C"

@@ -359,9 +359,13 @@ class HipVectorEnv(VectorEnv):
         return self._handle
 
 
-def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> HipVectorEnv:
+def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> VectorEnv:
     """gym.vector.make (gym/vector/__init__.py:12-73) for the engine's ids.  `asynchronous` is accepted and
     ignored: there are no sub-processes, all sub-envs step in one kernel launch."""
     kwargs.pop("disable_env_checker", None)
     kwargs.pop("wrappers", None)
+    from . import toy_text
+
+    if id in toy_text.TOY_TEXT_REGISTRY:  # FrozenLake / Taxi / CliffWalking: the table-driven engine (SURVEY.md §8f-4)
+        return toy_text.HipTabularVectorEnv(id, num_envs, **kwargs)
     return HipVectorEnv(id, num_envs, **kwargs)

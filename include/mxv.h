@@ -239,6 +239,68 @@ int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_
 int mxv_norm_reward_apply(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, void *out_dev, double epsilon,
                           const double *all_sums_dev, int32_t world, int64_t total_rows);
 
+/* -- tabular toy_text environments: FrozenLake-v1 / FrozenLake8x8-v1 / Taxi-v3 / CliffWalking-v0 ---------
+ *    One table-driven engine for the reference classes whose step() is `i = categorical_sample(P[s][a] probabilities);
+ *    p, s, r, t = P[s][a][i]` and whose reset() is `categorical_sample(initial_state_distrib)` (gym/envs/toy_text/
+ *    frozen_lake.py:247-270, taxi.py:254-278, cliffwalking.py:148-166, utils.py:4-8), with TimeLimit and SyncVectorEnv's
+ *    autoreset fused as above.  The caller supplies the MDP as dense host tables [S][A][M] (M = longest transition list):
+ *    cum_prob = np.cumsum of the list's probabilities, padded with -1; prob / next_state / reward / terminated per
+ *    transition (padding ignored); initial_cum[S] = np.cumsum(initial_state_distrib).  Observations and actions are
+ *    int64 [N] (MultiDiscrete, gym/vector/utils/spaces.py:53-68), rewards float64, info["prob"] float64.
+ *    RNG: actions from the Philox action stream above; transitions from a Philox4x32-10 call keyed by the env's seed, ctr =
+ *    (b_lo, b_hi, 0, 3 << 28), b = t >> 1: words (x, y) serve step 2b, (z, w) step 2b+1 — first the transition's uniform, then
+ *    the uniform of an autoreset inside that step; explicit resets use the reset stream above (word x);
+ *    uniform = (word + 0.5) * 2^-32. -------------------------------- */
+typedef struct mxv_tab mxv_tab;
+typedef struct mxv_tab_config {
+    int32_t device;
+    int32_t num_states;        /* S */
+    int32_t num_actions;       /* A */
+    int32_t max_transitions;   /* M */
+    int64_t num_envs;
+    int64_t env_offset;        /* global index of local env 0 (multiple of MXV_ENV_ALIGN) */
+    int32_t max_episode_steps; /* TimeLimit; <= 0 disables (CliffWalking-v0 has none) */
+    int32_t flags;             /* reserved, 0 */
+    uint64_t seed;
+    uint64_t action_seed;
+} mxv_tab_config;
+int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const double *prob_host,
+                   const int32_t *next_state_host, const double *reward_host, const uint8_t *terminated_host,
+                   const double *initial_cum_host, mxv_tab **out);
+int mxv_tab_destroy(mxv_tab *h);
+const char *mxv_tab_last_error(const mxv_tab *h);
+int mxv_tab_seed(mxv_tab *h, uint64_t base_seed, const uint64_t *per_env_seeds_host);
+int mxv_tab_seed_actions(mxv_tab *h, uint64_t action_seed);
+/* mask_dev NULL = all envs; obs_dev (may be NULL) receives the states as int64. */
+int mxv_tab_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev);
+/* One vector step.  uniforms_dev: NULL = Philox; else double[2][N] = (transition uniform, autoreset uniform) per env — the
+ * values the reference's np_random.random() returned, for bit-exact replays.  On terminated | truncated: obs = the reset
+ * state, prob = 1.0 (reset()'s info), final_obs / final_prob = the terminal state and its transition probability
+ * (info["final_observation"], info["final_info"]["prob"]; rows of other envs untouched).  Any output but obs_dev may be NULL. */
+int mxv_tab_step(mxv_tab *h, const int64_t *actions_dev, const double *uniforms_dev, int64_t *obs_dev, double *reward_dev,
+                 uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
+                 double *final_prob_dev);
+/* K steps in ONE launch (state + TimeLimit counter in registers), actions sampled on device (Discrete(A).sample()) or read
+ * from a tape int64 [K][N]; per_step != 0: outputs are [K][N] trajectories, else overwritten K times. */
+int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, int64_t *actions_out_dev, int64_t *obs_dev, double *reward_dev,
+                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
+                    double *final_prob_dev);
+int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *obs_dev,
+                         double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev,
+                         int64_t *final_obs_dev, double *final_prob_dev);
+/* host-buffer convenience (staged copies, synchronising) */
+int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host);
+int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uniforms_host, int64_t *obs_host,
+                      double *reward_host, uint8_t *terminated_host, uint8_t *truncated_host, double *prob_host,
+                      int64_t *final_obs_host, double *final_prob_host);
+/* env.unwrapped.s and TimeLimit._elapsed_steps: int32 [N] each (either may be NULL) */
+int mxv_tab_get_state(mxv_tab *h, int32_t *state_host, int32_t *elapsed_host);
+int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elapsed_host);
+int mxv_tab_get_counters(mxv_tab *h, uint64_t *t, uint32_t *r);
+int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r);
+int mxv_tab_sync(mxv_tab *h);
+int mxv_tab_set_stream(mxv_tab *h, void *stream);
+
 /* -- stream / sync -------------------------------------------------------------------------------- */
 /* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last
  * sync saw an out-of-range action (and clears the latch). */

@@ -21,7 +21,7 @@ DISCRETE = {0: 2, 2: 3, 3: 3}  # env_id -> number of actions
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Returns the library path."""
-    srcs = [os.path.join(_HERE, f) for f in ("classic_control.c", "normalize.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("classic_control.c", "normalize.c", "tabular.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
@@ -51,6 +51,10 @@ def lib():
                                   vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_norm_obs_batches.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, C.c_int, vp]
         L.orc_norm_reward_steps.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, i64, i64, C.c_int, vp]
+        L.orc_tab_reset.argtypes = [C.c_int, vp, i64, u64, vp, u64, u64, u32, vp, vp, vp, vp]
+        L.orc_tab_step.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, u64, vp, u64, u64, u64, C.c_int,
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orc_tab_step.restype = i64
         L.orc_norm_obs_sums.argtypes = [vp, i64, i64, C.c_int, vp]
         L.orc_norm_obs_apply.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, vp, C.c_int, i64, vp]
         L.orc_norm_reward_sums.argtypes = [vp, vp, vp, vp, i64, i64, C.c_double, vp]
@@ -269,3 +273,64 @@ class RunningNorm:
         lib().orc_norm_reward_apply(_p(self.ret_mean), _p(self.ret_var), _p(self.ret_count), self.rew_epsilon, _p(rs),
                                     rs.shape[0], self.n, _p(a), a.shape[0], int(total_rows), _p(out))
         return out.reshape(r.shape)
+
+
+class OracleTabEnv:
+    """Batched CPU twin of the mxv_tab engine (oracle/tabular.c): tabular toy_text env under SyncVectorEnv + TimeLimit.
+    Tables as in include/mxv.h: cum_prob / prob / next_state / reward / terminated [S][A][M], initial_cum [S]."""
+
+    def __init__(self, cum_prob, prob, next_state, reward, terminated, initial_cum, num_envs, max_episode_steps,
+                 seed=0, action_seed=0, env_offset=0):
+        self.cum = np.ascontiguousarray(cum_prob, np.float64)
+        self.S, self.A, self.M = self.cum.shape
+        self.prob = np.ascontiguousarray(prob, np.float64)
+        self.next = np.ascontiguousarray(next_state, np.int32)
+        self.reward = np.ascontiguousarray(reward, np.float64)
+        self.term_tab = np.ascontiguousarray(terminated, np.uint8)
+        self.init_cum = np.ascontiguousarray(initial_cum, np.float64)
+        self.n = int(num_envs)
+        self.max_episode_steps = -1 if max_episode_steps is None else int(max_episode_steps)
+        self.base_seed = int(seed) & (2**64 - 1)
+        self.action_seed = int(action_seed) & (2**64 - 1)
+        self.env0 = int(env_offset)
+        self.seeds = None
+        self.state = np.zeros(self.n, np.int32)
+        self.elapsed = np.zeros(self.n, np.int32)
+        self.t = 0
+        self.r = 0
+
+    def reset(self, seed=None, mask=None):
+        if seed is not None:
+            if np.ndim(seed) == 0:
+                self.base_seed, self.seeds = int(seed) & (2**64 - 1), None
+            else:
+                self.seeds = np.asarray(seed, dtype=np.uint64).copy()
+            self.t = 0
+            self.r = 0
+        self.r += 1
+        obs = np.zeros(self.n, np.int64)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_tab_reset(self.S, _p(self.init_cum), self.n, self.env0, _p(self.seeds), self.base_seed, self.t, self.r,
+                            _p(m), _p(self.state), _p(self.elapsed), _p(obs))
+        return obs
+
+    def step(self, actions=None, uniforms=None):
+        """-> dict(actions, obs, reward, terminated, truncated, prob, final_obs, final_prob, final_mask)"""
+        n = self.n
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
+        u = None if uniforms is None else np.ascontiguousarray(uniforms, dtype=np.float64).reshape(2, n)
+        out = dict(actions=np.zeros(n, np.int64), obs=np.zeros(n, np.int64), reward=np.zeros(n, np.float64),
+                   terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), prob=np.zeros(n, np.float64),
+                   final_obs=np.zeros(n, np.int64), final_prob=np.zeros(n, np.float64), final_mask=np.zeros(n, np.uint8))
+        bad = lib().orc_tab_step(self.S, self.A, self.M, _p(self.cum), _p(self.prob), _p(self.next), _p(self.reward),
+                                 _p(self.term_tab), _p(self.init_cum), n, self.env0, _p(self.seeds), self.base_seed,
+                                 self.action_seed, self.t, self.max_episode_steps, _p(a), _p(u), _p(self.state),
+                                 _p(self.elapsed), _p(out["actions"]), _p(out["obs"]), _p(out["reward"]),
+                                 _p(out["terminated"]), _p(out["truncated"]), _p(out["prob"]), _p(out["final_obs"]),
+                                 _p(out["final_prob"]), _p(out["final_mask"]))
+        if bad:
+            raise KeyError(f"{bad} invalid action(s)")
+        self.t += 1
+        for k in ("terminated", "truncated", "final_mask"):
+            out[k] = out[k].astype(bool)
+        return out

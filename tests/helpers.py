@@ -182,3 +182,46 @@ def norm_obs_bound(raw_obs, ref_norm, rtol=1e-5):
     std = np.where(rng_y > 0, rng_x / np.where(rng_y > 0, rng_y, 1), np.inf)   # [T][O]
     scale = (2.0 ** -24) * (2.0 + np.sqrt(n)) * xmax[None, :] / std    # [T][O]
     return rtol * np.abs(ref_norm) + scale[:, None, :] * (1.0 + np.abs(ref_norm)) + 1e-300
+
+
+# ---- tabular toy_text envs ---------------------------------------------------------------------------
+TOYTEXT_CASES = ["FrozenLake-v1", "FrozenLake8x8-v1", "FrozenLake-v1_deterministic", "FrozenLake-v1_limit7", "Taxi-v3",
+                 "CliffWalking-v0"]
+
+
+def load_toytext_golden(tag):
+    return np.load(os.path.join(GOLDEN, f"toytext_{tag}.npz"))
+
+
+def toytext_mdp(g):
+    """The product's MDP builder for a golden case (gym_amd.toy_text is host-only code: importable without a GPU)."""
+    from gym_amd import toy_text
+
+    gid = str(g["id"])
+    kw = {} if gid in ("Taxi-v3", "CliffWalking-v0") else {"is_slippery": bool(g["is_slippery"])}
+    return toy_text.TOY_TEXT_REGISTRY[gid].build(**kw)
+
+
+def replay_toytext(g, make_engine):
+    """Feed the golden's actions and the reference's recorded uniforms to an engine and compare every output bit for bit.
+    make_engine(mdp, n, limit) -> object with set_state(state, elapsed) and step(actions, uniforms) -> dict as OracleTabEnv."""
+    mdp = toytext_mdp(g)
+    T, n = g["actions"].shape
+    eng = make_engine(mdp, n, int(g["max_episode_steps"]))
+    eng.set_state(g["obs0"].astype(np.int32), np.zeros(n, np.int32))
+    ndone = 0
+    for t in range(T):
+        out = eng.step(g["actions"][t], g["uniforms"][t])
+        done = g["final_mask"][t]
+        assert np.array_equal(out["obs"], g["obs"][t]), t
+        assert np.array_equal(out["reward"], g["reward"][t]), t
+        assert np.array_equal(out["terminated"], g["terminated"][t]) and np.array_equal(out["truncated"], g["truncated"][t]), t
+        prob = out["prob"].astype(np.int64) if g["prob_is_int"][t] else out["prob"]   # VectorEnv._add_info's dtype quirk
+        assert np.array_equal(prob, g["prob"][t]), t
+        assert np.array_equal(out["terminated"] | out["truncated"], done), t
+        assert np.array_equal(out["final_obs"][done], g["final_obs"][t][done]), t
+        assert np.array_equal(out["final_prob"][done], g["final_prob"][t][done]), t
+        if mdp.action_mask is not None:
+            assert np.array_equal(mdp.action_mask[out["obs"]], g["step_action_mask"][t]), t
+        ndone += int(done.sum())
+    return ndone

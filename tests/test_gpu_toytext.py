@@ -1,0 +1,231 @@
+"""SURVEY.md §8(f)-4 on the MI355X: the table-driven toy_text engine (mxv_tab_*, through the C ABI).
+
+  (a) the reference's SyncVectorEnv trajectories replayed with the reference's own recorded uniforms: BIT-EXACT
+      (observations, rewards, flags, infos["prob"] incl. the _add_info dtype quirk, final_observation / final_info);
+  (b) Philox mode against the oracle twin (sampled actions, transition and reset streams): bit-exact, fused K-step
+      launch == K single-step launches == action-tape replay;
+  (c) the HipTabularVectorEnv surface (dtypes, infos, errors) — what gym.vector.SyncVectorEnv returns for these ids;
+  (d) 2^20 envs: shard invariance, rewind-and-replay, MDP consistency of every recorded transition.
+"""
+import numpy as np
+import pytest
+
+from helpers import TOYTEXT_CASES, load_toytext_golden, replay_toytext, toytext_mdp
+
+pytestmark = pytest.mark.gpu
+
+
+def _tab(mdp, n, limit, **kw):
+    from gym_amd import _native
+
+    return _native.Tab(mdp.num_states, mdp.num_actions, mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated,
+                       mdp.initial_cum, n, limit, **kw)
+
+
+class _HipAdapter:
+    def __init__(self, mdp, n, limit):
+        self.h = _tab(mdp, n, limit)
+
+    def set_state(self, state, elapsed):
+        self.h.set_state(state, elapsed)
+
+    def step(self, actions, uniforms):
+        obs, rew, term, trunc, prob, fin, fprob = self.h.step_host(actions, uniforms)
+        return dict(obs=obs, reward=rew, terminated=term, truncated=trunc, prob=prob, final_obs=fin, final_prob=fprob)
+
+
+@pytest.mark.parametrize("tag", TOYTEXT_CASES)
+def test_device_replays_reference_trajectories_bit_exact(tag):
+    g = load_toytext_golden(tag)
+    ndone = replay_toytext(g, _HipAdapter)
+    assert ndone == int(g["final_mask"].sum()) and ndone > 0
+
+
+@pytest.mark.parametrize("gid,limit", [("FrozenLake-v1", 100), ("FrozenLake8x8-v1", 9), ("Taxi-v3", 13), ("CliffWalking-v0", None)])
+def test_philox_mode_equals_oracle_twin_and_fused_equals_single_steps(gid, limit):
+    import torch
+    from gym_amd.toy_text import TabularRollout
+    from oracle.oracle import OracleTabEnv
+
+    n, K = 3001, 50
+    runs = {}
+    for mode in ("fused", "single", "tape"):
+        r = TabularRollout(gid, n, seed=31, action_seed=32, max_episode_steps=limit)
+        obs0 = r.reset(seed=31).cpu().numpy().copy()
+        if mode == "fused":
+            out = r.rollout_per_step(K)
+        elif mode == "single":
+            out = r.trajectory_buffers(K)
+            for k in range(K):
+                r.handle.rollout(1, out["obs"][k], out["reward"][k], out["terminated"][k], out["truncated"][k], out["prob"][k],
+                                 actions_out_dev=out["actions"][k], per_step=False)
+        else:
+            out = r.rollout_tape(torch.from_numpy(runs["fused"][1]["actions"]).cuda())
+        r.synchronize()
+        runs[mode] = (obs0, {k: v.cpu().numpy() for k, v in out.items()}, r.handle.get_state())
+        r.close()
+    for mode in ("single", "tape"):
+        assert np.array_equal(runs["fused"][0], runs[mode][0])
+        for k, v in runs["fused"][1].items():
+            assert np.array_equal(v, runs[mode][1][k]), (mode, k)
+        assert all(np.array_equal(a, b) for a, b in zip(runs["fused"][2], runs[mode][2]))
+    from gym_amd.toy_text import TOY_TEXT_REGISTRY
+    mdp = TOY_TEXT_REGISTRY[gid].build()
+    orc = OracleTabEnv(mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum, n, limit,
+                       seed=31, action_seed=32)
+    assert np.array_equal(orc.reset(seed=31), runs["fused"][0])
+    dev = runs["fused"][1]
+    ndone = 0
+    for k in range(K):
+        o = orc.step()
+        for name in ("actions", "obs", "reward", "prob"):
+            assert np.array_equal(o[name], dev[name][k]), (k, name)
+        assert np.array_equal(o["terminated"], dev["terminated"][k].astype(bool))
+        assert np.array_equal(o["truncated"], dev["truncated"][k].astype(bool))
+        ndone += int(o["final_mask"].sum())
+    assert np.array_equal(orc.state, runs["fused"][2][0]) and np.array_equal(orc.elapsed, runs["fused"][2][1])
+    if limit is not None:
+        assert ndone > 0
+
+
+def test_hip_tabular_vector_env_contract():
+    import gym_amd
+    from gym_amd import error
+    from gym_amd.spaces import Discrete, MultiDiscrete
+    from gym_amd.toy_text import HipTabularVectorEnv
+
+    env = gym_amd.make("FrozenLake-v1", 8, max_episode_steps=5)
+    assert isinstance(env, HipTabularVectorEnv) and env.num_envs == 8 and env.is_vector_env
+    assert isinstance(env.single_observation_space, Discrete) and env.single_observation_space.n == 16
+    assert isinstance(env.observation_space, MultiDiscrete) and isinstance(env.action_space, MultiDiscrete)
+    with pytest.raises(error.ResetNeeded):
+        env.step(np.zeros(8, np.int64))
+    obs, infos = env.reset(seed=7)
+    assert obs.dtype == np.int64 and obs.shape == (8,) and np.all(obs == 0)           # the single start state
+    assert infos["prob"].dtype == np.int64 and np.all(infos["prob"] == 1) and infos["_prob"].all()   # {"prob": 1}
+    obs2, _ = env.reset(seed=7)
+    assert np.array_equal(obs, obs2)
+    seen_int = seen_float = False
+    env.action_space.seed(0)
+    for _ in range(40):
+        obs, rew, term, trunc, infos = env.step(env.action_space.sample())
+        assert obs.dtype == np.int64 and rew.dtype == np.float64 and term.dtype == np.bool_ and trunc.dtype == np.bool_
+        done = term | trunc
+        if done[0]:   # VectorEnv._add_info: sub-env 0's int 1 types the whole array
+            assert infos["prob"].dtype == np.int64
+            seen_int = True
+        else:
+            assert infos["prob"].dtype == np.float64
+            seen_float = True
+        assert np.all(np.asarray(infos["prob"])[done] == 1)
+        if done.any():
+            assert infos["final_observation"].dtype == np.int64 and np.array_equal(infos["_final_observation"], done)
+            assert np.all(infos["final_observation"][~done] == 0)
+            fi = infos["final_info"]
+            assert fi.dtype == object and all((fi[i] is None) != bool(done[i]) for i in range(8))
+            assert all(set(fi[i]) == {"prob"} and fi[i]["prob"] in (1.0, 1.0 / 3.0) for i in np.flatnonzero(done))
+            assert np.all(obs[done] == 0)                                                # returned obs = the reset state
+        else:
+            assert "final_observation" not in infos
+    assert seen_int and seen_float
+    with pytest.raises(KeyError):
+        env.step(np.array([0, 1, 2, 3, 4, 0, 0, 0]))
+    P = env.get_attr("P")[0]
+    assert P[0][0] == [(1.0 / 3.0, 0, 0.0, False), (1.0 / 3.0, 0, 0.0, False), (1.0 / 3.0, 4, 0.0, False)]
+    env.close()
+    with pytest.raises(error.ClosedEnvironmentError):
+        env.reset()
+
+    taxi = gym_amd.make("Taxi-v3", 5)
+    obs, infos = taxi.reset(seed=[1, 2, 3, 4, 5])
+    assert infos["prob"].dtype == np.float64                                             # {"prob": 1.0}
+    am = infos["action_mask"]
+    assert am.dtype == object and am[0].dtype == np.int8 and am[0].shape == (6,)
+    assert np.array_equal(np.stack(list(am)), taxi.mdp.action_mask[obs])
+    obs, rew, term, trunc, infos = taxi.step(np.array([4, 4, 5, 0, 1]))
+    assert set(np.unique(rew)) <= {-1.0, -10.0, 20.0}
+    assert np.array_equal(np.stack(list(infos["action_mask"])), taxi.mdp.action_mask[obs])
+    taxi.close()
+    with pytest.raises(TypeError):
+        gym_amd.make("CliffWalking-v0", 4, is_slippery=False)
+    det = gym_amd.make("FrozenLake-v1", 4, is_slippery=False)
+    det.reset(seed=0)
+    o, r, te, tr, _ = det.step(np.array([2, 2, 1, 1]))           # RIGHT -> 1, DOWN -> 4, deterministically
+    assert np.array_equal(o, [1, 1, 4, 4])
+    det.close()
+
+
+def test_full_size_properties():
+    """2^20 FrozenLake8x8 envs, 64-step fused rollouts."""
+    import torch
+    from gym_amd.toy_text import TabularRollout
+
+    n, K = 1 << 20, 64
+    full = TabularRollout("FrozenLake8x8-v1", n, seed=9, action_seed=10)
+    obs0 = full.reset(seed=9).clone()
+    a = full.rollout_per_step(K)
+    full.synchronize()
+    # shard invariance: the same logical vector env on 4 handles (global-index Philox streams)
+    parts = []
+    for w in range(4):
+        sh = TabularRollout("FrozenLake8x8-v1", n // 4, env_offset=w * (n // 4), seed=9, action_seed=10)
+        o0 = sh.reset(seed=9).clone()
+        parts.append((o0, sh.rollout_per_step(K)))
+        sh.synchronize()
+        sh.close()
+    assert torch.equal(obs0, torch.cat([p[0] for p in parts]))
+    for k in a:
+        assert torch.equal(a[k], torch.cat([p[1][k] for p in parts], dim=1)), k
+    # rewind and replay the recorded actions: identical trajectory (transition uniforms depend on (seed, env, t) only)
+    full.handle.set_state(obs0.cpu().numpy().astype(np.int32), np.zeros(n, np.int32))
+    full.handle.set_counters(0, 1)
+    b = full.rollout_tape(a["actions"])
+    full.synchronize()
+    for k in ("obs", "reward", "terminated", "truncated", "prob"):
+        assert torch.equal(a[k], b[k]), k
+    # every recorded transition is a transition of the MDP
+    mdp = full.mdp
+    obs = a["obs"].cpu().numpy()
+    act = a["actions"].cpu().numpy()
+    done = (a["terminated"] | a["truncated"]).cpu().numpy().astype(bool)
+    rew = a["reward"].cpu().numpy()
+    prev = np.concatenate([obs0.cpu().numpy()[None], obs[:-1]])
+    k = 17
+    nxt_ok = np.zeros(n, bool)
+    for i in range(mdp.max_transitions):
+        nxt_ok |= (mdp.next_state[prev[k], act[k], i] == obs[k]) & (mdp.cum_prob[prev[k], act[k], i] >= 0)
+    assert nxt_ok[~done[k]].all()
+    assert np.all(obs[k][done[k]] == 0)                        # autoreset to the start state
+    assert set(np.unique(rew)) <= {0.0, 1.0} and rew.sum() > 0  # some random walks reach the goal
+    assert np.all(rew[~a["terminated"].cpu().numpy().astype(bool)] == 0)
+    p = a["prob"].cpu().numpy()
+    assert np.array_equal(p == 1.0, done) and np.all(np.isin(p, [1.0, 1.0 / 3.0]))   # reset()'s prob 1 vs slippery 1/3
+    assert 0.005 < done.mean() < 0.3                           # random FrozenLake8x8 episodes last tens of steps
+    full.close()
+
+
+def test_large_table_falls_back_to_global_memory():
+    """A custom 20x20 map (33 600 B of cum/prob/reward + ... > 64 KiB of LDS) runs from L2 instead; same semantics."""
+    from gym_amd.toy_text import frozen_lake_mdp
+    from oracle.oracle import OracleTabEnv
+
+    rng = np.random.default_rng(0)
+    rows = [["F"] * 20 for _ in range(20)]
+    for _ in range(40):
+        rows[rng.integers(20)][rng.integers(20)] = "H"
+    rows[0][0], rows[19][19] = "S", "G"
+    mdp = frozen_lake_mdp(desc=["".join(r) for r in rows])
+    assert mdp.num_states * 4 * 3 * 28 + mdp.num_states * 8 > 64 * 1024
+    n = 2048
+    h = _tab(mdp, n, 50, seed=1, action_seed=2)
+    orc = OracleTabEnv(mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum, n, 50, seed=1,
+                       action_seed=2)
+    assert np.array_equal(h.reset_host(), orc.reset())
+    rng = np.random.default_rng(1)
+    for _ in range(30):
+        a = rng.integers(0, 4, n)
+        obs, rew, term, trunc, prob, fin, fprob = h.step_host(a)
+        o = orc.step(a)
+        assert np.array_equal(obs, o["obs"]) and np.array_equal(rew, o["reward"]) and np.array_equal(term, o["terminated"])
+        assert np.array_equal(trunc, o["truncated"]) and np.array_equal(prob, o["prob"])
+    h.close()

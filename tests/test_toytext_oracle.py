@@ -1,0 +1,79 @@
+"""SURVEY.md §8(f)-4 on the CPU: (1) the product's MDP builders (gym_amd/toy_text.py, host code) against the reference's
+own `env.P` tables dumped into the goldens; (2) the oracle (oracle/tabular.c) replaying the reference's SyncVectorEnv
+trajectories with the reference's recorded uniforms: BIT-EXACT observations, rewards, flags, infos; (3) the Philox
+contract's shard invariance on the oracle."""
+import numpy as np
+import pytest
+
+from helpers import TOYTEXT_CASES, load_toytext_golden, replay_toytext, toytext_mdp
+from oracle.oracle import OracleTabEnv
+
+
+@pytest.mark.parametrize("tag", TOYTEXT_CASES)
+def test_mdp_tables_equal_reference(tag):
+    g = load_toytext_golden(tag)
+    mdp = toytext_mdp(g)
+    cnt = g["table_num_transitions"]
+    S, A = cnt.shape
+    assert (mdp.num_states, mdp.num_actions, mdp.max_transitions) == (S, A, g["table_prob"].shape[2])
+    live = np.arange(mdp.max_transitions)[None, None, :] < cnt[:, :, None]
+    assert np.array_equal(mdp.cum_prob >= 0, live)
+    for name, arr in (("prob", mdp.prob), ("next_state", mdp.next_state), ("reward", mdp.reward), ("terminated", mdp.terminated)):
+        assert np.array_equal(arr[live], g[f"table_{name}"][live]), name
+    # cum_prob is np.cumsum of each list (toy_text/utils.py:6-7)
+    for s in range(S):
+        for a in range(A):
+            k = cnt[s, a]
+            assert np.array_equal(mdp.cum_prob[s, a, :k], np.cumsum(g["table_prob"][s, a, :k]))
+    assert np.array_equal(mdp.initial_distrib, g["table_initial_distrib"])
+    assert mdp.reset_prob_is_int == bool(g["reset_prob_dtype_is_int"])
+    if "table_action_mask" in g:
+        assert np.array_equal(mdp.action_mask, g["table_action_mask"])
+    else:
+        assert mdp.action_mask is None
+
+
+class _OracleAdapter:
+    def __init__(self, mdp, n, limit):
+        self.o = OracleTabEnv(mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum, n, limit)
+
+    def set_state(self, state, elapsed):
+        self.o.state[:] = state
+        self.o.elapsed[:] = elapsed
+
+    def step(self, actions, uniforms):
+        return self.o.step(actions, uniforms)
+
+
+@pytest.mark.parametrize("tag", TOYTEXT_CASES)
+def test_oracle_replays_reference_trajectories_bit_exact(tag):
+    g = load_toytext_golden(tag)
+    ndone = replay_toytext(g, _OracleAdapter)
+    assert ndone == int(g["final_mask"].sum()) and ndone > 0
+
+
+def test_oracle_philox_streams_are_shard_invariant():
+    g = load_toytext_golden("FrozenLake8x8-v1")
+    mdp = toytext_mdp(g)
+    n, T = 64, 40
+    args = (mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum)
+    full = OracleTabEnv(*args, n, 200, seed=3, action_seed=4)
+    halves = [OracleTabEnv(*args, n // 2, 200, seed=3, action_seed=4, env_offset=o) for o in (0, n // 2)]
+    o_full = full.reset(seed=3)
+    o_half = np.concatenate([h.reset(seed=3) for h in halves])
+    assert np.array_equal(o_full, o_half)
+    for _ in range(T):
+        a = full.step()
+        b = [h.step() for h in halves]
+        for k in ("actions", "obs", "reward", "terminated", "truncated", "prob"):
+            assert np.array_equal(a[k], np.concatenate([x[k] for x in b])), k
+    assert full.state.max() > 0
+
+
+def test_invalid_action_raises_keyerror_like_the_reference():
+    g = load_toytext_golden("Taxi-v3")
+    mdp = toytext_mdp(g)
+    o = OracleTabEnv(mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum, 4, 200)
+    o.reset(seed=0)
+    with pytest.raises(KeyError):
+        o.step(np.array([0, 6, 1, 2]))
