@@ -35,6 +35,7 @@ EXPORTS = (
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -119,6 +120,9 @@ def _load():
         "mxv_sync": ([vp], C.c_int),
         "mxv_get_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_set_stream": ([vp, vp], C.c_int),
+        "mxv_host_io": ([vp] + [C.POINTER(vp)] * 6, C.c_int),
+        "mxv_step_mapped": ([vp], C.c_int),
+        "mxv_reset_mapped": ([vp, vp], C.c_int),
         "mxv_norm_create": ([i32, i32, i64, vp, C.POINTER(vp)], C.c_int),
         "mxv_norm_destroy": ([vp], C.c_int),
         "mxv_norm_last_error": ([vp], C.c_char_p),
@@ -194,6 +198,19 @@ def _ptr(x):
     return x.data_ptr()  # torch tensor
 
 
+class _DestroyLater:
+    """Owns the mxv_destroy of a handle whose pinned I/O block is referenced by NumPy views."""
+
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        try:
+            lib.mxv_destroy(self._h)
+        except Exception:
+            pass
+
+
 class Handle:
     """One engine handle = one device + one stream + N device-resident envs (see include/mxv.h)."""
 
@@ -230,7 +247,11 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib.mxv_destroy(self._h)
+            keep = getattr(self, "_io_keep", None)
+            if keep is not None:
+                self._io_keep = None   # mapped-I/O views may outlive close(): the last one to die destroys the handle
+            else:
+                lib.mxv_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -304,6 +325,33 @@ class Handle:
         self._check(lib.mxv_step_host(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                       trunc.ctypes.data, _ptr(fin)))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin
+
+    def host_io(self):
+        """NumPy views of the pinned, device-mapped I/O block (zero-copy stepping): dict(actions, obs, reward, terminated,
+        truncated, final_obs).  Valid until close(); overwritten by every step_mapped() / reset_mapped()."""
+        ptrs = [C.c_void_p() for _ in range(6)]
+        self._check(lib.mxv_host_io(self._h, *[C.byref(p) for p in ptrs]))
+        n, O = self.num_envs, self.O
+        if getattr(self, "_io_keep", None) is None:
+            self._io_keep = _DestroyLater(self._h)
+        keep = self._io_keep
+
+        def view(p, dtype, shape):
+            count = int(np.prod(shape))
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p.value)
+            buf._keepalive = keep   # every array derived from this buffer keeps the pinned block (the handle) alive
+            return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+        return dict(actions=view(ptrs[0], self.action_dtype, (n,)), obs=view(ptrs[1], np.float32, (n, O)),
+                    reward=view(ptrs[2], self.reward_dtype, (n,)), terminated=view(ptrs[3], np.bool_, (n,)),
+                    truncated=view(ptrs[4], np.bool_, (n,)), final_obs=view(ptrs[5], np.float32, (n, O)))
+
+    def step_mapped(self):
+        self._check(lib.mxv_step_mapped(self._h))
+
+    def reset_mapped(self, bounds=None):
+        b, bp = self._bounds(bounds)
+        self._check(lib.mxv_reset_mapped(self._h, bp))
 
     def get_state(self):
         st = np.empty((self.S, self.num_envs), dtype=np.float64)

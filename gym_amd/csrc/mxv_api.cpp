@@ -91,6 +91,17 @@ struct mxv_handle {
     float *st_obs = nullptr, *st_final = nullptr;
     void *st_reward = nullptr;
     uint8_t *st_term = nullptr, *st_trunc = nullptr, *st_mask = nullptr;
+    // Small vector envs (all step I/O <= kHostMapLimit bytes) stage through ONE block of pinned, device-mapped host memory:
+    // the kernel reads the actions from it and writes its outputs into it over PCIe, so a *_host call is one launch and one
+    // stream synchronisation instead of one H2D and five D2H copies — the latency-bound regime of BASELINE configs[0].
+    // Larger vector envs keep device staging (a kernel writing 1-byte flags over PCIe is slow) and move it with two DMA
+    // copies between the device block and an identically laid out pinned block (the zero-copy calls) or per-array
+    // hipMemcpy to the caller's pageable buffers (the copying calls).
+    void *hm_block = nullptr;   // pinned host block (exists when hostmap or after mxv_host_io)
+    void *dv_block = nullptr;   // device staging block (exists when !hostmap)
+    size_t io_total = 0, io_out_off = 0, io_out_bytes = 0, io_act_bytes = 0;
+    int32_t *hm_err = nullptr;
+    bool hostmap = false;       // the kernels address the pinned block directly
     // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
     using GraphKey = std::tuple<int, int, void *, void *, void *, void *, void *, void *>;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -229,16 +240,43 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     return MXV_OK;
 }
 
-int ensure_staging(mxv_handle *h) {
-    if (h->st_obs) return MXV_OK;
+// Up to this size the step kernels address the pinned block directly; above it they use device staging.
+constexpr size_t kHostMapLimit = 2 * 1024 * 1024;
+
+// Layout of one I/O block (pinned and device copies share it): actions | obs | final_obs | reward | term | trunc | mask | err
+int ensure_staging(mxv_handle *h, bool want_pinned = false) {
     const size_t n = (size_t)h->cfg.num_envs;
-    MXV_HIP(h, hipMalloc(&h->st_actions, n * 8));
-    MXV_HIP(h, hipMalloc((void **)&h->st_obs, n * h->O * sizeof(float)));
-    MXV_HIP(h, hipMalloc((void **)&h->st_final, n * h->O * sizeof(float)));
-    MXV_HIP(h, hipMalloc(&h->st_reward, n * 8));
-    MXV_HIP(h, hipMalloc((void **)&h->st_term, n));
-    MXV_HIP(h, hipMalloc((void **)&h->st_trunc, n));
-    MXV_HIP(h, hipMalloc((void **)&h->st_mask, n));
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_act = up(n * 8), b_obs = up(n * h->O * sizeof(float)), b_rew = up(n * 8), b_flag = up(n);
+    if (!h->st_obs) {
+        h->io_total = b_act + 2 * b_obs + b_rew + 3 * b_flag + 256;
+        h->io_act_bytes = n * h->action_bytes();
+        h->io_out_off = b_act;
+        h->io_out_bytes = 2 * b_obs + b_rew + 2 * b_flag;
+        h->hostmap = h->io_total <= kHostMapLimit;
+        if (h->hostmap) {
+            MXV_HIP(h, hipHostMalloc(&h->hm_block, h->io_total, hipHostMallocDefault));
+        } else {
+            MXV_HIP(h, hipMalloc(&h->dv_block, h->io_total));
+        }
+        char *p = (char *)(h->hostmap ? h->hm_block : h->dv_block);
+        h->st_actions = p; p += b_act;
+        h->st_obs = (float *)p; p += b_obs;
+        h->st_final = (float *)p; p += b_obs;
+        h->st_reward = p; p += b_rew;
+        h->st_term = (uint8_t *)p; p += b_flag;
+        h->st_trunc = (uint8_t *)p; p += b_flag;
+        h->st_mask = (uint8_t *)p; p += b_flag;
+        if (h->hostmap) {
+            h->hm_err = (int32_t *)p;
+            *h->hm_err = 0;
+        }
+    }
+    if (want_pinned && !h->hm_block) {  // large env: pinned mirror of the device block for the zero-copy calls
+        MXV_HIP(h, hipHostMalloc(&h->hm_block, h->io_total, hipHostMallocDefault));
+        h->hm_err = (int32_t *)((char *)h->hm_block + h->io_total - 256);
+        *h->hm_err = 0;
+    }
     return MXV_OK;
 }
 
@@ -332,8 +370,8 @@ int mxv_destroy(mxv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graphs(h);
-    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->st_actions, h->st_obs, h->st_final,
-                    h->st_reward, h->st_term, h->st_trunc, h->st_mask};
+    if (h->hm_block) (void)hipHostFree(h->hm_block);
+    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -517,6 +555,13 @@ int mxv_reset_host(mxv_handle *h, const uint8_t *mask_host, const double *bounds
     if (int rc = use_device(h)) return rc;
     if (int rc = ensure_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
+    if (h->hostmap) {
+        if (mask_host) std::memcpy(h->st_mask, mask_host, n);
+        if (int rc = do_reset(h, mask_host ? h->st_mask : nullptr, bounds2_host, obs_host ? h->st_obs : nullptr)) return rc;
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+        if (obs_host) std::memcpy(obs_host, h->st_obs, n * h->O * sizeof(float));
+        return MXV_OK;
+    }
     if (mask_host) MXV_HIP(h, hipMemcpyAsync(h->st_mask, mask_host, n, hipMemcpyHostToDevice, h->stream));
     if (int rc = do_reset(h, mask_host ? h->st_mask : nullptr, bounds2_host, obs_host ? h->st_obs : nullptr)) return rc;
     if (obs_host)
@@ -532,7 +577,10 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     if (int rc = use_device(h)) return rc;
     if (int rc = ensure_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
-    MXV_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * h->action_bytes(), hipMemcpyHostToDevice, h->stream));
+    if (h->hostmap)
+        std::memcpy(h->st_actions, actions_host, n * h->action_bytes());
+    else
+        MXV_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * h->action_bytes(), hipMemcpyHostToDevice, h->stream));
     float *keep_r = h->ep_return_out;
     int32_t *keep_l = h->ep_length_out;
     if (h->ep_acc) {  // host callers read the statistics of this step with mxv_episode_stats_host()
@@ -547,6 +595,25 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
                          terminated_host ? h->st_term : nullptr, truncated_host ? h->st_trunc : nullptr,
                          final_obs_host ? h->st_final : nullptr))
         return rc;
+    if (h->hostmap) {  // outputs are already in host memory once the stream drains; one 4-byte copy fetches the error latch
+        MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+        std::memcpy(obs_host, h->st_obs, n * h->O * sizeof(float));
+        if (reward_host) std::memcpy(reward_host, h->st_reward, n * h->reward_bytes());
+        if (terminated_host) std::memcpy(terminated_host, h->st_term, n);
+        if (truncated_host) std::memcpy(truncated_host, h->st_trunc, n);
+        if (final_obs_host) std::memcpy(final_obs_host, h->st_final, n * h->O * sizeof(float));
+        if (*h->hm_err != 0) {
+            const int32_t e = *h->hm_err;
+            *h->hm_err = 0;
+            MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+            h->t -= 1;  // the reference raises before stepping anything further
+            if (e & 1)
+                return fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA);
+            return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
+        }
+        return MXV_OK;
+    }
     MXV_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (reward_host)
         MXV_HIP(h, hipMemcpyAsync(reward_host, h->st_reward, n * h->reward_bytes(), hipMemcpyDeviceToHost, h->stream));
@@ -560,6 +627,75 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     int rc = check_latched(h);  // synchronises
     if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
     return rc;
+}
+
+int mxv_host_io(mxv_handle *h, void **actions, float **obs, void **reward, uint8_t **terminated, uint8_t **truncated,
+                float **final_obs) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_staging(h, /*want_pinned=*/true)) return rc;
+    const ptrdiff_t shift = (char *)h->hm_block - (char *)(h->hostmap ? h->hm_block : h->dv_block);  // same layout
+    auto host = [&](void *kernel_side) { return (void *)((char *)kernel_side + shift); };
+    if (actions) *actions = host(h->st_actions);
+    if (obs) *obs = (float *)host(h->st_obs);
+    if (reward) *reward = host(h->st_reward);
+    if (terminated) *terminated = (uint8_t *)host(h->st_term);
+    if (truncated) *truncated = (uint8_t *)host(h->st_trunc);
+    if (final_obs) *final_obs = (float *)host(h->st_final);
+    return MXV_OK;
+}
+
+}  // extern "C" (re-opened below)
+
+namespace {
+
+int mapped_finish(mxv_handle *h, bool stepped) {
+    if (!h->hostmap)  // one DMA copy brings obs | final_obs | reward | terminated | truncated into the pinned mirror
+        MXV_HIP(h, hipMemcpyAsync((char *)h->hm_block + h->io_out_off, (char *)h->dv_block + h->io_out_off, h->io_out_bytes,
+                                  hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    if (*h->hm_err != 0) {
+        const int32_t e = *h->hm_err;
+        *h->hm_err = 0;
+        MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+        if (stepped) h->t -= 1;  // the reference raises before stepping anything further
+        if (e & 1) return fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA);
+        return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
+    }
+    return MXV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mxv_step_mapped(mxv_handle *h) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->hm_block) return fail(h, MXV_ERR_INVALID_ARG, "call mxv_host_io() first: the mapped I/O block does not exist yet");
+    if (int rc = use_device(h)) return rc;
+    if (!h->hostmap)
+        MXV_HIP(h, hipMemcpyAsync(h->dv_block, h->hm_block, h->io_act_bytes, hipMemcpyHostToDevice, h->stream));
+    float *keep_r = h->ep_return_out;
+    int32_t *keep_l = h->ep_length_out;
+    if (h->ep_acc) {
+        h->ep_return_out = h->st_ep_r;
+        h->ep_length_out = h->st_ep_l;
+    }
+    struct Restore {
+        mxv_handle *h; float *r; int32_t *l;
+        ~Restore() { h->ep_return_out = r; h->ep_length_out = l; }
+    } restore{h, keep_r, keep_l};
+    if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, h->st_reward, h->st_term, h->st_trunc, h->st_final)) return rc;
+    return mapped_finish(h, true);
+}
+
+int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->hm_block) return fail(h, MXV_ERR_INVALID_ARG, "call mxv_host_io() first: the mapped I/O block does not exist yet");
+    if (int rc = use_device(h)) return rc;
+    if (int rc = do_reset(h, nullptr, bounds2_host, h->st_obs)) return rc;
+    return mapped_finish(h, false);
 }
 
 int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host) {

@@ -150,12 +150,18 @@ class HipVectorEnv(VectorEnv):
     render_mode = None
 
     def __init__(self, id: str, num_envs: int = 1, *, device: int = 0, max_episode_steps: Optional[int] = None,
-                 env_offset: int = 0, copy: bool = True, **kwargs):
+                 env_offset: int = 0, copy: bool = True, zero_copy: bool = False, **kwargs):
         self.spec = _spec(id)
         self.kind = self.spec.kind
         observation_space, action_space = single_spaces(self.kind)
         super().__init__(num_envs=num_envs, observation_space=observation_space, action_space=action_space)
-        self.copy = copy
+        # copy=False is SyncVectorEnv's (sync_vector_env.py:61-63,163): reset/step return the internal observation buffer —
+        # here a view of the engine's pinned, device-mapped I/O block that the kernel writes over PCIe (one launch and one
+        # synchronisation per step, no staging copies); rewards / flags are still fresh copies, as in the reference.
+        # zero_copy=True additionally returns rewards / terminated / truncated as views of that block.
+        self.copy = copy and not zero_copy
+        self.zero_copy = zero_copy
+        self._views = None
         limit = self.spec.max_episode_steps if max_episode_steps is None else max_episode_steps
         self._max_episode_steps = -1 if limit is None else int(limit)
         self._discrete = isinstance(action_space, Discrete)
@@ -273,10 +279,20 @@ class HipVectorEnv(VectorEnv):
                     if not (isinstance(s, (int, np.integer)) and s >= 0):
                         raise error.Error(f"Seed must be a non-negative integer or omitted, not {s}")
                 self._handle.seed(0, np.array(seeds, dtype=np.uint64))
-        obs = self._handle.reset_host(bounds=bounds)
+        if self.copy:
+            obs = self._handle.reset_host(bounds=bounds)
+        else:
+            io = self._io()   # creates the mapped block on first use
+            self._handle.reset_mapped(bounds=bounds)
+            obs = io["obs"]
         self._was_reset = True
         self._actions = None
         return obs, {}
+
+    def _io(self):
+        if self._views is None:
+            self._views = self._handle.host_io()
+        return self._views
 
     # -- step ----------------------------------------------------------------------------------------
     def step_async(self, actions):
@@ -306,7 +322,16 @@ class HipVectorEnv(VectorEnv):
         if not self._was_reset:
             raise error.ResetNeeded("Cannot call env.step() before calling env.reset()")
         try:
-            obs, rew, term, trunc, fin = self._handle.step_host(actions, want_final=True)
+            if self.copy:
+                obs, rew, term, trunc, fin = self._handle.step_host(actions, want_final=True)
+            else:
+                io = self._io()
+                io["actions"][:] = actions
+                self._handle.step_mapped()
+                obs, fin = io["obs"], io["final_obs"]
+                rew, term, trunc = io["reward"], io["terminated"], io["truncated"]
+                if not self.zero_copy:
+                    rew, term, trunc = rew.copy(), term.copy(), trunc.copy()
         except _native.MxvError as e:
             if e.code == _native.ERR_INVALID_ACTION:
                 raise AssertionError(f"{actions!r} ({type(actions)}) invalid") from None
@@ -318,11 +343,19 @@ class HipVectorEnv(VectorEnv):
         if done.any():
             n = self.num_envs
             idx = np.flatnonzero(done)
+            rows = None
+            if not self.copy:
+                rows = np.take(fin, idx, axis=0)   # rows of the finished envs only, copied out of the shared block
+                done = done.copy()
 
             def build_final_obs():
                 arr = np.full(n, None, dtype=object)
-                for i in idx:
-                    arr[i] = fin[i].copy()
+                if rows is not None:
+                    for j, i in enumerate(idx):
+                        arr[i] = rows[j].copy()
+                else:
+                    for i in idx:
+                        arr[i] = fin[i].copy()
                 return arr
 
             def build_final_info():

@@ -165,6 +165,18 @@ int mxv_reset_host(mxv_handle *h, const uint8_t *mask_host, const double *bounds
 int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void *reward_host,
                   uint8_t *terminated_host, uint8_t *truncated_host, float *final_obs_host);
 
+/* Zero-copy form of the two calls above (SyncVectorEnv(copy=False), sync_vector_env.py:61-63,163: "return the internal
+ * buffer"): mxv_host_io allocates ONE block of pinned, device-mapped host memory holding the step I/O of all envs and returns
+ * host pointers into it (actions in the handle's action dtype, obs/final_obs float32 [N][O], reward in the handle's reward
+ * dtype, flags uint8 [N]); mxv_step_mapped / mxv_reset_mapped take the actions from and leave the outputs in that block,
+ * then synchronise.  Small envs (block <= 2 MiB): the kernel itself reads/writes the block over PCIe — one launch, no
+ * copies; larger envs: device staging plus one DMA copy each way (1-byte flag stores over PCIe would throttle the kernel).
+ * The buffers are overwritten by the next call.  Any out-pointer may be NULL. */
+int mxv_host_io(mxv_handle *h, void **actions, float **obs, void **reward, uint8_t **terminated, uint8_t **truncated,
+                float **final_obs);
+int mxv_step_mapped(mxv_handle *h);
+int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host);
+
 /* -- state access (parity hook + checkpoint/resume) ---------------------------------------------- */
 /* state_soa_host: double[S][N]; elapsed_host: int32[N]; either may be NULL.  Synchronises. */
 int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host);

@@ -207,7 +207,7 @@ def test_error_behaviour():
     env.step(np.ones(8, dtype=np.int64))             # still usable after the errors
     env.close()
     with pytest.raises(error.UnregisteredEnv):
-        _make("FrozenLake-v1", 8)
+        _make("Blackjack-v1", 8)                     # not a P-table env: out of scope
     with pytest.raises(TypeError):
         _make("CartPole-v1", 8, g=1.0)               # not a CartPole kwarg
     env = _make("Pendulum-v1", 4, g=9.81)            # pendulum.py:91
@@ -271,3 +271,44 @@ def test_set_attr_per_env_values_like_the_reference_test():
     r.synchronize()
     assert np.isfinite(out["obs"].cpu().numpy()).all()
     r.close()
+
+
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1"])
+@pytest.mark.parametrize("n", [8, 50000])
+def test_copy_false_and_zero_copy_equal_the_copying_path(env_id, n):
+    """SyncVectorEnv(copy=False) (sync_vector_env.py:61-63,163): the returned observations are the internal buffer — here a
+    view of the pinned, device-mapped I/O block the kernel writes over PCIe.  Same numbers as copy=True, step for step; the
+    observation array is reused, rewards/flags are fresh unless zero_copy=True; views stay valid after close()."""
+    import gym_amd
+
+    envs = [gym_amd.make(env_id, n), gym_amd.make(env_id, n, copy=False), gym_amd.make(env_id, n, zero_copy=True)]
+    outs = [e.reset(seed=3)[0] for e in envs]
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    envs[0].action_space.seed(1)
+    prev_obs_id = outs[1].__array_interface__["data"][0]
+    ndone = 0
+    for t in range(30):
+        a = envs[0].action_space.sample()
+        res = [e.step(a) for e in envs]
+        for r in res[1:]:
+            for x, y in zip(res[0][:4], r[:4]):
+                assert x.dtype == y.dtype and np.array_equal(x, y)
+        assert res[1][0].__array_interface__["data"][0] == prev_obs_id          # the same buffer every step
+        done = res[0][2] | res[0][3]
+        if done.any():
+            for r in res[1:]:
+                fo = r[4]["final_observation"]
+                ref = res[0][4]["final_observation"]
+                assert all(np.array_equal(fo[i], ref[i]) for i in np.flatnonzero(done))
+            ndone += int(done.sum())
+    if env_id == "CartPole-v1":
+        assert ndone > 0
+    rew_copy, rew_view = res[1][1], res[2][1]
+    envs[1].step(a)
+    envs[2].step(a)
+    assert rew_copy is not envs[1]._io()["reward"]                              # copy=False: rewards are copies
+    assert rew_view.__array_interface__["data"][0] == envs[2]._io()["reward"].__array_interface__["data"][0]
+    obs_view = res[2][0]
+    for e in envs:
+        e.close()
+    assert np.isfinite(obs_view).all() and obs_view.shape == (n, outs[0].shape[1])   # still readable after close()

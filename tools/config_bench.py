@@ -37,8 +37,8 @@ def fused(env_id, n, steps=2000, chunk=100):
     return best
 
 
-def compat_loop(env_id, n, steps):
-    env = gym_amd.make(env_id, num_envs=n)
+def compat_loop(env_id, n, steps, **kw):
+    env = gym_amd.make(env_id, num_envs=n, **kw)
     env.reset(seed=0)
     env.action_space.seed(0)
     acts = [env.action_space.sample() for _ in range(8)]
@@ -80,6 +80,12 @@ def main():
         sps, us = compat_loop("CartPole-v1", n, steps)
         out.append({"config": cfg, "env": "CartPole-v1", "num_envs": n, "mode": "HipVectorEnv.step (NumPy in/out, PCIe + "
                     "Python inclusive)", "us_per_step": round(us, 1), "env_steps_per_s": float(f"{sps:.4g}")})
+    for label, kw in (("copy=False", dict(copy=False)), ("zero_copy=True", dict(zero_copy=True))):
+        for n, steps in ((8, 1000), (1 << 20, 30)):
+            sps, us = compat_loop("CartPole-v1", n, steps, **kw)
+            out.append({"config": f"gym-compatible loop, {label}", "env": "CartPole-v1", "num_envs": n,
+                        "mode": "HipVectorEnv.step, outputs are views of the pinned device-mapped I/O block",
+                        "us_per_step": round(us, 1), "env_steps_per_s": float(f"{sps:.4g}")})
     for o in out:
         print(json.dumps(o), flush=True)
 
