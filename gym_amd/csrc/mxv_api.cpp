@@ -76,6 +76,7 @@ struct mxv_handle {
     uint32_t r = 0;
     bool was_reset = false;
     bool state_injected = false;  // set by mxv_set_state, consumed by the next step launch
+    bool step_noise = false;      // Acrobot torque_noise_max > 0 (acrobot.py:202-205): the step draws from the step-noise stream
     EnvParams P{};
     bool default_params = true;
     float *ep_acc = nullptr;        // running episode returns when episode statistics are enabled
@@ -173,6 +174,7 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.flags = h->cfg.flags;
     a.K = 1;
     a.state_injected = h->state_injected ? 1 : 0;
+    a.step_noise = h->step_noise ? 1 : 0;
     a.slice = 0;
     a.act_slice = 0;
     a.params_pe = h->params_pe;
@@ -748,9 +750,10 @@ int mxv_get_params(mxv_handle *h, double *params_host) {
 int mxv_set_params(mxv_handle *h, const double *params_host) {
     MXV_CHECK_HANDLE(h);
     if (!params_host) return fail(h, MXV_ERR_INVALID_ARG, "params pointer is NULL");
-    if (h->cfg.env_id == MXV_ACROBOT && params_host[10] != 0.0)
-        return fail(h, MXV_ERR_UNSUPPORTED, "Acrobot torque_noise_max != 0 is not supported");
+    if (h->cfg.env_id == MXV_ACROBOT && params_host[10] < 0.0)
+        return fail(h, MXV_ERR_INVALID_ARG, "Acrobot torque_noise_max must be >= 0");
     std::memcpy(h->P.p, params_host, sizeof h->P.p);
+    h->step_noise = h->cfg.env_id == MXV_ACROBOT && params_host[10] > 0.0;
     double d[MXV_MAX_PARAMS];
     default_params(h->cfg.env_id, d);
     h->default_params = std::memcmp(d, h->P.p, sizeof d) == 0;
@@ -768,10 +771,13 @@ int mxv_set_params_per_env(mxv_handle *h, const double *params_host) {
     MXV_CHECK_HANDLE(h);
     if (!params_host) return fail(h, MXV_ERR_INVALID_ARG, "params pointer is NULL");
     const size_t n = (size_t)h->cfg.num_envs;
+    bool noise = false;
     if (h->cfg.env_id == MXV_ACROBOT)
-        for (size_t i = 0; i < n; ++i)
-            if (params_host[10 * n + i] != 0.0)
-                return fail(h, MXV_ERR_UNSUPPORTED, "Acrobot torque_noise_max != 0 is not supported");
+        for (size_t i = 0; i < n; ++i) {
+            if (params_host[10 * n + i] < 0.0) return fail(h, MXV_ERR_INVALID_ARG, "Acrobot torque_noise_max must be >= 0");
+            noise = noise || params_host[10 * n + i] > 0.0;
+        }
+    h->step_noise = noise;
     if (int rc = use_device(h)) return rc;
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     free_graphs(h);

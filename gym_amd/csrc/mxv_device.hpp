@@ -74,6 +74,7 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 
 constexpr uint32_t kStreamAction = 1u;
 constexpr uint32_t kStreamReset = 2u;
+constexpr uint32_t kStreamStepNoise = 4u;  // (3 = the tabular engine's transition stream, mxv_tab.hip)
 
 // u in (0,1): (w + 0.5) * 2^-32, exact in fp64.
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
@@ -96,6 +97,16 @@ __device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r)
     c.z = r;
     c.w = (kStreamReset << 28);
     return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// Step-noise stream (Acrobot's torque noise, acrobot.py:202-205): key = the env's seed, ctr = (t_lo, t_hi, 0, 4 << 28), word x.
+__device__ __forceinline__ uint32_t step_noise_word(uint64_t seed, uint64_t t) {
+    U4 c;
+    c.x = (uint32_t)t;
+    c.y = (uint32_t)(t >> 32);
+    c.z = 0;
+    c.w = (kStreamStepNoise << 28);
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32)).x;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -407,9 +418,15 @@ struct Env<MXV_ACROBOT> {
         if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
     }
     template <int DEF, bool SAFE = true>
-    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int ai, float, double &reward,
-                                                float *obs) {
-        const double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
+    // `noise_word`: for this env the Box-action slot of the shared step() signature carries the raw Philox word of the
+    // step-noise stream (bit pattern in a float), consumed only when torque_noise_max > 0 (never on the default path).
+    __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int ai, float noise_word,
+                                                double &reward, float *obs) {
+        double torque = (double)(ai - 1);  // AVAIL_TORQUE[a] = [-1.0, 0.0, +1] :157,199
+        if constexpr (DEF != PM_DEFAULT) {
+            const double nm = P.get(10, 0.0);  // torque += np_random.uniform(-torque_noise_max, torque_noise_max) :202-205
+            if (nm > 0.0) torque += -nm + (nm - (-nm)) * u01(__float_as_uint(noise_word));
+        }
         const double dt = P.get(0, 0.2) - 0;    // t[i+1] - this, t = [0, self.dt] :210,449
         const double dt2 = dt / 2.0;            // :450
         const double y0[4] = {s[0], s[1], s[2], s[3]};

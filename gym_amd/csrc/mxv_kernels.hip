@@ -169,6 +169,17 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
             }
         }
 
+        if constexpr (ENV == MXV_ACROBOT && DEF != PM_DEFAULT) {  // torque noise: one draw per env-step when the attribute is set
+            if (a.step_noise) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const int64_t e = valid[j] ? env_of(j) : 0;
+                    const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
+                    af[j] = __uint_as_float(step_noise_word(seed, t));
+                }
+            }
+        }
+
         // ---- dynamics + TimeLimit, E independent chains ----
         float obs[E][O];
         double rew[E];
@@ -578,7 +589,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
     const bool def = pm == PM_DEFAULT;
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
-    if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV) {
+    if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise) {
         constexpr int ER = rollout_envs_per_lane(ENV);
         const int64_t rtile = (int64_t)ER * kWave;
         const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);

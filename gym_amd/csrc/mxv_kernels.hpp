@@ -31,6 +31,7 @@ struct StepArgs {
     int32_t flags;         // MXV_FLAG_*
     int32_t K;             // vector steps fused into this launch (>= 1)
     int32_t state_injected; // mxv_set_state() ran since the last launch: no invariant on the state may be assumed
+    int32_t step_noise;     // Acrobot torque_noise_max > 0 somewhere: draw the step-noise word (step_kernel launches only)
     int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
     int64_t act_slice;     // action tape advance per step (envs) or 0
     const double *params_pe; // [MXV_MAX_PARAMS][N] per-env physics parameters (PM_PER_ENV launches) or nullptr

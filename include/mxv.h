@@ -81,7 +81,8 @@ enum {
  *               8 theta_threshold_radians 9 x_threshold 10 kinematics_integrator (0 euler, 1 semi-implicit)
  *  Pendulum   : 0 max_speed 1 max_torque 2 dt 3 g 4 m 5 l
  *  Acrobot    : 0 dt 1 LINK_LENGTH_1 2 LINK_LENGTH_2 3 LINK_MASS_1 4 LINK_MASS_2 5 LINK_COM_POS_1 6 LINK_COM_POS_2
- *               7 LINK_MOI 8 MAX_VEL_1 9 MAX_VEL_2 10 torque_noise_max (must be 0) 11 book_or_nips (0 book, 1 nips)
+ *               7 LINK_MOI 8 MAX_VEL_1 9 MAX_VEL_2 10 torque_noise_max (> 0: torque += uniform(-m, m) from the
+ *               step-noise stream: key = env seed, ctr = (t_lo, t_hi, 0, 4 << 28), word x) 11 book_or_nips (0 book, 1 nips)
  *  MountainCar: 0 min_position 1 max_position 2 max_speed 3 goal_position 4 goal_velocity 5 force 6 gravity
  *  MountainCarContinuous: 0 min_action 1 max_action 2 min_position 3 max_position 4 max_speed 5 goal_position
  *               6 goal_velocity 7 power

@@ -76,7 +76,7 @@ void orc_default_params(int env_id, double *P) {
         P[7] = 1.0;        /* LINK_MOI */
         P[8] = 4 * M_PI;   /* MAX_VEL_1 */
         P[9] = 9 * M_PI;   /* MAX_VEL_2 */
-        P[10] = 0.0;       /* torque_noise_max (only 0 supported) */
+        P[10] = 0.0;       /* torque_noise_max */
         P[11] = 0.0;       /* book_or_nips: 0 book, 1 nips */
         break;
     case ORC_MOUNTAINCAR: /* gym/envs/classic_control/mountain_car.py:103-111 */
@@ -238,10 +238,12 @@ static void acrobot_obs(const double *s, float *obs) { /* :225-230 */
     obs[4] = (float)s[2];      obs[5] = (float)s[3];
 }
 
-static void acrobot_step(const double *P, double *s, int64_t action, float *obs, double *reward,
+/* `noise` = the value np_random.uniform(-torque_noise_max, torque_noise_max) returned (:202-205), 0.0 when the attribute is 0 */
+static void acrobot_step(const double *P, double *s, int64_t action, double noise, float *obs, double *reward,
                          int *terminated) {
     static const double AVAIL_TORQUE[3] = {-1.0, 0.0, +1.0}; /* :157 */
-    double torque = AVAIL_TORQUE[action];                    /* :199 (torque_noise_max == 0) */
+    double torque = AVAIL_TORQUE[action];                    /* :199 */
+    if (P[10] > 0.0) torque += noise;                        /* :202-205 */
     double y0[5] = {s[0], s[1], s[2], s[3], torque};         /* :208 np.append → float64 */
     /* rk4(self._dsdt, s_augmented, [0, self.dt]) :210, body :447-463 */
     double dt = P[0] - 0;     /* t[i+1] - this */
@@ -266,6 +268,12 @@ static void acrobot_step(const double *P, double *s, int64_t action, float *obs,
     *terminated = (-cos(s[0]) - cos(s[1] + s[0]) > 1.0); /* :235 */
     *reward = (!*terminated) ? -1.0 : 0.0;               /* :219 */
     acrobot_obs(s, obs);
+}
+
+/* AcrobotEnv.step with the noise draw supplied by the caller (golden replay of np_random.uniform's own values) */
+void orc_acrobot_step_noise(const double *P, double *s, int64_t action, double noise, float *obs, double *reward,
+                            int *terminated) {
+    acrobot_step(P, s, action, noise, obs, reward, terminated);
 }
 
 /* ------------------------------------------------------------------------------------
@@ -506,12 +514,12 @@ void orc_vec_reset(int env_id, int64_t n, uint64_t env0, const uint64_t *seeds, 
 }
 
 /* One env, one step of dynamics only (no TimeLimit / autoreset). actions: int64 or float32. */
-static void env_step(int env_id, const double *P, double *s, int fresh, int64_t ai, float af,
+static void env_step(int env_id, const double *P, double *s, int fresh, int64_t ai, float af, double noise,
                      float *obs, double *reward, int *term) {
     switch (env_id) {
     case ORC_CARTPOLE: cartpole_step(P, s, ai, obs, reward, term); break;
     case ORC_PENDULUM: pendulum_step(P, s, af, obs, reward, term); break;
-    case ORC_ACROBOT: acrobot_step(P, s, ai, obs, reward, term); break;
+    case ORC_ACROBOT: acrobot_step(P, s, ai, noise, obs, reward, term); break;
     case ORC_MOUNTAINCAR: mountaincar_step(P, s, ai, obs, reward, term); break;
     default: mcc_step(P, s, fresh, af, obs, reward, term); break;
     }
@@ -549,7 +557,15 @@ int64_t orc_vec_step(int env_id, int64_t n, uint64_t env0, const double *P, int 
         } else {
             af = act_f32[i];
         }
-        env_step(env_id, P, s, elapsed[i] == 0, ai, af, o, &rew, &term);
+        double noise = 0.0;
+        if (env_id == ORC_ACROBOT && P[10] > 0.0) { /* RNG contract, step-noise stream: key = env seed, ctr = (t, 0, 4<<28), word x */
+            uint32_t ctr[4] = {(uint32_t)t, (uint32_t)(t >> 32), 0u, 4u << 28}, key[2], w[4];
+            uint64_t seed = seeds ? seeds[i] : base_seed + env0 + (uint64_t)i;
+            key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
+            orc_philox4x32_10(ctr, key, w);
+            noise = -P[10] + (P[10] - (-P[10])) * u01(w[0]);       /* np_random.uniform(low, high) = low + (high-low)*u */
+        }
+        env_step(env_id, P, s, elapsed[i] == 0, ai, af, noise, o, &rew, &term);
         elapsed[i] += 1;                                           /* time_limit.py:51 */
         if (max_episode_steps > 0 && elapsed[i] >= max_episode_steps) trunc = 1; /* :53-54 */
         reward[i] = rew;

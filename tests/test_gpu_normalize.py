@@ -270,3 +270,26 @@ def test_errors():
     with pytest.raises(_native.MxvError):
         nm.observations(0, x, x, True, 1e-8)
     nm.close()
+
+
+def test_reference_known_answers():
+    """tests/wrappers/test_normalize.py of the reference, restated on the tensors its DummyRewardEnv produces: two sub-envs
+    whose observation and reward at step t are (t, t+1); `obs_rms.mean` after reset / first step (:84-103) and
+    `return_rms.mean` after the first / second step (:106-127), to the reference's 4 decimals."""
+    import torch
+    from gym_amd.normalize import RunningNormalizer
+
+    rn = RunningNormalizer(2, 1, gamma=0.99)
+    dev = torch.device("cuda")
+    obs = lambda t: torch.tensor([[t], [t + 1]], dtype=torch.float32, device=dev)
+    rn.normalize_obs(obs(0))                                   # envs.reset()
+    np.testing.assert_almost_equal(rn.obs_rms.mean, np.mean([0.5]), decimal=4)
+    rn.normalize_obs(obs(1))                                   # first step
+    np.testing.assert_almost_equal(rn.obs_rms.mean, np.mean([1.0]), decimal=4)
+    zeros = torch.zeros(2, dtype=torch.uint8, device=dev)
+    rew = lambda t: torch.tensor([t, t + 1], dtype=torch.float64, device=dev)
+    rn.normalize_rewards(rew(1), zeros, zeros)
+    np.testing.assert_almost_equal(rn.return_rms.mean, np.mean([1.5]), decimal=4)
+    rn.normalize_rewards(rew(2), zeros, zeros)
+    np.testing.assert_almost_equal(rn.return_rms.mean, np.mean([[1, 2], [2 + rn.gamma * 1, 3 + rn.gamma * 2]]), decimal=4)
+    rn.close()

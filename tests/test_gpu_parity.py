@@ -263,3 +263,69 @@ def test_fused_rollout_equals_single_steps_and_oracle(name):
         np.testing.assert_allclose(obs[k], robs, rtol=OBS_RTOL, atol=1e-30)
     for r in (a, b, c):
         r.close()
+
+
+def test_acrobot_torque_noise_matches_oracle_twin():
+    """acrobot.py:202-205 `torque += np_random.uniform(-torque_noise_max, torque_noise_max)`: the noise comes from the
+    engine's Philox step-noise stream (one word per env-step, keyed by the env's seed), so device and oracle twin stay
+    aligned step by step; the arithmetic itself is pinned against the reference by tests/golden/Acrobot_noise_p1.npz
+    (oracle, bit-exact).  Broadcast value, then per-env values (noise on the even envs only); a K-step launch (routed to
+    the per-step kernel) equals K single steps; noise really changes the trajectories."""
+    from gym_amd import _native
+    from gym_amd.rollout import DeviceRollout
+
+    n, steps = 2048, 24
+    for per_env in (False, True):
+        h = _native.Handle(ENV_IDS["Acrobot"], n, 40, seed=5, action_seed=6)
+        noisy = OracleEngine("Acrobot", n, 40, seed=5, action_seed=6).o
+        quiet = OracleEngine("Acrobot", n, 40, seed=5, action_seed=6).o
+        p = h.get_params()
+        nm = 0.7 if per_env else 0.35
+        noisy.P[10] = nm
+        if per_env:
+            table = np.repeat(p[:, None], n, axis=1)
+            table[10, ::2] = nm
+            h.set_params_per_env(table)
+        else:
+            p[10] = nm
+            h.set_params(p)
+        pick = (np.arange(n) % 2 == 0) if per_env else np.ones(n, bool)   # envs that follow the noisy oracle
+        h.reset_host()
+        for o in (noisy, quiet):
+            o.reset(seed=5)
+        rng = np.random.default_rng(1)
+        for t in range(steps):
+            st, el = h.get_state()
+            for o in (noisy, quiet):
+                o.state[:], o.elapsed[:] = st, el
+            a = rng.integers(0, 3, n)
+            obs, rew, term, trunc, fin = h.step_host(a)
+            rn, rq = noisy.step(a), quiet.step(a)
+            robs = np.where(pick[:, None], rn[0], rq[0])
+            assert np.array_equal(term, np.where(pick, rn[2], rq[2])) and np.array_equal(trunc, np.where(pick, rn[3], rq[3]))
+            assert ulps32(obs, robs).max() <= MAX_OBS_ULPS
+            np.testing.assert_allclose(h.get_state()[0], np.where(pick[None, :], noisy.state, quiet.state), rtol=1e-12, atol=1e-13)
+            assert not np.array_equal(rn[0], rq[0])                       # the noise is not a no-op
+        h.close()
+    outs = []
+    for K in (1, 12):
+        r = DeviceRollout("Acrobot-v1", n, seed=5, action_seed=6)
+        p = r.handle.get_params()
+        p[10] = 0.35
+        r.handle.set_params(p)
+        r.reset(seed=5)
+        tr = r.trajectory_buffers(12)
+        if K == 1:
+            for k in range(12):
+                r.handle.rollout(1, tr["obs"][k], tr["reward"][k], tr["terminated"][k], tr["truncated"][k], None, tr["actions"][k])
+        else:
+            r.rollout_per_step(12, out=tr)
+        r.synchronize()
+        outs.append(tr["obs"].cpu().numpy().copy())
+        r.close()
+    assert np.array_equal(outs[0], outs[1])
+    q = DeviceRollout("Acrobot-v1", n, seed=5, action_seed=6)
+    q.reset(seed=5)
+    qo = q.rollout_per_step(12)["obs"].cpu().numpy()
+    q.close()
+    assert not np.array_equal(qo[0], outs[0][0])
