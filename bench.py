@@ -66,6 +66,32 @@ def cpu_baseline(sample_steps: int):
     }
 
 
+def measure_variant(args, ShardedRollout, torch):
+    """Same workload, MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32 outputs; short (a tenth of the headline's steps)."""
+    sr = ShardedRollout(ENV_ID, ENVS_PER_GPU, rank=0, world_size=1, device=torch.cuda.current_device(), seed=0,
+                        action_seed=1, reward_f32=True, action_i32=True)
+    eng = sr.engine
+    sr.reset(seed=0)
+    traj = eng.trajectory_buffers(args.chunk)
+    launches = max(8, args.steps // args.chunk // 4)
+    t_spin = time.perf_counter()  # same clock-ramp treatment as the headline: --spinup-ms of untimed work first
+    while (time.perf_counter() - t_spin) * 1e3 < max(args.spinup_ms, 1.0):
+        sr.rollout_per_step(args.chunk, mode="fused", out=traj, record_actions=True)
+        sr.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(eng.stream)
+    for _ in range(launches):
+        sr.rollout_per_step(args.chunk, mode="fused", out=traj, record_actions=True)
+    ev1.record(eng.stream)
+    sr.synchronize()
+    ms = ev0.elapsed_time(ev1) / launches
+    sr.close()
+    b = algorithmic_bytes_per_env_step("fused", args.chunk)
+    steps_s = ENVS_PER_GPU * args.chunk / (ms * 1e-3)
+    return {"value": steps_s, "unit": "env-steps/s", "us_per_step": ms * 1e3 / args.chunk,
+            "outputs": "float32 rewards, int32 actions (26 real B/env-step)", "roofline_frac": steps_s * b / 1e9 / HBM_PEAK_GBS}
+
+
 def read_traffic(mode: str, chunk: int):
     """HBM bytes per launch of the SAME launch shape from the committed PMC passes (profiles/traffic_*.json,
     written by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs), or None."""
@@ -100,6 +126,7 @@ def main():
                          "instead of 34); off by default: the headline keeps the reference's float64 / int64 dtypes")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary compact-outputs measurement (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -228,9 +255,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_steps)
-        print(json.dumps(out), flush=True)
 
     sr.close()
+    if rank == 0:
+        if world == 1 and mode == "fused" and not args.compact_outputs and not args.no_variants:
+            # reported beside the headline, never instead of it: the same workload with the engine's contract-minimal output
+            # dtypes (float32 rewards, int32 actions: SURVEY.md §8d's algorithmic bytes, 26 real B/env-step instead of 34)
+            out["variants"] = {"compact_outputs": measure_variant(args, ShardedRollout, torch)}
+        print(json.dumps(out), flush=True)
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
