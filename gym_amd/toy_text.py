@@ -23,7 +23,7 @@ from . import _native, error
 from .spaces import Discrete
 from .vector_env import LazyInfos, VectorEnv, _Pending
 
-__all__ = ["TabularMDP", "frozen_lake_mdp", "taxi_mdp", "cliff_walking_mdp", "HipTabularVectorEnv", "TabularRollout",
+__all__ = ["TabularMDP", "generate_random_map", "frozen_lake_mdp", "taxi_mdp", "cliff_walking_mdp", "HipTabularVectorEnv", "TabularRollout",
            "TOY_TEXT_REGISTRY"]
 
 
@@ -83,15 +83,43 @@ FROZEN_LAKE_MAPS = {
 }
 
 
+def _has_path(board, size: int) -> bool:
+    """Depth-first search from (0, 0): can G be reached without stepping on H? (frozen_lake.py:33-49)"""
+    frontier, seen = [(0, 0)], set()
+    while frontier:
+        r, c = frontier.pop()
+        if (r, c) in seen:
+            continue
+        seen.add((r, c))
+        for dr, dc in ((1, 0), (0, 1), (-1, 0), (0, -1)):
+            nr, nc = r + dr, c + dc
+            if 0 <= nr < size and 0 <= nc < size:
+                if board[nr][nc] == "G":
+                    return True
+                if board[nr][nc] != "H":
+                    frontier.append((nr, nc))
+    return False
+
+
+def generate_random_map(size: int = 8, p: float = 0.8) -> List[str]:
+    """frozen_lake.py:52-72: i.i.d. tiles (frozen with probability p) from NumPy's GLOBAL generator, S and G pinned to the
+    corners, redrawn until a path exists."""
+    while True:
+        p = min(1, p)
+        board = np.random.choice(["F", "H"], (size, size), p=[p, 1 - p])
+        board[0][0] = "S"
+        board[-1][-1] = "G"
+        if _has_path(board, size):
+            return ["".join(row) for row in board]
+
+
 def frozen_lake_mdp(desc: Optional[Sequence[str]] = None, map_name: Optional[str] = "4x4", is_slippery: bool = True) -> TabularMDP:
     """Actions LEFT=0, DOWN=1, RIGHT=2, UP=3 (:11-14).  On ice the agent moves in the chosen direction or, when slippery,
     in one of the two perpendicular ones, each with probability 1/3 in the order (a-1)%4, a, (a+1)%4 (:213-221); moves are
     clamped to the grid (:180-189); stepping on G pays 1.0, G and H end the episode (:191-197) and are absorbing with a
     single (1.0, s, 0, True) transition (:208-209)."""
     if desc is None:
-        if map_name is None:
-            raise NotImplementedError("random maps (generate_random_map) are not provided; pass desc= or map_name=")
-        desc = FROZEN_LAKE_MAPS[map_name]
+        desc = generate_random_map() if map_name is None else FROZEN_LAKE_MAPS[map_name]   # :168-171
     grid = [[(c.decode() if isinstance(c, bytes) else str(c)) for c in row] for row in desc]
     nrow, ncol = len(grid), len(grid[0])
     moves = {0: (0, -1), 1: (1, 0), 2: (0, 1), 3: (-1, 0)}

@@ -8,6 +8,8 @@ import pytest
 from helpers import TOYTEXT_CASES, load_toytext_golden, replay_toytext, toytext_mdp
 from oracle.oracle import OracleTabEnv
 
+REF_MAP_SEED3_SIZE6 = ['SFFFHH', 'FFFFFF', 'FFFFFF', 'FFFFFF', 'FFFFFH', 'HFHHFG']
+
 
 @pytest.mark.parametrize("tag", TOYTEXT_CASES)
 def test_mdp_tables_equal_reference(tag):
@@ -77,3 +79,50 @@ def test_invalid_action_raises_keyerror_like_the_reference():
     o.reset(seed=0)
     with pytest.raises(KeyError):
         o.step(np.array([0, 6, 1, 2]))
+
+
+def test_taxi_action_mask_restates_reference_test():
+    """tests/envs/test_env_implementation.py:129-136: an action is masked in exactly the states it cannot change."""
+    from gym_amd.toy_text import taxi_mdp
+
+    mdp = taxi_mdp()
+    for state in range(mdp.num_states):
+        for action, possible in enumerate(mdp.action_mask[state]):
+            _, next_state, _, _ = mdp.transitions(state, action)[0]
+            assert (state != next_state) if possible else (state == next_state)
+
+
+@pytest.mark.parametrize("map_size", [5, 10, 16])
+def test_frozenlake_dfs_map_generation_restates_reference_test(map_size):
+    """tests/envs/test_env_implementation.py:97-126: every generated map has a path from S to G."""
+    from gym_amd.toy_text import frozen_lake_mdp, generate_random_map
+
+    np.random.seed(map_size)
+    new_frozenlake = generate_random_map(map_size)
+    assert len(new_frozenlake) == map_size and len(new_frozenlake[0]) == map_size
+    directions = [(1, 0), (0, 1), (-1, 0), (0, -1)]
+    frontier, discovered = [(0, 0)], set()
+    found = False
+    while frontier and not found:
+        row, col = frontier.pop()
+        if (row, col) not in discovered:
+            discovered.add((row, col))
+            for dr, dc in directions:
+                nr, nc = row + dr, col + dc
+                if 0 <= nr < map_size and 0 <= nc < map_size:
+                    if new_frozenlake[nr][nc] == "G":
+                        found = True
+                    if new_frozenlake[nr][nc] not in "#H":
+                        frontier.append((nr, nc))
+    assert found, "No path through the frozenlake was found."
+    mdp = frozen_lake_mdp(desc=new_frozenlake)               # and it is a well-formed MDP for the engine
+    assert mdp.num_states == map_size * map_size and mdp.initial_distrib[0] == 1.0
+
+
+def test_generate_random_map_equals_reference_under_the_same_global_seed():
+    """Same draws from NumPy's global generator -> the same board as gym.envs.toy_text.frozen_lake.generate_random_map
+    (values recorded from the reference in this container: np.random.seed(3); generate_random_map(6))."""
+    from gym_amd.toy_text import generate_random_map
+
+    np.random.seed(3)
+    assert generate_random_map(6) == REF_MAP_SEED3_SIZE6
