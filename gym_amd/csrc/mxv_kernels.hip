@@ -301,7 +301,7 @@ struct alignas(16) ResetEntry {
 };
 
 template <int ENV, bool DEF, int E, bool SAFE>
-__global__ void __launch_bounds__(kWave) rollout_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     constexpr int TILE = E * kWave;

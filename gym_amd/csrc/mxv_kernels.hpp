@@ -108,6 +108,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_MIN_WAVES
 #define MXV_MIN_WAVES 1
 #endif
+// rollout_kernel's minimum waves per SIMD (tuning hook; 1 = let the register allocator decide: 113 VGPRs = 4 waves for CartPole)
+#ifndef MXV_ROLLOUT_MIN_WAVES
+#define MXV_ROLLOUT_MIN_WAVES 1
+#endif
 // 1: XCD-aware workgroup -> tile map (see xcd_contiguous_tile in mxv_kernels.hip); 0: tiles in workgroup-id order.
 #ifndef MXV_XCD_MAP
 #define MXV_XCD_MAP 1

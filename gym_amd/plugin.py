@@ -8,8 +8,9 @@ Three ways in, none of which touches the reference tree:
   * entry point:   an installed distribution declares  [project.entry-points."gym.envs"]  hip = "gym_amd.plugin:register_envs"
                    (pyproject.toml) and gym loads it at import (registration.py:266-309, gym/envs/__init__.py:5)
 
-The registered ids are `hip/<reference id>` for every id of gym_amd.registration.registry.  Their entry point returns
-a HipVectorEnv — a *vector* env — so the specs switch off everything gym.make would wrap around a single env:
+The registered ids are `hip/<reference id>` for every id of gym_amd.registration.registry (classic control) and of
+gym_amd.toy_text.TOY_TEXT_REGISTRY (FrozenLake / Taxi / CliffWalking).  Their entry point returns a HipVectorEnv /
+HipTabularVectorEnv — a *vector* env — so the specs switch off everything gym.make would wrap around a single env:
 `order_enforce=False`, `disable_env_checker=True`, `max_episode_steps=None` (TimeLimit lives inside the kernels; pass
 `time_limit=` to change it, not gym.make's own `max_episode_steps=` which would add the single-env wrapper).
 """
@@ -22,19 +23,21 @@ NAMESPACE = "hip"
 
 def make_vector(id: str, num_envs: int = 1, time_limit=None, **kwargs):
     """Entry point of the registered specs."""
-    from .vector_env import HipVectorEnv
+    from .vector_env import make
 
     if time_limit is not None:
         kwargs["max_episode_steps"] = time_limit
-    return HipVectorEnv(id, num_envs, **kwargs)
+    return make(id, num_envs, **kwargs)
 
 
 def register_envs(gym_module=None) -> list:
     """Register `hip/<id>` for every supported id; returns the registered ids.  Safe to call twice."""
     if gym_module is None:
         import gym as gym_module  # the reference (or its successor) must be importable for this entry point
+    from .toy_text import TOY_TEXT_REGISTRY
+
     done = []
-    for env_id, spec in registry.items():
+    for env_id, spec in list(registry.items()) + list(TOY_TEXT_REGISTRY.items()):
         full = f"{NAMESPACE}/{env_id}"
         if full not in gym_module.envs.registry:
             gym_module.register(id=full, entry_point="gym_amd.plugin:make_vector", reward_threshold=spec.reward_threshold,

@@ -11,7 +11,9 @@ for s in "$@"; do
     F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DMXV_ENVS_PER_LANE=$e -DMXV_ENVS_PER_LANE_ACROBOT=$ea -DMXV_CONSEC=$c -DMXV_MIN_WAVES=$mw $extra"
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_kernels.hip" -o "$tmp/k.o" 2>/dev/null &&
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_api.cpp" -o "$tmp/a.o" &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv_$name.so" "$tmp/k.o" "$tmp/a.o" && echo "built $name"
+    /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_norm.hip" -o "$tmp/n.o" 2>/dev/null &&
+    /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_tab.hip" -o "$tmp/t.o" 2>/dev/null &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv_$name.so" "$tmp/k.o" "$tmp/a.o" "$tmp/n.o" "$tmp/t.o" && echo "built $name"
     rm -rf "$tmp"
   ) &
 done
