@@ -72,6 +72,32 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
     return c;
 }
 
+// Same function for a per-lane (VGPR) key: the two three-input XORs of a round are one v_bitop3_b32 each (truth table 0x96 =
+// a ^ b ^ c; gfx950's compiler emits two v_xor_b32 for them), 20 VALU instructions fewer per call.  Bit-identical by
+// construction.  Only for callers whose key lives in VGPRs (the inline-asm operands are VGPR-constrained; a uniform key would
+// first be copied into one).
+__device__ __forceinline__ uint32_t xor3_vgpr(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ U4 philox4x32_10_vkey(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < MXV_EXP_PHILOX_ROUNDS; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = xor3_vgpr((uint32_t)(p1 >> 32), c.y, k0);
+        n.y = (uint32_t)p1;
+        n.z = xor3_vgpr((uint32_t)(p0 >> 32), c.w, k1);
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
 constexpr uint32_t kStreamAction = 1u;
 constexpr uint32_t kStreamReset = 2u;
 constexpr uint32_t kStreamStepNoise = 4u;  // (3 = the tabular engine's transition stream, mxv_tab.hip)
@@ -96,7 +122,7 @@ __device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r)
     c.y = (uint32_t)(t >> 32);
     c.z = r;
     c.w = (kStreamReset << 28);
-    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return philox4x32_10_vkey(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 // Step-noise stream (Acrobot's torque noise, acrobot.py:202-205): key = the env's seed, ctr = (t_lo, t_hi, 0, 4 << 28), word x.
@@ -106,7 +132,7 @@ __device__ __forceinline__ uint32_t step_noise_word(uint64_t seed, uint64_t t) {
     c.y = (uint32_t)(t >> 32);
     c.z = 0;
     c.w = (kStreamStepNoise << 28);
-    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32)).x;
+    return philox4x32_10_vkey(c, (uint32_t)seed, (uint32_t)(seed >> 32)).x;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
                     c.x = (uint32_t)t; c.y = (uint32_t)(t >> 32); c.z = 0u; c.w = (kStreamReset << 28);
                     key = reset_key((uint32_t)i);
                 }
-                const U4 w = philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+                const U4 w = philox4x32_10_vkey(c, (uint32_t)key, (uint32_t)(key >> 32));
                 if (is_act)
                     reinterpret_cast<uint4 *>(lds_act)[(q % H) * NACT + lane % NACT] = make_uint4(w.x, w.y, w.z, w.w);
                 else
@@ -508,6 +508,235 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
             if (p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
             if (p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
         }
+
+        // ---- advance the scalar output bases to the next trajectory slice ----
+        p_obs += slice * (int64_t)(O * sizeof(float));
+        if (p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
+        if (p_act != nullptr) p_act += slice * (int64_t)act_b;
+        if (p_term != nullptr) p_term += slice;
+        if (p_trunc != nullptr) p_trunc += slice;
+        if (p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
+        if (p_epr != nullptr) p_epr += slice;
+        if (p_epl != nullptr) p_epl += slice;
+    }
+
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (!valid[j]) continue;
+#pragma unroll
+        for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
+        a.elapsed[le[j]] = el[j];
+        if (a.ep_acc) a.ep_acc[le[j]] = er[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// rollout_kernel_v2: same contract, tile and store pattern as rollout_kernel, with the cross-lane hand-offs removed.
+// A finished env is reset by ITS OWN lane (key and counter come from registers; the new state, aux values and observation
+// never leave the lane), and the lanes without a finished env draw the action words of future steps, ranked among
+// themselves with mbcnt: the k-th free lane draws group k % NACT of step filled + k / NACT.  Which lane evaluates
+// Philox(g, t) does not change its value, so the RNG contract and every output bit are those of rollout_kernel.
+// What is left in LDS is the 1-KiB ring of action words: per wave-step ONE LDS round trip (the ring read, prefetched
+// one step ahead) instead of three (ring read, compacted-list read, reset-entry read), 1 KiB instead of 9.7 KiB per
+// workgroup.  A lane with two finished envs (E = 2: ~0.2 % of wave-steps) or a wave without enough free lanes for a
+// forced refill (every Pendulum env truncating at step 200) takes extra passes.
+// ------------------------------------------------------------------------------------------------------------
+template <int ENV, bool DEF, int E, bool SAFE>
+__global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v2(const StepArgs a) {
+    using EV = Env<ENV>;
+    constexpr int S = EV::S, O = EV::O, NA = EV::NA;
+    constexpr int TILE = E * kWave;
+    constexpr int NACT = TILE / 4;        // lanes that draw the action words of ONE step
+    constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
+    static_assert(NACT <= kWave, "E must be <= 4");
+    constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
+    __shared__ uint32_t lds_act[H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
+
+    const int lane = threadIdx.x;
+    const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int64_t tile0 = (int64_t)tile * TILE;
+    const int64_t n = a.n;
+    const Par<DEF> P(a.P);
+    const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
+    const bool act_i32 = (a.flags & MXV_FLAG_ACTION_I32) != 0;
+    const bool rew_f32 = (a.flags & MXV_FLAG_REWARD_F32) != 0;
+    const uint64_t group0 = (a.env0 + (uint64_t)tile0) >> 2;
+
+    double s[E][S], aux[E][AUXN];
+    int32_t el[E];
+    bool valid[E];
+    uint32_t le[E];  // env index inside the shard (fits 32 bits: mxv_create caps num_envs)
+    uint64_t seed[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t e = tile0 + j * kWave + lane;
+        valid[j] = e < n;
+        le[j] = (uint32_t)(valid[j] ? e : 0);
+#pragma unroll
+        for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
+        el[j] = a.elapsed[le[j]];
+        seed[j] = a.seeds ? a.seeds[le[j]] : a.base_seed + a.env0 + (uint64_t)le[j];
+        EV::prime(s[j], aux[j]);
+    }
+    float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
+#pragma unroll
+    for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[le[j]] : 0.0f;
+    float *p_epr = a.ep_return_out;
+    int32_t *p_epl = a.ep_length_out;
+
+    // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
+    int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
+    if (lane < filled * NACT) {
+        const U4 w = action_words(a.action_seed, t0 + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT));
+        reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t word[E];  // this step's action words (read one step ahead)
+#pragma unroll
+    for (int j = 0; j < E; ++j) word[j] = lds_act[j * kWave + lane];
+
+    char *p_obs = reinterpret_cast<char *>(a.obs);
+    char *p_rew = reinterpret_cast<char *>(a.reward);
+    char *p_act = reinterpret_cast<char *>(a.actions_out);
+    char *p_term = reinterpret_cast<char *>(a.terminated);
+    char *p_trunc = reinterpret_cast<char *>(a.truncated);
+    char *p_fin = reinterpret_cast<char *>(a.final_obs);
+    const int64_t slice = a.slice;
+    const uint32_t rew_b = rew_f32 ? 4u : 8u;
+    const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
+
+    for (int step = 0; step < a.K; ++step) {
+        const uint64_t t = t0 + (uint64_t)step;
+
+        // ---- this step's actions ----
+        int ai[E];
+        float af[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], ai[j], af[j]);
+        if (p_act != nullptr) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if (!valid[j]) continue;
+                char *q = p_act + le[j] * act_b;
+                if constexpr (NA > 0) {
+                    if (act_i32)
+                        *reinterpret_cast<int32_t *>(q) = ai[j];
+                    else
+                        *reinterpret_cast<int64_t *>(q) = (int64_t)ai[j];
+                } else {
+                    *reinterpret_cast<float *>(q) = af[j];
+                }
+            }
+        }
+
+        // ---- dynamics + TimeLimit, E independent chains ----
+        float obs[E][O];
+        double rew[E];
+        bool term[E], trunc[E], pend[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            term[j] = EV::template step<DEF, SAFE>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            el[j] += 1;                                              // time_limit.py:51
+            trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
+            pend[j] = valid[j] && (term[j] || trunc[j]);
+        }
+        if (a.ep_acc != nullptr) {  // record_episode_statistics.py:119-143
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
+                if (pend[j]) {
+                    if (p_epr) p_epr[le[j]] = er[j];
+                    if (p_epl) p_epl[le[j]] = el[j];
+                    er[j] = 0.0f;
+                }
+            }
+        }
+        // outputs that do not depend on the reset go out first: reward, flags, info["final_observation"]
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (!valid[j]) continue;
+            if (p_rew != nullptr) {
+                char *q = p_rew + le[j] * rew_b;
+                if (rew_f32)
+                    *reinterpret_cast<float *>(q) = (float)rew[j];
+                else
+                    *reinterpret_cast<double *>(q) = rew[j];
+            }
+            if (p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
+            if (p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
+            if (pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);
+        }
+
+        // ---- masked Philox passes: every lane with a finished env resets it (sync_vector_env.py:152-156); the free
+        //      lanes draw action words of future steps.  Normally exactly one pass, or none at all. ----
+        while (true) {
+            int jsel = -1;
+#pragma unroll
+            for (int j = E - 1; j >= 0; --j)
+                if (pend[j]) jsel = j;
+            const bool resets = jsel >= 0;
+            const uint64_t busy = __ballot(resets);
+            const bool must = (filled == step + 1) && (step + 1 < a.K);      // the next step has no action words yet
+            if (busy == 0 && !must) break;
+            // ring capacity: this step's slot is consumed, so steps (step, step + H] fit
+            const int horizon = (a.K < step + 1 + H) ? a.K : step + 1 + H;
+            const int room = horizon - filled;
+            const int nfree = kWave - (int)__popcll(busy);
+            int nfit = nfree / NACT;                                         // future steps the free lanes can draw
+            nfit = nfit < room ? nfit : room;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(~busy >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)~busy, 0u));
+            const bool is_act = !resets && (int)rank < nfit * NACT;
+            if (resets || is_act) {
+                U4 c;
+                uint64_t key;
+                const int q = filled + (int)rank / NACT;                     // launch-relative step drawn by an action lane
+                if (is_act) {
+                    const uint64_t g = group0 + (uint64_t)(rank % NACT), tq = t0 + (uint64_t)q;
+                    c.x = (uint32_t)g; c.y = (uint32_t)(g >> 32); c.z = (uint32_t)tq;
+                    c.w = ((uint32_t)(tq >> 32) & 0x0fffffffu) | (kStreamAction << 28);
+                    key = a.action_seed;
+                } else {
+                    c.x = (uint32_t)t; c.y = (uint32_t)(t >> 32); c.z = 0u; c.w = (kStreamReset << 28);
+                    key = seed[0];
+#pragma unroll
+                    for (int j = 1; j < E; ++j) key = (j == jsel) ? seed[j] : key;
+                }
+                const U4 w = philox4x32_10_vkey(c, (uint32_t)key, (uint32_t)(key >> 32));
+                if (is_act) {
+                    reinterpret_cast<uint4 *>(lds_act)[(q % H) * NACT + rank % NACT] = make_uint4(w.x, w.y, w.z, w.w);
+                } else {
+                    double ns[S], naux[AUXN];
+                    float nobs[O];
+                    EV::reset(w, a.b0, a.b1, ns);
+                    EV::observe(ns, nobs, naux);
+#pragma unroll
+                    for (int j = 0; j < E; ++j)
+                        if (j == jsel) {
+#pragma unroll
+                            for (int k = 0; k < EV::AUX; ++k) aux[j][k] = naux[k];
+#pragma unroll
+                            for (int k = 0; k < S; ++k) s[j][k] = ns[k];
+#pragma unroll
+                            for (int k = 0; k < O; ++k) obs[j][k] = nobs[k];
+                            el[j] = 0;  // time_limit.py:67
+                            pend[j] = false;
+                        }
+                }
+            }
+            filled += nfit;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        // ---- next step's action words (LDS latency hides behind the observation stores) ----
+        if (step + 1 < a.K) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < E; ++j) word[j] = lds_act[((step + 1) % H) * TILE + j * kWave + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
 
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
@@ -584,6 +813,27 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
 
 __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
+// rollout_kernel (resets compacted through LDS) or rollout_kernel_v2 (owner-lane resets, prefetched action words), per env
+// kind from the same-box A/B in profiles/r01h_rollout_v2_ab.txt: v2 wins 2-4 % for Pendulum / MountainCar /
+// MountainCarContinuous, v1 1-2 % for CartPole and Acrobot.  MXV_ROLLOUT_V2 = 0 / 1 forces one of them (tuning builds).
+template <int ENV>
+constexpr bool use_rollout_v2() {
+#if MXV_ROLLOUT_V2 == 0
+    return false;
+#elif MXV_ROLLOUT_V2 == 1
+    return true;
+#else
+    return ENV == MXV_PENDULUM || ENV == MXV_MOUNTAINCAR || ENV == MXV_MOUNTAINCAR_CONT;
+#endif
+}
+template <int ENV, bool DEF, int ER, bool SAFE>
+void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
+    if constexpr (use_rollout_v2<ENV>())
+        hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE>), dim3(grid), dim3(kWave), 0, stream, a);
+    else
+        hipLaunchKernelGGL((rollout_kernel<ENV, DEF, ER, SAFE>), dim3(grid), dim3(kWave), 0, stream, a);
+}
+
 template <int ENV>
 hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
     const bool def = pm == PM_DEFAULT;
@@ -596,12 +846,11 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
         bool fast = false;
         if constexpr (ENV == MXV_CARTPOLE) fast = def && !a.state_injected;  // see Env<MXV_CARTPOLE>::step, SAFE
         if (!def) {
-            hipLaunchKernelGGL((rollout_kernel<ENV, false, ER, true>), dim3(rgrid), dim3(kWave), 0, stream, a);
+            launch_rollout<ENV, false, ER, true>(rgrid, stream, a);
         } else if (fast) {
-            if constexpr (ENV == MXV_CARTPOLE)
-                hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, false>), dim3(rgrid), dim3(kWave), 0, stream, a);
+            if constexpr (ENV == MXV_CARTPOLE) launch_rollout<ENV, true, ER, false>(rgrid, stream, a);
         } else {
-            hipLaunchKernelGGL((rollout_kernel<ENV, true, ER, true>), dim3(rgrid), dim3(kWave), 0, stream, a);
+            launch_rollout<ENV, true, ER, true>(rgrid, stream, a);
         }
         return hipGetLastError();
     }

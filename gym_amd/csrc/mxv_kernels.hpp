@@ -108,6 +108,11 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_MIN_WAVES
 #define MXV_MIN_WAVES 1
 #endif
+// 1: rollout_kernel_v2 (owner-lane resets, prefetched action words); 0: rollout_kernel (compacted resets through LDS);
+// 2 (default): chosen per env kind (use_rollout_v2 in mxv_kernels.hip)
+#ifndef MXV_ROLLOUT_V2
+#define MXV_ROLLOUT_V2 2
+#endif
 // rollout_kernel's minimum waves per SIMD (tuning hook; 1 = let the register allocator decide: 113 VGPRs = 4 waves for CartPole)
 #ifndef MXV_ROLLOUT_MIN_WAVES
 #define MXV_ROLLOUT_MIN_WAVES 1

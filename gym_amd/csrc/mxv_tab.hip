@@ -84,7 +84,7 @@ __device__ __forceinline__ U4 transition_words(uint64_t seed, uint64_t b) {  // 
     c.y = (uint32_t)(b >> 32);
     c.z = 0;
     c.w = (kStreamTransition << 28);
-    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return philox4x32_10_vkey(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 // categorical_sample(initial_state_distrib): first index whose cumulative probability exceeds u, 0 if none.
