@@ -300,7 +300,7 @@ struct alignas(16) ResetEntry {
     float o[O];
 };
 
-template <int ENV, bool DEF, int E, bool SAFE>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
 __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -320,8 +320,13 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
     const int64_t n = a.n;
     const Par<DEF> P(a.P);
     const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
-    const bool act_i32 = (a.flags & MXV_FLAG_ACTION_I32) != 0;
-    const bool rew_f32 = (a.flags & MXV_FLAG_REWARD_F32) != 0;
+    // OUT != 0: every per-step output array is present, no final_obs, no episode statistics, dtypes fixed (1: float64 rewards
+    // + int64 actions, 2: float32 + int32) — the trajectory-recording launch.  The ~25 wave-uniform branches and ~60 scalar
+    // instructions per step that the optional outputs cost fold away at compile time.
+    constexpr bool FULL = OUT != 0;
+    const bool act_i32 = FULL ? (OUT == 2) : ((a.flags & MXV_FLAG_ACTION_I32) != 0);
+    const bool rew_f32 = FULL ? (OUT == 2) : ((a.flags & MXV_FLAG_REWARD_F32) != 0);
+    const bool ep_on = !FULL && a.ep_acc != nullptr;
     const uint64_t group0 = (a.env0 + (uint64_t)tile0) >> 2;
 
     double s[E][S], aux[E][AUXN];
@@ -340,9 +345,9 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
     }
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
 #pragma unroll
-    for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[le[j]] : 0.0f;
-    float *p_epr = a.ep_return_out;
-    int32_t *p_epl = a.ep_length_out;
+    for (int j = 0; j < E; ++j) er[j] = ep_on ? a.ep_acc[le[j]] : 0.0f;
+    float *p_epr = FULL ? nullptr : a.ep_return_out;
+    int32_t *p_epl = FULL ? nullptr : a.ep_length_out;
 
     // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
     int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
     char *p_act = reinterpret_cast<char *>(a.actions_out);
     char *p_term = reinterpret_cast<char *>(a.terminated);
     char *p_trunc = reinterpret_cast<char *>(a.truncated);
-    char *p_fin = reinterpret_cast<char *>(a.final_obs);
+    char *p_fin = FULL ? nullptr : reinterpret_cast<char *>(a.final_obs);
     const int64_t slice = a.slice;
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 #pragma unroll
         for (int j = 0; j < E; ++j)
             action_from_word<ENV, DEF>(P, lds_act[(step % H) * TILE + j * kWave + lane], ai[j], af[j]);
-        if (p_act != nullptr) {
+        if (FULL || p_act != nullptr) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if (!valid[j]) continue;
@@ -400,7 +405,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = valid[j] && (term[j] || trunc[j]);
         }
-        if (a.ep_acc != nullptr) {  // record_episode_statistics.py:119-143
+        if (ep_on) {  // record_episode_statistics.py:119-143
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
@@ -422,7 +427,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
             total += (uint32_t)__popcll(m);
             if (pend[j]) {
                 lds_q[slot[j]] = (uint32_t)(j * kWave + lane);
-                if (p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);  // info["final_observation"]
+                if (!FULL && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);  // info["final_observation"]
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -498,26 +503,26 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
             }
             if (!valid[j]) continue;
             store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
-            if (p_rew != nullptr) {
+            if (FULL || p_rew != nullptr) {
                 char *q = p_rew + le[j] * rew_b;
                 if (rew_f32)
                     *reinterpret_cast<float *>(q) = (float)rew[j];
                 else
                     *reinterpret_cast<double *>(q) = rew[j];
             }
-            if (p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
-            if (p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
+            if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
+            if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
         }
 
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
-        if (p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
-        if (p_act != nullptr) p_act += slice * (int64_t)act_b;
-        if (p_term != nullptr) p_term += slice;
-        if (p_trunc != nullptr) p_trunc += slice;
-        if (p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
-        if (p_epr != nullptr) p_epr += slice;
-        if (p_epl != nullptr) p_epl += slice;
+        if (FULL || p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
+        if (FULL || p_act != nullptr) p_act += slice * (int64_t)act_b;
+        if (FULL || p_term != nullptr) p_term += slice;
+        if (FULL || p_trunc != nullptr) p_trunc += slice;
+        if (!FULL && p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
+        if (!FULL && p_epr != nullptr) p_epr += slice;
+        if (!FULL && p_epl != nullptr) p_epl += slice;
     }
 
 #pragma unroll
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
         a.elapsed[le[j]] = el[j];
-        if (a.ep_acc) a.ep_acc[le[j]] = er[j];
+        if (ep_on) a.ep_acc[le[j]] = er[j];
     }
 }
 
@@ -541,7 +546,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 // workgroup.  A lane with two finished envs (E = 2: ~0.2 % of wave-steps) or a wave without enough free lanes for a
 // forced refill (every Pendulum env truncating at step 200) takes extra passes.
 // ------------------------------------------------------------------------------------------------------------
-template <int ENV, bool DEF, int E, bool SAFE>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
 __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v2(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -558,8 +563,13 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
     const int64_t n = a.n;
     const Par<DEF> P(a.P);
     const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
-    const bool act_i32 = (a.flags & MXV_FLAG_ACTION_I32) != 0;
-    const bool rew_f32 = (a.flags & MXV_FLAG_REWARD_F32) != 0;
+    // OUT != 0: every per-step output array is present, no final_obs, no episode statistics, dtypes fixed (1: float64 rewards
+    // + int64 actions, 2: float32 + int32) — the trajectory-recording launch.  The ~25 wave-uniform branches and ~60 scalar
+    // instructions per step that the optional outputs cost fold away at compile time.
+    constexpr bool FULL = OUT != 0;
+    const bool act_i32 = FULL ? (OUT == 2) : ((a.flags & MXV_FLAG_ACTION_I32) != 0);
+    const bool rew_f32 = FULL ? (OUT == 2) : ((a.flags & MXV_FLAG_REWARD_F32) != 0);
+    const bool ep_on = !FULL && a.ep_acc != nullptr;
     const uint64_t group0 = (a.env0 + (uint64_t)tile0) >> 2;
 
     double s[E][S], aux[E][AUXN];
@@ -580,9 +590,9 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
     }
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
 #pragma unroll
-    for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[le[j]] : 0.0f;
-    float *p_epr = a.ep_return_out;
-    int32_t *p_epl = a.ep_length_out;
+    for (int j = 0; j < E; ++j) er[j] = ep_on ? a.ep_acc[le[j]] : 0.0f;
+    float *p_epr = FULL ? nullptr : a.ep_return_out;
+    int32_t *p_epl = FULL ? nullptr : a.ep_length_out;
 
     // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
     int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
@@ -601,7 +611,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
     char *p_act = reinterpret_cast<char *>(a.actions_out);
     char *p_term = reinterpret_cast<char *>(a.terminated);
     char *p_trunc = reinterpret_cast<char *>(a.truncated);
-    char *p_fin = reinterpret_cast<char *>(a.final_obs);
+    char *p_fin = FULL ? nullptr : reinterpret_cast<char *>(a.final_obs);
     const int64_t slice = a.slice;
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
@@ -614,7 +624,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
         float af[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], ai[j], af[j]);
-        if (p_act != nullptr) {
+        if (FULL || p_act != nullptr) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if (!valid[j]) continue;
@@ -641,7 +651,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = valid[j] && (term[j] || trunc[j]);
         }
-        if (a.ep_acc != nullptr) {  // record_episode_statistics.py:119-143
+        if (ep_on) {  // record_episode_statistics.py:119-143
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
@@ -656,16 +666,16 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             if (!valid[j]) continue;
-            if (p_rew != nullptr) {
+            if (FULL || p_rew != nullptr) {
                 char *q = p_rew + le[j] * rew_b;
                 if (rew_f32)
                     *reinterpret_cast<float *>(q) = (float)rew[j];
                 else
                     *reinterpret_cast<double *>(q) = rew[j];
             }
-            if (p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
-            if (p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
-            if (pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);
+            if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
+            if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
+            if (!FULL && pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);
         }
 
         // ---- masked Philox passes: every lane with a finished env resets it (sync_vector_env.py:152-156); the free
@@ -740,13 +750,13 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
 
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
-        if (p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
-        if (p_act != nullptr) p_act += slice * (int64_t)act_b;
-        if (p_term != nullptr) p_term += slice;
-        if (p_trunc != nullptr) p_trunc += slice;
-        if (p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
-        if (p_epr != nullptr) p_epr += slice;
-        if (p_epl != nullptr) p_epl += slice;
+        if (FULL || p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
+        if (FULL || p_act != nullptr) p_act += slice * (int64_t)act_b;
+        if (FULL || p_term != nullptr) p_term += slice;
+        if (FULL || p_trunc != nullptr) p_trunc += slice;
+        if (!FULL && p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
+        if (!FULL && p_epr != nullptr) p_epr += slice;
+        if (!FULL && p_epl != nullptr) p_epl += slice;
     }
 
 #pragma unroll
@@ -755,7 +765,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
         a.elapsed[le[j]] = el[j];
-        if (a.ep_acc) a.ep_acc[le[j]] = er[j];
+        if (ep_on) a.ep_acc[le[j]] = er[j];
     }
 }
 
@@ -826,12 +836,26 @@ constexpr bool use_rollout_v2() {
     return ENV == MXV_PENDULUM || ENV == MXV_MOUNTAINCAR || ENV == MXV_MOUNTAINCAR_CONT;
 #endif
 }
+template <int ENV, bool DEF, int ER, bool SAFE, int OUT>
+void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
+    if constexpr (use_rollout_v2<ENV>())
+        hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
+    else
+        hipLaunchKernelGGL((rollout_kernel<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
+}
 template <int ENV, bool DEF, int ER, bool SAFE>
 void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
-    if constexpr (use_rollout_v2<ENV>())
-        hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE>), dim3(grid), dim3(kWave), 0, stream, a);
-    else
-        hipLaunchKernelGGL((rollout_kernel<ENV, DEF, ER, SAFE>), dim3(grid), dim3(kWave), 0, stream, a);
+    // the trajectory-recording shape (all outputs, no final_obs / statistics) has its own straight-line instantiations
+    int out = 0;
+    if (DEF && a.reward && a.actions_out && a.terminated && a.truncated && !a.final_obs && !a.ep_acc) {
+        const int f = a.flags & (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32);
+        out = f == 0 ? 1 : (f == (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32) ? 2 : 0);
+    }
+    if constexpr (DEF) {
+        if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a);
+        if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a);
+    }
+    launch_rollout_out<ENV, DEF, ER, SAFE, 0>(grid, stream, a);
 }
 
 template <int ENV>
