@@ -54,6 +54,7 @@ struct TabArgs {
     const int32_t *nt;       // [S*A*M] next_state | terminated << 31
     const double *init_cum;  // [S] cumulative initial-state distribution
     int32_t S, A, M, log2S;
+    int32_t single_start;    // >= 0: the initial distribution is a point mass on this state (FrozenLake, CliffWalking): no search
     // step I/O
     const int64_t *actions;  // [N] (or [K][N] tape) or nullptr -> Philox action stream
     int64_t *actions_out;    // optional
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
         if (term || trunc) {  // sync_vector_env.py:152-156: the returned observation/info are the reset's
             if (a.final_obs) a.final_obs[o] = (int64_t)ns;
             if (a.final_prob) a.final_prob[o] = p;
-            s = sample_initial(init_cum, a.S, a.log2S, u_reset);
+            s = a.single_start >= 0 ? a.single_start : sample_initial(init_cum, a.S, a.log2S, u_reset);
             el = 0;
             p = 1.0;                                               // reset() returns {"prob": 1}
         }
@@ -264,6 +265,7 @@ struct mxv_tab {
     size_t lds_bytes = 0;
     bool lds_table = false;
     int log2S = 0;
+    int single_start = -1;
     uint64_t base_seed = 0, action_seed = 0, t = 0;
     uint32_t r = 0;
     bool was_reset = false;
@@ -323,6 +325,7 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const int64_t *actions, int64_t
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds;
     a.cum = h->cum; a.prob = h->prob; a.reward = h->reward; a.nt = h->nt; a.init_cum = h->init_cum;
     a.S = h->cfg.num_states; a.A = h->cfg.num_actions; a.M = h->cfg.max_transitions; a.log2S = h->log2S;
+    a.single_start = h->single_start;
     a.actions = actions; a.actions_out = actions_out; a.uniforms = uniforms;
     a.obs = obs; a.reward_out = reward; a.terminated = term; a.truncated = trunc; a.prob_out = prob;
     a.final_obs = final_obs; a.final_prob = final_prob;
@@ -402,6 +405,12 @@ int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const
     h->base_seed = cfg->seed;
     h->action_seed = cfg->action_seed;
     while ((1 << h->log2S) < S) h->log2S += 1;
+    // categorical_sample over a point mass returns that state for every u in [0, 1): cumulative sums 0,...,0,1,...,1
+    for (int i = 0; i < S; ++i) {
+        const double prev = i ? initial_cum_host[i - 1] : 0.0;
+        if (prev == 0.0 && initial_cum_host[i] == 1.0 && initial_cum_host[S - 1] == 1.0) h->single_start = i;
+        if (initial_cum_host[i] != 0.0) break;
+    }
     bool all_one = true;
     for (size_t i = 0; i < entries; ++i)
         if (cum_prob_host[i] >= 0.0 && prob_host[i] != 1.0) all_one = false;
