@@ -546,8 +546,8 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 // workgroup.  A lane with two finished envs (E = 2: ~0.2 % of wave-steps) or a wave without enough free lanes for a
 // forced refill (every Pendulum env truncating at step 200) takes extra passes.
 // ------------------------------------------------------------------------------------------------------------
-template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
-__global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v2(const StepArgs a) {
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, int WAVES = MXV_ROLLOUT_V2_WAVES>
+__global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v2(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     constexpr int TILE = E * kWave;
@@ -555,10 +555,13 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v
     constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
     static_assert(NACT <= kWave, "E must be <= 4");
     constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
-    __shared__ uint32_t lds_act[H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
+    // WAVES waves per workgroup, each an independent tile with a private ring (no barrier anywhere): a workgroup only groups
+    // WAVES consecutive tiles onto one CU so that their stores of a step land next to each other
+    __shared__ uint32_t lds_ring[WAVES][H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
+    uint32_t *lds_act = lds_ring[threadIdx.x / kWave];
 
-    const int lane = threadIdx.x;
-    const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x % kWave;
+    const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x) * WAVES + threadIdx.x / kWave;
     const int64_t tile0 = (int64_t)tile * TILE;
     const int64_t n = a.n;
     const Par<DEF> P(a.P);
@@ -839,7 +842,8 @@ constexpr bool use_rollout_v2() {
 template <int ENV, bool DEF, int ER, bool SAFE, int OUT>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
     if constexpr (use_rollout_v2<ENV>())
-        hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
+        hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE, OUT>), dim3((grid + MXV_ROLLOUT_V2_WAVES - 1) / MXV_ROLLOUT_V2_WAVES),
+                           dim3(kWave * MXV_ROLLOUT_V2_WAVES), 0, stream, a);
     else
         hipLaunchKernelGGL((rollout_kernel<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
 }

@@ -113,6 +113,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_V2
 #define MXV_ROLLOUT_V2 2
 #endif
+// waves (= independent tiles) per workgroup of rollout_kernel_v2
+#ifndef MXV_ROLLOUT_V2_WAVES
+#define MXV_ROLLOUT_V2_WAVES 1
+#endif
 // rollout_kernel's minimum waves per SIMD (tuning hook; 1 = let the register allocator decide: 113 VGPRs = 4 waves for CartPole)
 #ifndef MXV_ROLLOUT_MIN_WAVES
 #define MXV_ROLLOUT_MIN_WAVES 1
