@@ -114,11 +114,15 @@ class DeviceRollout:
                 self.handle.set_episode_outputs(*tgt)
                 self._ep_attached = tgt[0]
 
-    def trajectory_buffers(self, K: int):
-        """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk)."""
+    def trajectory_buffers(self, K: int, want_final: bool = False):
+        """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk).  want_final adds
+        `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
+        of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content."""
         n, dev = self.num_envs, self.device
         with torch.cuda.stream(self.stream):
             extra = {}
+            if want_final:
+                extra["final_obs"] = torch.zeros((K, n, self.O), dtype=torch.float32, device=dev)
             if getattr(self, "episode_stats", False):
                 extra = dict(ep_return=torch.zeros((K, n), dtype=torch.float32, device=dev),
                              ep_length=torch.zeros((K, n), dtype=torch.int32, device=dev))
@@ -133,7 +137,7 @@ class DeviceRollout:
         out = self.trajectory_buffers(K) if out is None else out
         assert out["obs"].shape[0] >= K
         self._attach_episode_outputs(out)
-        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], None,
+        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
                             out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
         return out
@@ -145,8 +149,8 @@ class DeviceRollout:
         assert actions.numel() == K * self.num_envs
         out = self.trajectory_buffers(K) if out is None else out
         self._attach_episode_outputs(out)
-        self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"], None,
-                                 per_step=True)
+        self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"],
+                                 out.get("final_obs"), per_step=True)
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
         return out
 

@@ -329,3 +329,36 @@ def test_acrobot_torque_noise_matches_oracle_twin():
     qo = q.rollout_per_step(12)["obs"].cpu().numpy()
     q.close()
     assert not np.array_equal(qo[0], outs[0][0])
+
+
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum"])
+def test_trajectory_final_observations(name):
+    """rollout_per_step(want_final): final_obs[k, i] holds info["final_observation"] of step k for the envs that finished
+    there (sync_vector_env.py:152-156) and is untouched elsewhere; fused == per-step launches; the terminal observation
+    differs from the returned (post-reset) one."""
+    from gym_amd.rollout import DeviceRollout
+
+    n, K, limit = 3000, 40, 9
+    res = {}
+    for mode in ("fused", "eager"):
+        r = DeviceRollout(GYM_IDS_LOCAL[name], n, seed=3, action_seed=4, max_episode_steps=limit)
+        r.reset(seed=3)
+        tr = r.trajectory_buffers(K, want_final=True)
+        r.rollout_per_step(K, mode=mode, out=tr)
+        r.synchronize()
+        res[mode] = {k: v.cpu().numpy() for k, v in tr.items()}
+        r.close()
+    a, b = res["fused"], res["eager"]
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    done = (a["terminated"] | a["truncated"]).astype(bool)
+    assert done.any() and np.all(a["final_obs"][~done] == 0)
+    assert np.all(np.any(a["final_obs"][done] != a["obs"][done], axis=1))
+    if name == "CartPole":   # a terminated CartPole's terminal observation is outside the thresholds, the reset one inside
+        term = a["terminated"].astype(bool)
+        fo = a["final_obs"][term]
+        assert np.all((np.abs(fo[:, 0]) > 2.4) | (np.abs(fo[:, 2]) > 12 * 2 * np.pi / 360))
+        assert np.all(np.abs(a["obs"][term]) <= 0.05)
+
+
+GYM_IDS_LOCAL = {"CartPole": "CartPole-v1", "Pendulum": "Pendulum-v1"}
