@@ -42,6 +42,8 @@ EXPORTS = (
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_set_stream",
+    "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
+    "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_sync", "mxv_bj_set_stream",
 )
 
 
@@ -71,6 +73,22 @@ class MxvTabConfig(C.Structure):
         ("seed", C.c_uint64),
         ("action_seed", C.c_uint64),
     ]
+
+
+class MxvBjConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("natural", C.c_int32),
+        ("sab", C.c_int32),
+        ("max_episode_steps", C.c_int32),
+        ("num_envs", C.c_int64),
+        ("env_offset", C.c_int64),
+        ("seed", C.c_uint64),
+        ("action_seed", C.c_uint64),
+    ]
+
+
+BJ_MAX_DRAWS = 24
 
 
 class MxvError(RuntimeError):
@@ -152,6 +170,19 @@ def _load():
         "mxv_tab_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_tab_sync": ([vp], C.c_int),
         "mxv_tab_set_stream": ([vp, vp], C.c_int),
+        "mxv_bj_create": ([C.POINTER(MxvBjConfig), C.POINTER(vp)], C.c_int),
+        "mxv_bj_destroy": ([vp], C.c_int),
+        "mxv_bj_last_error": ([vp], C.c_char_p),
+        "mxv_bj_seed": ([vp, u64, vp, u64], C.c_int),
+        "mxv_bj_reset": ([vp, vp, vp, vp], C.c_int),
+        "mxv_bj_step": ([vp] * 8, C.c_int),
+        "mxv_bj_rollout": ([vp, i32, i32] + [vp] * 7, C.c_int),
+        "mxv_bj_reset_host": ([vp, vp, vp], C.c_int),
+        "mxv_bj_step_host": ([vp] * 8, C.c_int),
+        "mxv_bj_get_state": ([vp, vp, vp], C.c_int),
+        "mxv_bj_set_state": ([vp, vp, vp, u64, u32], C.c_int),
+        "mxv_bj_sync": ([vp], C.c_int),
+        "mxv_bj_set_stream": ([vp, vp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the .so does not export a declared symbol
@@ -609,3 +640,91 @@ class Tab:
 
     def set_stream(self, stream_ptr: int):
         self._check(lib.mxv_tab_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+
+class Blackjack:
+    """One mxv_bj handle: N device-resident Blackjack-v1 tables (see include/mxv.h)."""
+
+    def __init__(self, num_envs, *, natural=False, sab=False, max_episode_steps=-1, device=0, env_offset=0, seed=0, action_seed=0):
+        self.num_envs, self.device = int(num_envs), int(device)
+        cfg = MxvBjConfig(self.device, int(bool(natural)), int(bool(sab)), int(max_episode_steps), self.num_envs,
+                          int(env_offset), int(seed) & (2**64 - 1), int(action_seed) & (2**64 - 1))
+        h = C.c_void_p()
+        rc = lib.mxv_bj_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_bj_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_bj_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.mxv_bj_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seed(self, base_seed: int, per_env_seeds=None, action_seed: int = 0):
+        p = None
+        if per_env_seeds is not None:
+            per_env_seeds = np.ascontiguousarray(per_env_seeds, dtype=np.uint64)
+            assert per_env_seeds.shape == (self.num_envs,)
+            p = per_env_seeds.ctypes.data
+        self._check(lib.mxv_bj_seed(self._h, int(base_seed) & (2**64 - 1), p, int(action_seed) & (2**64 - 1)))
+
+    def reset(self, obs_dev=None, mask_dev=None, cards_dev=None):
+        self._check(lib.mxv_bj_reset(self._h, _ptr(mask_dev), _ptr(cards_dev), _ptr(obs_dev)))
+
+    def step(self, actions_dev, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None, cards_dev=None):
+        self._check(lib.mxv_bj_step(self._h, _ptr(actions_dev), _ptr(cards_dev), _ptr(obs_dev), _ptr(reward_dev),
+                                    _ptr(terminated_dev), _ptr(truncated_dev), _ptr(final_obs_dev)))
+
+    def rollout(self, K, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None,
+                actions_out_dev=None, actions_tape_dev=None, per_step=False):
+        self._check(lib.mxv_bj_rollout(self._h, int(K), int(per_step), _ptr(actions_tape_dev), _ptr(actions_out_dev),
+                                       _ptr(obs_dev), _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev),
+                                       _ptr(final_obs_dev)))
+
+    def reset_host(self, cards=None) -> np.ndarray:
+        """-> obs int64 [3][N].  cards: None or int8 [N][4] (dealer's two cards, then the player's)."""
+        obs = np.empty((3, self.num_envs), np.int64)
+        c = None if cards is None else np.ascontiguousarray(cards, dtype=np.int8).reshape(self.num_envs, 4)
+        self._check(lib.mxv_bj_reset_host(self._h, _ptr(c), obs.ctypes.data))
+        return obs
+
+    def step_host(self, actions, cards=None):
+        """-> obs i64[3][N], reward f64[N], terminated bool[N], truncated bool[N], final_obs i64[3][N]."""
+        n = self.num_envs
+        a = np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
+        c = None if cards is None else np.ascontiguousarray(cards, dtype=np.int8).reshape(n, BJ_MAX_DRAWS)
+        obs = np.empty((3, n), np.int64)
+        rew = np.empty(n, np.float64)
+        term = np.empty(n, np.uint8)
+        trunc = np.empty(n, np.uint8)
+        fin = np.zeros((3, n), np.int64)
+        self._check(lib.mxv_bj_step_host(self._h, a.ctypes.data, _ptr(c), obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+                                         trunc.ctypes.data, fin.ctypes.data))
+        return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin
+
+    def get_state(self):
+        st = np.empty(self.num_envs, np.int32)
+        el = np.empty(self.num_envs, np.int32)
+        self._check(lib.mxv_bj_get_state(self._h, st.ctypes.data, el.ctypes.data))
+        return st, el
+
+    def set_state(self, state=None, elapsed=None, t: int = 0, r: int = 1):
+        st = None if state is None else np.ascontiguousarray(state, dtype=np.int32).reshape(self.num_envs)
+        el = None if elapsed is None else np.ascontiguousarray(elapsed, dtype=np.int32).reshape(self.num_envs)
+        self._check(lib.mxv_bj_set_state(self._h, _ptr(st), _ptr(el), int(t), int(r)))
+
+    def sync(self):
+        self._check(lib.mxv_bj_sync(self._h))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(lib.mxv_bj_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -11,6 +11,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_api.cpp" -o "$out/mxv_api.o" &
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_norm.hip" -o "$out/mxv_norm.o" &
 "$HIPCC" "${FLAGS[@]}" -c "$here/mxv_tab.hip" -o "$out/mxv_tab.o" &
+"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_bj.hip" -o "$out/mxv_bj.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o" "$out/mxv_norm.o" "$out/mxv_tab.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o" "$out/mxv_norm.o" "$out/mxv_tab.o" "$out/mxv_bj.o"
 echo "built $out/libmxv.so"

@@ -190,8 +190,45 @@ class MultiDiscrete(Space):
         return isinstance(other, MultiDiscrete) and np.all(self.nvec == other.nvec)
 
 
+class Tuple(Space):
+    """Product of spaces (gym/spaces/tuple.py:12-160), as far as Blackjack's observation space needs it."""
+
+    def __init__(self, spaces, seed=None):
+        self.spaces = tuple(spaces)
+        super().__init__(None, None, seed)
+
+    def seed(self, seed=None) -> list:
+        out = super().seed(seed)
+        sub = self.np_random.integers(np.iinfo(np.int32).max, size=len(self.spaces))   # tuple.py:67-79: one sub-seed per space
+        for sp, sd in zip(self.spaces, sub):
+            out += sp.seed(int(sd))
+        return out
+
+    def sample(self, mask=None):
+        return tuple(sp.sample() for sp in self.spaces)
+
+    def contains(self, x) -> bool:
+        if isinstance(x, (list, np.ndarray)):
+            x = tuple(x)
+        return isinstance(x, tuple) and len(x) == len(self.spaces) and all(sp.contains(v) for sp, v in zip(self.spaces, x))
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, i):
+        return self.spaces[i]
+
+    def __repr__(self):
+        return "Tuple(" + ", ".join(str(s) for s in self.spaces) + ")"
+
+    def __eq__(self, other):
+        return isinstance(other, Tuple) and self.spaces == other.spaces
+
+
 def batch_space(space: Space, n: int = 1) -> Space:
-    """gym/vector/utils/spaces.py:17-68 for Box and Discrete."""
+    """gym/vector/utils/spaces.py:17-68 for Box and Discrete (and Tuple: :102-108)."""
+    if isinstance(space, Tuple):
+        return Tuple(tuple(batch_space(sp, n) for sp in space.spaces), seed=deepcopy(space.np_random))
     if isinstance(space, Box):
         repeats = tuple([n] + [1] * space.low.ndim)
         low, high = np.tile(space.low, repeats), np.tile(space.high, repeats)

@@ -24,7 +24,7 @@ from .spaces import Discrete
 from .vector_env import LazyInfos, VectorEnv, _Pending
 
 __all__ = ["TabularMDP", "generate_random_map", "frozen_lake_mdp", "taxi_mdp", "cliff_walking_mdp", "HipTabularVectorEnv", "TabularRollout",
-           "TOY_TEXT_REGISTRY"]
+           "HipBlackjackVectorEnv", "TOY_TEXT_REGISTRY"]
 
 
 @dataclass
@@ -464,3 +464,114 @@ class TabularRollout:
 
     def close(self):
         self.handle.close()
+
+
+# ---- Blackjack-v1 (gym/envs/toy_text/blackjack.py): not a P table — its own kernel (gym_amd/csrc/mxv_bj.hip) ---------------
+class HipBlackjackVectorEnv(VectorEnv):
+    """`num_envs` Blackjack tables on one MI355X with SyncVectorEnv's contract: observations are a tuple of three int64
+    arrays (player total, dealer's showing card, usable ace) — batch_space(Tuple(Discrete(32), Discrete(11), Discrete(2)));
+    rewards float64; infos empty except `final_observation` (object array of (int, int, bool) tuples) / `final_info`."""
+
+    metadata = {"render_modes": []}
+    render_mode = None
+
+    def __init__(self, id: str = "Blackjack-v1", num_envs: int = 1, *, device: int = 0, natural: bool = False, sab: bool = True,
+                 max_episode_steps: Optional[int] = None, env_offset: int = 0, **kwargs):
+        from .spaces import Tuple
+
+        kwargs.pop("render_mode", None)
+        if kwargs:
+            raise TypeError(f"{id} got an unexpected keyword argument {next(iter(kwargs))!r}")
+        self.spec = ToyTextSpec(id, None, None)
+        self.natural, self.sab = bool(natural), bool(sab)     # gym/envs/__init__.py:95-99 registers sab=True, natural=False
+        super().__init__(num_envs, Tuple((Discrete(32), Discrete(11), Discrete(2))), Discrete(2))
+        entropy = int.from_bytes(os.urandom(8), "little")
+        self._handle = _native.Blackjack(num_envs, natural=natural, sab=sab, device=device, env_offset=env_offset,
+                                         max_episode_steps=-1 if max_episode_steps is None else int(max_episode_steps),
+                                         seed=entropy, action_seed=entropy ^ 0x9E3779B97F4A7C15)
+        self._actions = None
+        self._was_reset = False
+
+    @staticmethod
+    def _obs(cols):
+        return (cols[0].copy(), cols[1].copy(), cols[2].copy())
+
+    def reset_wait(self, seed: Optional[Union[int, List[int]]] = None, options: Optional[dict] = None):
+        self._assert_is_running()
+        if seed is not None:
+            if isinstance(seed, (int, np.integer)):
+                if seed < 0:
+                    raise error.Error(f"Seed must be a non-negative integer or omitted, not {seed}")
+                self._handle.seed(int(seed), None, int(seed) ^ 0x9E3779B97F4A7C15)
+            else:
+                seeds = list(seed)
+                assert len(seeds) == self.num_envs
+                self._handle.seed(0, np.array(seeds, dtype=np.uint64), int(seeds[0]) ^ 0x9E3779B97F4A7C15)
+        cols = self._handle.reset_host()
+        self._was_reset = True
+        self._actions = None
+        return self._obs(cols), {}
+
+    def step_async(self, actions):
+        self._assert_is_running()
+        if self._actions is not None:
+            raise error.AlreadyPendingCallError("Calling `step_async` while waiting for a pending call to `step` to "
+                                                "complete.", "step")
+        a = np.asarray(actions)
+        if a.shape != (self.num_envs,) or not np.issubdtype(a.dtype, np.integer):
+            raise AssertionError(f"{actions!r} ({type(actions)}) invalid")
+        self._actions = np.ascontiguousarray(a, dtype=np.int64)
+
+    def step_wait(self):
+        self._assert_is_running()
+        if self._actions is None:
+            raise error.NoAsyncCallError("Calling `step_wait` without any prior call to `step_async`.", "step")
+        actions, self._actions = self._actions, None
+        if not self._was_reset:
+            raise error.ResetNeeded("Cannot call env.step() before calling env.reset()")
+        try:
+            cols, rew, term, trunc, fin = self._handle.step_host(actions)
+        except _native.MxvError as e:
+            if e.code == _native.ERR_INVALID_ACTION:
+                raise AssertionError(f"{actions!r} ({type(actions)}) invalid") from None   # blackjack.py:122
+            raise
+        n = self.num_envs
+        done = term | trunc
+        infos = LazyInfos()
+        if done.any():
+            idx = np.flatnonzero(done)
+
+            def build_final_obs():
+                arr = np.full(n, None, dtype=object)
+                for i in idx:
+                    arr[i] = (int(fin[0, i]), int(fin[1, i]), bool(fin[2, i]))   # _get_obs(): (int, int, bool)
+                return arr
+
+            def build_final_info():
+                arr = np.full(n, None, dtype=object)
+                for i in idx:
+                    arr[i] = {}
+                return arr
+
+            dict.__setitem__(infos, "final_observation", _Pending(build_final_obs))
+            dict.__setitem__(infos, "_final_observation", done.copy())
+            dict.__setitem__(infos, "final_info", _Pending(build_final_info))
+            dict.__setitem__(infos, "_final_info", done.copy())
+        return self._obs(cols), rew, term, trunc, infos
+
+    def close_extras(self, **kwargs):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            h.close()
+
+    def _assert_is_running(self):
+        if self.closed:
+            raise error.ClosedEnvironmentError(f"Trying to operate on `{type(self).__name__}`, after a call to `close()`.")
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def handle(self) -> "_native.Blackjack":
+        return self._handle

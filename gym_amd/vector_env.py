@@ -399,6 +399,8 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
     kwargs.pop("wrappers", None)
     from . import toy_text
 
+    if id == "Blackjack-v1":
+        return toy_text.HipBlackjackVectorEnv(id, num_envs, **kwargs)
     if id in toy_text.TOY_TEXT_REGISTRY:  # FrozenLake / Taxi / CliffWalking: the table-driven engine
         return toy_text.HipTabularVectorEnv(id, num_envs, **kwargs)
     return HipVectorEnv(id, num_envs, **kwargs)

@@ -314,6 +314,46 @@ int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r);
 int mxv_tab_sync(mxv_tab *h);
 int mxv_tab_set_stream(mxv_tab *h, void *stream);
 
+/* -- Blackjack-v1 (gym/envs/toy_text/blackjack.py:48-160), the toy_text env that is not a P table ------------
+ *    Observation = (player total, dealer's first card, usable ace) as three int64 columns obs[3][N] (Tuple(Discrete(32),
+ *    Discrete(11), Discrete(2)) batched: three MultiDiscrete arrays); actions int64 {0 stick, 1 hit}; reward float64.
+ *    Cards: card = deck[(word * 13) >> 32], deck = [1..10, 10, 10, 10] (:14-19), words from the Philox draw stream (key = env
+ *    seed, ctr = (t_lo, t_hi, call, 5 << 28), four cards per call, consumed in the reference's order: the hit card or the
+ *    dealer's cards, then on termination the new dealer hand, then the new player hand); explicit reset: the reset stream
+ *    (words x, y dealer; z, w player).  cards_*: optional injected draws, int8 [N][MXV_BJ_MAX_DRAWS] per step (resp. [N][4]
+ *    for a reset) in consumption order — the values np_random.choice(deck) returned, for bit-exact replays. ------------------ */
+#define MXV_BJ_MAX_DRAWS 24
+typedef struct mxv_bj mxv_bj;
+typedef struct mxv_bj_config {
+    int32_t device;
+    int32_t natural;           /* BlackjackEnv(natural=...): a winning natural pays 1.5 (ignored when sab) */
+    int32_t sab;               /* BlackjackEnv(sab=...): Sutton & Barto rules (Blackjack-v1 registers sab=True) */
+    int32_t max_episode_steps; /* <= 0: none (Blackjack-v1 has no TimeLimit) */
+    int64_t num_envs;
+    int64_t env_offset;
+    uint64_t seed;
+    uint64_t action_seed;
+} mxv_bj_config;
+int mxv_bj_create(const mxv_bj_config *cfg, mxv_bj **out);
+int mxv_bj_destroy(mxv_bj *h);
+const char *mxv_bj_last_error(const mxv_bj *h);
+int mxv_bj_seed(mxv_bj *h, uint64_t base_seed, const uint64_t *per_env_seeds_host, uint64_t action_seed);
+int mxv_bj_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int64_t *obs_dev);
+int mxv_bj_step(mxv_bj *h, const int64_t *actions_dev, const int8_t *cards_dev, int64_t *obs_dev, double *reward_dev,
+                uint8_t *terminated_dev, uint8_t *truncated_dev, int64_t *final_obs_dev);
+/* K steps in one launch; actions from actions_tape_dev int64 [K][N], or sampled (NULL; recorded in actions_out_dev if given);
+ * per_step != 0: outputs are [K][...] trajectories (obs [K][3][N]). */
+int mxv_bj_rollout(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *actions_out_dev,
+                   int64_t *obs_dev, double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, int64_t *final_obs_dev);
+int mxv_bj_reset_host(mxv_bj *h, const int8_t *cards_host, int64_t *obs_host);
+int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards_host, int64_t *obs_host, double *reward_host,
+                     uint8_t *terminated_host, uint8_t *truncated_host, int64_t *final_obs_host);
+/* packed hands (see mxv_bj.hip) + TimeLimit counters, int32 [N] each; set_state also restores the step index / reset ordinal */
+int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host);
+int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapsed_host, uint64_t t, uint32_t r);
+int mxv_bj_sync(mxv_bj *h);
+int mxv_bj_set_stream(mxv_bj *h, void *stream);
+
 /* -- stream / sync -------------------------------------------------------------------------------- */
 /* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last
  * sync saw an out-of-range action (and clears the latch). */

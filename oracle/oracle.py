@@ -55,6 +55,10 @@ def lib():
         L.orc_tab_step.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, u64, vp, u64, u64, u64, C.c_int,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_tab_step.restype = i64
+        L.orc_bj_reset.argtypes = [i64, u64, vp, u64, u64, u32, vp, vp, vp, vp, vp]
+        L.orc_bj_step.argtypes = [i64, u64, vp, u64, u64, u64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp,
+                                  vp, vp, vp, vp, vp]
+        L.orc_bj_step.restype = i64
         L.orc_norm_obs_sums.argtypes = [vp, i64, i64, C.c_int, vp]
         L.orc_norm_obs_apply.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, vp, C.c_int, i64, vp]
         L.orc_norm_reward_sums.argtypes = [vp, vp, vp, vp, i64, i64, C.c_double, vp]
@@ -330,6 +334,54 @@ class OracleTabEnv:
                                  _p(out["final_prob"]), _p(out["final_mask"]))
         if bad:
             raise KeyError(f"{bad} invalid action(s)")
+        self.t += 1
+        for k in ("terminated", "truncated", "final_mask"):
+            out[k] = out[k].astype(bool)
+        return out
+
+
+class OracleBlackjack:
+    """Batched CPU twin of the mxv_bj engine (oracle/tabular.c, Blackjack-v1 under SyncVectorEnv): hands kept as card lists
+    like the reference; cards injected (the reference's own np_random.choice draws) or from the Philox draw stream."""
+
+    MAX_DRAWS = 24
+
+    def __init__(self, num_envs, natural=False, sab=True, max_episode_steps=-1, seed=0, action_seed=0, env_offset=0):
+        self.n = int(num_envs)
+        self.natural, self.sab = int(bool(natural)), int(bool(sab))
+        self.max_episode_steps = -1 if max_episode_steps is None else int(max_episode_steps)
+        self.base_seed = int(seed) & (2**64 - 1)
+        self.action_seed = int(action_seed) & (2**64 - 1)
+        self.env0 = int(env_offset)
+        self.seeds = None
+        self.dealer = np.zeros((self.n, 33), np.int32)
+        self.player = np.zeros((self.n, 33), np.int32)
+        self.elapsed = np.zeros(self.n, np.int32)
+        self.t = 0
+        self.r = 0
+
+    def reset(self, seed=None, cards=None):
+        if seed is not None:
+            self.base_seed, self.t, self.r = int(seed) & (2**64 - 1), 0, 0
+        self.r += 1
+        obs = np.zeros((3, self.n), np.int64)
+        c = None if cards is None else np.ascontiguousarray(cards, dtype=np.int8).reshape(self.n, 4)
+        lib().orc_bj_reset(self.n, self.env0, _p(self.seeds), self.base_seed, self.t, self.r, _p(c), _p(self.dealer),
+                           _p(self.player), _p(self.elapsed), _p(obs))
+        return obs
+
+    def step(self, actions=None, cards=None):
+        n = self.n
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
+        c = None if cards is None else np.ascontiguousarray(cards, dtype=np.int8).reshape(n, self.MAX_DRAWS)
+        out = dict(actions=np.zeros(n, np.int64), obs=np.zeros((3, n), np.int64), reward=np.zeros(n), terminated=np.zeros(n, np.uint8),
+                   truncated=np.zeros(n, np.uint8), final_obs=np.zeros((3, n), np.int64), final_mask=np.zeros(n, np.uint8))
+        bad = lib().orc_bj_step(n, self.env0, _p(self.seeds), self.base_seed, self.action_seed, self.t, self.natural, self.sab,
+                                self.max_episode_steps, _p(a), _p(c), self.MAX_DRAWS, _p(self.dealer), _p(self.player),
+                                _p(self.elapsed), _p(out["actions"]), _p(out["obs"]), _p(out["reward"]), _p(out["terminated"]),
+                                _p(out["truncated"]), _p(out["final_obs"]), _p(out["final_mask"]))
+        if bad:
+            raise AssertionError(f"{bad} invalid action(s)")
         self.t += 1
         for k in ("terminated", "truncated", "final_mask"):
             out[k] = out[k].astype(bool)

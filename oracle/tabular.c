@@ -111,3 +111,100 @@ int64_t orc_tab_step(int S, int A, int M, const double *cum, const double *prob,
     }
     return bad;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Blackjack-v1 — gym/envs/toy_text/blackjack.py.  Hands are kept as card lists exactly like the reference (:17-45); the
+ * cards come either from the caller (the values np_random.choice(deck) returned, :18) or from the engine's Philox draw
+ * stream (include/mxv.h: key = env seed, ctr = (t, call, 5 << 28), card = deck[(word * 13) >> 32]).
+ * ---------------------------------------------------------------------------------------------------------------------- */
+#define BJ_MAX_HAND 32
+typedef struct { int c[BJ_MAX_HAND]; int n; } bj_hand;
+static int bj_sum(const bj_hand *h) { int s = 0; for (int i = 0; i < h->n; ++i) s += h->c[i]; return s; }
+static int bj_has_ace(const bj_hand *h) { for (int i = 0; i < h->n; ++i) if (h->c[i] == 1) return 1; return 0; }
+static int bj_usable(const bj_hand *h) { return bj_has_ace(h) && bj_sum(h) + 10 <= 21; }          /* :26-27 */
+static int bj_total(const bj_hand *h) { return bj_usable(h) ? bj_sum(h) + 10 : bj_sum(h); }        /* :30-33 */
+static int bj_score(const bj_hand *h) { return bj_total(h) > 21 ? 0 : bj_total(h); }               /* :36-41 */
+static int bj_natural(const bj_hand *h) {                                                          /* sorted(hand) == [1, 10] */
+    return h->n == 2 && ((h->c[0] == 1 && h->c[1] == 10) || (h->c[0] == 10 && h->c[1] == 1));
+}
+static const int BJ_DECK[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10};
+
+typedef struct { const int8_t *inj; uint64_t seed, t; int cursor; uint32_t w[4]; } bj_src;
+static int bj_next(bj_src *s) {
+    int c;
+    if (s->inj) {
+        c = s->inj[s->cursor];
+    } else {
+        if ((s->cursor & 3) == 0) tab_stream_words(s->seed, s->t, (uint32_t)(s->cursor >> 2), 5u, s->w);
+        c = BJ_DECK[(int)(((uint64_t)s->w[s->cursor & 3] * 13u) >> 32)];
+    }
+    s->cursor++;
+    return c;
+}
+
+/* state per env: dealer and player card lists (caller-owned arrays of bj_hand-compatible layout: int[33] each = 32 cards + n) */
+void orc_bj_reset(int64_t n, uint64_t env0, const uint64_t *seeds, uint64_t base_seed, uint64_t t, uint32_t r,
+                  const int8_t *cards, int32_t *dealer, int32_t *player, int32_t *elapsed, int64_t *obs) {
+    for (int64_t i = 0; i < n; ++i) {
+        bj_hand *d = (bj_hand *)(dealer + i * (BJ_MAX_HAND + 1)), *p = (bj_hand *)(player + i * (BJ_MAX_HAND + 1));
+        int c[4];
+        if (cards) {
+            for (int k = 0; k < 4; ++k) c[k] = cards[i * 4 + k];
+        } else {
+            uint32_t w[4];
+            tab_stream_words(seeds ? seeds[i] : base_seed + env0 + (uint64_t)i, t, r, 2u, w);
+            for (int k = 0; k < 4; ++k) c[k] = BJ_DECK[(int)(((uint64_t)w[k] * 13u) >> 32)];
+        }
+        d->c[0] = c[0]; d->c[1] = c[1]; d->n = 2;      /* :157 dealer first */
+        p->c[0] = c[2]; p->c[1] = c[3]; p->n = 2;      /* :158 */
+        elapsed[i] = 0;
+        obs[i] = bj_total(p); obs[n + i] = d->c[0]; obs[2 * n + i] = bj_usable(p);
+    }
+}
+
+int64_t orc_bj_step(int64_t n, uint64_t env0, const uint64_t *seeds, uint64_t base_seed, uint64_t action_seed, uint64_t t,
+                    int natural, int sab, int max_steps, const int64_t *actions, const int8_t *cards, int max_draws,
+                    int32_t *dealer, int32_t *player, int32_t *elapsed, int64_t *actions_out, int64_t *obs, double *rew,
+                    uint8_t *term, uint8_t *trunc, int64_t *final_obs, uint8_t *final_mask) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        bj_hand *d = (bj_hand *)(dealer + i * (BJ_MAX_HAND + 1)), *p = (bj_hand *)(player + i * (BJ_MAX_HAND + 1));
+        const uint64_t ge = env0 + (uint64_t)i;
+        int64_t a;
+        if (actions) {
+            a = actions[i];
+            if (a < 0 || a > 1) { bad++; continue; }
+        } else {
+            a = (int64_t)(((uint64_t)tab_action_word(action_seed, t, ge) * 2u) >> 32);
+        }
+        if (actions_out) actions_out[i] = a;
+        bj_src src = {cards ? cards + i * max_draws : 0, seeds ? seeds[i] : base_seed + ge, t, 0, {0, 0, 0, 0}};
+        int te;
+        double r;
+        if (a) {                                                   /* hit :123-130 */
+            p->c[p->n++] = bj_next(&src);
+            te = bj_total(p) > 21;
+            r = te ? -1.0 : 0.0;
+        } else {                                                   /* stick :131-146 */
+            te = 1;
+            while (bj_total(d) < 17) d->c[d->n++] = bj_next(&src);
+            const int ps = bj_score(p), ds = bj_score(d);
+            r = (double)(ps > ds) - (double)(ps < ds);
+            if (sab && bj_natural(p) && !bj_natural(d)) r = 1.0;
+            else if (!sab && natural && bj_natural(p) && r == 1.0) r = 1.5;
+        }
+        elapsed[i] += 1;
+        const int tr = max_steps > 0 && elapsed[i] >= max_steps;
+        final_mask[i] = 0;
+        if (te || tr) {
+            final_obs[i] = bj_total(p); final_obs[n + i] = d->c[0]; final_obs[2 * n + i] = bj_usable(p);
+            final_mask[i] = 1;
+            d->c[0] = bj_next(&src); d->c[1] = bj_next(&src); d->n = 2;
+            p->c[0] = bj_next(&src); p->c[1] = bj_next(&src); p->n = 2;
+            elapsed[i] = 0;
+        }
+        obs[i] = bj_total(p); obs[n + i] = d->c[0]; obs[2 * n + i] = bj_usable(p);
+        rew[i] = r; term[i] = (uint8_t)te; trunc[i] = (uint8_t)tr;
+    }
+    return bad;
+}

@@ -225,3 +225,26 @@ def replay_toytext(g, make_engine):
             assert np.array_equal(mdp.action_mask[out["obs"]], g["step_action_mask"][t]), t
         ndone += int(done.sum())
     return ndone
+
+
+# ---- Blackjack-v1 -------------------------------------------------------------------------------------------------------
+BLACKJACK_CASES = ["sab", "natural", "plain"]
+
+
+def replay_blackjack(tag, make_engine):
+    """Deal an engine the cards the reference drew (tests/golden/blackjack_<tag>.npz) and compare every output exactly.
+    make_engine(n, natural, sab) -> object with reset(cards[n,4]) -> obs[3,n] and step(actions, cards[n,24]) -> dict."""
+    g = np.load(os.path.join(GOLDEN, f"blackjack_{tag}.npz"))
+    T, n = g["actions"].shape
+    eng = make_engine(n, bool(g["natural"]), bool(g["sab"]))
+    assert np.array_equal(eng.reset(g["cards0"]), g["obs0"])
+    ndone = 0
+    for t in range(T):
+        out = eng.step(g["actions"][t], g["cards"][t])
+        done = g["final_mask"][t]
+        assert np.array_equal(out["obs"], g["obs"][t]), t
+        assert np.array_equal(out["reward"], g["reward"][t]), t
+        assert np.array_equal(out["terminated"], g["terminated"][t]) and np.array_equal(out["truncated"], g["truncated"][t]), t
+        assert np.array_equal(out["final_obs"][:, done], g["final_obs"][t][:, done]), t
+        ndone += int(done.sum())
+    return ndone, g

@@ -207,7 +207,7 @@ def test_error_behaviour():
     env.step(np.ones(8, dtype=np.int64))             # still usable after the errors
     env.close()
     with pytest.raises(error.UnregisteredEnv):
-        _make("Blackjack-v1", 8)                     # not a P-table env: out of scope
+        _make("LunarLander-v2", 8)                   # Box2D: out of scope
     with pytest.raises(TypeError):
         _make("CartPole-v1", 8, g=1.0)               # not a CartPole kwarg
     env = _make("Pendulum-v1", 4, g=9.81)            # pendulum.py:91
