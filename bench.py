@@ -168,6 +168,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's kernels run on high-priority streams: a chunk's all-gather gets CUs as soon as rollout waves retire instead of
+        # queueing behind the next chunk's (long-running, chip-filling) rollout launch
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from gym_amd.distributed import ShardedRollout
