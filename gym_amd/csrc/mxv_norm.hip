@@ -402,6 +402,7 @@ int dispatch_obs_apply(mxv_norm *nm, int K, const float *x, void *y, int out_f32
 int checks(mxv_norm *nm, int K) {
     if (!nm) return nfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_norm");
     if (K <= 0) return nfail(nm, MXV_ERR_INVALID_ARG, "K must be positive");
+    if (K > 65535) return nfail(nm, MXV_ERR_INVALID_ARG, "K must be <= 65535 batches per call (grid.y)");
     NRM_HIP(nm, hipSetDevice(nm->device));
     return MXV_OK;
 }
