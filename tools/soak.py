@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Parity soak on the MI355X: the device-vs-oracle-twin rollout comparison of tests/test_gpu_parity.py (Philox actions,
+TimeLimit, autoreset; masks / actions / reset states bit-exact, observations <= 2 float32 ulps) over many seeds, sizes and
+time limits, plus the tabular and Blackjack twins.  Prints one line per case; exits non-zero on the first mismatch."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    import test_gpu_parity as tp
+    from helpers import ENV_NAMES
+
+    t0 = time.time()
+    total = 0
+    for seed in (11, 222, 3333, 44444):
+        for name in ENV_NAMES:
+            for n, steps, limit in ((4097, 300, None), (1000, 120, 17)):
+                nd = tp._rollout_compare(name, n=n, steps=steps, seed=seed, limit=limit, env_offset=(seed % 7) * 4096)
+                total += n * steps
+                print(f"ok {name:22s} seed={seed:<6d} n={n:<5d} steps={steps:<4d} limit={limit} dones={nd}", flush=True)
+    # tabular + blackjack twins
+    from gym_amd import _native
+    from gym_amd.toy_text import TOY_TEXT_REGISTRY
+    from oracle.oracle import OracleBlackjack, OracleTabEnv
+
+    for seed in (5, 66, 777):
+        for gid, spec in TOY_TEXT_REGISTRY.items():
+            mdp = spec.build()
+            n, steps = 5003, 150
+            h = _native.Tab(mdp.num_states, mdp.num_actions, mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated,
+                            mdp.initial_cum, n, 23, seed=seed, action_seed=seed + 1)
+            o = OracleTabEnv(mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum, n, 23,
+                             seed=seed, action_seed=seed + 1)
+            assert np.array_equal(h.reset_host(), o.reset())
+            for t in range(steps):
+                r = o.step()
+                obs, rew, term, trunc, prob, fin, fprob = h.step_host(r["actions"])
+                assert np.array_equal(obs, r["obs"]) and np.array_equal(rew, r["reward"]) and np.array_equal(term, r["terminated"])
+                assert np.array_equal(trunc, r["truncated"]) and np.array_equal(prob, r["prob"]), (gid, seed, t)
+            h.close()
+            total += n * steps
+            print(f"ok {gid:22s} seed={seed}", flush=True)
+        hb = _native.Blackjack(4099, sab=True, seed=seed, action_seed=seed + 1)
+        ob = OracleBlackjack(4099, sab=True, seed=seed, action_seed=seed + 1)
+        assert np.array_equal(hb.reset_host(), ob.reset())
+        for t in range(200):
+            r = ob.step()
+            obs, rew, term, trunc, fin = hb.step_host(r["actions"])
+            assert np.array_equal(obs, r["obs"]) and np.array_equal(rew, r["reward"]) and np.array_equal(term, r["terminated"])
+        hb.close()
+        total += 4099 * 200
+        print(f"ok Blackjack-v1 seed={seed}", flush=True)
+    print(f"soak passed: {total:.3e} env-steps compared in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
