@@ -362,3 +362,27 @@ def test_trajectory_final_observations(name):
 
 
 GYM_IDS_LOCAL = {"CartPole": "CartPole-v1", "Pendulum": "Pendulum-v1"}
+
+
+def test_tuned_trajectory_buffers_leave_results_unchanged():
+    """DeviceRollout.tuned_trajectory_buffers times the fused rollout on several candidate buffer sets and keeps the fastest;
+    env state, TimeLimit and RNG counters are restored, so the trajectory that follows is bit-identical to an untuned run."""
+    from gym_amd.rollout import DeviceRollout
+
+    n, K = 1 << 16, 32
+    outs = []
+    for tune in (False, True):
+        r = DeviceRollout("CartPole-v1", n, seed=13, action_seed=14)
+        r.reset(seed=13)
+        if tune:
+            traj, report = r.tuned_trajectory_buffers(K, candidates=3, launches=2)
+            assert report["candidates"] == 3 and len(report["us_per_step"]) == 3
+            assert report["chosen_us_per_step"] == min(report["us_per_step"])
+        else:
+            traj = r.trajectory_buffers(K)
+        r.rollout_per_step(K, out=traj)
+        r.synchronize()
+        outs.append({k: v.cpu().numpy() for k, v in traj.items()})
+        r.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
