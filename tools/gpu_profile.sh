@@ -18,6 +18,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $GRAFT_REPO_ROOT
 # keep only what tools/summarize_profile.py reads (the raw traces are large)
-find $out -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name meta.txt -delete
+find $out -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name meta.txt ! -path "*/trace/*kernel_trace.csv" -delete
 tail -2 $out/trace.log
 du -sh $out

@@ -87,6 +87,24 @@ raw = (step_f + step_w) * 1024
 corr_r = step_f * 1024 / ratios["copy8"]["fetch_ratio"]
 corr_w = step_w * 1024 / ratios["copy8"]["write_ratio"]
 step_stat = next(r for r in stats if "step_kernel" in r["Name"] or "rollout_kernel" in r["Name"])
+# The bench command also runs the placement tuning, the spin-up and the warm-up on the same kernel: the figure comparable with
+# the bench line's avg_launch_us is the mean over the dispatches of the TIMED region = the last steps/chunk launches.
+timed_avg = timed_n = None
+bench_line = None
+try:
+    ts_steps = int(META[2].split(":")[1].split("/")[0])
+    n_timed = ts_steps // CHUNK if MODE == "fused" else ts_steps
+    tr_path = next(os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(src, "trace")) for f in fs if f.endswith("kernel_trace.csv"))
+    disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr_path))
+                   if "step_kernel" in r["Kernel_Name"] or "rollout_kernel" in r["Kernel_Name"]))
+    last = disp[-n_timed:]
+    timed_avg, timed_n = sum(e - s for s, e in last) / len(last), len(last)
+    for line in open(os.path.join(src, "trace.log")):
+        if line.startswith("{") and '"roofline"' in line:
+            bench_line = json.loads(line)
+except Exception as exc:  # older profile directories hold no per-dispatch trace
+    print("no timed-region figure:", exc)
+
 traffic = {
     "round": R,
     "mode": MODE,
@@ -95,6 +113,9 @@ traffic = {
     "kernel": short(step_stat["Name"]),
     "avg_launch_ns_rocprof": float(step_stat["AverageNs"]),
     "calls": int(step_stat["Calls"]),
+    "avg_launch_ns_rocprof_timed_region": timed_avg,
+    "timed_region_launches": timed_n,
+    "bench_line_avg_launch_us_same_run": bench_line["roofline"]["avg_launch_us"] if bench_line else None,
     "FETCH_SIZE_KiB_per_launch": step_f,
     "WRITE_SIZE_KiB_per_launch": step_w,
     "raw_bytes_per_launch": raw,
@@ -122,6 +143,12 @@ with open(os.path.join(dst, f"{R}_summary.md"), "w") as f:
     f.write("\n## Calibration on known 64 MiB copies\n\n| kernel | FETCH ratio | WRITE ratio |\n|---|---|---|\n")
     for k, v in ratios.items():
         f.write(f"| {k} | {v['fetch_ratio']:.3f} | {v['write_ratio']:.3f} |\n")
+    if timed_avg is not None:
+        f.write(f"\nTimed region (last {timed_n} dispatches of the step kernel in the per-dispatch trace): **{timed_avg / 1e3:.2f} us/launch**"
+                + (f"; the bench line printed by the same run reports avg_launch_us = {bench_line['roofline']['avg_launch_us']:.2f} "
+                   f"(HIP events), value = {bench_line['value']:.4g} env-steps/s, placement = {bench_line['config'].get('placement')}.\n"
+                   if bench_line else ".\n")
+                + "(The all-dispatch average in the table above also covers the placement-tuning, spin-up and warm-up launches.)\n")
     f.write(f"\nStep kernel: raw {(raw) / 1e6:.1f} MB/launch; corrected read {corr_r / 1e6:.1f} MB + write {corr_w / 1e6:.1f} MB = "
             f"**{(corr_r + corr_w) / 1e6:.1f} MB/launch** at {float(step_stat['AverageNs']) / 1e3:.2f} us/launch "
             f"= {(corr_r + corr_w) / float(step_stat['AverageNs']):.0f} GB/s of real traffic.\n")
