@@ -376,8 +376,8 @@ def test_tuned_trajectory_buffers_leave_results_unchanged():
         r.reset(seed=13)
         if tune:
             traj, report = r.tuned_trajectory_buffers(K, candidates=3, launches=2)
-            assert report["candidates"] == 3 and len(report["us_per_step"]) == 3
-            assert report["chosen_us_per_step"] == min(report["us_per_step"])
+            assert report["candidates"] == 3 and len(report["us_per_step"]) == 3 and len(report["mixes_us_per_step"]) == 6
+            assert report["chosen_us_per_step"] > 0
         else:
             traj = r.trajectory_buffers(K)
         r.rollout_per_step(K, out=traj)
