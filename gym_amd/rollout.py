@@ -147,7 +147,11 @@ class DeviceRollout:
 
         st, el = self.handle.get_state()
         t, r = self.handle.get_counters()
-        sets = [self.trajectory_buffers(K, want_final=want_final) for _ in range(max(1, candidates))]
+        per_step = self.num_envs * (4 * self.O * (2 if want_final else 1) + self.reward.element_size()
+                                    + self.actions.element_size() + 2)
+        free, _ = torch.cuda.mem_get_info(self.device)
+        candidates = max(1, min(int(candidates), int(0.8 * free) // max(1, K * per_step)))  # never tune the device out of memory
+        sets = [self.trajectory_buffers(K, want_final=want_final) for _ in range(candidates)]
 
         def timed(traj, warm):
             for _ in range(warm):
