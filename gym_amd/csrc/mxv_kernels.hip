@@ -47,6 +47,10 @@ constexpr unsigned kXcds = 8;
 __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned ntiles) {
 #if MXV_XCD_MAP
     const unsigned x = bid % kXcds, idx = bid / kXcds;
+#if MXV_XCD_BLOCK > 0
+    // XCDs take turns in blocks of MXV_XCD_BLOCK tiles (tuning variant; tiles past the end are skipped by the callers' bounds)
+    if (ntiles % (kXcds * MXV_XCD_BLOCK) == 0) return ((idx / MXV_XCD_BLOCK) * kXcds + x) * MXV_XCD_BLOCK + idx % MXV_XCD_BLOCK;
+#endif
     const unsigned base = ntiles / kXcds, rem = ntiles % kXcds;
     return x * base + (x < rem ? x : rem) + idx;
 #else

@@ -125,6 +125,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_XCD_MAP
 #define MXV_XCD_MAP 1
 #endif
+// > 0: the XCD-aware map hands each XCD blocks of this many tiles in turn instead of one contiguous eighth (tuning hook)
+#ifndef MXV_XCD_BLOCK
+#define MXV_XCD_BLOCK 0
+#endif
 constexpr int kBlock = 256;
 
 // param_mode: PM_DEFAULT / PM_BROADCAST / PM_PER_ENV (mxv_device.hpp)

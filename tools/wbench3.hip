@@ -11,8 +11,13 @@
 #include <vector>
 
 constexpr int kWave = 64, E = 2, TILE = E * kWave;
+__device__ int g_blk = 0;  // 0: XCD x owns the x-th contiguous eighth; B > 0: XCDs take turns in blocks of B tiles
 __device__ __forceinline__ unsigned tile_of(unsigned bid, unsigned nt) {
     const unsigned x = bid % 8, idx = bid / 8, base = nt / 8, rem = nt % 8;
+    if (g_blk > 0) {  // workgroup idx-th of XCD x -> block (idx / B) of that XCD, blocks dealt round-robin over the XCDs
+        const unsigned B = (unsigned)g_blk;
+        return ((idx / B) * 8 + x) * B + idx % B;
+    }
     return x * base + (x < rem ? x : rem) + idx;
 }
 template <int LAYOUT>
@@ -65,9 +70,21 @@ float run_once(int64_t n, int K) {
     for (int i = 0; i < 5; ++i) if (p[i]) hipFree(p[i]);
     return best * 1e3f / K;
 }
-int main() {
+int main(int argc, char **argv) {
     const int64_t n = 1 << 20; const int K = 128;
     std::vector<void *> junk;
+    if (argc > 1) {  // tile-map granularity sweep on layout A
+        for (int blk : {0, 4, 16, 64, 256}) {
+            hipMemcpyToSymbol(HIP_SYMBOL(g_blk), &blk, sizeof blk);
+            printf("layout A, XCD blocks of %3d tiles:", blk);
+            for (int t = 0; t < 10; ++t) {
+                void *j; hipMalloc(&j, (size_t)(37 + 29 * t) << 20); junk.push_back(j);
+                printf(" %.2f", run_once<0>(n, K));
+            }
+            printf("\n");
+        }
+        return 0;
+    }
     for (int l = 0; l < 3; ++l) {
         printf("layout %c:", "ABC"[l]);
         for (int t = 0; t < 14; ++t) {
