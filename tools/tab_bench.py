@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--chunk", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--tune", action="store_true", help="placement-tuned trajectory tensors")
     args = ap.parse_args()
     import torch
     from gym_amd.toy_text import TabularRollout
@@ -22,7 +23,10 @@ def main():
     for gid in args.ids.split(","):
         r = TabularRollout(gid, args.n, seed=0, action_seed=1)
         r.reset(seed=0)
-        out = r.trajectory_buffers(args.chunk)
+        if args.tune:
+            out, rep = r.tuned_trajectory_buffers(args.chunk)
+        else:
+            out, rep = r.trajectory_buffers(args.chunk), None
         for _ in range(3):
             r.rollout_per_step(args.chunk, out=out)
         r.synchronize()
@@ -35,7 +39,7 @@ def main():
         ms = e0.elapsed_time(e1) / args.reps
         us = ms * 1e3 / args.chunk
         print(json.dumps({"id": gid, "n": args.n, "chunk": args.chunk, "us_per_step": us,
-                          "env_steps_per_s": args.n / (us * 1e-6), "GBs_at_34B": 34 * args.n / (us * 1e-6) / 1e9}))
+                          "env_steps_per_s": args.n / (us * 1e-6), "GBs_at_34B": 34 * args.n / (us * 1e-6) / 1e9, "placement": rep}))
         r.close()
 
 
