@@ -12,6 +12,10 @@
 
 #include "../../include/mxv.h"
 
+#ifndef MXV_CARTPOLE_RCP
+#define MXV_CARTPOLE_RCP 1  // tuning hook: 0 = the compiler's `/` for CartPole's one runtime division
+#endif
+
 namespace mxv {
 
 struct EnvParams {
@@ -267,8 +271,13 @@ struct Env<MXV_CARTPOLE> {
         else
             sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
         const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
-        const double thetaacc = (gravity * sintheta - costheta * temp) /
-                                (length * (4.0 / 3.0 - div_par<DEF>(masspole * (costheta * costheta), total_mass)));  // :144-146
+        const double ta_num = gravity * sintheta - costheta * temp;
+        const double ta_den = length * (4.0 / 3.0 - div_par<DEF>(masspole * (costheta * costheta), total_mass));  // :144-146
+        double thetaacc;
+        if constexpr (DEF == PM_DEFAULT && !SAFE && MXV_CARTPOLE_RCP)  // ta_den in [0.62, 0.67], ta_num normal and never -0: the scale / fix-up
+            thetaacc = div_with_rcp(ta_num, ta_den, refined_rcp(ta_den));  // steps of `/` are identities (same bits, 3 slots fewer)
+        else
+            thetaacc = ta_num / ta_den;
         const double xacc = temp - div_par<DEF>(polemass_length * thetaacc * costheta, total_mass);      // :147
         if (!semi_implicit) {  // "euler" :149-153
             x = x + tau * x_dot;
