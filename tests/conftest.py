@@ -35,8 +35,15 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
-    """The oracle (oracle/classic_control.c) is test infrastructure: build it once per session."""
+    """The oracle (oracle/*.c) is test infrastructure: build it once per session.  A fresh checkout holds no built libmxv.so
+    either (build artefacts are not in the history): build it with hipcc — it cross-compiles without a GPU — so that the
+    ABI / no-fallback tests can load it."""
+    import subprocess
+
     from oracle import oracle
 
     oracle.build()
+    lib = os.path.join(ROOT, "gym_amd", "_lib", "libmxv.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["bash", os.path.join(ROOT, "gym_amd", "csrc", "build.sh")])
     yield
