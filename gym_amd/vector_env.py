@@ -373,6 +373,7 @@ class HipVectorEnv(VectorEnv):
     # -- misc ----------------------------------------------------------------------------------------
     def close_extras(self, **kwargs):
         h = getattr(self, "_handle", None)
+        self._views = None   # arrays the caller still holds keep the pinned block (and with it the handle) alive
         if h is not None:
             h.close()
 
