@@ -420,8 +420,10 @@ struct Env<MXV_ACROBOT> {
         double ddtheta2, ddtheta1;
         if constexpr (DEF == PM_DEFAULT) {  // "book" dynamics, three quotients by d1 share one reciprocal (same bits as `/`)
             const double r1 = refined_rcp(d1);
-            ddtheta2 = (a + div_with_rcp(d2, d1, r1) * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
-                       (m2 * (lc2 * lc2) + I2 - div_with_rcp(d2 * d2, d1, r1));  // :270-275
+            // the quotient by (m2 lc2^2 + I2 - d2^2/d1) in [0.57, 1.25]: same reciprocal-based sequence, no scaling / fix-up needed
+            const double den2 = m2 * (lc2 * lc2) + I2 - div_with_rcp(d2 * d2, d1, r1);
+            ddtheta2 = div_with_rcp(a + div_with_rcp(d2, d1, r1) * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2, den2,
+                                    refined_rcp(den2));  // :270-275
             ddtheta1 = div_with_rcp(-(d2 * ddtheta2 + phi1), d1, r1);              // :276
         } else {
             if (nips) {  // :266-269
