@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
     int dfirst;
     unpack(a.state[e], p, d, dfirst);
     int32_t el = a.elapsed[e];
+    mxv::settle_entry_loads();
     for (int k = 0; k < a.K; ++k) {
         const uint64_t t = a.t + (uint64_t)k;
         const int64_t o = (int64_t)k * a.slice * 3 + e;   // observation columns: o, o + slice', ...

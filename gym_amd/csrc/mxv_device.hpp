@@ -47,6 +47,29 @@ struct Par {
 
 constexpr double kPi = 3.141592653589793;
 
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt left open), placed between a kernel's entry loads and its K-step loop.  On gfx9-class
+// ISAs vmcnt counts stores as well as loads: without this the compiler parks the waits for the ENTRY loads at their first
+// use inside the loop, where from the second iteration on they wait for the acknowledgement of the stores of the previous
+// (and the current) step — the whole HBM write latency, once per wave and step.  With the loads settled at entry the loop
+// body carries no vmcnt wait at all and a wave keeps several steps of output stores in flight.
+#ifndef MXV_SETTLE_LOADS
+#define MXV_SETTLE_LOADS 1  // tuning hook: 0 = leave the waits where the compiler puts them
+#endif
+__device__ __forceinline__ void settle_entry_loads() {
+#if MXV_SETTLE_LOADS
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+}
+// The same for a load INSIDE the loop on a conditional path (per-env seeds of a reset draw): using the value in the branch
+// that loaded it keeps the compiler's vmcnt wait inside that branch instead of at the join every wave passes through.
+template <typename T>
+__device__ __forceinline__ T landed(T v) {
+#if MXV_SETTLE_LOADS
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  Counter-based: no RNG state is kept in memory.
 // ------------------------------------------------------------------------------------------

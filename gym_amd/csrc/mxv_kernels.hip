@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     __shared__ uint32_t sw[CONSEC ? 4 : TILE];
 
     const int nsteps = MULTI ? a.K : 1;  // MULTI = false: the plain step() launch, no loop-carried bookkeeping
+    if (MULTI) settle_entry_loads();
     for (int step = 0; step < nsteps; ++step) {
         const uint64_t t = t0 + (uint64_t)step;
         const int64_t so = MULTI ? (int64_t)step * a.slice : 0;      // output slice offset (envs): [K][N] trajectories or 0
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     const int64_t e = valid[j] ? env_of(j) : 0;
-                    const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
+                    const uint64_t seed = a.seeds ? landed(a.seeds[e]) : a.base_seed + a.env0 + (uint64_t)e;
                     af[j] = __uint_as_float(step_noise_word(seed, t));
                 }
             }
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                         for (int k = 0; k < O; ++k) cur[k] = obs[j][k];
                     }
                 if (a.final_obs != nullptr && v) store_obs<O>(a.final_obs, so + e, cur);  // info["final_observation"]
-                const uint64_t seed = a.seeds ? a.seeds[v ? e : 0] : a.base_seed + a.env0 + (uint64_t)e;
+                const uint64_t seed = a.seeds ? landed(a.seeds[v ? e : 0]) : a.base_seed + a.env0 + (uint64_t)e;
                 const U4 w = reset_words(seed, t, 0u);
                 double ns[S], naux[AUXN];
                 float nobs[O];
@@ -372,6 +373,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
 
+    settle_entry_loads();
     for (int step = 0; step < a.K; ++step) {
         const uint64_t t = t0 + (uint64_t)step;
 
@@ -446,7 +448,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
         auto reset_key = [&](uint32_t i) -> uint64_t {
             const uint32_t q = lds_q[i];
             const uint32_t e = (uint32_t)tile0 + q;
-            return a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
+            return a.seeds ? landed(a.seeds[e]) : a.base_seed + a.env0 + (uint64_t)e;
         };
         // wave-uniform schedule.  Ring capacity: step's own slot was consumed above, so steps (step, step + H] fit.
         const int horizon = (a.K < step + 1 + H) ? a.K : step + 1 + H;
@@ -592,7 +594,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
         el[j] = a.elapsed[le[j]];
-        seed[j] = a.seeds ? a.seeds[le[j]] : a.base_seed + a.env0 + (uint64_t)le[j];
+        seed[j] = a.seeds ? landed(a.seeds[le[j]]) : a.base_seed + a.env0 + (uint64_t)le[j];
         EV::prime(s[j], aux[j]);
     }
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
@@ -623,6 +625,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
 
+    settle_entry_loads();
     for (int step = 0; step < a.K; ++step) {
         const uint64_t t = t0 + (uint64_t)step;
 
@@ -784,7 +787,7 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= a.n) return;
     if (a.mask != nullptr && a.mask[e] == 0) return;
-    const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
+    const uint64_t seed = a.seeds ? landed(a.seeds[e]) : a.base_seed + a.env0 + (uint64_t)e;
     const U4 w = reset_words(seed, a.t, a.r);
     double s[S];
     EV::reset(w, a.b0, a.b1, s);

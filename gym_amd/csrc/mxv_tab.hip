@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
     uint64_t act_block = ~0ull, tr_block = ~0ull;
     uint32_t act_word[4] = {0, 0, 0, 0};
     U4 tw{0, 0, 0, 0};
+    mxv::settle_entry_loads();
     for (int k = 0; k < a.K; ++k) {
         const uint64_t t = a.t + (uint64_t)k;
         const int64_t o = (int64_t)k * a.slice + e;
