@@ -11,6 +11,7 @@ __version__ = "0.1.0"
 _LAZY = {
     "HipVectorEnv": ("gym_amd.vector_env", "HipVectorEnv"),
     "VectorEnv": ("gym_amd.vector_env", "VectorEnv"),
+    "VectorEnvWrapper": ("gym_amd.vector_env", "VectorEnvWrapper"),
     "make": ("gym_amd.vector_env", "make"),
     "DeviceRollout": ("gym_amd.rollout", "DeviceRollout"),
     "ShardedRollout": ("gym_amd.distributed", "ShardedRollout"),

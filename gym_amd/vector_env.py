@@ -128,11 +128,67 @@ class VectorEnv:
         if not getattr(self, "closed", True):
             self.close()
 
+    @property
+    def unwrapped(self):
+        """gym.Env.unwrapped (gym/core.py:186-192): a vector env is its own base env."""
+        return self
+
     def __repr__(self) -> str:
         spec_ = getattr(self, "spec", None)
         if spec_ is None:
             return f"{self.__class__.__name__}({self.num_envs})"
         return f"{self.__class__.__name__}({spec_.id}, {self.num_envs})"
+
+
+class VectorEnvWrapper(VectorEnv):
+    """gym.vector.VectorEnvWrapper (gym/vector/vector_env.py:277-337): base class of user wrappers around a vector env.
+    The VectorEnv methods are forwarded explicitly, every other public attribute implicitly; a subclass overrides
+    `step_wait` / `reset_wait` (as the reference's own test wrappers do) and `step()` / `reset()` pick that up."""
+
+    def __init__(self, env: VectorEnv):
+        assert isinstance(env, VectorEnv)
+        self.env = env
+
+    def reset_async(self, **kwargs):
+        return self.env.reset_async(**kwargs)
+
+    def reset_wait(self, **kwargs):
+        return self.env.reset_wait(**kwargs)
+
+    def step_async(self, actions):
+        return self.env.step_async(actions)
+
+    def step_wait(self):
+        return self.env.step_wait()
+
+    def close(self, **kwargs):
+        return self.env.close(**kwargs)
+
+    def close_extras(self, **kwargs):
+        return self.env.close_extras(**kwargs)
+
+    def call(self, name, *args, **kwargs):
+        return self.env.call(name, *args, **kwargs)
+
+    def set_attr(self, name, values):
+        return self.env.set_attr(name, values)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(f"attempted to get missing private attribute '{name}'")
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    def __repr__(self):
+        return f"<{self.__class__.__name__}, {self.env}>"
+
+    def __del__(self):
+        env = self.__dict__.get("env")
+        if env is not None:
+            env.__del__()
 
 
 class HipVectorEnv(VectorEnv):

@@ -77,6 +77,43 @@ def test_call_get_attr_set_attr_gravity():
     env.close()
 
 
+def test_vector_env_wrapper_like_the_reference_tests():
+    """tests/vector/test_vector_env_wrapper.py:7-36 with gym_amd's VectorEnvWrapper around the engine's envs."""
+    import gym_amd
+
+    class DummyWrapper(gym_amd.VectorEnvWrapper):
+        def __init__(self, env):
+            self.env = env
+            self.counter = 0
+
+        def reset_async(self, **kwargs):
+            super().reset_async()
+            self.counter += 1
+
+    wrapped = DummyWrapper(gym_amd.make("FrozenLake-v1", asynchronous=False))
+    wrapped.reset()
+    assert wrapped.counter == 1
+    wrapped.close()
+
+    env = _make("CartPole-v1", 3)
+    wrapped = DummyWrapper(_make("CartPole-v1", 3))
+    assert np.allclose(wrapped.call("gravity"), env.call("gravity"))
+    env.set_attr("gravity", [20.0, 20.0, 20.0])
+    wrapped.set_attr("gravity", [20.0, 20.0, 20.0])
+    assert np.allclose(wrapped.get_attr("gravity"), env.get_attr("gravity"))
+    # a wrapped env steps exactly like the bare one
+    o0, _ = env.reset(seed=3)
+    o1, _ = wrapped.reset(seed=3)
+    assert wrapped.counter == 1 and np.array_equal(o0, o1)
+    a = np.array([1, 0, 1])
+    for x, y in zip(env.step(a)[:4], wrapped.step(a)[:4]):
+        assert np.array_equal(x, y)
+    assert wrapped.unwrapped is wrapped.env and wrapped.num_envs == 3
+    env.close()
+    wrapped.close()
+    assert wrapped.env.closed
+
+
 @pytest.mark.parametrize("name", ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous"])
 def test_adapter_rollout_matches_oracle_with_final_observation(name):
     """Every value HipVectorEnv returns over a rollout with many episode ends (short TimeLimit), against the oracle

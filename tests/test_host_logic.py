@@ -124,6 +124,61 @@ def test_vector_env_base_surface():
     assert v.closed
 
 
+def test_vector_env_wrapper_forwards_like_the_reference():
+    """gym.vector.VectorEnvWrapper (vector_env.py:277-337): explicit forwarding of the VectorEnv methods, implicit of
+    public attributes, private ones refused; a subclass hooks reset_async like tests/vector/test_vector_env_wrapper.py."""
+    from gym_amd.vector_env import VectorEnv, VectorEnvWrapper
+
+    calls = []
+
+    class Fake(VectorEnv):
+        gravity = 9.8
+
+        def reset_async(self, seed=None, options=None):
+            calls.append(("reset_async", seed))
+
+        def reset_wait(self, seed=None, options=None):
+            return "obs", {}
+
+        def step_async(self, actions):
+            calls.append(("step_async", actions))
+
+        def step_wait(self):
+            return "step"
+
+        def call(self, name, *a, **k):
+            return (getattr(self, name),) * self.num_envs
+
+        def set_attr(self, name, values):
+            setattr(self, name, values)
+
+    class Counting(VectorEnvWrapper):
+        def __init__(self, env):
+            self.env = env
+            self.counter = 0
+
+        def reset_async(self, **kwargs):
+            super().reset_async(**kwargs)
+            self.counter += 1
+
+    obs, act = single_spaces(spec("CartPole-v1").kind)
+    base = Fake(3, obs, act)
+    w = Counting(base)
+    assert w.reset(seed=7) == ("obs", {}) and w.counter == 1 and calls[-1] == ("reset_async", 7)
+    assert w.step([0, 1, 0]) == "step" and calls[-1] == ("step_async", [0, 1, 0])
+    assert w.num_envs == 3 and w.single_action_space is act and w.unwrapped is base
+    assert w.call("gravity") == (9.8, 9.8, 9.8) and w.get_attr("gravity") == (9.8, 9.8, 9.8)
+    w.set_attr("gravity", 20.0)
+    assert base.gravity == 20.0
+    with pytest.raises(AttributeError):
+        w._private
+    assert repr(w).startswith("<Counting, ")
+    with pytest.raises(AssertionError):
+        VectorEnvWrapper(object())
+    w.close()
+    assert base.closed
+
+
 def test_plugin_registers_with_the_live_reference_registry():
     """gym.register / import hook route gym.make to the engine's entry point."""
     gym = _ref_gym()
