@@ -510,11 +510,14 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
             hipError_t le = hipSuccess;
             for (int k = 0; k < K && le == hipSuccess; ++k) le = launch_k(k, h->t_dev, (uint64_t)k);
             hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-            if (le != hipSuccess) return fail(h, MXV_ERR_HIP, "graph capture launch: %s", hipGetErrorString(le));
-            MXV_HIP(h, ce);
+            if (le != hipSuccess || ce != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return fail(h, MXV_ERR_HIP, "graph capture: %s", hipGetErrorString(le != hipSuccess ? le : ce));
+            }
             hipGraphExec_t exec = nullptr;
-            MXV_HIP(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            MXV_HIP(h, hipGraphDestroy(graph));
+            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            MXV_HIP(h, ie);
             it = h->graphs.emplace(key, exec).first;
         }
         MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));

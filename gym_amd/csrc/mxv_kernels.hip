@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned n
 }
 
 // Word `idx` (0..3, runtime) of a Philox result.
-__device__ __forceinline__ uint32_t pick_word(const U4 &w, uint32_t idx) {
+[[maybe_unused]] __device__ __forceinline__ uint32_t pick_word(const U4 &w, uint32_t idx) {
     return idx == 0 ? w.x : (idx == 1 ? w.y : (idx == 2 ? w.z : w.w));
 }
 
