@@ -9,8 +9,8 @@ Three ways in, none of which touches the reference tree:
                    (pyproject.toml) and gym loads it at import (registration.py:266-309, gym/envs/__init__.py:5)
 
 The registered ids are `hip/<reference id>` for every id of gym_amd.registration.registry (classic control) and of
-gym_amd.toy_text.TOY_TEXT_REGISTRY (FrozenLake / Taxi / CliffWalking).  Their entry point returns a HipVectorEnv /
-HipTabularVectorEnv — a *vector* env — so the specs switch off everything gym.make would wrap around a single env:
+gym_amd.toy_text.TOY_TEXT_REGISTRY (FrozenLake / Taxi / CliffWalking) plus Blackjack-v1.  Their entry point returns a HipVectorEnv /
+HipTabularVectorEnv / HipBlackjackVectorEnv — a *vector* env — so the specs switch off everything gym.make would wrap around a single env:
 `order_enforce=False`, `disable_env_checker=True`, `max_episode_steps=None` (TimeLimit lives inside the kernels; pass
 `time_limit=` to change it, not gym.make's own `max_episode_steps=` which would add the single-env wrapper).
 """
@@ -37,10 +37,12 @@ def register_envs(gym_module=None) -> list:
     from .toy_text import TOY_TEXT_REGISTRY
 
     done = []
-    for env_id, spec in list(registry.items()) + list(TOY_TEXT_REGISTRY.items()):
+    thresholds = [(env_id, spec.reward_threshold) for env_id, spec in list(registry.items()) + list(TOY_TEXT_REGISTRY.items())]
+    thresholds.append(("Blackjack-v1", None))  # gym/envs/__init__.py:95-99
+    for env_id, reward_threshold in thresholds:
         full = f"{NAMESPACE}/{env_id}"
         if full not in gym_module.envs.registry:
-            gym_module.register(id=full, entry_point="gym_amd.plugin:make_vector", reward_threshold=spec.reward_threshold,
+            gym_module.register(id=full, entry_point="gym_amd.plugin:make_vector", reward_threshold=reward_threshold,
                                 max_episode_steps=None, order_enforce=False, disable_env_checker=True,
                                 kwargs={"id": env_id})
         done.append(full)

@@ -186,7 +186,7 @@ def test_plugin_registers_with_the_live_reference_registry():
     import gym_amd.plugin as plugin
 
     ids = plugin.register_envs(gym)
-    assert "hip/CartPole-v1" in ids and "hip/Taxi-v3" in ids and len(ids) == len(registry) + 4
+    assert "hip/CartPole-v1" in ids and "hip/Taxi-v3" in ids and "hip/Blackjack-v1" in ids and len(ids) == len(registry) + 5
     s = gym.spec("hip/Pendulum-v1")
     assert s.max_episode_steps is None and s.order_enforce is False and s.disable_env_checker is True
     assert s.kwargs == {"id": "Pendulum-v1"} and s.namespace == "hip"
