@@ -298,10 +298,15 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kWave = 64;
 
-template <int S, int O, int AUXN>
+template <int S, int O, int AUX>
 struct alignas(16) ResetEntry {
     double s[S];
-    double x[AUXN];  // Env::AUX values (sized 1 when the env has none; never read then)
+    double x[AUX];  // Env::AUX values carried across steps
+    float o[O];
+};
+template <int S, int O>
+struct alignas(16) ResetEntry<S, O, 0> {  // no carried values: CartPole's entry is 48 B, 7.5 KiB of LDS per workgroup
+    double s[S];
     float o[O];
 };
 
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
     constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
     static_assert(NACT < kWave, "E must be < 4: the merged call needs free lanes");
     constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
-    using Entry = ResetEntry<S, O, AUXN>;
+    using Entry = ResetEntry<S, O, EV::AUX>;
     __shared__ uint32_t lds_act[H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
     __shared__ uint32_t lds_q[TILE];      // compacted list of finished envs (tile-local index)
     __shared__ Entry lds_res[TILE];       // their new state + observation
@@ -442,7 +447,12 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
         auto draw_reset = [&](uint32_t i, const U4 &w) {
             Entry r;
             EV::reset(w, a.b0, a.b1, r.s);
-            EV::observe(r.s, r.o, r.x);
+            if constexpr (EV::AUX > 0) {
+                EV::observe(r.s, r.o, r.x);
+            } else {
+                double none[1];
+                EV::observe(r.s, r.o, none);
+            }
             lds_res[i] = r;
         };
         auto reset_key = [&](uint32_t i) -> uint64_t {
@@ -501,8 +511,10 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
                 const Entry r = lds_res[slot[j]];
 #pragma unroll
                 for (int k = 0; k < S; ++k) s[j][k] = r.s[k];
+                if constexpr (EV::AUX > 0) {
 #pragma unroll
-                for (int k = 0; k < EV::AUX; ++k) aux[j][k] = r.x[k];
+                    for (int k = 0; k < EV::AUX; ++k) aux[j][k] = r.x[k];
+                }
 #pragma unroll
                 for (int k = 0; k < O; ++k) obs[j][k] = r.o[k];
                 el[j] = 0;  // time_limit.py:67
