@@ -80,6 +80,14 @@ def main():
         sps, us = compat_loop("CartPole-v1", n, steps)
         out.append({"config": cfg, "env": "CartPole-v1", "num_envs": n, "mode": "HipVectorEnv.step (NumPy in/out, PCIe + "
                     "Python inclusive)", "us_per_step": round(us, 1), "env_steps_per_s": float(f"{sps:.4g}")})
+    # the same PCIe + Python inclusive loop for the other configs' env kinds at their per-GPU sizes (number iii)
+    for cfg, env_id, n in (("config3", "Pendulum-v1", 1 << 19), ("config3", "MountainCarContinuous-v0", 1 << 19),
+                           ("config4 (per-GPU shard of 2^22)", "Acrobot-v1", 1 << 19)):
+        for label, kw in (("copies", {}), ("zero_copy=True", dict(zero_copy=True))):
+            sps, us = compat_loop(env_id, n, 30, **kw)
+            out.append({"config": f"gym-compatible loop, {cfg}, {label}", "env": env_id, "num_envs": n,
+                        "mode": "HipVectorEnv.step (NumPy in/out, PCIe + Python inclusive)", "us_per_step": round(us, 1),
+                        "env_steps_per_s": float(f"{sps:.4g}")})
     for label, kw in (("copy=False", dict(copy=False)), ("zero_copy=True", dict(zero_copy=True))):
         for n, steps in ((8, 1000), (1 << 20, 30)):
             sps, us = compat_loop("CartPole-v1", n, steps, **kw)
