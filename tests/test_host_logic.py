@@ -179,6 +179,15 @@ def test_vector_env_wrapper_forwards_like_the_reference():
     assert base.closed
 
 
+def test_make_refuses_per_sub_env_wrappers_loudly():
+    """gym.vector.make(wrappers=...) wraps every Python sub-env (gym/vector/__init__.py:53-64); the engine has none and must
+    not silently drop them."""
+    import gym_amd
+
+    with pytest.raises(NotImplementedError):
+        gym_amd.make("CartPole-v1", num_envs=4, wrappers=[lambda e: e])
+
+
 def test_plugin_registers_with_the_live_reference_registry():
     """gym.register / import hook route gym.make to the engine's entry point."""
     gym = _ref_gym()
