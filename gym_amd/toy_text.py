@@ -273,7 +273,8 @@ class HipTabularVectorEnv(VectorEnv):
     def __init__(self, id: str, num_envs: int = 1, *, device: int = 0, max_episode_steps: Optional[int] = None,
                  env_offset: int = 0, **kwargs):
         self.spec = _spec(id)
-        kwargs.pop("render_mode", None)
+        if kwargs.pop("render_mode", None) is not None:
+            raise TypeError(f"{id}: the device engine does not render (render_mode must be None)")
         for k in kwargs:
             if k not in self.spec.kwargs:
                 raise TypeError(f"{id} got an unexpected keyword argument {k!r}")
@@ -523,7 +524,8 @@ class HipBlackjackVectorEnv(VectorEnv):
                  max_episode_steps: Optional[int] = None, env_offset: int = 0, **kwargs):
         from .spaces import Tuple
 
-        kwargs.pop("render_mode", None)
+        if kwargs.pop("render_mode", None) is not None:
+            raise TypeError(f"{id}: the device engine does not render (render_mode must be None)")
         if kwargs:
             raise TypeError(f"{id} got an unexpected keyword argument {next(iter(kwargs))!r}")
         self.spec = ToyTextSpec(id, None, None)
