@@ -24,7 +24,7 @@ from .spaces import Discrete
 from .vector_env import LazyInfos, VectorEnv, _Pending
 
 __all__ = ["TabularMDP", "generate_random_map", "frozen_lake_mdp", "taxi_mdp", "cliff_walking_mdp", "HipTabularVectorEnv", "TabularRollout",
-           "HipBlackjackVectorEnv", "TOY_TEXT_REGISTRY"]
+           "HipBlackjackVectorEnv", "TOY_TEXT_REGISTRY", "taxi_encode", "taxi_decode"]
 
 
 @dataclass
@@ -157,6 +157,24 @@ _TAXI_EAST_WALLS = {(0, 1), (1, 1), (3, 0), (3, 2), (4, 0), (4, 2)}
 
 def _taxi_encode(row, col, pass_loc, dest):
     return ((row * 5 + col) * 5 + pass_loc) * 4 + dest   # taxi.py:208-217
+
+
+def taxi_encode(taxi_row, taxi_col, pass_loc, dest_idx) -> int:
+    """TaxiEnv.encode (taxi.py:208-219)."""
+    return _taxi_encode(taxi_row, taxi_col, pass_loc, dest_idx)
+
+
+def taxi_decode(i: int):
+    """TaxiEnv.decode (taxi.py:221-231): (taxi_row, taxi_col, pass_loc, dest_idx); like the reference, an iterator."""
+    out = [i % 4]
+    i //= 4
+    out.append(i % 5)
+    i //= 5
+    out.append(i % 5)
+    i //= 5
+    out.append(i)
+    assert 0 <= i < 5
+    return reversed(out)
 
 
 def taxi_mdp() -> TabularMDP:
@@ -389,6 +407,13 @@ class HipTabularVectorEnv(VectorEnv):
             return (P,) * self.num_envs
         if name == "initial_state_distrib":
             return (self.mdp.initial_distrib.copy(),) * self.num_envs
+        if self.spec.id == "Taxi-v3" and name in ("encode", "decode", "action_mask"):  # TaxiEnv's pure helpers (taxi.py:208-252)
+            if name == "encode":
+                return (taxi_encode(*args, **kwargs),) * self.num_envs
+            if name == "decode":
+                return tuple(taxi_decode(*args, **kwargs) for _ in range(self.num_envs))
+            (state,) = args or (kwargs["state"],)
+            return tuple(self.mdp.action_mask[int(state)].copy() for _ in range(self.num_envs))
         raise AttributeError(f"{self.spec.id} sub-environments have no attribute {name!r}")
 
     def close_extras(self, **kwargs):

@@ -155,6 +155,23 @@ def test_hip_tabular_vector_env_contract():
     det.close()
 
 
+def test_taxi_helpers_through_call():
+    """TaxiEnv.encode / decode / action_mask (taxi.py:208-252) answered through VectorEnv.call like any sub-env method."""
+    import gym_amd
+
+    env = gym_amd.make("Taxi-v3", num_envs=3)
+    obs, info = env.reset(seed=4)
+    for s in obs.tolist():
+        parts = [list(d) for d in env.call("decode", s)]
+        assert parts[0] == parts[1] == parts[2] and env.call("encode", *parts[0]) == (s,) * 3
+        masks = env.call("action_mask", s)
+        assert len(masks) == 3 and masks[0].dtype == np.int8 and masks[0].shape == (6,)
+    assert all(np.array_equal(info["action_mask"][i], env.call("action_mask", int(obs[i]))[0]) for i in range(3))
+    with pytest.raises(AttributeError):
+        env.call("no_such_method")
+    env.close()
+
+
 def test_full_size_properties():
     """2^20 FrozenLake8x8 envs, 64-step fused rollouts."""
     import torch

@@ -2,6 +2,8 @@
 own `env.P` tables dumped into the goldens; (2) the oracle (oracle/tabular.c) replaying the reference's SyncVectorEnv
 trajectories with the reference's recorded uniforms: BIT-EXACT observations, rewards, flags, infos; (3) the Philox
 contract's shard invariance on the oracle."""
+import sys
+
 import numpy as np
 import pytest
 
@@ -90,6 +92,27 @@ def test_taxi_action_mask_restates_reference_test():
         for action, possible in enumerate(mdp.action_mask[state]):
             _, next_state, _, _ = mdp.transitions(state, action)[0]
             assert (state != next_state) if possible else (state == next_state)
+
+
+def test_taxi_encode_decode_restates_reference_test():
+    """tests/envs/test_env_implementation.py:139-148 (encode(decode(s)) == s), here over all 500 states, and against the live
+    reference's TaxiEnv when it is importable."""
+    from gym_amd.toy_text import taxi_decode, taxi_encode
+
+    for state in range(500):
+        assert taxi_encode(*taxi_decode(state)) == state
+    try:
+        sys.path.insert(0, "/root/reference")
+        from gym.envs.toy_text.taxi import TaxiEnv
+    except Exception:
+        return
+    finally:
+        if sys.path and sys.path[0] == "/root/reference":
+            sys.path.pop(0)
+    env = TaxiEnv()
+    for state in range(0, 500, 7):
+        assert list(env.decode(state)) == list(taxi_decode(state))
+        assert env.encode(*env.decode(state)) == taxi_encode(*taxi_decode(state))
 
 
 @pytest.mark.parametrize("map_size", [5, 10, 16])
