@@ -34,7 +34,7 @@ EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
-    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -135,6 +135,7 @@ def _load():
         "mxv_episode_stats": ([vp, i32], C.c_int),
         "mxv_set_episode_outputs": ([vp, vp, vp], C.c_int),
         "mxv_episode_stats_host": ([vp, vp, vp, vp], C.c_int),
+        "mxv_set_running_returns": ([vp, vp], C.c_int),
         "mxv_sync": ([vp], C.c_int),
         "mxv_get_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_set_stream": ([vp, vp], C.c_int),
@@ -260,6 +261,11 @@ class Handle:
         if rc != OK:
             raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
         self._h = h
+        self.max_episode_steps = int(max_episode_steps)
+        self._base_seed, self._per_env_seeds = int(seed) & (2**64 - 1), None
+        self._action_seed = int(action_seed) & (2**64 - 1)
+        self._stats_on = False
+        self._per_env_params = False
 
     # -- plumbing -------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -299,9 +305,12 @@ class Handle:
             assert per_env_seeds.shape == (self.num_envs,)
             p = per_env_seeds.ctypes.data
         self._check(lib.mxv_seed(self._h, int(base_seed) & (2**64 - 1), p))
+        self._base_seed = int(base_seed) & (2**64 - 1)
+        self._per_env_seeds = None if per_env_seeds is None else per_env_seeds.copy()
 
     def seed_actions(self, action_seed: int):
         self._check(lib.mxv_seed_actions(self._h, int(action_seed) & (2**64 - 1)))
+        self._action_seed = int(action_seed) & (2**64 - 1)
 
     @staticmethod
     def _bounds(bounds):
@@ -416,6 +425,7 @@ class Handle:
         p = np.ascontiguousarray(params, dtype=np.float64)
         assert p.shape == (MAX_PARAMS,)
         self._check(lib.mxv_set_params(self._h, p.ctypes.data))
+        self._per_env_params = False
 
     def get_params_per_env(self) -> np.ndarray:
         """[MAX_PARAMS, N] attribute-major table (broadcast values are expanded)."""
@@ -427,9 +437,48 @@ class Handle:
         p = np.ascontiguousarray(table, dtype=np.float64)
         assert p.shape == (MAX_PARAMS, self.num_envs), p.shape
         self._check(lib.mxv_set_params_per_env(self._h, p.ctypes.data))
+        self._per_env_params = True
 
     def episode_stats(self, enable: bool = True):
         self._check(lib.mxv_episode_stats(self._h, 1 if enable else 0))
+        self._stats_on = bool(enable)
+
+    def set_running_returns(self, running):
+        r = np.ascontiguousarray(running, dtype=np.float32)
+        assert r.shape == (self.num_envs,)
+        self._check(lib.mxv_set_running_returns(self._h, r.ctypes.data))
+
+    # -- checkpoint -----------------------------------------------------------------------
+    def snapshot(self) -> dict:
+        """Everything a fresh handle needs to continue this one bit-identically (plain NumPy / ints: picklable): env state,
+        TimeLimit counters, RNG seeds and counters, physics parameters, running episode returns."""
+        state, elapsed = self.get_state()
+        t, r = self.get_counters()
+        snap = dict(env_id=self.env_id, num_envs=self.num_envs, max_episode_steps=self.max_episode_steps,
+                    env_offset=self.env_offset, flags=self.flags, base_seed=self._base_seed,
+                    per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
+                    action_seed=self._action_seed, state=state, elapsed=elapsed, t=t, r=r,
+                    params=self.get_params_per_env() if self._per_env_params else self.get_params(),
+                    per_env_params=self._per_env_params, stats_on=self._stats_on, running_returns=None)
+        if self._stats_on:
+            snap["running_returns"] = self.episode_stats_host(want_running=True)[2]
+        return snap
+
+    def restore(self, snap: dict):
+        for k in ("env_id", "num_envs", "env_offset", "flags", "max_episode_steps"):
+            if snap[k] != getattr(self, k):
+                raise ValueError(f"snapshot {k}={snap[k]!r} does not fit this handle ({getattr(self, k)!r})")
+        self.seed(snap["base_seed"], snap["per_env_seeds"])   # resets the counters; set below
+        self.seed_actions(snap["action_seed"])
+        if snap["per_env_params"]:
+            self.set_params_per_env(snap["params"])
+        else:
+            self.set_params(snap["params"])
+        self.episode_stats(bool(snap["stats_on"]))
+        if snap["stats_on"]:
+            self.set_running_returns(snap["running_returns"])
+        self.set_state(snap["state"], snap["elapsed"])
+        self.set_counters(snap["t"], snap["r"])
 
     def set_episode_outputs(self, ep_return_dev=None, ep_length_dev=None):
         self._check(lib.mxv_set_episode_outputs(self._h, _ptr(ep_return_dev), _ptr(ep_length_dev)))

@@ -859,6 +859,17 @@ int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_len
     return MXV_OK;
 }
 
+int mxv_set_running_returns(mxv_handle *h, const float *running_return_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->ep_acc) return fail(h, MXV_ERR_INVALID_ARG, "episode statistics are not enabled (mxv_episode_stats)");
+    if (!running_return_host) return fail(h, MXV_ERR_INVALID_ARG, "running_return pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipMemcpyAsync(h->ep_acc, running_return_host, (size_t)h->cfg.num_envs * sizeof(float), hipMemcpyHostToDevice,
+                              h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
 int mxv_sync(mxv_handle *h) {
     MXV_CHECK_HANDLE(h);
     if (int rc = use_device(h)) return rc;

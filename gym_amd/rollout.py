@@ -124,7 +124,7 @@ class DeviceRollout:
             if want_final:
                 extra["final_obs"] = torch.zeros((K, n, self.O), dtype=torch.float32, device=dev)
             if getattr(self, "episode_stats", False):
-                extra = dict(ep_return=torch.zeros((K, n), dtype=torch.float32, device=dev),
+                extra.update(ep_return=torch.zeros((K, n), dtype=torch.float32, device=dev),
                              ep_length=torch.zeros((K, n), dtype=torch.int32, device=dev))
             return dict(**extra, obs=torch.empty((K, n, self.O), dtype=torch.float32, device=dev),
                         reward=torch.empty((K, n), dtype=self.reward_dtype, device=dev),
@@ -141,12 +141,13 @@ class DeviceRollout:
         (profiles/r01h_placement_probe.txt).  This allocates `candidates` sets side by side, times `launches` fused
         launches on each after a warm-up, then `mixes` (default 2 x candidates) random recombinations of their tensors —
         new combinations at no extra memory — keeps the fastest combination and frees every tensor it does not use.  The env
-        state, TimeLimit counters and RNG counters are restored afterwards, so tuning does not change any result (call it
-        before enable_episode_stats(): running episode returns are not part of that snapshot).  Returns (buffers, report)."""
+        state, TimeLimit counters, RNG counters and running episode returns are restored afterwards, so tuning does not change
+        any result.  Returns (buffers, report)."""
         import random
 
         st, el = self.handle.get_state()
         t, r = self.handle.get_counters()
+        running = self.handle.episode_stats_host(want_running=True)[2] if self.handle._stats_on else None
         per_step = self.num_envs * (4 * self.O * (2 if want_final else 1) + self.reward.element_size()
                                     + self.actions.element_size() + 2)
         free, _ = torch.cuda.mem_get_info(self.device)
@@ -192,9 +193,25 @@ class DeviceRollout:
         del sets, traj
         self.handle.set_state(st, el)
         self.handle.set_counters(t, r)
+        if running is not None:
+            self.handle.set_running_returns(running)
         torch.cuda.empty_cache()
         return best, {"candidates": len(times), "us_per_step": [round(x, 3) for x in times],
                       "mixes_us_per_step": [round(x, 3) for x in mix_times], "chosen_us_per_step": round(best_us, 3)}
+
+    # -- checkpoint / resume -------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Snapshot (NumPy arrays and ints, picklable) from which load_state_dict() continues bit-identically: env state,
+        TimeLimit counters, RNG seeds + counters, physics parameters, running episode returns.  Output tensors are not part
+        of it (they are rewritten by the next call)."""
+        self.stream.synchronize()
+        return self.handle.snapshot()
+
+    def load_state_dict(self, snap: dict):
+        self.stream.synchronize()
+        if snap["stats_on"] and not getattr(self, "episode_stats", False):
+            self.enable_episode_stats()
+        self.handle.restore(snap)
 
     def rollout_per_step(self, K: int, *, mode: str = "fused", out: Optional[dict] = None, record_actions: bool = True):
         """K sampled steps, every step's outputs kept in [K, N, ...] trajectory tensors (returned as a dict)."""

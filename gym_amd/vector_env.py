@@ -442,6 +442,24 @@ class HipVectorEnv(VectorEnv):
         """gym.Env surface used by gym.make (`env.unwrapped.spec = ...`, gym/envs/registration.py:656)."""
         return self
 
+    # -- pickling: how the reference's envs are checkpointed (tests/envs/test_envs.py:118-135) ----------------------
+    def __getstate__(self):
+        self._assert_is_running()
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_handle", "_views")}
+        d["_snapshot"] = self._handle.snapshot()
+        d["_device"] = self._handle.device
+        return d
+
+    def __setstate__(self, d):
+        d = dict(d)
+        snap, device = d.pop("_snapshot"), d.pop("_device")
+        self.__dict__.update(d)
+        self._views = None
+        self._handle = _native.Handle(snap["env_id"], snap["num_envs"], snap["max_episode_steps"], device=device,
+                                      env_offset=snap["env_offset"], seed=snap["base_seed"], action_seed=snap["action_seed"],
+                                      flags=snap["flags"])
+        self._handle.restore(snap)
+
     # -- escape hatch for device-resident use ----------------------------------------------------------
     @property
     def handle(self) -> "_native.Handle":

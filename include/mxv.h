@@ -212,6 +212,10 @@ int mxv_set_episode_outputs(mxv_handle *h, float *ep_return_dev, int32_t *ep_len
 /* Host view after mxv_step_host: returns / lengths of the episodes that ended in that step (valid where its
  * terminated | truncated is set) and the running returns of all envs (episode_returns).  Any pointer may be NULL. */
 int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host);
+/* Checkpoint restore of the running returns read with mxv_episode_stats_host(running_return_host): float32[N].  Together
+ * with mxv_set_state / mxv_set_counters / mxv_seed* / mxv_set_params* this rebuilds a handle that continues bit-identically
+ * (the reference's envs are restored by pickling: tests/envs/test_envs.py:118-135). */
+int mxv_set_running_returns(mxv_handle *h, const float *running_return_host);
 
 /* -- running normalisation: gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-145), SURVEY.md
  *    §8f-2.  One mxv_norm = one RunningMeanStd (normalize.py:8-29: fp64 mean[dim], var[dim], count = 1e-4 at creation)

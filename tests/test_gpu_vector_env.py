@@ -77,6 +77,73 @@ def test_call_get_attr_set_attr_gravity():
     env.close()
 
 
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1", "Acrobot-v1"])
+def test_pickle_round_trip_continues_identically(env_id):
+    """tests/envs/test_envs.py:118-135 (test_pickle_env) for the vector env: the unpickled copy resets and steps like the
+    original — here for 60 steps across autoresets, bit for bit, with a short TimeLimit so episodes end."""
+    import pickle
+
+    env = _make(env_id, 6, max_episode_steps=7)
+    env.reset(seed=11)
+    env.action_space.seed(5)
+    if env_id == "CartPole-v1":
+        env.set_attr("gravity", [9.8, 9.7, 9.6, 9.5, 9.4, 9.3])  # per-env attributes travel too
+    for _ in range(9):
+        env.step(env.action_space.sample())
+    twin = pickle.loads(pickle.dumps(env))
+    assert twin.get_attr("gravity" if env_id == "CartPole-v1" else ("g" if env_id == "Pendulum-v1" else "LINK_MASS_1")) == \
+        env.get_attr("gravity" if env_id == "CartPole-v1" else ("g" if env_id == "Pendulum-v1" else "LINK_MASS_1"))
+    for step in range(60):
+        if step == 20:   # an unseeded reset continues the same streams in both
+            o0, _ = env.reset()
+            o1, _ = twin.reset()
+            assert np.array_equal(o0, o1)
+        a = env.action_space.sample()
+        assert np.array_equal(a, twin.action_space.sample())   # the spaces' generators were pickled with the env
+        r0, r1 = env.step(a), twin.step(a)
+        for x, y in zip(r0[:4], r1[:4]):
+            assert np.array_equal(x, y)
+        assert set(r0[4].keys()) == set(r1[4].keys())
+        if "final_observation" in r0[4]:
+            for u, v in zip(r0[4]["final_observation"], r1[4]["final_observation"]):
+                assert (u is None and v is None) or np.array_equal(u, v)
+    env.close()
+    twin.close()
+
+
+def test_device_rollout_state_dict_resumes_bit_identically():
+    """Checkpoint / resume of the device-resident API incl. the fused episode statistics' running returns."""
+    import pickle
+
+    import torch
+
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout("CartPole-v1", 3000, seed=3, action_seed=4)
+    r.enable_episode_stats()
+    r.reset(seed=3)
+    r.rollout_per_step(40)
+    snap = pickle.loads(pickle.dumps(r.state_dict()))
+    a = {k: v.clone() for k, v in r.rollout_per_step(64).items()}
+    r.synchronize()
+    fresh = DeviceRollout("CartPole-v1", 3000, seed=99, action_seed=98)
+    fresh.load_state_dict(snap)
+    b = fresh.rollout_per_step(64)
+    fresh.synchronize()
+    assert set(a) == set(b)
+    done = (a["terminated"] | a["truncated"]).bool()
+    for k in a:
+        if k in ("ep_return", "ep_length"):   # written only where an episode ended
+            assert torch.equal(a[k][done], b[k][done]), k
+        else:
+            assert torch.equal(a[k], b[k]), k
+    assert done.any() and "ep_return" in a
+    with pytest.raises(ValueError):
+        DeviceRollout("CartPole-v1", 2999).load_state_dict(snap)
+    r.close()
+    fresh.close()
+
+
 def test_vector_env_wrapper_like_the_reference_tests():
     """tests/vector/test_vector_env_wrapper.py:7-36 with gym_amd's VectorEnvWrapper around the engine's envs."""
     import gym_amd
