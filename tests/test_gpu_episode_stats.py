@@ -70,6 +70,34 @@ def test_fused_rollout_statistics_equal_single_steps_and_oracle_twin(name):
     assert episodes >= n * (2 * K // limit)
 
 
+def test_final_obs_and_statistics_recorded_together():
+    """Trajectory tensors with final_obs AND the fused statistics in one launch: both equal what separate runs record."""
+    import torch
+
+    from gym_amd.rollout import DeviceRollout
+
+    K, n = 48, 2500
+    runs = {}
+    for tag, stats, final in (("both", True, True), ("stats", True, False), ("final", False, True)):
+        r = DeviceRollout("CartPole-v1", n, seed=8, action_seed=9)
+        if stats:
+            r.enable_episode_stats()
+        r.reset(seed=8)
+        out = r.trajectory_buffers(K, want_final=final)
+        assert ("final_obs" in out) == final and ("ep_return" in out) == stats
+        r.rollout_per_step(K, out=out)
+        r.synchronize()
+        runs[tag] = {k: v.clone() for k, v in out.items()}
+        r.close()
+    both, done = runs["both"], (runs["both"]["terminated"] | runs["both"]["truncated"]).bool()
+    assert done.any()
+    for k in ("obs", "reward", "terminated", "truncated", "actions"):
+        assert torch.equal(both[k], runs["stats"][k]) and torch.equal(both[k], runs["final"][k]), k
+    assert torch.equal(both["final_obs"][done], runs["final"]["final_obs"][done])
+    assert torch.equal(both["ep_return"][done], runs["stats"]["ep_return"][done])
+    assert torch.equal(both["ep_length"][done], runs["stats"]["ep_length"][done])
+
+
 @pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1"])
 @pytest.mark.parametrize("deque_size", [2, 5])
 def test_wrapper_like_the_reference_test(env_id, deque_size):
