@@ -43,7 +43,7 @@ EXPORTS = (
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_set_stream",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
-    "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_sync", "mxv_bj_set_stream",
+    "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
 )
 
 
@@ -182,6 +182,7 @@ def _load():
         "mxv_bj_step_host": ([vp] * 8, C.c_int),
         "mxv_bj_get_state": ([vp, vp, vp], C.c_int),
         "mxv_bj_set_state": ([vp, vp, vp, u64, u32], C.c_int),
+        "mxv_bj_get_counters": ([vp, vp, vp], C.c_int),
         "mxv_bj_sync": ([vp], C.c_int),
         "mxv_bj_set_stream": ([vp, vp], C.c_int),
     }
@@ -594,6 +595,8 @@ class Tab:
         if rc != OK:
             raise MxvError(rc, (lib.mxv_tab_last_error(None) or b"").decode())
         self._h = h
+        self._base_seed, self._per_env_seeds = int(seed) & (2**64 - 1), None
+        self._action_seed = int(action_seed) & (2**64 - 1)
 
     def _check(self, rc: int):
         if rc != OK:
@@ -617,9 +620,28 @@ class Tab:
             assert per_env_seeds.shape == (self.num_envs,)
             p = per_env_seeds.ctypes.data
         self._check(lib.mxv_tab_seed(self._h, int(base_seed) & (2**64 - 1), p))
+        self._base_seed = int(base_seed) & (2**64 - 1)
+        self._per_env_seeds = None if per_env_seeds is None else per_env_seeds.copy()
 
     def seed_actions(self, action_seed: int):
         self._check(lib.mxv_tab_seed_actions(self._h, int(action_seed) & (2**64 - 1)))
+        self._action_seed = int(action_seed) & (2**64 - 1)
+
+    def snapshot(self) -> dict:
+        """State + TimeLimit counters + RNG seeds and counters (the table itself belongs to the caller's MDP)."""
+        st, el = self.get_state()
+        t, r = self.get_counters()
+        return dict(num_envs=self.num_envs, state=st, elapsed=el, t=t, r=r, base_seed=self._base_seed,
+                    per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
+                    action_seed=self._action_seed)
+
+    def restore(self, snap: dict):
+        if snap["num_envs"] != self.num_envs:
+            raise ValueError(f"snapshot of {snap['num_envs']} envs does not fit this handle ({self.num_envs})")
+        self.seed(snap["base_seed"], snap["per_env_seeds"])
+        self.seed_actions(snap["action_seed"])
+        self.set_state(snap["state"], snap["elapsed"])
+        self.set_counters(snap["t"], snap["r"])
 
     def reset(self, obs_dev=None, mask_dev=None):
         self._check(lib.mxv_tab_reset(self._h, _ptr(mask_dev), _ptr(obs_dev)))
@@ -703,6 +725,8 @@ class Blackjack:
         if rc != OK:
             raise MxvError(rc, (lib.mxv_bj_last_error(None) or b"").decode())
         self._h = h
+        self._base_seed, self._per_env_seeds = int(seed) & (2**64 - 1), None
+        self._action_seed = int(action_seed) & (2**64 - 1)
 
     def _check(self, rc: int):
         if rc != OK:
@@ -726,6 +750,27 @@ class Blackjack:
             assert per_env_seeds.shape == (self.num_envs,)
             p = per_env_seeds.ctypes.data
         self._check(lib.mxv_bj_seed(self._h, int(base_seed) & (2**64 - 1), p, int(action_seed) & (2**64 - 1)))
+        self._base_seed = int(base_seed) & (2**64 - 1)
+        self._per_env_seeds = None if per_env_seeds is None else per_env_seeds.copy()
+        self._action_seed = int(action_seed) & (2**64 - 1)
+
+    def get_counters(self):
+        t, r = C.c_uint64(), C.c_uint32()
+        self._check(lib.mxv_bj_get_counters(self._h, C.byref(t), C.byref(r)))
+        return t.value, r.value
+
+    def snapshot(self) -> dict:
+        st, el = self.get_state()
+        t, r = self.get_counters()
+        return dict(num_envs=self.num_envs, state=st, elapsed=el, t=t, r=r, base_seed=self._base_seed,
+                    per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
+                    action_seed=self._action_seed)
+
+    def restore(self, snap: dict):
+        if snap["num_envs"] != self.num_envs:
+            raise ValueError(f"snapshot of {snap['num_envs']} envs does not fit this handle ({self.num_envs})")
+        self.seed(snap["base_seed"], snap["per_env_seeds"], snap["action_seed"])
+        self.set_state(snap["state"], snap["elapsed"], snap["t"], snap["r"])
 
     def reset(self, obs_dev=None, mask_dev=None, cards_dev=None):
         self._check(lib.mxv_bj_reset(self._h, _ptr(mask_dev), _ptr(cards_dev), _ptr(obs_dev)))

@@ -450,6 +450,13 @@ int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host) {
     return MXV_OK;
 }
 
+int mxv_bj_get_counters(mxv_bj *h, uint64_t *t, uint32_t *r) {
+    BJ_CHECK(h);
+    if (t) *t = h->t;
+    if (r) *r = h->r;
+    return MXV_OK;
+}
+
 int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapsed_host, uint64_t t, uint32_t r) {
     BJ_CHECK(h);
     BJ_HIP(h, hipSetDevice(h->cfg.device));

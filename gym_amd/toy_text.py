@@ -301,8 +301,26 @@ class HipTabularVectorEnv(VectorEnv):
         limit = self.spec.max_episode_steps if max_episode_steps is None else max_episode_steps
         entropy = int.from_bytes(os.urandom(8), "little")
         self._handle = _make_handle(self.mdp, num_envs, limit, device, env_offset, entropy, entropy ^ 0x9E3779B97F4A7C15)
+        self._limit, self._env_offset = limit, env_offset
         self._actions = None
         self._was_reset = False
+
+    # -- pickling (the reference's checkpoint: tests/envs/test_envs.py:118-135) ----------------------------------------
+    def __getstate__(self):
+        self._assert_is_running()
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_handle", "spec")}
+        d["_spec_id"] = self.spec.id               # the registry entry holds the (unpicklable) builder
+        d["_snapshot"] = self._handle.snapshot()
+        d["_ctor"] = (self._handle.device, self._limit, self._env_offset)
+        return d
+
+    def __setstate__(self, d):
+        d = dict(d)
+        snap, (device, limit, env_offset) = d.pop("_snapshot"), d.pop("_ctor")
+        self.spec = _spec(d.pop("_spec_id"))
+        self.__dict__.update(d)
+        self._handle = _make_handle(self.mdp, self.num_envs, limit, device, env_offset, snap["base_seed"], snap["action_seed"])
+        self._handle.restore(snap)
 
     # -- infos ---------------------------------------------------------------------------------------------------
     def _mask_info(self, infos, states):
@@ -560,8 +578,25 @@ class HipBlackjackVectorEnv(VectorEnv):
         self._handle = _native.Blackjack(num_envs, natural=natural, sab=sab, device=device, env_offset=env_offset,
                                          max_episode_steps=-1 if max_episode_steps is None else int(max_episode_steps),
                                          seed=entropy, action_seed=entropy ^ 0x9E3779B97F4A7C15)
+        self._ctor = (device, env_offset, max_episode_steps)
         self._actions = None
         self._was_reset = False
+
+    def __getstate__(self):
+        self._assert_is_running()
+        d = {k: v for k, v in self.__dict__.items() if k != "_handle"}
+        d["_snapshot"] = self._handle.snapshot()
+        return d
+
+    def __setstate__(self, d):
+        d = dict(d)
+        snap = d.pop("_snapshot")
+        self.__dict__.update(d)
+        device, env_offset, limit = self._ctor
+        self._handle = _native.Blackjack(self.num_envs, natural=self.natural, sab=self.sab, device=device, env_offset=env_offset,
+                                         max_episode_steps=-1 if limit is None else int(limit),
+                                         seed=snap["base_seed"], action_seed=snap["action_seed"])
+        self._handle.restore(snap)
 
     @staticmethod
     def _obs(cols):

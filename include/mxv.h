@@ -355,6 +355,8 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
 /* packed hands (see mxv_bj.hip) + TimeLimit counters, int32 [N] each; set_state also restores the step index / reset ordinal */
 int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host);
 int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapsed_host, uint64_t t, uint32_t r);
+/* step index / reset ordinal of the draw streams (checkpointing: what mxv_bj_set_state takes back) */
+int mxv_bj_get_counters(mxv_bj *h, uint64_t *t, uint32_t *r);
 int mxv_bj_sync(mxv_bj *h);
 int mxv_bj_set_stream(mxv_bj *h, void *stream);
 

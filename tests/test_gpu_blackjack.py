@@ -110,6 +110,32 @@ def test_hip_blackjack_vector_env_contract():
     nat.close()
 
 
+def test_pickle_round_trip_continues_identically():
+    import pickle
+
+    import gym_amd
+
+    env = gym_amd.make("Blackjack-v1", num_envs=64, natural=True, sab=False)
+    env.reset(seed=5)
+    env.action_space.seed(6)
+    for _ in range(5):
+        env.step(env.action_space.sample())
+    twin = pickle.loads(pickle.dumps(env))
+    assert twin.natural and not twin.sab
+    for step in range(30):
+        if step == 11:
+            for u, v in zip(env.reset()[0], twin.reset()[0]):
+                assert np.array_equal(u, v)
+        a = env.action_space.sample()
+        r0, r1 = env.step(a), twin.step(a)
+        for u, v in zip(r0[0], r1[0]):
+            assert np.array_equal(u, v)
+        for x, y in zip(r0[1:4], r1[1:4]):
+            assert np.array_equal(x, y)
+    env.close()
+    twin.close()
+
+
 def test_full_size_properties():
     """2^20 tables, 32 sampled steps in one launch: sharding invariance and game statistics."""
     import torch

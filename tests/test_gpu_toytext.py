@@ -172,6 +172,32 @@ def test_taxi_helpers_through_call():
     env.close()
 
 
+@pytest.mark.parametrize("gid", ["FrozenLake-v1", "Taxi-v3"])
+def test_pickle_round_trip_continues_identically(gid):
+    """tests/envs/test_envs.py:118-135 for the tabular vector envs: the unpickled copy steps like the original, bit for bit."""
+    import pickle
+
+    import gym_amd
+
+    env = gym_amd.make(gid, num_envs=50, max_episode_steps=9)
+    env.reset(seed=21)
+    env.action_space.seed(2)
+    for _ in range(7):
+        env.step(env.action_space.sample())
+    twin = pickle.loads(pickle.dumps(env))
+    for step in range(40):
+        if step == 15:
+            assert np.array_equal(env.reset()[0], twin.reset()[0])
+        a = env.action_space.sample()
+        assert np.array_equal(a, twin.action_space.sample())
+        r0, r1 = env.step(a), twin.step(a)
+        for x, y in zip(r0[:4], r1[:4]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(r0[4]["prob"], r1[4]["prob"]) and set(r0[4]) == set(r1[4])
+    env.close()
+    twin.close()
+
+
 def test_full_size_properties():
     """2^20 FrozenLake8x8 envs, 64-step fused rollouts."""
     import torch
