@@ -70,6 +70,35 @@ def test_fused_rollout_statistics_equal_single_steps_and_oracle_twin(name):
     assert episodes >= n * (2 * K // limit)
 
 
+def test_wrapped_env_pickles_with_its_statistics():
+    """RecordEpisodeStatistics around the engine pickles as one object: queues, counts and the running returns inside the
+    engine continue identically in the copy."""
+    import pickle
+
+    import gym_amd
+
+    env = gym_amd.RecordEpisodeStatistics(gym_amd.make("CartPole-v1", num_envs=32, max_episode_steps=12), deque_size=50)
+    env.reset(seed=2)
+    env.action_space.seed(3)
+    for _ in range(20):
+        env.step(env.action_space.sample())
+    twin = pickle.loads(pickle.dumps(env))
+    assert twin.episode_count == env.episode_count and list(twin.return_queue) == list(env.return_queue)
+    assert np.array_equal(twin.episode_returns, env.episode_returns)
+    for _ in range(40):
+        a = env.action_space.sample()
+        r0, r1 = env.step(a), twin.step(a)
+        for x, y in zip(r0[:4], r1[:4]):
+            assert np.array_equal(x, y)
+        assert ("episode" in r0[4]) == ("episode" in r1[4])
+        if "episode" in r0[4]:
+            assert np.array_equal(r0[4]["episode"]["r"], r1[4]["episode"]["r"])
+            assert np.array_equal(r0[4]["episode"]["l"], r1[4]["episode"]["l"])
+    assert twin.episode_count == env.episode_count and list(twin.length_queue) == list(env.length_queue)
+    env.close()
+    twin.close()
+
+
 def test_final_obs_and_statistics_recorded_together():
     """Trajectory tensors with final_obs AND the fused statistics in one launch: both equal what separate runs record."""
     import torch
