@@ -153,5 +153,18 @@ class RunningNormalizer:
         self.backend.set_obs_state(sd["obs_mean"], sd["obs_var"], sd["obs_count"])
         self.backend.set_reward_state(sd["ret_mean"], sd["ret_var"], sd["ret_count"], sd.get("returns"))
 
+    # -- pickling: the statistics travel, the device objects are rebuilt (process-local: no stream, no process group) ------
+    def __getstate__(self):
+        if not isinstance(self.backend, HipNormBackend):
+            raise TypeError("only the HIP backend pickles")
+        return dict(num_envs=self.num_envs, obs_dim=self.obs_dim, gamma=self.gamma, obs_epsilon=self.obs_epsilon,
+                    reward_epsilon=self.reward_epsilon, world_size=self.world_size, total_envs=self.total_envs,
+                    device=self._dev.index or 0, state=self.state_dict())
+
+    def __setstate__(self, d):
+        self.__init__(d["num_envs"], d["obs_dim"], device=d["device"], gamma=d["gamma"], obs_epsilon=d["obs_epsilon"],
+                      reward_epsilon=d["reward_epsilon"], world_size=d["world_size"], total_envs=d["total_envs"])
+        self.load_state_dict(d["state"])
+
     def close(self):
         self.backend.close()

@@ -144,6 +144,21 @@ class VectorListInfo(_VectorWrapper):
         return list_info
 
 
+class _TorchPickle:
+    """Mixin of the Normalize* wrappers: the cached torch module handle is dropped when pickling and re-imported after."""
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_torch", None)
+        return d
+
+    def __setstate__(self, d):
+        import torch
+
+        self.__dict__.update(d)
+        self._torch = torch
+
+
 def _hip_base(env, who: str) -> HipVectorEnv:
     base = getattr(env, "unwrapped", env)
     if not isinstance(base, HipVectorEnv):
@@ -151,7 +166,7 @@ def _hip_base(env, who: str) -> HipVectorEnv:
     return base
 
 
-class NormalizeObservation(_VectorWrapper):
+class NormalizeObservation(_TorchPickle, _VectorWrapper):
     """gym.wrappers.NormalizeObservation for a HipVectorEnv (normalize.py:50-93): every reset()/step() folds the batch of
     N observations into `obs_rms` and returns (obs - mean) / sqrt(var + epsilon) as float64."""
 
@@ -191,7 +206,7 @@ class NormalizeObservation(_VectorWrapper):
         return self.env.close()
 
 
-class NormalizeReward(_VectorWrapper):
+class NormalizeReward(_TorchPickle, _VectorWrapper):
     """gym.wrappers.NormalizeReward for a HipVectorEnv (normalize.py:96-145): discounted returns per env, their running
     variance, rewards / sqrt(var + epsilon); the accumulators of finished envs are zeroed."""
 

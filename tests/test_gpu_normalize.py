@@ -174,6 +174,32 @@ def test_wrappers_on_hip_vector_env(name):
     bare.close()
 
 
+def test_wrapper_stack_pickles_with_its_statistics():
+    """NormalizeReward(NormalizeObservation(RecordEpisodeStatistics(env))) pickles as one object; the copy's running
+    statistics and outputs continue identically."""
+    import pickle
+
+    import gym_amd
+
+    env = gym_amd.make("CartPole-v1", num_envs=64, max_episode_steps=15)
+    env = gym_amd.NormalizeReward(gym_amd.NormalizeObservation(gym_amd.RecordEpisodeStatistics(env)), gamma=0.95)
+    env.reset(seed=4)
+    env.action_space.seed(1)
+    for _ in range(25):
+        env.step(env.action_space.sample())
+    twin = pickle.loads(pickle.dumps(env))
+    assert np.array_equal(twin.obs_rms.mean, env.obs_rms.mean) and twin.obs_rms.count == env.obs_rms.count
+    assert twin.return_rms.var == env.return_rms.var and np.array_equal(twin.returns, env.returns)
+    for _ in range(40):
+        a = env.action_space.sample()
+        r0, r1 = env.step(a), twin.step(a)
+        for x, y in zip(r0[:4], r1[:4]):
+            assert np.array_equal(x, y)
+    assert np.array_equal(twin.obs_rms.var, env.obs_rms.var) and twin.return_rms.mean == env.return_rms.mean
+    env.close()
+    twin.close()
+
+
 def test_full_size_properties():
     """2^20 CartPole envs, 8-step trajectory chunk produced by the fused rollout kernel."""
     import torch
