@@ -305,7 +305,7 @@ class HipTabularVectorEnv(VectorEnv):
         self._actions = None
         self._was_reset = False
 
-    # -- pickling (the reference's checkpoint: tests/envs/test_envs.py:118-135) ----------------------------------------
+    # -- pickling (the reference's checkpoint: tests/envs/test_envs.py:192-200) ----------------------------------------
     def __getstate__(self):
         self._assert_is_running()
         d = {k: v for k, v in self.__dict__.items() if k not in ("_handle", "spec")}

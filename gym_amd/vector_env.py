@@ -442,7 +442,7 @@ class HipVectorEnv(VectorEnv):
         """gym.Env surface used by gym.make (`env.unwrapped.spec = ...`, gym/envs/registration.py:656)."""
         return self
 
-    # -- pickling: how the reference's envs are checkpointed (tests/envs/test_envs.py:118-135) ----------------------
+    # -- pickling: how the reference's envs are checkpointed (tests/envs/test_envs.py:192-200) ----------------------
     def __getstate__(self):
         self._assert_is_running()
         d = {k: v for k, v in self.__dict__.items() if k not in ("_handle", "_views")}

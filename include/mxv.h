@@ -214,7 +214,7 @@ int mxv_set_episode_outputs(mxv_handle *h, float *ep_return_dev, int32_t *ep_len
 int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host);
 /* Checkpoint restore of the running returns read with mxv_episode_stats_host(running_return_host): float32[N].  Together
  * with mxv_set_state / mxv_set_counters / mxv_seed* / mxv_set_params* this rebuilds a handle that continues bit-identically
- * (the reference's envs are restored by pickling: tests/envs/test_envs.py:118-135). */
+ * (the reference's envs are restored by pickling: tests/envs/test_envs.py:192-200). */
 int mxv_set_running_returns(mxv_handle *h, const float *running_return_host);
 
 /* -- running normalisation: gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-145), SURVEY.md

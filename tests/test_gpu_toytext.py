@@ -174,7 +174,7 @@ def test_taxi_helpers_through_call():
 
 @pytest.mark.parametrize("gid", ["FrozenLake-v1", "Taxi-v3"])
 def test_pickle_round_trip_continues_identically(gid):
-    """tests/envs/test_envs.py:118-135 for the tabular vector envs: the unpickled copy steps like the original, bit for bit."""
+    """tests/envs/test_envs.py:192-200 for the tabular vector envs: the unpickled copy steps like the original, bit for bit."""
     import pickle
 
     import gym_amd

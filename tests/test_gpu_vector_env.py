@@ -79,7 +79,7 @@ def test_call_get_attr_set_attr_gravity():
 
 @pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1", "Acrobot-v1"])
 def test_pickle_round_trip_continues_identically(env_id):
-    """tests/envs/test_envs.py:118-135 (test_pickle_env) for the vector env: the unpickled copy resets and steps like the
+    """tests/envs/test_envs.py:192-200 (test_pickle_env) for the vector env: the unpickled copy resets and steps like the
     original — here for 60 steps across autoresets, bit for bit, with a short TimeLimit so episodes end."""
     import pickle
 
