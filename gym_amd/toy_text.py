@@ -160,7 +160,7 @@ def _taxi_encode(row, col, pass_loc, dest):
 
 
 def taxi_encode(taxi_row, taxi_col, pass_loc, dest_idx) -> int:
-    """TaxiEnv.encode (taxi.py:208-219)."""
+    """TaxiEnv.encode (taxi.py:210-219)."""
     return _taxi_encode(taxi_row, taxi_col, pass_loc, dest_idx)
 
 
@@ -425,7 +425,7 @@ class HipTabularVectorEnv(VectorEnv):
             return (P,) * self.num_envs
         if name == "initial_state_distrib":
             return (self.mdp.initial_distrib.copy(),) * self.num_envs
-        if self.spec.id == "Taxi-v3" and name in ("encode", "decode", "action_mask"):  # TaxiEnv's pure helpers (taxi.py:208-252)
+        if self.spec.id == "Taxi-v3" and name in ("encode", "decode", "action_mask"):  # TaxiEnv.s pure helpers (taxi.py:210-252)
             if name == "encode":
                 return (taxi_encode(*args, **kwargs),) * self.num_envs
             if name == "decode":

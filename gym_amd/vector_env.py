@@ -130,7 +130,7 @@ class VectorEnv:
 
     @property
     def unwrapped(self):
-        """gym.Env.unwrapped (gym/core.py:186-192): a vector env is its own base env."""
+        """gym.Env.unwrapped (gym/core.py:186-193): a vector env is its own base env."""
         return self
 
     def __repr__(self) -> str:
@@ -472,7 +472,7 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
     ignored: there are no sub-processes, all sub-envs step in one kernel launch."""
     kwargs.pop("disable_env_checker", None)
     if kwargs.pop("wrappers", None) is not None:
-        # gym/vector/__init__.py:53-64 applies them to every Python sub-env; there are no Python sub-envs here
+        # gym/vector/__init__.py:56-65 applies them to every Python sub-env; there are no Python sub-envs here
         raise NotImplementedError("per-sub-environment `wrappers` cannot run inside the device engine; wrap the vector env "
                                   "instead (gym_amd.VectorEnvWrapper, RecordEpisodeStatistics, NormalizeObservation/Reward) "
                                   "or pass the env's own keyword arguments / max_episode_steps")

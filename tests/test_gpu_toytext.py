@@ -156,7 +156,7 @@ def test_hip_tabular_vector_env_contract():
 
 
 def test_taxi_helpers_through_call():
-    """TaxiEnv.encode / decode / action_mask (taxi.py:208-252) answered through VectorEnv.call like any sub-env method."""
+    """TaxiEnv.encode / decode / action_mask (taxi.py:210-252) answered through VectorEnv.call like any sub-env method."""
     import gym_amd
 
     env = gym_amd.make("Taxi-v3", num_envs=3)

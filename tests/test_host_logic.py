@@ -180,7 +180,7 @@ def test_vector_env_wrapper_forwards_like_the_reference():
 
 
 def test_make_refuses_per_sub_env_wrappers_loudly():
-    """gym.vector.make(wrappers=...) wraps every Python sub-env (gym/vector/__init__.py:53-64); the engine has none and must
+    """gym.vector.make(wrappers=...) wraps every Python sub-env (gym/vector/__init__.py:56-65); the engine has none and must
     not silently drop them."""
     import gym_amd
 
