@@ -1,5 +1,5 @@
 // mxv_norm.hip — SURVEY.md §8(f)-2: gym.wrappers.NormalizeObservation / NormalizeReward
-// (gym/wrappers/normalize.py:8-145) for a vector env, as gfx950 kernels behind the mxv_norm_* C ABI (include/mxv.h).
+// (gym/wrappers/normalize.py:8-144) for a vector env, as gfx950 kernels behind the mxv_norm_* C ABI (include/mxv.h).
 //
 // The reference normalises one batch per step() call: RunningMeanStd.update(batch) (:17-29, a Chan/Welford merge of
 // the batch mean/var into the running mean/var, :32-47) followed by an element-wise affine map (:90-93, :143-145).

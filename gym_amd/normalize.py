@@ -1,4 +1,4 @@
-"""RunningNormalizer — gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-145) on device
+"""RunningNormalizer — gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-144) on device
 tensors.
 
 The reference wraps a vector env and, per step() call, folds the batch of N observations (resp. the N discounted

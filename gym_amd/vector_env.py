@@ -141,7 +141,7 @@ class VectorEnv:
 
 
 class VectorEnvWrapper(VectorEnv):
-    """gym.vector.VectorEnvWrapper (gym/vector/vector_env.py:277-337): base class of user wrappers around a vector env.
+    """gym.vector.VectorEnvWrapper (gym/vector/vector_env.py:277-332): base class of user wrappers around a vector env.
     The VectorEnv methods are forwarded explicitly, every other public attribute implicitly; a subclass overrides
     `step_wait` / `reset_wait` (as the reference's own test wrappers do) and `step()` / `reset()` pick that up."""
 

@@ -6,7 +6,7 @@ for a HipVectorEnv: same attributes (`return_queue`, `length_queue`, `episode_co
 returns and lengths are accumulated inside the step kernel (float32 returns exactly like the reference's np.float32
 accumulator; the length is the TimeLimit counter), so no Python loop over the N sub-envs runs per step.
 `VectorListInfo` mirrors gym.wrappers.VectorListInfo (gym/wrappers/vector_list_info.py:43-111).
-`NormalizeObservation` / `NormalizeReward` mirror gym.wrappers.normalize (gym/wrappers/normalize.py:50-145): same
+`NormalizeObservation` / `NormalizeReward` mirror gym.wrappers.normalize (gym/wrappers/normalize.py:50-144): same
 attributes (`obs_rms`, `return_rms`, `returns`, `gamma`, `epsilon`) and result dtypes (float64), with the batch moments,
 the running update and the affine map computed by the mxv_norm_* kernels (gym_amd.normalize.RunningNormalizer).
 """
@@ -207,7 +207,7 @@ class NormalizeObservation(_TorchPickle, _VectorWrapper):
 
 
 class NormalizeReward(_TorchPickle, _VectorWrapper):
-    """gym.wrappers.NormalizeReward for a HipVectorEnv (normalize.py:96-145): discounted returns per env, their running
+    """gym.wrappers.NormalizeReward for a HipVectorEnv (normalize.py:96-144): discounted returns per env, their running
     variance, rewards / sqrt(var + epsilon); the accumulators of finished envs are zeroed."""
 
     def __init__(self, env, gamma: float = 0.99, epsilon: float = 1e-8):

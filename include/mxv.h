@@ -217,7 +217,7 @@ int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_len
  * (the reference's envs are restored by pickling: tests/envs/test_envs.py:192-200). */
 int mxv_set_running_returns(mxv_handle *h, const float *running_return_host);
 
-/* -- running normalisation: gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-145), SURVEY.md
+/* -- running normalisation: gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-144), SURVEY.md
  *    §8f-2.  One mxv_norm = one RunningMeanStd (normalize.py:8-29: fp64 mean[dim], var[dim], count = 1e-4 at creation)
  *    plus, for rewards, the wrapper's per-env discounted-return accumulator (:123), device resident.  It works on the
  *    tensors the step calls produce, K consecutive batches per call ([K][num_envs][dim]; K = 1 for a single step()):

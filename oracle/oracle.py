@@ -209,7 +209,7 @@ class EpisodeStats:
 
 class RunningNorm:
     """gym.wrappers.NormalizeObservation / NormalizeReward restated for a batched stream (oracle/normalize.c follows
-    gym/wrappers/normalize.py:8-145).  mode 0 = the reference's own arithmetic (float32 row-by-row batch moments, NumPy
+    gym/wrappers/normalize.py:8-144).  mode 0 = the reference's own arithmetic (float32 row-by-row batch moments, NumPy
     pairwise sums) — pinned bit-exact by tests/golden/normalize_*.npz; mode 1 = exact batch sums rounded to the
     reference's moment dtype, the definition the device kernels implement."""
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden vectors for SURVEY.md §8(f)-2 — gym.wrappers.NormalizeObservation / NormalizeReward — made by RUNNING THE
-REFERENCE's own wrappers (gym/wrappers/normalize.py:8-145) over its SyncVectorEnv, in the build container only:
+REFERENCE's own wrappers (gym/wrappers/normalize.py:8-144) over its SyncVectorEnv, in the build container only:
 
     python tests/golden/make_golden_normalize.py          -> tests/golden/normalize_<Env>.npz
 

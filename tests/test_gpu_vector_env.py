@@ -145,7 +145,7 @@ def test_device_rollout_state_dict_resumes_bit_identically():
 
 
 def test_vector_env_wrapper_like_the_reference_tests():
-    """tests/vector/test_vector_env_wrapper.py:7-36 with gym_amd's VectorEnvWrapper around the engine's envs."""
+    """tests/vector/test_vector_env_wrapper.py:7-31 with gym_amd's VectorEnvWrapper around the engine's envs."""
     import gym_amd
 
     class DummyWrapper(gym_amd.VectorEnvWrapper):

@@ -125,7 +125,7 @@ def test_vector_env_base_surface():
 
 
 def test_vector_env_wrapper_forwards_like_the_reference():
-    """gym.vector.VectorEnvWrapper (vector_env.py:277-337): explicit forwarding of the VectorEnv methods, implicit of
+    """gym.vector.VectorEnvWrapper (vector_env.py:277-332): explicit forwarding of the VectorEnv methods, implicit of
     public attributes, private ones refused; a subclass hooks reset_async like tests/vector/test_vector_env_wrapper.py."""
     from gym_amd.vector_env import VectorEnv, VectorEnvWrapper
 
