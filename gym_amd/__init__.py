@@ -27,6 +27,10 @@ _LAZY = {
 
 
 def __getattr__(name):
+    if name in ("vector", "wrappers", "spaces", "error", "plugin", "toy_text"):  # sub-modules, gym-shaped
+        import importlib
+
+        return importlib.import_module(f"gym_amd.{name}")
     if name in _LAZY:
         import importlib
 

@@ -179,6 +179,24 @@ def test_vector_env_wrapper_forwards_like_the_reference():
     assert base.closed
 
 
+def test_gym_shaped_namespaces():
+    """`import gym_amd as gym`: gym.vector.make / gym.vector.VectorEnv(Wrapper) / gym.wrappers.* / gym.spaces / gym.error."""
+    import gym_amd as gym
+    import gym_amd.vector
+
+    assert gym.vector.make is gym.make and gym.vector.VectorEnv is gym.VectorEnv
+    assert issubclass(gym.vector.VectorEnvWrapper, gym.vector.VectorEnv)
+    import gym_amd.spaces as spaces
+    import gym_amd.wrappers as wrappers
+
+    for name in ("RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward"):
+        assert getattr(wrappers, name) is getattr(gym, name)
+    for name in ("Box", "Discrete", "MultiDiscrete", "Tuple"):
+        assert hasattr(spaces, name)
+    for name in ("Error", "ResetNeeded", "AlreadyPendingCallError", "NoAsyncCallError", "ClosedEnvironmentError", "UnregisteredEnv"):
+        assert issubclass(getattr(gym.error, name), Exception)
+
+
 def test_make_refuses_per_sub_env_wrappers_loudly():
     """gym.vector.make(wrappers=...) wraps every Python sub-env (gym/vector/__init__.py:56-65); the engine has none and must
     not silently drop them."""
