@@ -205,14 +205,18 @@ def test_full_size_properties():
 
     n, K = 1 << 20, 64
     full = TabularRollout("FrozenLake8x8-v1", n, seed=9, action_seed=10)
-    obs0 = full.reset(seed=9).clone()
+    obs0 = full.reset(seed=9)
+    full.synchronize()   # engine stream -> finish before cloning on torch's current stream
+    obs0 = obs0.clone()
     a = full.rollout_per_step(K)
     full.synchronize()
     # shard invariance: the same logical vector env on 4 handles (global-index Philox streams)
     parts = []
     for w in range(4):
         sh = TabularRollout("FrozenLake8x8-v1", n // 4, env_offset=w * (n // 4), seed=9, action_seed=10)
-        o0 = sh.reset(seed=9).clone()
+        o0 = sh.reset(seed=9)
+        sh.synchronize()
+        o0 = o0.clone()
         parts.append((o0, sh.rollout_per_step(K)))
         sh.synchronize()
         sh.close()

@@ -124,8 +124,9 @@ def test_device_rollout_state_dict_resumes_bit_identically():
     r.reset(seed=3)
     r.rollout_per_step(40)
     snap = pickle.loads(pickle.dumps(r.state_dict()))
-    a = {k: v.clone() for k, v in r.rollout_per_step(64).items()}
-    r.synchronize()
+    out = r.rollout_per_step(64)
+    r.synchronize()   # the engine runs on its own stream: finish before cloning on torch's current stream
+    a = {k: v.clone() for k, v in out.items()}
     fresh = DeviceRollout("CartPole-v1", 3000, seed=99, action_seed=98)
     fresh.load_state_dict(snap)
     b = fresh.rollout_per_step(64)
