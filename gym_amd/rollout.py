@@ -6,6 +6,12 @@ tensors for the step I/O (torch is used for device memory and streams only), han
 pointers to the C ABI and keeps everything on one HIP stream.  Semantics are those of
 SyncVectorEnv.step_wait (gym/vector/sync_vector_env.py:135-169); dtypes are the engine's:
 obs float32 (N, O), reward float64 (float32 with reward_f32), terminated/truncated uint8 (N,).
+
+Stream ordering.  Every launch goes to `self.stream`, a stream of its own (so rollouts overlap with a learner's kernels and
+with RCCL).  Outputs are therefore ready *on that stream*: consume them inside `with torch.cuda.stream(r.stream):`, after
+`r.ready()` (the caller's current stream waits for the engine on the GPU, no host synchronisation) or after
+`r.synchronize()` (host wait).  Inputs go the other way: `step(actions)` / `rollout_tape(actions)` first make the engine's
+stream wait for the caller's current stream, so actions a policy just computed there are complete before the kernel reads them.
 """
 from __future__ import annotations
 
@@ -72,6 +78,7 @@ class DeviceRollout:
         """One vector step with caller-provided actions (device tensor of the engine's action dtype)."""
         assert actions.is_cuda and actions.dtype == self.action_dtype and actions.numel() == self.num_envs
         assert actions.is_contiguous()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the actions were produced on the caller's stream
         self._attach_episode_outputs(None)
         self.handle.step(actions, self.obs, self.reward, self.terminated, self.truncated,
                          self.final_obs if want_final else None)
@@ -229,6 +236,7 @@ class DeviceRollout:
         assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self.action_dtype
         assert actions.numel() == K * self.num_envs
         out = self.trajectory_buffers(K) if out is None else out
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))   # the tape was produced on the caller's stream
         self._attach_episode_outputs(out)
         self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"],
                                  out.get("final_obs"), per_step=True)
@@ -249,6 +257,11 @@ class DeviceRollout:
     def sample_actions(self) -> torch.Tensor:
         self.handle.sample_actions(self.actions)
         return self.actions
+
+    def ready(self):
+        """GPU-side ordering of the outputs: the caller's current torch stream waits for everything launched so far on the
+        engine's stream (no host synchronisation).  Use before touching output tensors outside `with torch.cuda.stream(r.stream)`."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def synchronize(self):
         """Wait for the engine's stream; raises if a step saw an out-of-range action."""

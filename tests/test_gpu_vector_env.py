@@ -111,6 +111,39 @@ def test_pickle_round_trip_continues_identically(env_id):
     twin.close()
 
 
+def test_device_rollout_stream_ordering_helpers():
+    """Actions computed on torch's current stream are complete before step() reads them, and ready() orders the outputs for
+    the current stream: no host synchronisation anywhere, results equal the host-synchronised run."""
+    import torch
+
+    from gym_amd.rollout import DeviceRollout
+
+    n = 1 << 18
+    outs = []
+    for synced in (True, False):
+        r = DeviceRollout("CartPole-v1", n, seed=1, action_seed=2)
+        r.reset(seed=1)
+        r.synchronize()
+        acc = torch.zeros(n, dtype=torch.float64, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for _ in range(30):
+            # a "policy" on the current stream: enough work that the tensor is not ready when step() is called
+            logits = torch.rand((n, 8), generator=g, device="cuda").cumsum(1)[:, -1]
+            actions = (logits > 4.0).to(torch.int64)
+            if synced:
+                torch.cuda.synchronize()
+            obs, rew, term, trunc = r.step(actions, want_final=False)
+            if synced:
+                r.synchronize()
+            else:
+                r.ready()
+            acc += obs[:, 0].to(torch.float64) + rew
+        torch.cuda.synchronize()
+        outs.append((acc.clone(), r.handle.get_state()[0]))
+        r.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_device_rollout_state_dict_resumes_bit_identically():
     """Checkpoint / resume of the device-resident API incl. the fused episode statistics' running returns."""
     import pickle
