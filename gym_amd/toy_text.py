@@ -542,10 +542,15 @@ class TabularRollout:
         K = actions.shape[0]
         assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self._torch.int64
         out = self.trajectory_buffers(K) if out is None else out
+        self.stream.wait_stream(self._torch.cuda.current_stream(self.device))   # the tape was produced on the caller's stream
         self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"],
                                  per_step=True)
         out["actions"] = actions
         return out
+
+    def ready(self):
+        """The caller's current torch stream waits (on the GPU) for everything launched on the engine's stream."""
+        self._torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def synchronize(self):
         self.handle.sync()
