@@ -25,6 +25,9 @@ import os
 import sys
 import time
 
+# the host driver supports dmabuf IPC only: RCCL / cross-process device memory needs this before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
