@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary compact-outputs measurement (N=1 only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1.  nccl (= RCCL) is the product path; gloo exists to exercise the "
+                         "multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices)")
     args = ap.parse_args()
 
     import torch
@@ -173,13 +176,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; gym_amd has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()   # debug path: more ranks than GPUs
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL's kernels run on high-priority streams: a chunk's all-gather gets CUs as soon as rollout waves retire instead of
         # queueing behind the next chunk's (long-running, chip-filling) rollout launch
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from gym_amd.distributed import ShardedRollout
 
@@ -198,13 +206,13 @@ def main():
         traj = eng.trajectory_buffers(args.chunk)
     launches = [0]
 
-    def run(steps):
+    def run(steps, gather=True):
         done = 0
         while done < steps:
             k = min(args.chunk, steps - done)
             sr.rollout_per_step(k, mode=mode, out=traj, record_actions=True)
             launches[0] += 1 if mode == "fused" else k
-            if world > 1:
+            if world > 1 and gather:
                 sr.gather_async()
             done += k
 
@@ -216,13 +224,16 @@ def main():
 
     # device spin-up: same workload, untimed, until --spinup-ms of wall time has passed; then W warmup steps
     # (which also instantiate the hipGraph(s) and RCCL communicators used in the timed region)
+    # The spin-up is time-based, so its iteration count differs between ranks: it must not contain a collective (every rank
+    # has to issue the same sequence of them) — the all-gathers start with the warm-up, whose step count is fixed.
     spin_steps = 0
     if args.spinup_ms > 0:
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            run(args.chunk)
+            run(args.chunk, gather=False)
             sr.synchronize()
             spin_steps += args.chunk
+    fence()   # ranks leave placement tuning and spin-up at different times
     run(args.warmup)
     if args.steps % args.chunk:
         run(args.steps % args.chunk)

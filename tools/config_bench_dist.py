@@ -25,11 +25,17 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MXV_DIST_BACKEND", "nccl")   # "gloo": exercise the multi-rank control flow on fewer GPUs than ranks
+    if backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     from gym_amd.distributed import ShardedRollout
     from gym_amd.mixed import DEFAULT_MIX, MixedRollout
 
@@ -46,14 +52,16 @@ def main():
             dist.barrier()
 
     def timed(obj, traj, total_envs, label, extra):
-        def run(n):
+        def run(n, gather=True):
             for _ in range(n // chunk):
                 obj.rollout_per_step(chunk, out=traj)
-                obj.gather_async()
+                if gather:
+                    obj.gather_async()
         t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 0.15:   # clock ramp
-            run(chunk)
+        while time.perf_counter() - t_spin < 0.15:   # clock ramp; time-based, so no collective inside (counts differ per rank)
+            run(chunk, gather=False)
             obj.synchronize()
+        fence(obj)
         run(warm)
         obj.gather()
         fence(obj)
