@@ -1,0 +1,46 @@
+"""bench.py's multi-rank control flow (one process per rank, env shards, packed all-gather per chunk, max-over-ranks timing)
+run for real with two ranks.  `gpurun` exposes one GPU, so the ranks share it and talk over gloo (`--backend gloo`: same
+code path, other transport); what this pins is that every rank issues the same sequence of collectives — a rank-dependent
+count (e.g. inside a time-based loop) deadlocks here exactly as it would over RCCL on eight GPUs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(script_args, env=None, timeout=240):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env={**os.environ, **(env or {})})
+    assert p.returncode == 0, p.stderr[-2000:]
+    return [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_two_ranks_complete_and_report_the_whole_job():
+    lines = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "512", "--warmup", "256", "--no-cpu-baseline",
+                       "--placement-candidates", "2"])
+    assert len(lines) == 1          # rank 0 prints the one line
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 512 and out["scaling"] == "weak"
+    assert out["config"]["num_envs_per_gpu"] == 1 << 20 and "2097152 total" in out["config"]["workload"]
+    assert out["value"] == pytest.approx((2 << 20) * 512 / (out["ms_per_step"] * 1e-3 * 512), rel=1e-6)
+    assert "cpu_baseline" not in out and out["roofline"]["bound"] == "hbm"
+
+
+def test_config_bench_dist_two_ranks_complete():
+    lines = _torchrun(["tools/config_bench_dist.py", "--chunk", "64", "--steps", "256"], env={"MXV_DIST_BACKEND": "gloo"})
+    assert [l["config"].split(":")[0] for l in lines] == ["config4", "config5"]
+    assert all(l["n_gpus"] == 2 for l in lines) and lines[0]["total_envs"] == 1 << 20 and lines[1]["total_envs"] == 1 << 18
