@@ -201,7 +201,11 @@ def main():
     # which of three speed modes the write-bound kernel runs in: pick the fastest of a few candidate sets.
     placement = None
     if mode == "fused" and args.placement_candidates > 1:
-        traj, placement = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
+        try:
+            traj, placement = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
+        except (RuntimeError, MemoryError) as e:   # e.g. out of device memory: measure on the first allocation instead
+            torch.cuda.empty_cache()
+            traj, placement = eng.trajectory_buffers(args.chunk), {"error": f"placement tuning failed: {e}"[:300]}
     else:
         traj = eng.trajectory_buffers(args.chunk)
     launches = [0]
