@@ -7,11 +7,19 @@ out="$here/../_lib"
 mkdir -p "$out"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result ${MXV_EXTRA_FLAGS:-})
-"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_kernels.hip" -o "$out/mxv_kernels.o" &
-"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_api.cpp" -o "$out/mxv_api.o" &
-"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_norm.hip" -o "$out/mxv_norm.o" &
-"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_tab.hip" -o "$out/mxv_tab.o" &
-"$HIPCC" "${FLAGS[@]}" -c "$here/mxv_bj.hip" -o "$out/mxv_bj.o" &
-wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "$out/mxv_kernels.o" "$out/mxv_api.o" "$out/mxv_norm.o" "$out/mxv_tab.o" "$out/mxv_bj.o"
+# stale objects must never survive a failed compile: remove them first, then wait for every compile BY PID
+# (a bare `wait` returns 0 even when a background job failed, so `set -e` would not fire).
+srcs=(mxv_kernels.hip mxv_api.cpp mxv_norm.hip mxv_tab.hip mxv_bj.hip)
+objs=()
+pids=()
+for s in "${srcs[@]}"; do
+    o="$out/${s%.*}.o"
+    rm -f "$o"
+    objs+=("$o")
+    "$HIPCC" "${FLAGS[@]}" -c "$here/$s" -o "$o" &
+    pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+rm -f "$out/libmxv.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv.so" "${objs[@]}" ${MXV_EXTRA_LIBS:-}
 echo "built $out/libmxv.so"

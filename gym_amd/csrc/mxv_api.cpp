@@ -239,6 +239,12 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     a.b1 = b[1];
     MXV_HIP(h, launch_reset(h->cfg.env_id, a, h->stream));
     h->was_reset = true;
+    // CartPole's range-reduction-free sin/cos (rollout fast path, SAFE = false) assumes |theta| <= pi/4 on entry; reset bounds
+    // from reset(options={"low","high"}) beyond that break the induction exactly like an injected state does: the next
+    // fused launch takes the SAFE instantiation (every such env terminates in its first step and autoresets with the
+    // default bounds, so one launch is enough).
+    if (h->cfg.env_id == MXV_CARTPOLE && std::fmax(std::fabs(b[0]), std::fabs(b[1])) > 0.78539816339744830962)
+        h->state_injected = true;
     return MXV_OK;
 }
 

@@ -93,31 +93,38 @@ class Box(Space):
             return above
         raise ValueError(f"manner is not in {{'below', 'above', 'both'}}, actual value: {manner}")
 
-    def sample(self, mask=None) -> np.ndarray:  # gym/spaces/box.py:171-222
+    def sample(self, mask=None) -> np.ndarray:
+        """Same distribution per coordinate and — because seeded streams must reproduce the reference's numbers — the same
+        ORDER of generator calls as gym/spaces/box.py:171-222: normal for the coordinates without any bound, shifted
+        exponential for those bounded on one side (lower-bounded first), uniform for the two-sided ones."""
         if mask is not None:
             raise error.Error(f"Box.sample cannot be provided a mask, actual value: {mask}")
-        high = self.high if self.dtype.kind == "f" else self.high.astype("int64") + 1
-        sample = np.empty(self.shape)
-        unbounded = ~self.bounded_below & ~self.bounded_above
-        upp_bounded = ~self.bounded_below & self.bounded_above
-        low_bounded = self.bounded_below & ~self.bounded_above
-        bounded = self.bounded_below & self.bounded_above
-        sample[unbounded] = self.np_random.normal(size=unbounded[unbounded].shape)
-        sample[low_bounded] = self.np_random.exponential(size=low_bounded[low_bounded].shape) + self.low[low_bounded]
-        sample[upp_bounded] = -self.np_random.exponential(size=upp_bounded[upp_bounded].shape) + self.high[upp_bounded]
-        sample[bounded] = self.np_random.uniform(low=self.low[bounded], high=high[bounded], size=bounded[bounded].shape)
+        rng = self.np_random
+        lo_ok, hi_ok = self.bounded_below, self.bounded_above
+        top = self.high if self.dtype.kind == "f" else self.high.astype("int64") + 1   # integer boxes include `high`
+        out = np.empty(self.shape)
+        draws = (
+            (~lo_ok & ~hi_ok, lambda m, k: rng.normal(size=k)),
+            (lo_ok & ~hi_ok, lambda m, k: rng.exponential(size=k) + self.low[m]),
+            (~lo_ok & hi_ok, lambda m, k: -rng.exponential(size=k) + self.high[m]),
+            (lo_ok & hi_ok, lambda m, k: rng.uniform(low=self.low[m], high=top[m], size=k)),
+        )
+        for m, draw in draws:   # one generator call per group, even for an empty group (the reference draws size-0 arrays too)
+            out[m] = draw(m, m[m].shape)
         if self.dtype.kind == "i":
-            sample = np.floor(sample)
-        return sample.astype(self.dtype)
+            out = np.floor(out)
+        return out.astype(self.dtype)
 
-    def contains(self, x) -> bool:  # gym/spaces/box.py:224-238
+    def contains(self, x) -> bool:
+        """Membership as in gym/spaces/box.py:224-238: castable dtype, exact shape, inside the closed bounds."""
         if not isinstance(x, np.ndarray):
             try:
                 x = np.asarray(x, dtype=self.dtype)
             except (ValueError, TypeError):
                 return False
-        return bool(np.can_cast(x.dtype, self.dtype) and x.shape == self.shape and np.all(x >= self.low)
-                    and np.all(x <= self.high))
+        if x.shape != self.shape or not np.can_cast(x.dtype, self.dtype):
+            return False
+        return bool(np.all(x >= self.low) and np.all(x <= self.high))
 
     def __repr__(self) -> str:
         return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"

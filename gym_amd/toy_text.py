@@ -290,7 +290,10 @@ class HipTabularVectorEnv(VectorEnv):
 
     def __init__(self, id: str, num_envs: int = 1, *, device: int = 0, max_episode_steps: Optional[int] = None,
                  env_offset: int = 0, **kwargs):
-        self.spec = _spec(id)
+        # `spec` is public and gets replaced: gym.make("hip/<id>") runs `env.unwrapped.spec = <gym EnvSpec "hip/<id>">`
+        # (gym/envs/registration.py:657).  The engine's own registry entry therefore lives in a private attribute and is what
+        # call() / pickling use.
+        self.spec = self._tt_spec = _spec(id)
         if kwargs.pop("render_mode", None) is not None:
             raise TypeError(f"{id}: the device engine does not render (render_mode must be None)")
         for k in kwargs:
@@ -308,8 +311,10 @@ class HipTabularVectorEnv(VectorEnv):
     # -- pickling (the reference's checkpoint: tests/envs/test_envs.py:192-200) ----------------------------------------
     def __getstate__(self):
         self._assert_is_running()
-        d = {k: v for k, v in self.__dict__.items() if k not in ("_handle", "spec")}
-        d["_spec_id"] = self.spec.id               # the registry entry holds the (unpicklable) builder
+        d = {k: v for k, v in self.__dict__.items() if k not in ("_handle", "spec", "_tt_spec")}
+        d["_spec_id"] = self._tt_spec.id           # the registry entry holds the (unpicklable) builder
+        if self.spec is not self._tt_spec:
+            d["_outer_spec"] = self.spec           # e.g. gym's EnvSpec after gym.make("hip/<id>")
         d["_snapshot"] = self._handle.snapshot()
         d["_ctor"] = (self._handle.device, self._limit, self._env_offset)
         return d
@@ -317,7 +322,8 @@ class HipTabularVectorEnv(VectorEnv):
     def __setstate__(self, d):
         d = dict(d)
         snap, (device, limit, env_offset) = d.pop("_snapshot"), d.pop("_ctor")
-        self.spec = _spec(d.pop("_spec_id"))
+        self._tt_spec = _spec(d.pop("_spec_id"))
+        self.spec = d.pop("_outer_spec", self._tt_spec)
         self.__dict__.update(d)
         self._handle = _make_handle(self.mdp, self.num_envs, limit, device, env_offset, snap["base_seed"], snap["action_seed"])
         self._handle.restore(snap)
@@ -425,14 +431,14 @@ class HipTabularVectorEnv(VectorEnv):
             return (P,) * self.num_envs
         if name == "initial_state_distrib":
             return (self.mdp.initial_distrib.copy(),) * self.num_envs
-        if self.spec.id == "Taxi-v3" and name in ("encode", "decode", "action_mask"):  # TaxiEnv.s pure helpers (taxi.py:210-252)
+        if self._tt_spec.id == "Taxi-v3" and name in ("encode", "decode", "action_mask"):  # TaxiEnv.s pure helpers (taxi.py:210-252)
             if name == "encode":
                 return (taxi_encode(*args, **kwargs),) * self.num_envs
             if name == "decode":
                 return tuple(taxi_decode(*args, **kwargs) for _ in range(self.num_envs))
             (state,) = args or (kwargs["state"],)
             return tuple(self.mdp.action_mask[int(state)].copy() for _ in range(self.num_envs))
-        raise AttributeError(f"{self.spec.id} sub-environments have no attribute {name!r}")
+        raise AttributeError(f"{self._tt_spec.id} sub-environments have no attribute {name!r}")
 
     def close_extras(self, **kwargs):
         h = getattr(self, "_handle", None)

@@ -38,7 +38,13 @@ class _Pending:
 class LazyInfos(dict):
     """infos dict whose `final_observation` / `final_info` object arrays (vector_env.py:208-258:
     length-N object ndarrays with None holes, plus `_key` boolean masks) are materialised on first
-    access — building them eagerly is a Python loop over every finished env of every step."""
+    access — building them eagerly is a Python loop over every finished env of every step.
+
+    Every way of getting a value out resolves the placeholder first, so callers only ever see what the reference's plain
+    dict holds: item access, get / pop / popitem / setdefault, items / values, iteration-based copies (`dict(infos)`,
+    `{**infos}`, `infos | other` — defining `__iter__` takes CPython's dict_merge off its raw-storage fast path, it then goes
+    through keys() + __getitem__), copy() (returns a plain dict), repr, ==, pickle and copy.copy / copy.deepcopy (reduce to
+    a plain dict)."""
 
     def _resolve(self, key):
         v = dict.__getitem__(self, key)
@@ -47,23 +53,76 @@ class LazyInfos(dict):
             dict.__setitem__(self, key, v)
         return v
 
+    def _resolve_all(self):
+        for k in list(dict.keys(self)):
+            self._resolve(k)
+        return self
+
     def __getitem__(self, key):
         return self._resolve(key)
+
+    def __iter__(self):
+        return iter(list(dict.keys(self)))
 
     def get(self, key, default=None):
         return self._resolve(key) if key in self else default
 
     def items(self):
-        return [(k, self._resolve(k)) for k in self.keys()]
+        return [(k, self._resolve(k)) for k in dict.keys(self)]
 
     def values(self):
-        return [self._resolve(k) for k in self.keys()]
+        return [self._resolve(k) for k in dict.keys(self)]
+
+    def pop(self, key, *default):
+        if key in self:
+            self._resolve(key)
+        return dict.pop(self, key, *default)
+
+    def popitem(self):
+        self._resolve_all()
+        return dict.popitem(self)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self._resolve(key)
+        return dict.setdefault(self, key, default)
+
+    def copy(self):
+        return dict(self.items())
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        import copy as _copy
+
+        return _copy.deepcopy(self.copy(), memo)
+
+    def __reduce_ex__(self, protocol):
+        return (dict, (self.copy(),))
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))
+
+    def __or__(self, other):
+        return self.copy() | (other.copy() if isinstance(other, LazyInfos) else other)
+
+    def __ror__(self, other):
+        return (other.copy() if isinstance(other, LazyInfos) else other) | self.copy()
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
+
+    def __repr__(self):
+        return repr(self.copy())
 
     def __eq__(self, other):
-        return dict(self.items()) == (dict(other.items()) if isinstance(other, dict) else other)
+        return self.copy() == (dict(other.items()) if isinstance(other, dict) else other)
 
     def __ne__(self, other):
         return not self.__eq__(other)
+
+    __hash__ = None
 
 
 class VectorEnv:

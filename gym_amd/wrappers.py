@@ -68,12 +68,20 @@ class RecordEpisodeStatistics(_VectorWrapper):
         self.return_queue = deque(maxlen=deque_size)
         self.length_queue = deque(maxlen=deque_size)
         self._enabled = False
+        # The engine's fused accumulator sums the RAW rewards of the dynamics.  The reference accumulates whatever the wrapped
+        # env's step() returns (record_episode_statistics.py:119-121), so with a NormalizeReward underneath the episode returns
+        # are sums of NORMALISED rewards: in that stacking order the returns are accumulated here on the host from the wrapped
+        # step's rewards (one vectorised float32 add per step, the reference's own arithmetic); lengths stay the TimeLimit counter.
+        self._host_returns = any(isinstance(w, NormalizeReward) for w in chain)
+        self._acc = None
 
     # episode_returns / episode_lengths are None before the first reset (record_episode_statistics.py:89-90)
     @property
     def episode_returns(self):
         if not self._enabled:
             return None
+        if self._host_returns:
+            return self._acc.copy()
         return self.env.handle.episode_stats_host(want_running=True)[2]
 
     @property
@@ -86,6 +94,8 @@ class RecordEpisodeStatistics(_VectorWrapper):
         if not self._enabled:
             self.env.handle.episode_stats(True)
             self._enabled = True
+        if self._host_returns:
+            self._acc = np.zeros(self.num_envs, dtype=np.float32)   # :91-94
         return self.env.reset(**kwargs)  # the engine zeroes the accumulators of every env it resets (:91-94)
 
     def step(self, action):
@@ -93,8 +103,13 @@ class RecordEpisodeStatistics(_VectorWrapper):
         assert isinstance(infos, dict), (f"`info` dtype is {type(infos)} while supported dtype is `dict`. This may be "
                                          "due to usage of other wrappers in the wrong order.")
         done = terminateds | truncateds
+        if self._host_returns:
+            self._acc += rewards   # float32 array += float64 rewards, like the reference's accumulator
         if done.any():
             r, l = self.env.handle.episode_stats_host()
+            if self._host_returns:
+                r = self._acc.copy()
+                self._acc[done] = 0
             t = round(time.perf_counter() - self.t0, 6)
             # add_vector_episode_statistics (:10-37): float64 arrays of length N, zero where no episode ended
             episode = {"r": np.where(done, r, 0).astype(np.float64), "l": np.where(done, l, 0).astype(np.float64),
