@@ -5,14 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: CartPole-v1, num_envs = 2^20 PER GPU (weak scaling), on-device autoreset,
+Workload = BASELINE.json configs[1]: CartPole-v1, num_envs = 2^20 (BASELINE.json's metric: the 2^20 logical envs are
+partitioned over the N GPUs, --scaling strong, the default; --scaling weak keeps 2^20 envs PER GPU), on-device autoreset,
 Philox-sampled actions, inputs/state resident in HBM.  A "step" is one vector step (SyncVectorEnv.step_wait) of
 every env of the job; EVERY step writes its observations, rewards, terminated/truncated flags and the sampled
 actions to its own slice of [chunk][N] trajectory tensors in HBM (nothing is skipped or overwritten in cache).
 --mode fused (default) runs a chunk of --chunk steps as ONE kernel launch with the env state in registers;
---mode graph / eager launch the same kernel once per step.  At N > 1 every rank steps its shard of the 2^20*N
-logical envs with no data-path collective; the final obs/reward/terminated/truncated tensors of each chunk are
+--mode graph / eager launch the same kernel once per step.  At N > 1 every rank steps its shard of the logical
+envs with no data-path collective; the final obs/reward/terminated/truncated tensors of each --chunk steps are
 all-gathered over RCCL asynchronously (north_star: all-gather only for the final tensors).
+
+Timing.  The timed region is --steps vector steps, bracketed by barrier + synchronize.  When that is shorter than
+--min-timed-ms (a 20-step region is 0.12 ms: below the resolution of a host fence and of the clock ramp) the region is
+REPEATED back to back inside the same bracket, `config.repeats` times `steps` steps, and every reported figure is
+per step of that longer run (`ms_per_step` = bracket / (repeats * steps), `value` = envs * repeats * steps / bracket).
+The launch shape does not depend on --steps: the rollout always advances in --chunk-step launches.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the step kernel against HBM: achieved = algorithmic bytes per
 launch (see algorithmic_bytes_per_env_step) / average launch duration measured with HIP events on
@@ -31,17 +38,18 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ENVS_PER_GPU = 1 << 20
+ENVS_TOTAL = 1 << 20      # BASELINE.json metric: num_envs = 2^20
 ENV_ID = "CartPole-v1"
 S_DIM, O_DIM = 4, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes_per_env_step(mode: str, chunk: int) -> float:
+def algorithmic_bytes_per_env_step(mode: str, chunk: float) -> float:
     """SURVEY.md §8(d).  One launch per step (eager/graph): read {state, action, counter} + write {state, obs,
     reward, 2 flags, counter} at the fp32 contract = 8*S + 4*O + 4 + 4 + 2 + 8 = 66 B for CartPole.  Fused chunk of
     K steps with the state resident in registers: outputs only, 4*O + 4 + 4 + 2, plus the state round trip
-    amortised over the chunk, 16*S/K."""
+    amortised over the chunk, 16*S/K — K being the steps the timed launches REALLY fused (bench passes the measured
+    steps per launch, not the --chunk argument)."""
     if mode == "fused":
         return 4 * O_DIM + 4 + 4 + 2 + 16.0 * S_DIM / chunk
     return 8 * S_DIM + 4 * O_DIM + 4 + 4 + 2 + 8
@@ -56,7 +64,7 @@ def cpu_baseline(sample_steps: int):
 
     from oracle.oracle import OracleVecEnv
 
-    n = ENVS_PER_GPU
+    n = ENVS_TOTAL
 
     def run(envs, steps, offset=0):
         o = OracleVecEnv(0, envs, 500, seed=0, action_seed=1, env_offset=offset)
@@ -94,7 +102,7 @@ def cpu_baseline(sample_steps: int):
 
 def measure_variant(args, ShardedRollout, torch):
     """Same workload, MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32 outputs; short (a tenth of the headline's steps)."""
-    sr = ShardedRollout(ENV_ID, ENVS_PER_GPU, rank=0, world_size=1, device=torch.cuda.current_device(), seed=0,
+    sr = ShardedRollout(ENV_ID, ENVS_TOTAL, rank=0, world_size=1, device=torch.cuda.current_device(), seed=0,
                         action_seed=1, reward_f32=True, action_i32=True)
     eng = sr.engine
     sr.reset(seed=0)
@@ -116,24 +124,33 @@ def measure_variant(args, ShardedRollout, torch):
     ms = ev0.elapsed_time(ev1) / launches
     sr.close()
     b = algorithmic_bytes_per_env_step("fused", args.chunk)
-    steps_s = ENVS_PER_GPU * args.chunk / (ms * 1e-3)
+    steps_s = ENVS_TOTAL * args.chunk / (ms * 1e-3)
     return {"value": steps_s, "unit": "env-steps/s", "us_per_step": ms * 1e3 / args.chunk,
             "outputs": "float32 rewards, int32 actions (26 real B/env-step)", "roofline_frac": steps_s * b / 1e9 / HBM_PEAK_GBS}
 
 
-def read_traffic(mode: str, chunk: int):
-    """HBM bytes per launch of the SAME launch shape from the committed PMC passes (profiles/traffic_*.json,
-    written by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs), or None."""
+def read_traffic(mode: str, steps_per_launch: float, envs: int, compact: bool):
+    """(HBM bytes per launch, source) for THIS launch shape from the committed PMC passes (profiles/traffic_*.json, written by
+    tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; counters cannot be read from inside the
+    process that is being timed), or (None, reason).  The profile's bytes per env-step are only transferable to a launch
+    with the same kernel, output dtypes and steps per launch: anything else reports null instead of a mismatched number."""
+    if compact:
+        return None, "no PMC pass of the compact-output kernel committed"
     pdir = os.path.join(ROOT, "profiles")
     try:
         for name in sorted((f for f in os.listdir(pdir) if f.startswith("traffic_") and f.endswith(".json")), reverse=True):
             with open(os.path.join(pdir, name)) as f:
                 j = json.load(f)
-            if j.get("mode", "eager") == mode and (mode != "fused" or int(j.get("chunk", 0)) == chunk):
-                return float(j["hbm_bytes_per_launch"])
-    except Exception:
-        pass
-    return None
+            if j.get("mode", "eager") != mode:
+                continue
+            if mode == "fused" and abs(float(j.get("chunk", 0)) - steps_per_launch) > 0.5:
+                continue
+            per_env_step = float(j["hbm_bytes_per_launch"]) / float(j["env_steps_per_launch"]) if "env_steps_per_launch" in j \
+                else float(j["hbm_bytes_per_launch"]) / (float(j.get("chunk", 1) if mode == "fused" else 1) * float(j.get("num_envs", ENVS_TOTAL)))
+            return per_env_step * envs * steps_per_launch, f"profiles/{name} (separate rocprofv3 --pmc passes of the same launch shape, scaled per env-step)"
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/traffic_*.json unreadable: {e}"
+    return None, "no committed PMC pass with this launch shape"
 
 
 def main():
@@ -141,12 +158,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20480)
     ap.add_argument("--warmup", type=int, default=2048)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, BASELINE.json's metric): 2^20 logical envs in total, 2^20/N per GPU; weak: 2^20 per GPU")
     ap.add_argument("--chunk", type=int, default=256,
                     help="steps per fused launch = rollout length between all-gathers of the final tensors (a typical "
                          "on-policy horizon; 9.3 GB of trajectory tensors at 2^20 envs)")
     ap.add_argument("--mode", default="fused", choices=["fused", "graph", "eager"],
                     help="fused: one launch per chunk, env state in registers; graph/eager: one launch per step")
     ap.add_argument("--no-graph", action="store_true", help="alias of --mode eager")
+    ap.add_argument("--min-timed-ms", type=float, default=60.0,
+                    help="the timed region is repeated back to back until it is nominally at least this long (see docstring)")
+    ap.add_argument("--repeats", type=int, default=0, help="force the number of repeats of the timed region (0 = from --min-timed-ms)")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="untimed device spin-up before the W warmup steps (DVFS: the GPU needs tens of ms of load to "
                          "reach its sustained clocks; a 2000-step run is 13 ms); 0 disables; reported in config")
@@ -154,7 +176,7 @@ def main():
                     help="float32 rewards + int32 actions (MXV_FLAG_REWARD_F32|ACTION_I32: 26 real bytes per env-step "
                          "instead of 34); off by default: the headline keeps the reference's float64 / int64 dtypes")
     ap.add_argument("--placement-candidates", type=int, default=8,
-                    help="candidate sets of trajectory tensors timed before the run; the fastest is kept (1 disables)")
+                    help="> 1: time that many candidate sets of trajectory tensors before the run and keep the fastest")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary compact-outputs measurement (N=1 only)")
@@ -191,14 +213,16 @@ def main():
 
     from gym_amd.distributed import ShardedRollout
 
-    total_envs = ENVS_PER_GPU * world
+    total_envs = ENVS_TOTAL * (world if args.scaling == "weak" else 1)
+    if total_envs % (4 * world):
+        raise SystemExit(f"{total_envs} envs do not split into {world} shards of a multiple of 4 envs")
+    local_envs = total_envs // world
     sr = ShardedRollout(ENV_ID, total_envs, rank=rank, world_size=world, device=local_rank, seed=0, action_seed=1,
                         reward_f32=args.compact_outputs, action_i32=args.compact_outputs)
     eng = sr.engine
     mode = "eager" if args.no_graph else args.mode
     sr.reset(seed=0)
-    # [chunk][N] obs / reward / flags / actions, reused every chunk.  Their physical placement relative to each other decides
-    # which of three speed modes the write-bound kernel runs in: pick the fastest of a few candidate sets.
+    # [chunk][N] obs / reward / flags / actions, reused every chunk
     placement = None
     if mode == "fused" and args.placement_candidates > 1:
         try:
@@ -209,16 +233,21 @@ def main():
     else:
         traj = eng.trajectory_buffers(args.chunk)
     launches = [0]
+    since_gather = [0]
 
     def run(steps, gather=True):
+        """`steps` vector steps as chunk-step launches; at N > 1 the final tensors are all-gathered (asynchronously, overlapping
+        the next launch) every time --chunk steps have accumulated — the cadence does not depend on how `steps` was cut."""
         done = 0
         while done < steps:
             k = min(args.chunk, steps - done)
             sr.rollout_per_step(k, mode=mode, out=traj, record_actions=True)
             launches[0] += 1 if mode == "fused" else k
-            if world > 1 and gather:
-                sr.gather_async()
             done += k
+            since_gather[0] += k
+            if world > 1 and gather and since_gather[0] >= args.chunk:
+                sr.gather_async()
+                since_gather[0] = 0
 
     def fence():
         sr.synchronize()
@@ -238,53 +267,65 @@ def main():
             sr.synchronize()
             spin_steps += args.chunk
     fence()   # ranks leave placement tuning and spin-up at different times
-    run(args.warmup)
-    if args.steps % args.chunk:
-        run(args.steps % args.chunk)
+    since_gather[0] = 0
+    run(max(args.warmup, 1))
     if world > 1:
         sr.gather()
     fence()
+
+    # repeats of the timed region: a pure function of the arguments (every rank must issue the same launches and collectives)
+    nominal_ms_per_step = 6.0e-3 * local_envs / ENVS_TOTAL
+    repeats = args.repeats if args.repeats > 0 else max(1, int(-(-args.min_timed_ms // max(args.steps * nominal_ms_per_step, 1e-9))))
+    timed_steps = args.steps * repeats
 
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     fence()
     launches[0] = 0
+    since_gather[0] = 0
     t0 = time.perf_counter()
     ev0.record(eng.stream)
-    run(args.steps)
+    run(timed_steps)
     ev1.record(eng.stream)
+    if world > 1:
+        sr.wait_gather()
     fence()
     elapsed = time.perf_counter() - t0
 
     launch_ms = ev0.elapsed_time(ev1) / launches[0]  # avg step-kernel launch duration on the engine's stream
-    steps_per_launch = args.steps / launches[0]
+    steps_per_launch = timed_steps / launches[0]
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     if rank == 0:
-        value = total_envs * args.steps / elapsed
-        b_env_step = algorithmic_bytes_per_env_step(mode, args.chunk)
-        algo_bytes = b_env_step * ENVS_PER_GPU * steps_per_launch
+        value = total_envs * timed_steps / elapsed
+        b_env_step = algorithmic_bytes_per_env_step(mode, steps_per_launch)
+        algo_bytes = b_env_step * local_envs * steps_per_launch
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_source = read_traffic(mode, steps_per_launch, local_envs, args.compact_outputs)
         out = {
-            "metric": "env-steps/sec at num_envs=2^20 per GPU, CartPole-v1",
+            "metric": "env-steps/sec at num_envs=2^20, CartPole-v1" if args.scaling == "strong"
+                      else "env-steps/sec at num_envs=2^20 per GPU, CartPole-v1",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / timed_steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{ENV_ID}, num_envs=2^20 per GPU ({total_envs} total), on-device autoreset + "
+                "workload": f"{ENV_ID}, num_envs={total_envs} ({local_envs} per GPU), on-device autoreset + "
                             "Philox4x32-10 sampled actions, fp64 state (BASELINE.json configs[1])",
-                "num_envs_per_gpu": ENVS_PER_GPU,
+                "num_envs_per_gpu": local_envs,
+                "repeats": repeats,
+                "timed_steps": timed_steps,
+                "timed_region_ms": elapsed * 1e3,
                 "launch": {"fused": f"fused: 1 launch per {args.chunk}-step chunk, env state in registers",
                            "graph": "1 launch per step, hipGraph replay", "eager": "1 launch per step, eager"}[mode],
                 "outputs": "per-step obs/reward/terminated/truncated/actions written to [chunk][N] trajectory tensors"
@@ -293,7 +334,8 @@ def main():
                 "chunk": args.chunk,
                 "placement": placement if placement is not None else "first allocation (no placement tuning)",
                 "spinup": f"{spin_steps} untimed steps ({args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps (clock ramp)",
-                "parallelism": f"env-shard x{world}" + (", async RCCL all-gather of final tensors per chunk" if world > 1 else ""),
+                "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.chunk} steps"
+                                                        if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm",
@@ -302,10 +344,12 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None if args.compact_outputs else read_traffic(mode, args.chunk),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_env_step": b_env_step,
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "env_steps_per_launch": ENVS_PER_GPU * steps_per_launch,
+                "env_steps_per_launch": local_envs * steps_per_launch,
+                "steps_per_launch": steps_per_launch,
                 "avg_launch_us": launch_ms * 1e3,
             },
         }

@@ -114,9 +114,10 @@ def compare_step(tag, got, ref, done_ref, strict):
                                    err_msg=f"{tag}: fp64 state")
 
 
-def run_p1(engine_cls, name, strict):
-    """Single raw-env steps from hand-set states (golden <env>_p1.npz)."""
-    g = load_golden(name, "p1")
+def run_p1(engine_cls, name, strict, kind="p1"):
+    """Single raw-env steps from hand-set states (golden <env>_p1.npz; kind="p1_threshold": Acrobot states whose post-step
+    height sits within ulps of the termination threshold, make_golden_goal.py)."""
+    g = load_golden(name, kind)
     n = len(g["action"])
     eng = engine_cls(name, n, 0, autoreset=False)
     elapsed = np.where(g["fresh"] == 1, 0, 5).astype(np.int32)
@@ -127,7 +128,7 @@ def run_p1(engine_cls, name, strict):
     got = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, final_obs=fin, state=st.T, elapsed=el)
     ref = dict(obs=g["obs"], reward=g["reward"], terminated=g["terminated"].astype(bool),
                truncated=np.zeros(n, dtype=bool), final_obs=g["obs"], state=g["state1"], elapsed=elapsed + 1)
-    compare_step(f"{name} P1", got, ref, done, strict)
+    compare_step(f"{name} {kind.upper()}", got, ref, done, strict)
     return int(term.sum())
 
 

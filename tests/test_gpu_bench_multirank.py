@@ -29,15 +29,36 @@ def _torchrun(script_args, env=None, timeout=240):
     return [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
 
 
-def test_bench_two_ranks_complete_and_report_the_whole_job():
+def test_bench_two_ranks_strong_scaling_is_the_default():
+    """BASELINE.json's metric: 2^20 logical envs in total, partitioned over the ranks (gather included in the timed region)."""
     lines = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "512", "--warmup", "256", "--no-cpu-baseline",
                        "--placement-candidates", "2"])
     assert len(lines) == 1          # rank 0 prints the one line
     out = lines[0]
-    assert out["n_gpus"] == 2 and out["steps"] == 512 and out["scaling"] == "weak"
-    assert out["config"]["num_envs_per_gpu"] == 1 << 20 and "2097152 total" in out["config"]["workload"]
-    assert out["value"] == pytest.approx((2 << 20) * 512 / (out["ms_per_step"] * 1e-3 * 512), rel=1e-6)
+    assert out["n_gpus"] == 2 and out["steps"] == 512 and out["scaling"] == "strong"
+    cfg = out["config"]
+    assert cfg["num_envs_per_gpu"] == 1 << 19 and "num_envs=1048576 (524288 per GPU)" in cfg["workload"]
+    assert cfg["timed_steps"] == cfg["repeats"] * 512
+    assert out["value"] == pytest.approx((1 << 20) / (out["ms_per_step"] * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in out and out["roofline"]["bound"] == "hbm"
+    assert out["roofline"]["env_steps_per_launch"] == pytest.approx((1 << 19) * out["roofline"]["steps_per_launch"])
+
+
+def test_bench_two_ranks_weak_scaling_and_the_drivers_short_run():
+    """--scaling weak keeps 2^20 envs per GPU; `--steps 20 --warmup 5` (what the driver passes) must repeat the 0.1-ms region
+    inside one bracket instead of timing a single launch, with the byte accounting of the launches that really ran."""
+    lines = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--scaling", "weak", "--steps", "20", "--warmup", "5",
+                       "--no-cpu-baseline", "--placement-candidates", "1"])
+    out = lines[0]
+    assert out["scaling"] == "weak" and out["config"]["num_envs_per_gpu"] == 1 << 20 and out["steps"] == 20
+    cfg, roof = out["config"], out["roofline"]
+    assert cfg["repeats"] >= 100 and cfg["timed_steps"] == 20 * cfg["repeats"] and cfg["timed_region_ms"] > 20.0
+    assert roof["steps_per_launch"] > 200         # chunk-step launches, not 20-step ones
+    b = 4 * 4 + 4 + 4 + 2 + 16.0 * 4 / roof["steps_per_launch"]
+    assert roof["algorithmic_bytes_per_env_step"] == pytest.approx(b)
+    assert roof["algorithmic_bytes_per_launch"] == pytest.approx(b * (1 << 20) * roof["steps_per_launch"])
+    assert roof["traffic"] is None or roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 2.0
+    assert out["value"] == pytest.approx((2 << 20) / (out["ms_per_step"] * 1e-3), rel=1e-6)
 
 
 def test_config_bench_dist_two_ranks_complete():

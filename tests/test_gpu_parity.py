@@ -25,6 +25,33 @@ def test_golden_trajectories(name, tag):
     run_p2(HipEngine, name, tag, strict=False)
 
 
+@pytest.mark.parametrize("name", ["Acrobot", "MountainCar", "MountainCarContinuous"])
+def test_golden_goal_reaching_trajectories(name):
+    """Terminations (and the autoresets after them) INSIDE trajectories of the envs a random policy never finishes
+    (tests/golden/make_golden_goal.py: the reference's SyncVectorEnv under a scripted goal-reaching policy)."""
+    assert run_p2(HipEngine, name, "goal", strict=False) >= 8
+
+
+def test_acrobot_termination_threshold_states():
+    """Acrobot_p1_threshold.npz: post-step height -cos(t1) - cos(t2 + t1) within 4e-15 of 1.0 (acrobot.py:235), found by
+    bisection on the reference.  The device rebuilds cos(t2 + t1) by angle addition: its mask must still be the reference's."""
+    from helpers import load_golden
+
+    g = load_golden("Acrobot", "p1_threshold")
+    try:
+        nterm = run_p1(HipEngine, "Acrobot", strict=False, kind="p1_threshold")
+    except AssertionError:
+        n = len(g["action"])
+        eng = HipEngine("Acrobot", n, 0, autoreset=False)
+        eng.set_state(g["state0"].T, np.full(n, 5, np.int32))
+        term = eng.step(g["action"])[2]
+        bad = np.flatnonzero(term != g["terminated"].astype(bool))
+        ulp = np.abs(g["margin"][bad]) / 2.0 ** -52
+        raise AssertionError(f"{bad.size} of {n} masks differ; |height - 1| of those in ulps of 1.0: "
+                             f"{np.sort(ulp)[:20]} ... max {ulp.max() if bad.size else 0}")
+    assert 1000 < nterm < 3000
+
+
 def test_known_answers_survey_appendix_b():
     from test_oracle_golden import kat_check
 
