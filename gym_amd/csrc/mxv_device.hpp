@@ -127,7 +127,8 @@ __device__ __forceinline__ U4 philox4x32_10_vkey(U4 c, uint32_t k0, uint32_t k1)
 
 constexpr uint32_t kStreamAction = 1u;
 constexpr uint32_t kStreamReset = 2u;
-constexpr uint32_t kStreamStepNoise = 4u;  // (3 = the tabular engine's transition stream, mxv_tab.hip)
+constexpr uint32_t kStreamStepNoise = 4u;  // (3 = the tabular engine's transition stream, 5 = Blackjack's draw stream)
+constexpr uint32_t kStreamActionBits = 6u; // Discrete(2) action stream of the classic engine: one bit per step
 
 // u in (0,1): (w + 0.5) * 2^-32, exact in fp64.
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
@@ -148,6 +149,21 @@ __device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r)
     c.x = (uint32_t)t;
     c.y = (uint32_t)(t >> 32);
     c.z = r;
+    c.w = (kStreamReset << 28);
+    return philox4x32_10_vkey(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// Reset stream of the classic-control engine: the k-th reset of an env since its seeding (explicit reset() or the autoreset
+// inside a vector step; k = 0, 1, 2, ...) draws from ctr = (k, 0, 0, 2 << 28) under the env's own 64-bit seed — the order in
+// which ONE env's generator is consumed in the reference (each sub-env owns a generator that advances once per reset of that
+// env, gym/envs/classic_control/cartpole.py:202), not a function of the global step index.  Because the draw of an env's NEXT
+// reset is known as soon as the current episode starts, the fused rollout computes it off the critical path, for many envs
+// per Philox call (rollout_kernel_v3).
+__device__ __forceinline__ U4 episode_reset_words(uint64_t seed, uint32_t k) {
+    U4 c;
+    c.x = k;
+    c.y = 0u;
+    c.z = 0u;
     c.w = (kStreamReset << 28);
     return philox4x32_10_vkey(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
@@ -639,10 +655,39 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
     }
 };
 
-// Action of one env from its stream word (see include/mxv.h, RNG contract).
+// Action stream of the classic-control engine (see include/mxv.h, RNG contract).  One Philox call serves the group of 4
+// consecutive global envs g = env >> 2; which STEPS it serves depends on the action space:
+//   Discrete(2)  (CartPole): a uniform action is one random bit, so a call is indexed by the 32-step block b = t >> 5
+//                (stream kStreamActionBits) and step t takes bit t & 31 of the env's word — exactly uniform (every bit of a
+//                Philox word is), and 1/32 of the Philox work of a word per step;
+//   Discrete(3), Box: one word per env and step (stream kStreamAction): (word * n) >> 32 resp. float32(lo + (hi - lo) * u01).
+template <int ENV>
+constexpr bool action_bits() { return Env<ENV>::NA == 2; }
+template <int ENV>
+constexpr int action_unit_shift() { return action_bits<ENV>() ? 5 : 0; }   // steps per call = 1 << shift
+
+template <int ENV>
+__device__ __forceinline__ U4 action_unit_counter(uint64_t unit, uint64_t g) {
+    U4 c;
+    c.x = (uint32_t)g;
+    c.y = (uint32_t)(g >> 32);
+    c.z = (uint32_t)unit;
+    c.w = ((uint32_t)(unit >> 32) & 0x0fffffffu) | ((action_bits<ENV>() ? kStreamActionBits : kStreamAction) << 28);
+    return c;
+}
+// words of group g for the call that covers step t
+template <int ENV>
+__device__ __forceinline__ U4 env_action_words(uint64_t action_seed, uint64_t t, uint64_t g) {
+    return philox4x32_10(action_unit_counter<ENV>(t >> action_unit_shift<ENV>(), g), (uint32_t)action_seed,
+                         (uint32_t)(action_seed >> 32));
+}
+
 template <int ENV, int DEF>
-__device__ __forceinline__ void action_from_word(const Par<DEF> &P, uint32_t w, int &ai, float &af) {
-    if constexpr (Env<ENV>::NA > 0) {
+__device__ __forceinline__ void action_from_word(const Par<DEF> &P, uint32_t w, uint64_t t, int &ai, float &af) {
+    if constexpr (action_bits<ENV>()) {
+        ai = (int)((w >> ((uint32_t)t & 31u)) & 1u);
+        af = 0.0f;
+    } else if constexpr (Env<ENV>::NA > 0) {
         ai = (int)(((uint64_t)w * (uint32_t)Env<ENV>::NA) >> 32);
         af = 0.0f;
     } else if constexpr (ENV == MXV_PENDULUM) {

@@ -103,6 +103,10 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
 #pragma unroll
     for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[valid[j] ? env_of(j) : 0] : 0.0f;
+    // reset ordinals (index of each env's next draw from the reset stream); only the autoreset path needs them
+    uint32_t ep[E], ep_in[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) ep[j] = ep_in[j] = autoreset ? a.episodes[valid[j] ? env_of(j) : 0] : 0u;
     __shared__ uint32_t sw[CONSEC ? 4 : TILE];
 
     const int nsteps = MULTI ? a.K : 1;  // MULTI = false: the plain step() launch, no loop-carried bookkeeping
@@ -120,22 +124,22 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
                 for (int j0 = 0; j0 < E; j0 += 4) {
                     const uint64_t ge = a.env0 + (uint64_t)env_of(j0);
-                    const U4 w = action_words(a.action_seed, t, ge >> 2);
+                    const U4 w = env_action_words<ENV>(a.action_seed, t, ge >> 2);
 #pragma unroll
                     for (int q = 0; q < 4 && j0 + q < E; ++q)
-                        action_from_word<ENV, DEF>(P.at(valid[j0 + q] ? env_of(j0 + q) : 0), pick_word(w, (uint32_t)((ge + q) & 3)), ai[j0 + q], af[j0 + q]);
+                        action_from_word<ENV, DEF>(P.at(valid[j0 + q] ? env_of(j0 + q) : 0), pick_word(w, (uint32_t)((ge + q) & 3)), t, ai[j0 + q], af[j0 + q]);
                 }
             } else {
                 // thread c computes the 4 words of group (env0 + tile0)/4 + c; LDS hands them to the owning lanes
                 if (MULTI && step > 0) __syncthreads();
                 for (int c = tid; c < TILE / 4; c += kBlock) {
                     const uint64_t g = ((a.env0 + (uint64_t)tile0) >> 2) + (uint64_t)c;
-                    const U4 w = action_words(a.action_seed, t, g);
+                    const U4 w = env_action_words<ENV>(a.action_seed, t, g);
                     reinterpret_cast<uint4 *>(sw)[c] = make_uint4(w.x, w.y, w.z, w.w);
                 }
                 __syncthreads();
 #pragma unroll
-                for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P.at(valid[j] ? env_of(j) : 0), sw[j * kBlock + tid], ai[j], af[j]);
+                for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P.at(valid[j] ? env_of(j) : 0), sw[j * kBlock + tid], t, ai[j], af[j]);
             }
             if (a.actions_out != nullptr) {
 #pragma unroll
@@ -219,17 +223,19 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
             if (jsel >= 0) {
                 const int64_t e = CONSEC ? tile0 + (int64_t)tid * E + jsel : tile0 + (int64_t)jsel * kBlock + tid;
                 bool v = false;
+                uint32_t k_reset = 0;
                 float cur[O];
 #pragma unroll
                 for (int j = 0; j < E; ++j)
                     if (j == jsel) {
                         v = valid[j];
+                        k_reset = ep[j];
 #pragma unroll
                         for (int k = 0; k < O; ++k) cur[k] = obs[j][k];
                     }
                 if (a.final_obs != nullptr && v) store_obs<O>(a.final_obs, so + e, cur);  // info["final_observation"]
                 const uint64_t seed = a.seeds ? landed(a.seeds[v ? e : 0]) : a.base_seed + a.env0 + (uint64_t)e;
-                const U4 w = reset_words(seed, t, 0u);
+                const U4 w = episode_reset_words(seed, k_reset);
                 double ns[S], naux[AUXN];
                 float nobs[O];
                 EV::reset(w, a.b0, a.b1, ns);
@@ -244,6 +250,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
                         for (int k = 0; k < O; ++k) obs[j][k] = nobs[k];
                         el[j] = 0;  // time_limit.py:67
+                        ep[j] += 1;
                         pend[j] = false;
                     }
             }
@@ -274,27 +281,32 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + e] = s[j][k];
         a.elapsed[e] = el[j];
+        if (ep[j] != ep_in[j]) a.episodes[e] = ep[j];
         if (a.ep_acc) a.ep_acc[e] = er[j];
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// rollout_kernel<ENV, DEF, E>: the sampled-action + autoreset fast path (mxv_step_sampled, mxv_rollout FUSED/GRAPH/
-// EAGER), a.K vector steps per launch with the env state in registers.
+// rollout_kernel_v3<ENV, DEF, E, SAFE, OUT>: the sampled-action + autoreset fast path (mxv_rollout FUSED), a.K vector steps
+// per launch with the env state in registers.
 //
-// Workgroup = ONE wave64 owning a tile of E*64 consecutive envs (lane L owns envs tile0 + j*64 + L): no s_barrier
-// anywhere, cross-lane traffic goes through a few KiB of LDS that only this wave touches (LDS operations of one
-// wave execute in order).  All Philox work is scheduled onto the 64 lanes of AT MOST ONE masked call per wave-step:
-//   * the envs that finished step t are compacted with ballot/mbcnt (about 6 of 128 CartPole envs per step) and their
-//     reset draws take the top lanes; the lane that draws also builds the new fp64 state AND its float32 observation,
-//     so the owner only copies them back: the reset arithmetic (Pendulum: a full-range sincos) is paid once per
-//     wave-step, not once per env chain;
-//   * every remaining block of 16E lanes draws the action words of one FUTURE step (one call = 4 consecutive envs)
-//     into a ring of 64/(16E) steps.  With nothing to reset (Pendulum, Acrobot, MountainCar between truncations) a
-//     wave therefore runs Philox once every 64/(16E) steps with all 64 lanes busy, and skips the call otherwise.
-// More finished envs than free lanes (e.g. every Pendulum env truncating at step 200) are handled by extra passes
-// of all 64 lanes.  Output addressing: the per-step base of every array is a scalar; lanes add a 32-bit byte offset
-// fixed for the whole launch, so the loop holds no 64-bit vector address arithmetic.
+// Workgroup = ONE wave64 owning a tile of E*64 consecutive envs (lane L owns envs tile0 + j*64 + L): no s_barrier anywhere;
+// every global access of a wave is a dense, line-aligned burst.  Output addressing: the per-step base of every array is a
+// scalar; lanes add a 32-bit byte offset fixed for the whole launch, so the loop holds no 64-bit vector address arithmetic.
+//
+// What the RNG contract (include/mxv.h) buys here: nothing random sits on the per-step critical path.
+//   * Resets.  The draw of an env's NEXT reset is a function of (its seed, its reset ordinal), known as soon as the current
+//     episode starts.  Every lane keeps, per env slot, a ready-made reset entry — new fp64 state, carried aux values and the
+//     float32 observation — in a lane-private LDS slot (LDS as a register spill area: no other lane reads it).  An env that
+//     finishes step t copies its entry (three ds_read_b128 for CartPole) and marks the slot empty; empty slots are refilled by
+//     look-ahead passes, one Philox call of the lanes that need one, every MXV_ROLLOUT_PASS_PERIOD steps per slot.  CartPole
+//     (~6 of a wave's 128 envs finish per step): 0.25 masked Philox calls + reset arithmetic per wave-step instead of 1.0;
+//     envs that only truncate (Pendulum at step 200, ...): one call per episode.  An env that finishes again before its
+//     slot was refilled (TimeLimit of a few steps) forces the pass early — any schedule gives the same bits, the words
+//     are pure functions of (seed, ordinal).
+//   * Actions.  Discrete(2): one random BIT per step; a full-wave Philox call (64 lanes x 4 words) holds the bits of
+//     64/(16E) blocks of 32 steps for the tile: one call per 64 (E = 2) steps.  Discrete(3) / Box: one word per step, a
+//     full-wave call serves 64/(16E) steps; the words wait in an LDS ring and the next step's word is read a step ahead.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kWave = 64;
 
@@ -305,24 +317,25 @@ struct alignas(16) ResetEntry {
     float o[O];
 };
 template <int S, int O>
-struct alignas(16) ResetEntry<S, O, 0> {  // no carried values: CartPole's entry is 48 B, 7.5 KiB of LDS per workgroup
+struct alignas(16) ResetEntry<S, O, 0> {  // no carried values: CartPole's entry is 48 B, 6 KiB of LDS per workgroup
     double s[S];
     float o[O];
 };
 
 template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
-__global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v3(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     constexpr int TILE = E * kWave;
-    constexpr int NACT = TILE / 4;        // lanes that draw the action words of ONE step
-    constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
-    static_assert(NACT < kWave, "E must be < 4: the merged call needs free lanes");
+    constexpr int NACT = TILE / 4;        // lanes that draw the action words of ONE unit (step, or 32-step block) for the tile
+    constexpr int H = kWave / NACT;       // units one full-wave call produces = slots of the LDS ring
+    constexpr int SH = action_unit_shift<ENV>();
+    constexpr int PERIOD = MXV_ROLLOUT_PASS_PERIOD;
+    static_assert(NACT <= kWave && (PERIOD & (PERIOD - 1)) == 0 && PERIOD >= E, "E <= 4; pass period a power of two >= E");
     constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
     using Entry = ResetEntry<S, O, EV::AUX>;
-    __shared__ uint32_t lds_act[H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
-    __shared__ uint32_t lds_q[TILE];      // compacted list of finished envs (tile-local index)
-    __shared__ Entry lds_res[TILE];       // their new state + observation
+    __shared__ uint32_t lds_act[H * TILE];  // slot (q % H) holds the action words of unit u0 + q
+    __shared__ Entry lds_res[TILE];         // lane-private: the ready-made next reset of env slot j * 64 + lane
 
     const int lane = threadIdx.x;
     const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
@@ -341,6 +354,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 
     double s[E][S], aux[E][AUXN];
     int32_t el[E];
+    uint32_t ep[E];  // reset ordinal = index of the env's next draw from the reset stream
     bool valid[E];
     uint32_t le[E];  // env index inside the shard (fits 32 bits: mxv_create caps num_envs)
 #pragma unroll
@@ -351,6 +365,7 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
         el[j] = a.elapsed[le[j]];
+        ep[j] = a.episodes[le[j]];
         EV::prime(s[j], aux[j]);
     }
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
@@ -359,13 +374,43 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
     float *p_epr = FULL ? nullptr : a.ep_return_out;
     int32_t *p_epl = FULL ? nullptr : a.ep_length_out;
 
-    // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
-    int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
-    if (lane < filled * NACT) {
-        const U4 w = action_words(a.action_seed, t0 + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT));
+    // ---- action words: units u0 .. u0 + H - 1 now, the following H units whenever the ring runs dry ----
+    const uint64_t u0 = t0 >> SH;
+    auto draw_units = [&](uint64_t q) {  // all 64 lanes: lane L draws group L % NACT of unit u0 + q + L / NACT
+        const U4 w = philox4x32_10(action_unit_counter<ENV>(u0 + q + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT)),
+                                   (uint32_t)a.action_seed, (uint32_t)(a.action_seed >> 32));
         reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    uint32_t word[E];
+    draw_units(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < E; ++j) word[j] = lds_act[j * kWave + lane];
+
+    // ---- reset entries: need[j] = this lane's slot j holds no entry (an i1 per lane: lives in an SGPR pair) ----
+    bool need[E];
+    auto fill_entries = [&](int j) {  // one Philox call of the lanes whose slot j is empty
+        if (need[j]) {
+            const uint64_t seed = a.seeds ? landed(a.seeds[le[j]]) : a.base_seed + a.env0 + (uint64_t)le[j];
+            const U4 w = episode_reset_words(seed, ep[j]);
+            Entry r;
+            EV::reset(w, a.b0, a.b1, r.s);
+            if constexpr (EV::AUX > 0) {
+                EV::observe(r.s, r.o, r.x);
+            } else {
+                double none[1];
+                EV::observe(r.s, r.o, none);
+            }
+            lds_res[j * kWave + lane] = r;
+        }
+        need[j] = false;
+    };
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        need[j] = valid[j];
+        fill_entries(j);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     // per-step output bases (scalars)
     char *p_obs = reinterpret_cast<char *>(a.obs);
@@ -385,10 +430,8 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
         // ---- this step's actions ----
         int ai[E];
         float af[E];
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int j = 0; j < E; ++j)
-            action_from_word<ENV, DEF>(P, lds_act[(step % H) * TILE + j * kWave + lane], ai[j], af[j]);
+        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], t, ai[j], af[j]);
         if (FULL || p_act != nullptr) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -427,100 +470,10 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
                 }
             }
         }
-
-        // ---- compact the finished envs of the wave (sync_vector_env.py:152-156) ----
-        uint32_t slot[E];
-        uint32_t total = 0;
+        // outputs that do not depend on the reset go out first: reward, flags, info["final_observation"]
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const uint64_t m = __ballot(pend[j]);
-            slot[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            total += (uint32_t)__popcll(m);
-            if (pend[j]) {
-                lds_q[slot[j]] = (uint32_t)(j * kWave + lane);
-                if (!FULL && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);  // info["final_observation"]
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-
-        // ---- at most ONE masked Philox call: this step's reset draws + action words of future steps ----
-        auto draw_reset = [&](uint32_t i, const U4 &w) {
-            Entry r;
-            EV::reset(w, a.b0, a.b1, r.s);
-            if constexpr (EV::AUX > 0) {
-                EV::observe(r.s, r.o, r.x);
-            } else {
-                double none[1];
-                EV::observe(r.s, r.o, none);
-            }
-            lds_res[i] = r;
-        };
-        auto reset_key = [&](uint32_t i) -> uint64_t {
-            const uint32_t q = lds_q[i];
-            const uint32_t e = (uint32_t)tile0 + q;
-            return a.seeds ? landed(a.seeds[e]) : a.base_seed + a.env0 + (uint64_t)e;
-        };
-        // wave-uniform schedule.  Ring capacity: step's own slot was consumed above, so steps (step, step + H] fit.
-        const int horizon = (a.K < step + 1 + H) ? a.K : step + 1 + H;
-        const int room = horizon - filled;                               // steps that may be drawn now
-        const bool must = (filled == step + 1) && (step + 1 < a.K);      // the next step has no action words yet
-        const int keep = must ? NACT : 0;
-        const int rlanes = (int)total < kWave - keep ? (int)total : kWave - keep;  // reset draws in this call
-        int nfit = (kWave - rlanes) / NACT;                              // future steps that fit beside them
-        nfit = nfit < room ? nfit : room;
-        if (rlanes == 0 && !must) nfit = 0;                              // nothing forces a call: skip it
-        if (rlanes > 0 || nfit > 0) {
-            const bool is_act = lane < nfit * NACT;
-            const int i = lane - (kWave - rlanes);                       // reset slot of the top lanes
-            if (is_act || i >= 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                U4 c;
-                uint64_t key;
-                const int q = filled + lane / NACT;                      // launch-relative step drawn by an action lane
-                if (is_act) {
-                    const uint64_t g = group0 + (uint64_t)(lane % NACT), tq = t0 + (uint64_t)q;
-                    c.x = (uint32_t)g; c.y = (uint32_t)(g >> 32); c.z = (uint32_t)tq;
-                    c.w = ((uint32_t)(tq >> 32) & 0x0fffffffu) | (kStreamAction << 28);
-                    key = a.action_seed;
-                } else {
-                    c.x = (uint32_t)t; c.y = (uint32_t)(t >> 32); c.z = 0u; c.w = (kStreamReset << 28);
-                    key = reset_key((uint32_t)i);
-                }
-                const U4 w = philox4x32_10_vkey(c, (uint32_t)key, (uint32_t)(key >> 32));
-                if (is_act)
-                    reinterpret_cast<uint4 *>(lds_act)[(q % H) * NACT + lane % NACT] = make_uint4(w.x, w.y, w.z, w.w);
-                else
-                    draw_reset((uint32_t)i, w);
-            }
-            filled += nfit;
-        }
-        for (uint32_t base = (uint32_t)rlanes; base < total; base += kWave) {  // rare: more finished envs than lanes
-            const uint32_t i = base + (uint32_t)lane;
-            if (i < total) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                draw_reset(i, reset_words(reset_key(i), t, 0u));
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-
-        // ---- owners take the new state + observation; this step's outputs ----
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            if (pend[j]) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const Entry r = lds_res[slot[j]];
-#pragma unroll
-                for (int k = 0; k < S; ++k) s[j][k] = r.s[k];
-                if constexpr (EV::AUX > 0) {
-#pragma unroll
-                    for (int k = 0; k < EV::AUX; ++k) aux[j][k] = r.x[k];
-                }
-#pragma unroll
-                for (int k = 0; k < O; ++k) obs[j][k] = r.o[k];
-                el[j] = 0;  // time_limit.py:67
-            }
             if (!valid[j]) continue;
-            store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
             if (FULL || p_rew != nullptr) {
                 char *q = p_rew + le[j] * rew_b;
                 if (rew_f32)
@@ -530,7 +483,49 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
             }
             if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
             if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
+            if (!FULL && pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);
         }
+
+        // ---- autoreset (sync_vector_env.py:152-156): finished envs take their ready-made entry ----
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (__any(pend[j])) {
+                if (__any(pend[j] && need[j])) fill_entries(j);  // rare: finished again before the look-ahead pass came round
+                if (pend[j]) {
+                    const Entry r = lds_res[j * kWave + lane];
+#pragma unroll
+                    for (int k = 0; k < S; ++k) s[j][k] = r.s[k];
+                    if constexpr (EV::AUX > 0) {
+#pragma unroll
+                        for (int k = 0; k < EV::AUX; ++k) aux[j][k] = r.x[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < O; ++k) obs[j][k] = r.o[k];
+                    el[j] = 0;  // time_limit.py:67
+                    ep[j] += 1;
+                    need[j] = true;
+                }
+            }
+        }
+
+        // ---- next step's action words (LDS latency hides behind the observation stores) ----
+        if (step + 1 < a.K) {
+            const uint64_t q0 = (t >> SH) - u0, q1 = ((t + 1) >> SH) - u0;
+            if (SH == 0 || q1 != q0) {
+                if (q1 % H == 0) draw_units(q1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int j = 0; j < E; ++j) word[j] = lds_act[(uint32_t)(q1 % H) * TILE + j * kWave + lane];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
+
+        // ---- look-ahead pass: refill the empty reset slots j of this wave, every PERIOD steps per slot ----
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if ((step & (PERIOD - 1)) == j * (PERIOD / E) && __any(need[j])) fill_entries(j);
 
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
@@ -549,12 +544,14 @@ __global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel(c
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
         a.elapsed[le[j]] = el[j];
+        a.episodes[le[j]] = ep[j];
         if (ep_on) a.ep_acc[le[j]] = er[j];
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// rollout_kernel_v2: same contract, tile and store pattern as rollout_kernel, with the cross-lane hand-offs removed.
+// rollout_kernel_v2 (A/B alternative of rollout_kernel_v3 for the envs with word-per-step actions; MXV_ROLLOUT_IMPL = 2):
+// same contract, tile and store pattern, resets drawn INSIDE the step by the owning lane.
 // A finished env is reset by ITS OWN lane (key and counter come from registers; the new state, aux values and observation
 // never leave the lane), and the lanes without a finished env draw the action words of future steps, ranked among
 // themselves with mbcnt: the k-th free lane draws group k % NACT of step filled + k / NACT.  Which lane evaluates
@@ -572,6 +569,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
     constexpr int NACT = TILE / 4;        // lanes that draw the action words of ONE step
     constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
     static_assert(NACT <= kWave, "E must be <= 4");
+    static_assert(!action_bits<ENV>(), "bit-sliced Discrete(2) actions are served by rollout_kernel_v3 only");
     constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
     // WAVES waves per workgroup, each an independent tile with a private ring (no barrier anywhere): a workgroup only groups
     // WAVES consecutive tiles onto one CU so that their stores of a step land next to each other
@@ -598,6 +596,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
     bool valid[E];
     uint32_t le[E];  // env index inside the shard (fits 32 bits: mxv_create caps num_envs)
     uint64_t seed[E];
+    uint32_t ep[E];  // reset ordinal = index of the env's next draw from the reset stream
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int64_t e = tile0 + j * kWave + lane;
@@ -606,6 +605,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
         el[j] = a.elapsed[le[j]];
+        ep[j] = a.episodes[le[j]];
         seed[j] = a.seeds ? landed(a.seeds[le[j]]) : a.base_seed + a.env0 + (uint64_t)le[j];
         EV::prime(s[j], aux[j]);
     }
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
     // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
     int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
     if (lane < filled * NACT) {
-        const U4 w = action_words(a.action_seed, t0 + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT));
+        const U4 w = env_action_words<ENV>(a.action_seed, t0 + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT));
         reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
         int ai[E];
         float af[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], ai[j], af[j]);
+        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], t, ai[j], af[j]);
         if (FULL || p_act != nullptr) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -729,10 +729,14 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
                     c.w = ((uint32_t)(tq >> 32) & 0x0fffffffu) | (kStreamAction << 28);
                     key = a.action_seed;
                 } else {
-                    c.x = (uint32_t)t; c.y = (uint32_t)(t >> 32); c.z = 0u; c.w = (kStreamReset << 28);
                     key = seed[0];
+                    uint32_t kk = ep[0];
 #pragma unroll
-                    for (int j = 1; j < E; ++j) key = (j == jsel) ? seed[j] : key;
+                    for (int j = 1; j < E; ++j) {
+                        key = (j == jsel) ? seed[j] : key;
+                        kk = (j == jsel) ? ep[j] : kk;
+                    }
+                    c.x = kk; c.y = 0u; c.z = 0u; c.w = (kStreamReset << 28);
                 }
                 const U4 w = philox4x32_10_vkey(c, (uint32_t)key, (uint32_t)(key >> 32));
                 if (is_act) {
@@ -752,6 +756,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
 #pragma unroll
                             for (int k = 0; k < O; ++k) obs[j][k] = nobs[k];
                             el[j] = 0;  // time_limit.py:67
+                            ep[j] += 1;
                             pend[j] = false;
                         }
                 }
@@ -787,6 +792,7 @@ __global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
         a.elapsed[le[j]] = el[j];
+        a.episodes[le[j]] = ep[j];
         if (ep_on) a.ep_acc[le[j]] = er[j];
     }
 }
@@ -800,7 +806,9 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
     if (e >= a.n) return;
     if (a.mask != nullptr && a.mask[e] == 0) return;
     const uint64_t seed = a.seeds ? landed(a.seeds[e]) : a.base_seed + a.env0 + (uint64_t)e;
-    const U4 w = reset_words(seed, a.t, a.r);
+    const uint32_t k = a.episodes[e];  // this env's reset ordinal since seeding
+    a.episodes[e] = k + 1u;
+    const U4 w = episode_reset_words(seed, k);
     double s[S];
     EV::reset(w, a.b0, a.b1, s);
 #pragma unroll
@@ -823,7 +831,7 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
     if (c * 4 >= a.n) return;
     const Par<DEF> P(a.P, a.params_pe, a.n);
     const uint64_t t = a.t + (a.t_dev ? *a.t_dev : 0);
-    const U4 w = action_words(a.action_seed, t, (a.env0 >> 2) + (uint64_t)c);
+    const U4 w = env_action_words<ENV>(a.action_seed, t, (a.env0 >> 2) + (uint64_t)c);
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -831,7 +839,7 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
         if (e >= a.n) break;
         int ai;
         float af;
-        action_from_word<ENV, DEF>(P.at(e), ws[q], ai, af);
+        action_from_word<ENV, DEF>(P.at(e), ws[q], t, ai, af);
         if constexpr (NA > 0) {
             if (a.flags & MXV_FLAG_ACTION_I32)
                 static_cast<int32_t *>(a.actions_out)[e] = ai;
@@ -845,18 +853,10 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
 
 __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
-// rollout_kernel (resets compacted through LDS) or rollout_kernel_v2 (owner-lane resets, prefetched action words), per env
-// kind from the same-box A/B in profiles/r01h_rollout_v2_ab.txt: v2 wins 2-4 % for Pendulum / MountainCar /
-// MountainCarContinuous, v1 1-2 % for CartPole and Acrobot.  MXV_ROLLOUT_V2 = 0 / 1 forces one of them (tuning builds).
+// rollout_kernel_v3 by default; MXV_ROLLOUT_IMPL = 2 builds the envs with word-per-step actions on rollout_kernel_v2 (A/B hook).
 template <int ENV>
 constexpr bool use_rollout_v2() {
-#if MXV_ROLLOUT_V2 == 0
-    return false;
-#elif MXV_ROLLOUT_V2 == 1
-    return true;
-#else
-    return ENV == MXV_PENDULUM || ENV == MXV_MOUNTAINCAR || ENV == MXV_MOUNTAINCAR_CONT;
-#endif
+    return MXV_ROLLOUT_IMPL == 2 && !action_bits<ENV>();
 }
 template <int ENV, bool DEF, int ER, bool SAFE, int OUT>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
@@ -864,7 +864,7 @@ void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
         hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE, OUT>), dim3((grid + MXV_ROLLOUT_V2_WAVES - 1) / MXV_ROLLOUT_V2_WAVES),
                            dim3(kWave * MXV_ROLLOUT_V2_WAVES), 0, stream, a);
     else
-        hipLaunchKernelGGL((rollout_kernel<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
+        hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
 }
 template <int ENV, bool DEF, int ER, bool SAFE>
 void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {

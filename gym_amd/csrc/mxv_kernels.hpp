@@ -11,6 +11,7 @@ namespace mxv {
 struct StepArgs {
     double *state;         // [S][N] fp64, struct-of-arrays
     int32_t *elapsed;      // [N] TimeLimit counters
+    uint32_t *episodes;    // [N] resets each env has had since seeding = index of its next draw from the reset stream
     const void *actions;   // int64/int32/float32 [N]; nullptr -> draw from the Philox action stream
     void *actions_out;     // optional record of the sampled actions
     float *obs;            // [N][O]
@@ -45,6 +46,7 @@ struct StepArgs {
 struct ResetArgs {
     double *state;
     int32_t *elapsed;
+    uint32_t *episodes;    // [N] reset ordinals (read: index of this draw; written back + 1)
     float *obs;            // may be nullptr
     const uint8_t *mask;   // may be nullptr (all)
     const uint64_t *seeds; // may be nullptr
@@ -52,8 +54,6 @@ struct ResetArgs {
     int64_t n;
     uint64_t env0;
     uint64_t base_seed;
-    uint64_t t;
-    uint32_t r;
     double b0, b1;
 };
 
@@ -108,10 +108,14 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_MIN_WAVES
 #define MXV_MIN_WAVES 1
 #endif
-// 1: rollout_kernel_v2 (owner-lane resets, prefetched action words); 0: rollout_kernel (compacted resets through LDS);
-// 2 (default): chosen per env kind (use_rollout_v2 in mxv_kernels.hip)
-#ifndef MXV_ROLLOUT_V2
-#define MXV_ROLLOUT_V2 2
+// fused-rollout implementation: 3 (default) = rollout_kernel_v3 (next-reset entries precomputed off the critical path, bit-sliced
+// Discrete(2) actions); 2 = rollout_kernel_v2 (owner-lane resets inside the step; not for Discrete(2) envs) — A/B hook
+#ifndef MXV_ROLLOUT_IMPL
+#define MXV_ROLLOUT_IMPL 3
+#endif
+// steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
+#ifndef MXV_ROLLOUT_PASS_PERIOD
+#define MXV_ROLLOUT_PASS_PERIOD 8
 #endif
 // waves (= independent tiles) per workgroup of rollout_kernel_v2
 #ifndef MXV_ROLLOUT_V2_WAVES
