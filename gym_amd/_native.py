@@ -34,7 +34,7 @@ EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
-    "mxv_set_counters", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -128,6 +128,8 @@ def _load():
         "mxv_set_state": ([vp, vp, vp], C.c_int),
         "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
+        "mxv_get_episodes": ([vp, vp], C.c_int),
+        "mxv_set_episodes": ([vp, vp], C.c_int),
         "mxv_get_params": ([vp, vp], C.c_int),
         "mxv_set_params": ([vp, vp], C.c_int),
         "mxv_set_params_per_env": ([vp, vp], C.c_int),
@@ -417,6 +419,18 @@ class Handle:
     def set_counters(self, t: int, r: int):
         self._check(lib.mxv_set_counters(self._h, int(t), int(r)))
 
+    def get_episodes(self) -> np.ndarray:
+        """Per-env reset ordinals (uint32 [N]): how many resets each env has had since seeding = the position of its reset
+        stream (RNG contract, include/mxv.h)."""
+        ep = np.empty(self.num_envs, dtype=np.uint32)
+        self._check(lib.mxv_get_episodes(self._h, ep.ctypes.data))
+        return ep
+
+    def set_episodes(self, episodes):
+        ep = np.ascontiguousarray(episodes, dtype=np.uint32)
+        assert ep.shape == (self.num_envs,)
+        self._check(lib.mxv_set_episodes(self._h, ep.ctypes.data))
+
     def get_params(self) -> np.ndarray:
         p = np.zeros(MAX_PARAMS, dtype=np.float64)
         self._check(lib.mxv_get_params(self._h, p.ctypes.data))
@@ -458,7 +472,7 @@ class Handle:
         snap = dict(env_id=self.env_id, num_envs=self.num_envs, max_episode_steps=self.max_episode_steps,
                     env_offset=self.env_offset, flags=self.flags, base_seed=self._base_seed,
                     per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
-                    action_seed=self._action_seed, state=state, elapsed=elapsed, t=t, r=r,
+                    action_seed=self._action_seed, state=state, elapsed=elapsed, t=t, r=r, episodes=self.get_episodes(),
                     params=self.get_params_per_env() if self._per_env_params else self.get_params(),
                     per_env_params=self._per_env_params, stats_on=self._stats_on, running_returns=None)
         if self._stats_on:
@@ -480,6 +494,7 @@ class Handle:
             self.set_running_returns(snap["running_returns"])
         self.set_state(snap["state"], snap["elapsed"])
         self.set_counters(snap["t"], snap["r"])
+        self.set_episodes(snap["episodes"])
 
     def set_episode_outputs(self, ep_return_dev=None, ep_length_dev=None):
         self._check(lib.mxv_set_episode_outputs(self._h, _ptr(ep_return_dev), _ptr(ep_length_dev)))

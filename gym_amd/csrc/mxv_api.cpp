@@ -68,6 +68,7 @@ struct mxv_handle {
     bool own_stream = false;
     double *state = nullptr;
     int32_t *elapsed = nullptr;
+    uint32_t *episodes = nullptr;  // [N] resets of each env since seeding = index of its next draw from the reset stream
     uint64_t *seeds = nullptr;  // optional per-env seeds
     uint64_t *t_dev = nullptr;  // device-resident step index for graph replay
     int32_t *err = nullptr;     // latched kernel error word
@@ -160,6 +161,7 @@ int check_latched(mxv_handle *h) {
 void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.state = h->state;
     a.elapsed = h->elapsed;
+    a.episodes = h->episodes;
     a.seeds = h->seeds;
     a.t_dev = nullptr;
     a.err = h->err;
@@ -226,6 +228,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     ResetArgs a{};
     a.state = h->state;
     a.elapsed = h->elapsed;
+    a.episodes = h->episodes;
     a.obs = obs_dev;
     a.mask = mask_dev;
     a.seeds = h->seeds;
@@ -233,8 +236,6 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     a.n = h->cfg.num_envs;
     a.env0 = (uint64_t)h->cfg.env_offset;
     a.base_seed = h->base_seed;
-    a.t = h->t;
-    a.r = h->r;
     a.b0 = b[0];
     a.b1 = b[1];
     MXV_HIP(h, launch_reset(h->cfg.env_id, a, h->stream));
@@ -361,10 +362,12 @@ int mxv_create(const mxv_config *cfg, mxv_handle **out) {
     h->own_stream = true;
     MXV_CREATE_HIP(hipMalloc((void **)&h->state, n * h->S * sizeof(double)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->elapsed, n * sizeof(int32_t)));
+    MXV_CREATE_HIP(hipMalloc((void **)&h->episodes, n * sizeof(uint32_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->t_dev, sizeof(uint64_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->err, sizeof(int32_t)));
     MXV_CREATE_HIP(hipMemsetAsync(h->state, 0, n * h->S * sizeof(double), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->elapsed, 0, n * sizeof(int32_t), h->stream));
+    MXV_CREATE_HIP(hipMemsetAsync(h->episodes, 0, n * sizeof(uint32_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->t_dev, 0, sizeof(uint64_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
     MXV_CREATE_HIP(hipStreamSynchronize(h->stream));
@@ -379,7 +382,7 @@ int mxv_destroy(mxv_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_graphs(h);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
-    void *bufs[] = {h->state, h->elapsed, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
+    void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -395,6 +398,8 @@ int mxv_seed(mxv_handle *h, uint64_t base_seed, const uint64_t *per_env_seeds_ho
     h->base_seed = base_seed;
     h->t = 0;
     h->r = 0;
+    // a (re)seeded env starts its reset stream from the beginning: reset ordinals back to 0
+    MXV_HIP(h, hipMemsetAsync(h->episodes, 0, (size_t)h->cfg.num_envs * sizeof(uint32_t), h->stream));
     if (per_env_seeds_host) {
         const size_t bytes = (size_t)h->cfg.num_envs * sizeof(uint64_t);
         if (!h->seeds) MXV_HIP(h, hipMalloc((void **)&h->seeds, bytes));
@@ -746,6 +751,24 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
     MXV_CHECK_HANDLE(h);
     h->t = t;
     h->r = r;
+    return MXV_OK;
+}
+
+int mxv_get_episodes(mxv_handle *h, uint32_t *episodes_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!episodes_host) return fail(h, MXV_ERR_INVALID_ARG, "episodes pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipMemcpyAsync(episodes_host, h->episodes, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!episodes_host) return fail(h, MXV_ERR_INVALID_ARG, "episodes pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipMemcpyAsync(h->episodes, episodes_host, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
     return MXV_OK;
 }
 

@@ -133,7 +133,9 @@ constexpr uint32_t kStreamActionBits = 6u; // Discrete(2) action stream of the c
 // u in (0,1): (w + 0.5) * 2^-32, exact in fp64.
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
 
-// Action-stream words of the 4 envs of group g (global env indices 4g..4g+3) at vector step t.
+// Word-per-step action stream: words of the 4 envs of group g (global env indices 4g..4g+3) at vector step t.  Used as is by
+// the tabular and Blackjack engines (mxv_tab.hip, mxv_bj.hip); the classic-control kernels go through env_action_words<ENV>
+// below, which is this stream for Discrete(3) / Box and the bit-sliced stream for Discrete(2).
 __device__ __forceinline__ U4 action_words(uint64_t action_seed, uint64_t t, uint64_t g) {
     U4 c;
     c.x = (uint32_t)g;
@@ -143,7 +145,7 @@ __device__ __forceinline__ U4 action_words(uint64_t action_seed, uint64_t t, uin
     return philox4x32_10(c, (uint32_t)action_seed, (uint32_t)(action_seed >> 32));
 }
 
-// Reset-stream words of one env (seed = that env's 64-bit seed) for the reset at step t, ordinal r.
+// Step-indexed reset words (explicit resets of the tabular and Blackjack engines: step t, ordinal r of the reset call).
 __device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r) {
     U4 c;
     c.x = (uint32_t)t;

@@ -13,6 +13,8 @@
 // while E*(S+1) loads per lane are in flight.  No MFMA: this is element-wise fp64 physics.
 // LDS is used only to transpose the Philox action words: one Philox call yields the words of 4
 // consecutive envs (group g = env>>2), which belong to 4 different lanes under the mapping above.
+#include <type_traits>
+
 #include "mxv_kernels.hpp"
 
 namespace mxv {
@@ -309,6 +311,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 //     full-wave call serves 64/(16E) steps; the words wait in an LDS ring and the next step's word is read a step ahead.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kWave = 64;
+constexpr int kSimds = 1024;  // 256 CUs x 4 SIMDs
 
 template <int S, int O, int AUX>
 struct alignas(16) ResetEntry {
@@ -322,8 +325,18 @@ struct alignas(16) ResetEntry<S, O, 0> {  // no carried values: CartPole's entry
     float o[O];
 };
 
+// Waves per SIMD the register allocator must leave room for.  2^20 envs at two envs per lane are 8192 single-wave workgroups
+// = exactly two rounds of 4 waves per SIMD: 128 VGPRs is the budget of the default-parameter kernels (the few values the
+// allocator then parks in scratch are stored before and reloaded after the K-step loop, never inside it; checked in the ISA).
+// The rarely launched instantiations (runtime parameters; CartPole right after a state injection) keep the allocator's choice.
+template <int ENV, bool DEF, bool SAFE>
+constexpr int rollout_min_waves() {
+    if (MXV_ROLLOUT_MIN_WAVES > 1) return MXV_ROLLOUT_MIN_WAVES;
+    return (!DEF || (ENV == MXV_CARTPOLE && SAFE)) ? 1 : 4;
+}
+
 template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
-__global__ void __launch_bounds__(kWave, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v3(const StepArgs a) {
+__global__ void __launch_bounds__(kWave, (rollout_min_waves<ENV, DEF, SAFE>())) rollout_kernel_v3(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     constexpr int TILE = E * kWave;
@@ -887,18 +900,29 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
     if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise) {
-        constexpr int ER = rollout_envs_per_lane(ENV);
-        const int64_t rtile = (int64_t)ER * kWave;
-        const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);
         bool fast = false;
         if constexpr (ENV == MXV_CARTPOLE) fast = def && !a.state_injected;  // see Env<MXV_CARTPOLE>::step, SAFE
-        if (!def) {
-            launch_rollout<ENV, false, ER, true>(rgrid, stream, a);
-        } else if (fast) {
-            if constexpr (ENV == MXV_CARTPOLE) launch_rollout<ENV, true, ER, false>(rgrid, stream, a);
-        } else {
-            launch_rollout<ENV, true, ER, true>(rgrid, stream, a);
-        }
+        auto go = [&](auto er_tag) {
+            constexpr int ER = decltype(er_tag)::value;
+            const int64_t rtile = (int64_t)ER * kWave;
+            const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);
+            if (!def) {
+                launch_rollout<ENV, false, ER, true>(rgrid, stream, a);
+            } else if (fast) {
+                if constexpr (ENV == MXV_CARTPOLE) launch_rollout<ENV, true, ER, false>(rgrid, stream, a);
+            } else {
+                launch_rollout<ENV, true, ER, true>(rgrid, stream, a);
+            }
+        };
+        // Two envs per lane (the tuned choice of the light envs: two independent chains of ILP) only pay when the shard fills
+        // the chip: below one E = 2 wave per SIMD (1024 SIMDs x 128 envs) the work is latency-bound and one env per lane
+        // puts twice as many waves on it (profiles/r02a_shard_sweep.jsonl: 0.76 vs 1.05 us per step at 2^16 CartPole envs,
+        // equal at 2^17) — the shard sizes of an 8-GPU strong-scaling or mixed-batch job.
+        constexpr int ER = rollout_envs_per_lane(ENV);
+        if (ER > 1 && a.n < (int64_t)kSimds * ER * kWave && MXV_ROLLOUT_SMALL_E1)
+            go(std::integral_constant<int, 1>{});
+        else
+            go(std::integral_constant<int, ER>{});
         return hipGetLastError();
     }
     constexpr int E = envs_per_lane(ENV);

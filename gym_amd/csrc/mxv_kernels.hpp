@@ -113,6 +113,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_IMPL
 #define MXV_ROLLOUT_IMPL 3
 #endif
+// 1: shards smaller than one E-env-per-lane wave per SIMD run the fused rollout with one env per lane (A/B hook)
+#ifndef MXV_ROLLOUT_SMALL_E1
+#define MXV_ROLLOUT_SMALL_E1 1
+#endif
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8

@@ -154,6 +154,7 @@ class DeviceRollout:
 
         st, el = self.handle.get_state()
         t, r = self.handle.get_counters()
+        episodes = self.handle.get_episodes()
         running = self.handle.episode_stats_host(want_running=True)[2] if self.handle._stats_on else None
         per_step = self.num_envs * (4 * self.O * (2 if want_final else 1) + self.reward.element_size()
                                     + self.actions.element_size() + 2)
@@ -200,6 +201,7 @@ class DeviceRollout:
         del sets, traj
         self.handle.set_state(st, el)
         self.handle.set_counters(t, r)
+        self.handle.set_episodes(episodes)
         if running is not None:
             self.handle.set_running_returns(running)
         torch.cuda.empty_cache()

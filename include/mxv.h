@@ -25,13 +25,18 @@
  * batch_space(Discrete) = MultiDiscrete, gym/vector/utils/spaces.py:53-68) or int32 with
  * MXV_FLAG_ACTION_I32; Box actions are float32 [N] (= [N][1]).
  *
- * RNG contract (Philox4x32-10, counter based, no RNG state in memory) — see DESIGN.md §RNG:
- *   actions : key = action_seed, ctr = (g_lo, g_hi, t_lo, (t_hi & 0x0fffffff) | 1<<28),
- *             g = global_env >> 2, word = out[global_env & 3];
- *             Discrete(n): (word*n)>>32 ; Box(lo,hi): float32(lo + (hi-lo)*(word+0.5)*2^-32)
- *   resets  : key = per-env seed (base_seed + global_env unless explicit), ctr = (t_lo, t_hi, r, 2<<28),
- *             r = 0 for an autoreset inside vector step t, r>=1 = ordinal of explicit reset calls.
- * t = index of the vector step since the last mxv_seed().
+ * RNG contract (Philox4x32-10, counter based) — see DESIGN.md §RNG.  g = global_env >> 2, word = out[global_env & 3]:
+ *   actions, Discrete(3) / Box : key = action_seed, ctr = (g_lo, g_hi, t_lo, (t_hi & 0x0fffffff) | 1<<28), one word per env and
+ *             step t;  Discrete(n): (word*n)>>32 ;  Box(lo,hi): float32(lo + (hi-lo)*(word+0.5)*2^-32)
+ *   actions, Discrete(2)       : a uniform action is one random bit: key = action_seed, ctr = (g_lo, g_hi, b_lo, (b_hi &
+ *             0x0fffffff) | 6<<28) with b = t >> 5 (one call per block of 32 steps), action = (word >> (t & 31)) & 1
+ *   resets  : key = per-env seed (base_seed + global_env unless explicit), ctr = (k, 0, 0, 2<<28), k = 0, 1, 2, ... = how many
+ *             resets (explicit reset() or autoreset inside a vector step) this env has had since the last mxv_seed(): each env
+ *             consumes its own reset stream in order, like the per-env generator of the reference (cartpole.py:202).  The
+ *             ordinals are device state (uint32 [N]): mxv_get_episodes / mxv_set_episodes for checkpoints.
+ *             uniform(low, high) = low + (high-low)*(word+0.5)*2^-32 in fp64, one word per state component.
+ * t = index of the vector step since the last mxv_seed().  Streams use GLOBAL env indices: any sharding of one logical vector env
+ * over several handles / GPUs draws the same numbers.
  */
 #ifndef MXV_H
 #define MXV_H
@@ -117,7 +122,7 @@ const char *mxv_last_error(const mxv_handle *h);
 
 /* -- seeding (Env.reset(seed=...), gym/core.py:149-151; SyncVectorEnv seeds env i with seed+i) -- */
 /* per_env_seeds_host: NULL -> env i uses base_seed + env_offset + i; else N explicit 64-bit seeds.
- * Restarts the step index t and the explicit-reset ordinal r at 0. */
+ * Restarts the step index t and every env's reset ordinal at 0. */
 int mxv_seed(mxv_handle *h, uint64_t base_seed, const uint64_t *per_env_seeds_host);
 int mxv_seed_actions(mxv_handle *h, uint64_t action_seed);
 
@@ -182,9 +187,13 @@ int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host);
 /* state_soa_host: double[S][N]; elapsed_host: int32[N]; either may be NULL.  Synchronises. */
 int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host);
 int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *elapsed_host);
-/* step index t / explicit-reset ordinal r (restore with mxv_set_counters when resuming). */
+/* step index t (position of the action stream) / number of explicit reset calls since seeding (informational) — restore with
+ * mxv_set_counters when resuming. */
 int mxv_get_counters(mxv_handle *h, uint64_t *t, uint32_t *r);
 int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r);
+/* per-env reset ordinals (position of each env's reset stream, see RNG contract): uint32[N].  Synchronises. */
+int mxv_get_episodes(mxv_handle *h, uint32_t *episodes_host);
+int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host);
 
 /* -- physics parameters (VectorEnv.get_attr/set_attr/call, sync_vector_env.py:171-214) ----------- */
 /* One value per attribute for all sub-envs (set_attr with a scalar or a list of equal values).  Default values run
@@ -264,9 +273,9 @@ int mxv_norm_reward_apply(mxv_norm *nm, int32_t K, const void *reward_dev, int32
  *    cum_prob = np.cumsum of the list's probabilities, padded with -1; prob / next_state / reward / terminated per
  *    transition (padding ignored); initial_cum[S] = np.cumsum(initial_state_distrib).  Observations and actions are
  *    int64 [N] (MultiDiscrete, gym/vector/utils/spaces.py:53-68), rewards float64, info["prob"] float64.
- *    RNG: actions from the Philox action stream above; transitions from a Philox4x32-10 call keyed by the env's seed, ctr =
+ *    RNG: actions from the word-per-step Philox action stream above (ctr stream id 1, Discrete(A): (word*A)>>32); transitions from a Philox4x32-10 call keyed by the env's seed, ctr =
  *    (b_lo, b_hi, 0, 3 << 28), b = t >> 1: words (x, y) serve step 2b, (z, w) step 2b+1 — first the transition's uniform, then
- *    the uniform of an autoreset inside that step; explicit resets use the reset stream above (word x);
+ *    the uniform of an autoreset inside that step; explicit resets: key = env seed, ctr = (t_lo, t_hi, r, 2<<28), r = ordinal of the reset call (word x);
  *    uniform = (word + 0.5) * 2^-32. -------------------------------- */
 typedef struct mxv_tab mxv_tab;
 typedef struct mxv_tab_config {
@@ -323,8 +332,9 @@ int mxv_tab_set_stream(mxv_tab *h, void *stream);
  *    Discrete(11), Discrete(2)) batched: three MultiDiscrete arrays); actions int64 {0 stick, 1 hit}; reward float64.
  *    Cards: card = deck[(word * 13) >> 32], deck = [1..10, 10, 10, 10] (:14-19), words from the Philox draw stream (key = env
  *    seed, ctr = (t_lo, t_hi, call, 5 << 28), four cards per call, consumed in the reference's order: the hit card or the
- *    dealer's cards, then on termination the new dealer hand, then the new player hand); explicit reset: the reset stream
- *    (words x, y dealer; z, w player).  cards_*: optional injected draws, int8 [N][MXV_BJ_MAX_DRAWS] per step (resp. [N][4]
+ *    dealer's cards, then on termination the new dealer hand, then the new player hand); explicit reset: key = env
+ *    seed, ctr = (t_lo, t_hi, r, 2 << 28), r = ordinal of the reset call (words x, y dealer; z, w player); actions: the
+ *    word-per-step action stream (stream id 1).  cards_*: optional injected draws, int8 [N][MXV_BJ_MAX_DRAWS] per step (resp. [N][4]
  *    for a reset) in consumption order — the values np_random.choice(deck) returned, for bit-exact replays. ------------------ */
 #define MXV_BJ_MAX_DRAWS 24
 typedef struct mxv_bj mxv_bj;

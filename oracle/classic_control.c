@@ -393,20 +393,23 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 
 #define ORC_STREAM_ACTION 1u
 #define ORC_STREAM_RESET 2u
+#define ORC_STREAM_ACTION_BITS 6u
 
 /* u in (0,1): (w + 0.5) * 2^-32, exact in fp64 */
 static double u01(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
 
 /* RNG contract, action stream (mirrors MultiDiscrete.sample gym/spaces/multi_discrete.py:123
- * `floor(random*nvec)` and Box.sample gym/spaces/box.py:216-222 `uniform(low, high).astype(f32)`):
- *   key = action_seed (lo, hi); counter = (g_lo, g_hi, t_lo, (t_hi & 0x0fffffff) | 1<<28),
- *   g = env >> 2, word = out[env & 3];
- *   Discrete(n): a = (word * n) >> 32 ;  Box(low, high): a = float32(low + (high-low) * u01(word)). */
-static uint32_t action_word(uint64_t action_seed, uint64_t t, uint64_t env) {
+ * `floor(random*nvec)` and Box.sample gym/spaces/box.py:216-222 `uniform(low, high).astype(f32)`), g = env >> 2,
+ * word = out[env & 3], key = action_seed (lo, hi):
+ *   Discrete(3) / Box: counter = (g_lo, g_hi, t_lo, (t_hi & 0x0fffffff) | 1<<28), one word per env and step;
+ *                      Discrete(n): a = (word * n) >> 32 ;  Box(low, high): a = float32(low + (high-low) * u01(word));
+ *   Discrete(2)      : one random bit per step: counter = (g_lo, g_hi, b_lo, (b_hi & 0x0fffffff) | 6<<28), b = t >> 5,
+ *                      a = (word >> (t & 31)) & 1. */
+static uint32_t action_word(uint64_t action_seed, uint64_t unit, uint32_t stream, uint64_t env) {
     uint32_t ctr[4], key[2], out[4];
     uint64_t g = env >> 2;
     ctr[0] = (uint32_t)g; ctr[1] = (uint32_t)(g >> 32);
-    ctr[2] = (uint32_t)t; ctr[3] = ((uint32_t)(t >> 32) & 0x0fffffffu) | (ORC_STREAM_ACTION << 28);
+    ctr[2] = (uint32_t)unit; ctr[3] = ((uint32_t)(unit >> 32) & 0x0fffffffu) | (stream << 28);
     key[0] = (uint32_t)action_seed; key[1] = (uint32_t)(action_seed >> 32);
     orc_philox4x32_10(ctr, key, out);
     return out[env & 3];
@@ -418,9 +421,10 @@ void orc_sample_actions(int env_id, int64_t n, uint64_t env0, uint64_t action_se
                         const double *P, int64_t *out_i64, float *out_f32) {
     int64_t i;
     for (i = 0; i < n; ++i) {
-        uint32_t w = action_word(action_seed, t, env0 + (uint64_t)i);
+        uint32_t w = (env_id == ORC_CARTPOLE) ? action_word(action_seed, t >> 5, ORC_STREAM_ACTION_BITS, env0 + (uint64_t)i)
+                                              : action_word(action_seed, t, ORC_STREAM_ACTION, env0 + (uint64_t)i);
         switch (env_id) {
-        case ORC_CARTPOLE: out_i64[i] = (int64_t)(((uint64_t)w * 2u) >> 32); break;
+        case ORC_CARTPOLE: out_i64[i] = (int64_t)((w >> (uint32_t)(t & 31u)) & 1u); break;
         case ORC_ACROBOT:
         case ORC_MOUNTAINCAR: out_i64[i] = (int64_t)(((uint64_t)w * 3u) >> 32); break;
         case ORC_PENDULUM: {
@@ -439,15 +443,14 @@ void orc_sample_actions(int env_id, int64_t n, uint64_t env0, uint64_t action_se
 }
 
 /* RNG contract, reset stream: key = per-env seed (lo, hi);
- *   counter = (t_lo, t_hi, r, 2<<28): t = vector-step index at which the (auto)reset happens,
- *   r = 0 for an autoreset inside step t, r >= 1 = ordinal of the explicit reset() call since seeding.
+ *   counter = (k, 0, 0, 2<<28): k = 0, 1, 2, ... = how many resets (explicit reset() or autoreset inside a vector step) this
+ *   env has had since it was seeded — each env consumes its own stream in order, like its np_random in the reference.
  *   state_k = low_k + (high_k - low_k) * u01(word_k)  — np_random.uniform(low, high) restated
  *   (cartpole.py:202, pendulum.py:154, acrobot.py:188-190 (+ .astype(float32)),
  *    mountain_car.py:160 and continuous_mountain_car.py:182 (velocity = 0)). */
-static void reset_state(int env_id, uint64_t seed, uint64_t t, uint32_t r, const double *bounds,
-                        double *s) {
+static void reset_state(int env_id, uint64_t seed, uint32_t k, const double *bounds, double *s) {
     uint32_t ctr[4], key[2], w[4];
-    ctr[0] = (uint32_t)t; ctr[1] = (uint32_t)(t >> 32); ctr[2] = r; ctr[3] = (ORC_STREAM_RESET << 28);
+    ctr[0] = k; ctr[1] = 0u; ctr[2] = 0u; ctr[3] = (ORC_STREAM_RESET << 28);
     key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
     orc_philox4x32_10(ctr, key, w);
     switch (env_id) {
@@ -497,7 +500,7 @@ void orc_default_reset_bounds(int env_id, double *bounds) {
  * gym/vector/sync_vector_env.py:90-129 + TimeLimit.reset gym/wrappers/time_limit.py:58-68.
  * seeds: per-env 64-bit seeds (NULL → base_seed + env0 + i, sync_vector_env.py:106-107). */
 void orc_vec_reset(int env_id, int64_t n, uint64_t env0, const uint64_t *seeds, uint64_t base_seed,
-                   uint64_t t, uint32_t r, const double *bounds, const uint8_t *mask, double *state,
+                   uint32_t *episodes, const double *bounds, const uint8_t *mask, double *state,
                    int32_t *elapsed, float *obs) {
     int S = ORC_STATE_DIM[env_id], O = ORC_OBS_DIM[env_id];
     int64_t i;
@@ -506,7 +509,8 @@ void orc_vec_reset(int env_id, int64_t n, uint64_t env0, const uint64_t *seeds, 
         double s[4];
         if (mask && !mask[i]) continue;
         uint64_t seed = seeds ? seeds[i] : base_seed + env0 + (uint64_t)i;
-        reset_state(env_id, seed, t, r, bounds, s);
+        reset_state(env_id, seed, episodes[i], bounds, s);
+        episodes[i] += 1;
         for (k = 0; k < S; ++k) state[(int64_t)k * n + i] = s[k];
         elapsed[i] = 0;
         if (obs) env_obs(env_id, s, obs + i * O);
@@ -527,13 +531,13 @@ static void env_step(int env_id, const double *P, double *s, int fresh, int64_t 
 
 /* SyncVectorEnv.step_wait — gym/vector/sync_vector_env.py:135-169 with TimeLimit.step
  * gym/wrappers/time_limit.py:50-54 inlined per sub-env.
- *   autoreset != 0: on terminated|truncated the env is reset from the Philox reset stream
- *     (counter (t, 0)), obs row = reset obs, final_obs row = terminal obs, final_mask = 1.
+ *   autoreset != 0: on terminated|truncated the env is reset from its Philox reset stream
+ *     (draw number episodes[i], then episodes[i] += 1), obs row = reset obs, final_obs row = terminal obs, final_mask = 1.
  *   autoreset == 0: dynamics + TimeLimit only (used by "external reset" trajectory tests).
  * Returns the number of envs whose discrete action was out of range (those envs are not
  * stepped): Discrete.contains assert, cartpole.py:131-132 / mountain_car.py:128-130. */
 int64_t orc_vec_step(int env_id, int64_t n, uint64_t env0, const double *P, int max_episode_steps,
-                     int autoreset, const uint64_t *seeds, uint64_t base_seed, uint64_t t,
+                     int autoreset, const uint64_t *seeds, uint64_t base_seed, uint64_t t, uint32_t *episodes,
                      const double *bounds, const int64_t *act_i64, const float *act_f32,
                      double *state, int32_t *elapsed, float *obs, double *reward,
                      uint8_t *terminated, uint8_t *truncated, float *final_obs,
@@ -576,7 +580,8 @@ int64_t orc_vec_step(int env_id, int64_t n, uint64_t env0, const double *P, int 
             if (final_obs) for (k = 0; k < O; ++k) final_obs[i * O + k] = o[k];
             if (final_mask) final_mask[i] = 1;
             uint64_t seed = seeds ? seeds[i] : base_seed + env0 + (uint64_t)i;
-            reset_state(env_id, seed, t, 0u, bounds, s);
+            reset_state(env_id, seed, episodes[i], bounds, s);
+            episodes[i] += 1;
             elapsed[i] = 0;
             env_obs(env_id, s, o);
         }
@@ -590,7 +595,7 @@ int64_t orc_vec_step(int env_id, int64_t n, uint64_t env0, const double *P, int 
  * summary (sum of rewards, number of dones) and leaves state/elapsed advanced.  Used as the CPU
  * baseline leg of bench.py and by the full-size property tests.  Scratch buffers are caller-owned. */
 void orc_rollout(int env_id, int64_t n, uint64_t env0, const double *P, int max_episode_steps,
-                 uint64_t base_seed, uint64_t action_seed, uint64_t t0, int K, const double *bounds,
+                 uint64_t base_seed, uint64_t action_seed, uint64_t t0, uint32_t *episodes, int K, const double *bounds,
                  double *state, int32_t *elapsed, int64_t *act_i64, float *act_f32, float *obs,
                  double *reward, uint8_t *terminated, uint8_t *truncated, double *sum_reward,
                  int64_t *num_done) {
@@ -601,7 +606,7 @@ void orc_rollout(int env_id, int64_t n, uint64_t env0, const double *P, int max_
     for (step = 0; step < K; ++step) {
         uint64_t t = t0 + (uint64_t)step;
         orc_sample_actions(env_id, n, env0, action_seed, t, P, act_i64, act_f32);
-        orc_vec_step(env_id, n, env0, P, max_episode_steps, 1, NULL, base_seed, t, bounds, act_i64,
+        orc_vec_step(env_id, n, env0, P, max_episode_steps, 1, NULL, base_seed, t, episodes, bounds, act_i64,
                      act_f32, state, elapsed, obs, reward, terminated, truncated, NULL, NULL);
         for (i = 0; i < n; ++i) {
             sr += reward[i];

@@ -43,11 +43,11 @@ def lib():
         L.orc_default_reset_bounds.argtypes = [C.c_int, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_sample_actions.argtypes = [C.c_int, i64, u64, u64, u64, vp, vp, vp]
-        L.orc_vec_reset.argtypes = [C.c_int, i64, u64, vp, u64, u64, u32, vp, vp, vp, vp, vp]
-        L.orc_vec_step.argtypes = [C.c_int, i64, u64, vp, C.c_int, C.c_int, vp, u64, u64, vp, vp, vp,
+        L.orc_vec_reset.argtypes = [C.c_int, i64, u64, vp, u64, vp, vp, vp, vp, vp, vp]
+        L.orc_vec_step.argtypes = [C.c_int, i64, u64, vp, C.c_int, C.c_int, vp, u64, u64, vp, vp, vp, vp,
                                    vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_vec_step.restype = i64
-        L.orc_rollout.argtypes = [C.c_int, i64, u64, vp, C.c_int, u64, u64, u64, C.c_int, vp, vp, vp,
+        L.orc_rollout.argtypes = [C.c_int, i64, u64, vp, C.c_int, u64, u64, u64, vp, C.c_int, vp, vp, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_norm_obs_batches.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, C.c_int, vp]
         L.orc_norm_reward_steps.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, i64, i64, C.c_int, vp]
@@ -112,7 +112,8 @@ class OracleVecEnv:
         self.state = np.zeros((self.S, self.n), dtype=np.float64)
         self.elapsed = np.zeros(self.n, dtype=np.int32)
         self.t = 0  # vector-step index since seeding
-        self.r = 0  # explicit reset ordinal since seeding
+        self.r = 0  # explicit reset calls since seeding (informational)
+        self.episodes = np.zeros(self.n, dtype=np.uint32)  # per-env reset ordinals = position of each env's reset stream
         self.discrete = self.env_id in DISCRETE
 
     # -- RNG-contract helpers ---------------------------------------------------------
@@ -133,11 +134,12 @@ class OracleVecEnv:
                 self.seeds = np.asarray(seed, dtype=np.uint64).copy()
             self.t = 0
             self.r = 0
+            self.episodes[:] = 0
         self.r += 1
         b = self.bounds if bounds is None else np.asarray(bounds, dtype=np.float64)
         obs = np.zeros((self.n, self.O), dtype=np.float32)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        lib().orc_vec_reset(self.env_id, self.n, self.env0, _p(self.seeds), self.base_seed, self.t, self.r,
+        lib().orc_vec_reset(self.env_id, self.n, self.env0, _p(self.seeds), self.base_seed, _p(self.episodes),
                             _p(b), _p(m), _p(self.state), _p(self.elapsed), _p(obs))
         return obs
 
@@ -156,7 +158,7 @@ class OracleVecEnv:
             af = np.ascontiguousarray(actions, dtype=np.float32).reshape(n)
             ai = None
         bad = lib().orc_vec_step(self.env_id, n, self.env0, _p(self.P), self.max_episode_steps,
-                                 int(self.autoreset), _p(self.seeds), self.base_seed, self.t, _p(self.bounds),
+                                 int(self.autoreset), _p(self.seeds), self.base_seed, self.t, _p(self.episodes), _p(self.bounds),
                                  _p(ai), _p(af), _p(self.state), _p(self.elapsed), _p(obs), _p(reward),
                                  _p(term), _p(trunc), _p(final_obs), _p(final_mask))
         if bad:
@@ -176,7 +178,7 @@ class OracleVecEnv:
         sr = C.c_double(0.0)
         nd = C.c_int64(0)
         lib().orc_rollout(self.env_id, n, self.env0, _p(self.P), self.max_episode_steps, self.base_seed,
-                          self.action_seed, self.t, int(K), _p(self.bounds), _p(self.state), _p(self.elapsed),
+                          self.action_seed, self.t, _p(self.episodes), int(K), _p(self.bounds), _p(self.state), _p(self.elapsed),
                           _p(ai), _p(af), _p(obs), _p(reward), _p(term), _p(trunc), C.byref(sr), C.byref(nd))
         self.t += int(K)
         return sr.value, nd.value, obs, reward, term.astype(bool), trunc.astype(bool)

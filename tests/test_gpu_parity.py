@@ -292,6 +292,65 @@ def test_fused_rollout_equals_single_steps_and_oracle(name):
         r.close()
 
 
+@pytest.mark.parametrize("limit", [1, 2, 5])
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_fused_rollout_with_tiny_time_limits_equals_single_steps(name, limit):
+    """rollout_kernel_v3 keeps every env's NEXT reset ready in a lane-private LDS slot, refilled by look-ahead passes every few
+    steps; an env that finishes again before its pass came round (TimeLimit of 1, 2, 5 steps) must force the refill early.
+    Several launches back to back (slots are rebuilt at every kernel entry), starting at a step index that is not a multiple
+    of 32 (Discrete(2) bit blocks) and crossing several blocks / ring refills; n is not a multiple of the tile."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    n = 2111
+    a = DeviceRollout(GYM_IDS[name], n, seed=31, action_seed=32, env_offset=256, max_episode_steps=limit)
+    b = DeviceRollout(GYM_IDS[name], n, seed=31, action_seed=32, env_offset=256, max_episode_steps=limit)
+    a.reset(seed=31), b.reset(seed=31)
+    for K in (7, 70, 33):
+        fa = a.rollout_per_step(K, mode="fused")
+        fb = b.rollout_per_step(K, mode="eager")
+        a.synchronize(), b.synchronize()
+        for key in ("obs", "reward", "terminated", "truncated", "actions"):
+            assert torch.equal(fa[key], fb[key]), (K, key)
+        assert fa["truncated"].sum().item() >= n * (K // limit - 1)
+    for x, y in zip(a.handle.get_state(), b.handle.get_state()):
+        assert np.array_equal(x, y)
+    ea, eb = a.handle.get_episodes(), b.handle.get_episodes()
+    assert np.array_equal(ea, eb) and ea.min() >= 1 + 110 // limit - 1
+    a.close(), b.close()
+
+
+def test_reset_ordinals_follow_each_env_and_survive_a_checkpoint():
+    """RNG contract: env i's k-th reset draws Philox(seed_i, (k, 0, 0, 2<<28)).  The ordinals are device state: they advance
+    with explicit resets (masked ones only for the masked envs) and autoresets, restart at mxv_seed, and travel with
+    snapshot()/restore()."""
+    from gym_amd import _native
+
+    n = 512
+    h = _native.Handle(ENV_IDS["CartPole"], n, 4, seed=5, action_seed=6)
+    h.reset_host()
+    assert np.all(h.get_episodes() == 1)
+    mask = (np.arange(n) % 4 == 0).astype(np.uint8)
+    h.reset_host(mask=mask)
+    assert np.array_equal(h.get_episodes(), 1 + mask)
+    for _ in range(8):                       # TimeLimit 4: everything autoresets at steps 4 and 8 (and some terminate earlier)
+        h.step_host(np.zeros(n, np.int64))
+    ep = h.get_episodes()
+    assert np.all(ep >= 3 + mask)
+    snap = h.snapshot()
+    g = _native.Handle(ENV_IDS["CartPole"], n, 4, seed=99, action_seed=98)
+    g.restore(snap)
+    assert np.array_equal(g.get_episodes(), ep)
+    for _ in range(9):
+        o1 = h.step_host(np.ones(n, np.int64))
+        o2 = g.step_host(np.ones(n, np.int64))
+        assert all(np.array_equal(x, y) for x, y in zip(o1, o2))
+    h.seed(5)
+    assert np.all(h.get_episodes() == 0)
+    h.close(), g.close()
+
+
 def test_acrobot_torque_noise_matches_oracle_twin():
     """acrobot.py:202-205 `torque += np_random.uniform(-torque_noise_max, torque_noise_max)`: the noise comes from the
     engine's Philox step-noise stream (one word per env-step, keyed by the env's seed), so device and oracle twin stay

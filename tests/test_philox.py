@@ -33,6 +33,47 @@ def test_oracle_action_stream_contract():
     assert [int((int(x) * 3) >> 32) for x in w] == list(a[20:24])
 
 
+def test_oracle_discrete2_actions_are_bit_slices_of_one_call_per_32_steps():
+    """Discrete(2): ctr = (g, b = t >> 5, stream 6), action = bit (t & 31) of the env's word — also across block boundaries
+    and for t beyond 2^32 * 32."""
+    o = oracle.OracleVecEnv(ENV_IDS["CartPole"], 64, 500, action_seed=(9 << 32) | 7, env_offset=4096)
+    for t in (0, 1, 31, 32, 33, 63, 64, 1000, (5 << 37) + 17):
+        a = o.sample_actions(t=t)
+        b = t >> 5
+        for g_local in (0, 5, 15):
+            g = (4096 >> 2) + g_local
+            w = oracle.philox4x32_10([g, 0, b & 0xFFFFFFFF, ((b >> 32) & 0x0FFFFFFF) | (6 << 28)], [7, 9])
+            assert [(int(x) >> (t & 31)) & 1 for x in w] == list(a[4 * g_local:4 * g_local + 4]), (t, g_local)
+    # one bit per step is exactly uniform: over 32 steps every env plays each bit of its word once
+    acts = np.stack([o.sample_actions(t=t) for t in range(64, 96)])           # block b = 2
+    w = np.array([oracle.philox4x32_10([(4096 >> 2) + g, 0, 2, 6 << 28], [7, 9]) for g in range(16)], dtype=np.uint64).reshape(-1)
+    assert np.array_equal((acts * (1 << np.arange(32, dtype=np.uint64))[:, None]).sum(axis=0), w)
+
+
+def test_oracle_reset_stream_is_indexed_by_each_envs_own_reset_ordinal():
+    """ctr = (k, 0, 0, 2 << 28), k = resets this env has had since seeding — whatever the vector step at which they happen."""
+    n, seed, off = 16, 1000, 8
+    o = oracle.OracleVecEnv(ENV_IDS["CartPole"], n, 3, seed=seed, env_offset=off)   # TimeLimit 3: autoresets every third step
+    o.reset(seed=seed)
+
+    def want(i, k):
+        w = oracle.philox4x32_10([k, 0, 0, 2 << 28], [(seed + off + i) & 0xFFFFFFFF, (seed + off + i) >> 32])
+        return np.array([-0.05 + (0.05 - (-0.05)) * ((float(x) + 0.5) * 2.0 ** -32) for x in w])
+
+    assert all(np.array_equal(o.state[:, i], want(i, 0)) for i in range(n)) and np.all(o.episodes == 1)
+    mask = np.zeros(n, np.uint8)
+    mask[[2, 5]] = 1
+    o.reset(mask=mask)                                     # a masked explicit reset advances only those envs
+    assert np.array_equal(o.state[:, 2], want(2, 1)) and np.array_equal(o.state[:, 3], want(3, 0))
+    for _ in range(3):
+        o.step(o.sample_actions())
+    assert np.all(o.elapsed == 0)                          # truncated + autoreset at the third step
+    assert np.array_equal(o.state[:, 2], want(2, 2)) and np.array_equal(o.state[:, 3], want(3, 1))
+    assert list(o.episodes[:6]) == [2, 2, 3, 2, 2, 3]
+    o.reset(seed=seed)                                     # reseeding restarts every stream
+    assert np.all(o.episodes == 1) and np.array_equal(o.state[:, 5], want(5, 0))
+
+
 def test_oracle_action_distribution():
     o = oracle.OracleVecEnv(ENV_IDS["CartPole"], 1 << 16, 500, action_seed=123)
     a = o.sample_actions(t=0)
