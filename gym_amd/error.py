@@ -21,7 +21,7 @@ class AlreadyPendingCallError(Error):
     """step_async() while a step is pending (gym/error.py:171)."""
 
     def __init__(self, message: str, name: str = ""):
-        super().__init__(message)
+        Exception.__init__(self, message)   # not super(): interop may put gym.error's class (message, name) next in the MRO
         self.name = name
 
 
@@ -29,7 +29,7 @@ class NoAsyncCallError(Error):
     """step_wait() without step_async() (gym/error.py:180)."""
 
     def __init__(self, message: str, name: str = ""):
-        super().__init__(message)
+        Exception.__init__(self, message)   # not super(): interop may put gym.error's class (message, name) next in the MRO
         self.name = name
 
 

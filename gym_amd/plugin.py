@@ -22,12 +22,14 @@ NAMESPACE = "hip"
 
 
 def make_vector(id: str, num_envs: int = 1, time_limit=None, **kwargs):
-    """Entry point of the registered specs."""
+    """Entry point of the registered specs.  The object it returns is an instance of the reference's gym.vector.VectorEnv with
+    gym.spaces spaces and gym.error exceptions (gym_amd.interop) — gym.make is calling, so gym is importable."""
+    from .interop import as_reference_env
     from .vector_env import make
 
     if time_limit is not None:
         kwargs["max_episode_steps"] = time_limit
-    return make(id, num_envs, **kwargs)
+    return as_reference_env(make(id, num_envs, **kwargs))
 
 
 def register_envs(gym_module=None) -> list:

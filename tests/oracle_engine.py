@@ -96,3 +96,38 @@ class OracleNormBackend:
 
     def close(self):
         pass
+
+
+class FakeHandle:
+    """Stand-in for gym_amd._native.Handle (the ctypes handle of the HIP engine) backed by the oracle, with just the calls
+    HipVectorEnv makes on the copying NumPy path.  Lets the HOST-side adapter (class hierarchy, spaces, errors, infos, wrapper
+    compatibility with the reference's own classes) be exercised in the GPU-less build container; never used by the product."""
+
+    def __init__(self, kind, num_envs, max_episode_steps, device=0, env_offset=0, seed=0, action_seed=0, flags=0):
+        self.o = OracleVecEnv(kind, num_envs, max_episode_steps, seed=seed, action_seed=action_seed, env_offset=env_offset)
+        self.env_id, self.num_envs, self.device, self.flags = kind, num_envs, device, flags
+        self.O, self.S = self.o.O, self.o.S
+        self.action_dtype = np.int64 if self.o.discrete else np.float32
+        self.closed = False
+
+    def get_params(self):
+        return self.o.P.copy()
+
+    def set_params(self, p):
+        self.o.P[:] = p
+
+    def seed(self, base_seed, per_env=None):
+        self.o.base_seed = int(base_seed) & (2**64 - 1)
+        self.o.seeds = None if per_env is None else np.asarray(per_env, dtype=np.uint64).copy()
+        self.o.t = self.o.r = 0
+        self.o.episodes[:] = 0
+
+    def reset_host(self, mask=None, bounds=None):
+        return self.o.reset(mask=mask, bounds=bounds)
+
+    def step_host(self, actions, want_final=True):
+        obs, rew, term, trunc, fin, _ = self.o.step(actions)
+        return obs, rew, term, trunc, fin
+
+    def close(self):
+        self.closed = True

@@ -29,7 +29,7 @@ def test_config4_last_rank_shard_of_acrobot():
 @pytest.mark.parametrize("name,n", [("CartPole", 4096), ("Acrobot", 2048), ("Pendulum", 1024)])
 def test_env_offset_beyond_2_pow_34_uses_the_high_counter_word(name, n):
     """g = global_env >> 2 no longer fits 32 bits: ctr.y of the action stream (and the 64-bit per-env seed) carry the rest."""
-    limit = 9 if name == "Pendulum" else None      # make sure resets happen in the window
+    limit = {"Pendulum": 9, "Acrobot": 13}.get(name)      # make sure resets happen in the window
     ndone = _rollout_compare(name, n=n, steps=40, seed=7, env_offset=(1 << 34) + 12 * 4096, limit=limit)
     other = _rollout_compare(name, n=n, steps=3, seed=7, env_offset=(3 << 35) + 4, limit=limit)
     assert ndone > 0 and other >= 0

