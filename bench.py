@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary compact-outputs measurement (N=1 only)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "mxv"],
+                    help="transport of the per-chunk all-gather at N > 1: torch.distributed (packed all_gather_into_tensor) or the C "
+                         "ABI's own RCCL collective (mxv_allgather_outputs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1.  nccl (= RCCL) is the product path; gloo exists to exercise the "
                          "multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices)")
@@ -218,7 +221,7 @@ def main():
         raise SystemExit(f"{total_envs} envs do not split into {world} shards of a multiple of 4 envs")
     local_envs = total_envs // world
     sr = ShardedRollout(ENV_ID, total_envs, rank=rank, world_size=world, device=local_rank, seed=0, action_seed=1,
-                        reward_f32=args.compact_outputs, action_i32=args.compact_outputs)
+                        reward_f32=args.compact_outputs, action_i32=args.compact_outputs, comm=args.comm)
     eng = sr.engine
     mode = "eager" if args.no_graph else args.mode
     sr.reset(seed=0)
@@ -334,8 +337,8 @@ def main():
                 "chunk": args.chunk,
                 "placement": placement if placement is not None else "first allocation (no placement tuning)",
                 "spinup": f"{spin_steps} untimed steps ({args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps (clock ramp)",
-                "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.chunk} steps"
-                                                        if world > 1 else ""),
+                "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.chunk} steps "
+                                                        f"({args.comm} transport)" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm",

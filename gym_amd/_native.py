@@ -29,12 +29,14 @@ ERR_UNSUPPORTED = -5
 MAX_PARAMS = 12
 ENV_ALIGN = 4
 ROLLOUT_EAGER, ROLLOUT_GRAPH, ROLLOUT_FUSED = 0, 1, 2
+COMM_ID_BYTES = 128
 
 EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -128,6 +130,12 @@ def _load():
         "mxv_set_state": ([vp, vp, vp], C.c_int),
         "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
+        "mxv_comm_unique_id": ([vp], C.c_int),
+        "mxv_comm_init": ([vp, C.c_int32, C.c_int32, vp], C.c_int),
+        "mxv_comm_destroy": ([vp], C.c_int),
+        "mxv_allgather_outputs": ([vp] * 9, C.c_int),
+        "mxv_allgather_wait": ([vp, C.c_int32], C.c_int),
+        "mxv_comm_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_get_episodes": ([vp, vp], C.c_int),
         "mxv_set_episodes": ([vp, vp], C.c_int),
         "mxv_get_params": ([vp, vp], C.c_int),
@@ -518,6 +526,40 @@ class Handle:
 
     def set_stream(self, stream_ptr: int):
         self._check(lib.mxv_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # -- collectives of a sharded vector env (RCCL behind the C ABI) ------------------------------------------------
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._check(lib.mxv_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)))
+        self.comm_world, self.comm_rank = int(world), int(rank)
+
+    def comm_destroy(self):
+        self._check(lib.mxv_comm_destroy(self._h))
+
+    def allgather_outputs(self, obs=None, reward=None, terminated=None, truncated=None, all_obs=None, all_reward=None,
+                          all_terminated=None, all_truncated=None):
+        """Asynchronous grouped all-gather of this shard's outputs into [world][...] device buffers (see include/mxv.h)."""
+        self._check(lib.mxv_allgather_outputs(self._h, _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated),
+                                              _ptr(all_obs), _ptr(all_reward), _ptr(all_terminated), _ptr(all_truncated)))
+
+    def allgather_wait(self, host_sync: bool = False):
+        self._check(lib.mxv_allgather_wait(self._h, int(bool(host_sync))))
+
+    @property
+    def comm_stream(self) -> int:
+        s = C.c_void_p()
+        self._check(lib.mxv_comm_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+
+def comm_unique_id() -> bytes:
+    """RCCL unique id (created on one rank, shipped to the others, passed to Handle.comm_init on every rank)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.mxv_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != OK:
+        raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
+    return buf.raw
 
 
 class Norm:

@@ -3,6 +3,8 @@
 // explicit-reset ordinal r), the staging buffers of the *_host convenience calls and the
 // hipGraph cache of mxv_rollout.  No torch types, no C++ types cross the boundary.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen() by mxv_comm_init (no link-time dependency)
 
 #include <cmath>
 #include <cstdarg>
@@ -107,6 +109,13 @@ struct mxv_handle {
     // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
     using GraphKey = std::tuple<int, int, void *, void *, void *, void *, void *, void *>;
     std::map<GraphKey, hipGraphExec_t> graphs;
+    // RCCL communicator of a sharded vector env (mxv_comm_init): the gather runs on a side stream so that the next rollout
+    // launch on `stream` overlaps it
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_outputs = nullptr, ev_gathered = nullptr;
+    bool gather_pending = false;
     std::string error;
 
     size_t action_bytes() const {
@@ -380,6 +389,7 @@ int mxv_destroy(mxv_handle *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)mxv_comm_destroy(h);
     free_graphs(h);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
@@ -920,6 +930,164 @@ int mxv_set_stream(mxv_handle *h, void *stream) {
     if (h->own_stream && h->stream) MXV_HIP(h, hipStreamDestroy(h->stream));
     h->stream = (hipStream_t)stream;
     h->own_stream = false;
+    return MXV_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Collectives behind the C ABI: the one exchange of a sharded vector env is what np.stack does in the
+// reference (gym/vector/sync_vector_env.py:159-169, gym/vector/utils/numpy_utils.py:49-50; AsyncVectorEnv gathers its workers'
+// results the same way, async_vector_env.py:319-346) — concatenating the shards' outputs in rank = global-env order.  RCCL is
+// used directly (ncclAllGather over xGMI), loaded with dlopen so that libmxv.so itself has no link-time dependency on it.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) {
+            a.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found");
+            return a;
+        }
+        auto sym = [&](const char *n) -> void * {
+            void *p = dlsym(a.lib, n);
+            if (!p && a.error.empty()) a.error = std::string("librccl.so lacks ") + n;
+            return p;
+        };
+        a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+        a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+        a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        return a;
+    }();
+    return api;
+}
+
+#define MXV_NCCL(h, expr)                                                                                              \
+    do {                                                                                                               \
+        ncclResult_t r_ = (expr);                                                                                      \
+        if (r_ != ncclSuccess) return fail((h), MXV_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString(r_));             \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mxv_comm_unique_id(void *id_out) {
+    static_assert(sizeof(ncclUniqueId) == MXV_COMM_ID_BYTES, "MXV_COMM_ID_BYTES must be RCCL's unique-id size");
+    if (!id_out) return fail(nullptr, MXV_ERR_INVALID_ARG, "unique-id pointer is NULL");
+    RcclApi &api = rccl();
+    if (!api.error.empty()) return fail(nullptr, MXV_ERR_UNSUPPORTED, "%s", api.error.c_str());
+    ncclUniqueId id;
+    MXV_NCCL(nullptr, api.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return MXV_OK;
+}
+
+int mxv_comm_init(mxv_handle *h, int32_t rank, int32_t world, const void *unique_id) {
+    MXV_CHECK_HANDLE(h);
+    if (!unique_id || world < 1 || rank < 0 || rank >= world)
+        return fail(h, MXV_ERR_INVALID_ARG, "mxv_comm_init: rank %d of %d with id %p", rank, world, unique_id);
+    RcclApi &api = rccl();
+    if (!api.error.empty()) return fail(h, MXV_ERR_UNSUPPORTED, "%s", api.error.c_str());
+    if (int rc = use_device(h)) return rc;
+    if (int rc = mxv_comm_destroy(h)) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    MXV_NCCL(h, api.CommInitRank(&h->comm, world, id, rank));
+    h->comm_rank = rank;
+    h->comm_world = world;
+    int lo = 0, hi = 0;  // the gather's kernels get CUs as soon as rollout waves retire instead of queueing behind the next launch
+    MXV_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    MXV_HIP(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    MXV_HIP(h, hipEventCreateWithFlags(&h->ev_outputs, hipEventDisableTiming));
+    MXV_HIP(h, hipEventCreateWithFlags(&h->ev_gathered, hipEventDisableTiming));
+    return MXV_OK;
+}
+
+int mxv_comm_destroy(mxv_handle *h) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->comm) return MXV_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    (void)rccl().CommDestroy(h->comm);
+    h->comm = nullptr;
+    if (h->ev_outputs) (void)hipEventDestroy(h->ev_outputs);
+    if (h->ev_gathered) (void)hipEventDestroy(h->ev_gathered);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    h->ev_outputs = h->ev_gathered = nullptr;
+    h->comm_stream = nullptr;
+    h->comm_world = 0;
+    h->gather_pending = false;
+    return MXV_OK;
+}
+
+int mxv_allgather_outputs(mxv_handle *h, const float *obs_dev, const void *reward_dev, const uint8_t *terminated_dev,
+                          const uint8_t *truncated_dev, float *all_obs_dev, void *all_reward_dev, uint8_t *all_terminated_dev,
+                          uint8_t *all_truncated_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->comm) return fail(h, MXV_ERR_INVALID_ARG, "mxv_allgather_outputs: call mxv_comm_init first");
+    if (int rc = use_device(h)) return rc;
+    RcclApi &api = rccl();
+    const size_t n = (size_t)h->cfg.num_envs;
+    // the gather reads what the handle's stream has produced so far; it runs on the communicator's own stream
+    MXV_HIP(h, hipEventRecord(h->ev_outputs, h->stream));
+    MXV_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_outputs, 0));
+    MXV_NCCL(h, api.GroupStart());  // the four gathers travel as one fused RCCL launch
+    ncclResult_t r = ncclSuccess;
+    if (obs_dev && all_obs_dev && r == ncclSuccess)
+        r = api.AllGather(obs_dev, all_obs_dev, n * h->O * sizeof(float), ncclUint8, h->comm, h->comm_stream);
+    if (reward_dev && all_reward_dev && r == ncclSuccess)
+        r = api.AllGather(reward_dev, all_reward_dev, n * h->reward_bytes(), ncclUint8, h->comm, h->comm_stream);
+    if (terminated_dev && all_terminated_dev && r == ncclSuccess)
+        r = api.AllGather(terminated_dev, all_terminated_dev, n, ncclUint8, h->comm, h->comm_stream);
+    if (truncated_dev && all_truncated_dev && r == ncclSuccess)
+        r = api.AllGather(truncated_dev, all_truncated_dev, n, ncclUint8, h->comm, h->comm_stream);
+    const ncclResult_t e = api.GroupEnd();
+    if (r != ncclSuccess || e != ncclSuccess)
+        return fail(h, MXV_ERR_HIP, "ncclAllGather: %s", api.GetErrorString(r != ncclSuccess ? r : e));
+    MXV_HIP(h, hipEventRecord(h->ev_gathered, h->comm_stream));
+    h->gather_pending = true;
+    return MXV_OK;
+}
+
+int mxv_allgather_wait(mxv_handle *h, int32_t host_sync) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->gather_pending) return MXV_OK;
+    if (int rc = use_device(h)) return rc;
+    if (host_sync) {
+        MXV_HIP(h, hipEventSynchronize(h->ev_gathered));
+        h->gather_pending = false;
+    } else {
+        MXV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered, 0));
+    }
+    return MXV_OK;
+}
+
+int mxv_comm_stream(mxv_handle *h, void **stream) {
+    MXV_CHECK_HANDLE(h);
+    if (!stream) return fail(h, MXV_ERR_INVALID_ARG, "stream pointer is NULL");
+    *stream = (void *)h->comm_stream;
     return MXV_OK;
 }
 

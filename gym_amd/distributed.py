@@ -8,6 +8,13 @@ concatenating the output tensors.  Per north_star that is one RCCL all-gather of
 terminated / truncated tensors of a rollout chunk — never per step (inbound xGMI is ~7.5x slower than HBM) — and
 it is issued asynchronously on RCCL's stream from a snapshot of the outputs so the next chunk's kernels overlap it.
 torch.distributed is used for the process group only (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+
+Two transports for that gather:
+  comm="torch" (default)  one packed torch.distributed.all_gather_into_tensor of a snapshot of the four tensors;
+  comm="mxv"              the C ABI's own collective (mxv_comm_init / mxv_allgather_outputs, include/mxv.h): RCCL called
+                          directly by libmxv.so on a high-priority side stream, four gathers grouped into one launch, received
+                          straight into the full (N_total, ...) tensors (no concatenation afterwards).  torch.distributed is
+                          then only the courier of the 128-byte RCCL unique id.  Needs the HIP engine.
 """
 from __future__ import annotations
 
@@ -42,10 +49,14 @@ class GatheredOutputs:
 
     def shards(self, i: int):
         o = self._o
+        if o.comm == "mxv":
+            return list(o._mxv_recv[i].chunk(o.world_size, dim=0))
         off, nb, dt, shape = o._layout[i]
         return [o._recv[r, off:off + nb].view(dt).view(shape) for r in range(o.world_size)]
 
     def full(self, i: int) -> torch.Tensor:
+        if self._o.comm == "mxv":      # received in place: [world][N_local, ...] IS the concatenation
+            return self._o._mxv_recv[i]
         if i not in self._full:
             with self._o._stream_ctx():
                 self._full[i] = torch.cat(self.shards(i), dim=0)
@@ -74,7 +85,10 @@ class ShardedRollout:
 
     def __init__(self, id: str, total_envs: int, *, rank: Optional[int] = None, world_size: Optional[int] = None,
                  device: Optional[int] = None, seed: int = 0, action_seed: int = 0, group=None,
-                 engine_factory: Optional[Callable] = None, **engine_kwargs):
+                 engine_factory: Optional[Callable] = None, comm: str = "torch", **engine_kwargs):
+        if comm not in ("torch", "mxv"):
+            raise ValueError(f"comm must be 'torch' or 'mxv', got {comm!r}")
+        self.comm = comm
         self.group = group
         distributed = dist.is_available() and dist.is_initialized()
         self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if distributed else 1)
@@ -93,6 +107,17 @@ class ShardedRollout:
         self._pending = None
         self._send = None
         self._recv = None
+        self._mxv_recv = None
+        if comm == "mxv":
+            handle = getattr(self.engine, "handle", None)
+            if handle is None or not hasattr(handle, "comm_init"):
+                raise TypeError("comm='mxv' needs the HIP engine (gym_amd.rollout.DeviceRollout): the collective lives in libmxv.so")
+            from . import _native
+
+            ids = [_native.comm_unique_id() if self.rank == 0 else None]
+            if self.world_size > 1:
+                dist.broadcast_object_list(ids, src=0, group=group)   # torch.distributed carries the 128-byte id, nothing else
+            handle.comm_init(self.rank, self.world_size, ids[0])
 
     # ------------------------------------------------------------------------------------------------
     def _stream_ctx(self):
@@ -144,8 +169,25 @@ class ShardedRollout:
             self._send_views = [self._send[o:o + nb].view(dt).view(shape) for o, nb, dt, shape in self._layout]
         return self._send, self._recv
 
+    def _gather_async_mxv(self):
+        finals = self.engine.final_tensors()
+        if self._mxv_recv is None:
+            with self._stream_ctx():
+                self._mxv_send = [torch.empty_like(t) for t in finals]
+                self._mxv_recv = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                                  for t in finals]
+        h = self.engine.handle
+        h.allgather_wait(host_sync=False)          # the previous gather must have read its snapshot before it is overwritten
+        with self._stream_ctx():
+            for dst, src in zip(self._mxv_send, finals):
+                dst.copy_(src, non_blocking=True)
+        h.allgather_outputs(*self._mxv_send, *self._mxv_recv)
+        self._pending = "mxv"
+
     def gather_async(self):
         """Snapshot the current output tensors and start their all-gather; returns immediately."""
+        if self.comm == "mxv":
+            return self._gather_async_mxv()
         self.wait_gather()
         send, recv = self._buffers()
         with self._stream_ctx():
@@ -162,6 +204,10 @@ class ShardedRollout:
         truncated), or None."""
         if self._pending is None:
             return None
+        if self._pending == "mxv":
+            self.engine.handle.allgather_wait(host_sync=False)   # the engine's stream is ordered after the gather
+            self._pending = None
+            return GatheredOutputs(self)
         with self._stream_ctx():
             for w in self._pending:
                 w.wait()
