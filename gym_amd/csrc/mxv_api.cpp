@@ -116,6 +116,7 @@ struct mxv_handle {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_outputs = nullptr, ev_gathered = nullptr;
     bool gather_pending = false;
+    hipEvent_t ev_mixed = nullptr;  // orders this handle's stream against a mixed-batch launch issued on another handle's stream
     std::string error;
 
     size_t action_bytes() const {
@@ -390,6 +391,7 @@ int mxv_destroy(mxv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)mxv_comm_destroy(h);
+    if (h->ev_mixed) (void)hipEventDestroy(h->ev_mixed);
     free_graphs(h);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
@@ -934,6 +936,68 @@ int mxv_set_stream(mxv_handle *h, void *stream) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Heterogeneous dispatch: K sampled steps of several homogeneous segments in ONE launch (BASELINE.json configs[4]).
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int32_t K, int32_t per_step, const mxv_step_outputs *outs) {
+    if (!handles || !outs || count < 1 || count > MXV_MAX_MIXED)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "mxv_rollout_mixed: 1..%d handles with their outputs", MXV_MAX_MIXED);
+    mxv_handle *h0 = handles[0];
+    MXV_CHECK_HANDLE(h0);
+    if (K < 2) return fail(h0, MXV_ERR_UNSUPPORTED, "mxv_rollout_mixed fuses K >= 2 steps (use mxv_step_sampled per handle for single steps)");
+    MixedArgs m{};
+    m.count = count;
+    uint32_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        mxv_handle *h = handles[i];
+        MXV_CHECK_HANDLE(h);
+        if (h->cfg.device != h0->cfg.device) return fail(h0, MXV_ERR_INVALID_ARG, "segment %d lives on another device", i);
+        for (int j = 0; j < i; ++j)
+            if (handles[j] == h) return fail(h0, MXV_ERR_INVALID_ARG, "handle listed twice (segments %d and %d)", j, i);
+        if (int rc = rollout_checks(h, K, outs[i].obs)) {
+            if (h != h0) h0->error = h->error;
+            return rc;
+        }
+        if (h->param_mode() != PM_DEFAULT || h->step_noise || (h->cfg.flags & MXV_FLAG_NO_AUTORESET))
+            return fail(h0, MXV_ERR_UNSUPPORTED, "segment %d needs the per-handle kernels (non-default physics attributes or no autoreset): "
+                                                 "launch it with mxv_rollout", i);
+        StepArgs &a = m.seg[i];
+        fill_step_args(h, a);
+        a.K = K;
+        a.slice = per_step ? h->cfg.num_envs : 0;
+        a.actions = nullptr;
+        a.actions_out = outs[i].actions_out;
+        a.obs = outs[i].obs;
+        a.reward = outs[i].reward;
+        a.terminated = outs[i].terminated;
+        a.truncated = outs[i].truncated;
+        a.final_obs = outs[i].final_obs;
+        m.kind[i] = h->cfg.env_id;
+        m.first_block[i] = blocks;
+        blocks += (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup
+    }
+    m.first_block[count] = blocks;
+    // the launch goes to the first handle's stream; the other handles' streams are ordered before and after it on the GPU
+    for (int i = 1; i < count; ++i) {
+        mxv_handle *h = handles[i];
+        if (h->stream == h0->stream) continue;
+        if (!h->ev_mixed) MXV_HIP(h0, hipEventCreateWithFlags(&h->ev_mixed, hipEventDisableTiming));
+        MXV_HIP(h0, hipEventRecord(h->ev_mixed, h->stream));
+        MXV_HIP(h0, hipStreamWaitEvent(h0->stream, h->ev_mixed, 0));
+    }
+    MXV_HIP(h0, launch_mixed_rollout(m, h0->stream));
+    for (int i = 0; i < count; ++i) {
+        mxv_handle *h = handles[i];
+        h->state_injected = false;
+        h->t += (uint64_t)K;
+        if (i > 0 && h->stream != h0->stream) {
+            MXV_HIP(h0, hipEventRecord(h->ev_mixed, h0->stream));
+            MXV_HIP(h0, hipStreamWaitEvent(h->stream, h->ev_mixed, 0));
+        }
+    }
+    return MXV_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Collectives behind the C ABI: the one exchange of a sharded vector env is what np.stack does in the

@@ -335,8 +335,20 @@ constexpr int rollout_min_waves() {
     return (!DEF || (ENV == MXV_CARTPOLE && SAFE)) ? 1 : 4;
 }
 
-template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
-__global__ void __launch_bounds__(kWave, (rollout_min_waves<ENV, DEF, SAFE>())) rollout_kernel_v3(const StepArgs a) {
+// LDS of one rollout workgroup (= one wave): the ring of action words and the lane-private reset entries.
+template <int ENV, int E>
+struct RolloutLds {
+    static constexpr int TILE = E * kWave;
+    static constexpr int H = kWave / (TILE / 4);
+    using Entry = ResetEntry<Env<ENV>::S, Env<ENV>::O, Env<ENV>::AUX>;
+    uint32_t act[H * TILE];  // slot (q % H) holds the action words of unit u0 + q
+    Entry res[TILE];         // lane-private: the ready-made next reset of env slot j * 64 + lane
+};
+
+// The kernel body as a device function of (arguments, workgroup index, workgroups of this segment, LDS): rollout_kernel_v3 runs
+// it for one homogeneous vector env, mixed_rollout_kernel for the segment a workgroup belongs to.
+template <int ENV, bool DEF, int E, bool SAFE, int OUT>
+__device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigned bid, const unsigned nblk, RolloutLds<ENV, E> &lds) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     constexpr int TILE = E * kWave;
@@ -347,11 +359,11 @@ __global__ void __launch_bounds__(kWave, (rollout_min_waves<ENV, DEF, SAFE>())) 
     static_assert(NACT <= kWave && (PERIOD & (PERIOD - 1)) == 0 && PERIOD >= E, "E <= 4; pass period a power of two >= E");
     constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
     using Entry = ResetEntry<S, O, EV::AUX>;
-    __shared__ uint32_t lds_act[H * TILE];  // slot (q % H) holds the action words of unit u0 + q
-    __shared__ Entry lds_res[TILE];         // lane-private: the ready-made next reset of env slot j * 64 + lane
+    uint32_t *const lds_act = lds.act;
+    Entry *const lds_res = lds.res;
 
     const int lane = threadIdx.x;
-    const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const uint32_t tile = xcd_contiguous_tile(bid, nblk);
     const int64_t tile0 = (int64_t)tile * TILE;
     const int64_t n = a.n;
     const Par<DEF> P(a.P);
@@ -559,6 +571,51 @@ __global__ void __launch_bounds__(kWave, (rollout_min_waves<ENV, DEF, SAFE>())) 
         a.elapsed[le[j]] = el[j];
         a.episodes[le[j]] = ep[j];
         if (ep_on) a.ep_acc[le[j]] = er[j];
+    }
+}
+
+
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
+__global__ void __launch_bounds__(kWave, (rollout_min_waves<ENV, DEF, SAFE>())) rollout_kernel_v3(const StepArgs a) {
+    __shared__ RolloutLds<ENV, E> lds;
+    rollout_body_v3<ENV, DEF, E, SAFE, OUT>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// mixed_rollout_kernel: heterogeneous dispatch in ONE launch (BASELINE.json configs[4]; SURVEY.md §2.3 "block -> segment
+// table, homogeneous workgroups").  A mixed batch is a concatenation of homogeneous segments {CartPole, Pendulum, Acrobot,
+// MountainCar, ...} (the reference has no other semantics: gym/vector/vector_env.py:20-23, sync_vector_env.py:220-234).  Every
+// workgroup (= one wave) looks up the segment its index falls into and runs THAT env kind's rollout body on the segment's
+// own arguments: waves stay homogeneous (no per-lane switch that would serialise four code paths), and all segments share
+// one grid, so the chip is filled by one launch instead of four small grids on four streams.  Each body is the code of
+// rollout_kernel_v3 with one env per lane (segments of a mixed batch are small): results are bit-identical to launching the
+// segments separately.
+// ------------------------------------------------------------------------------------------------------------
+union MixedLds {
+    RolloutLds<MXV_CARTPOLE, 1> cartpole;
+    RolloutLds<MXV_PENDULUM, 1> pendulum;
+    RolloutLds<MXV_ACROBOT, 1> acrobot;
+    RolloutLds<MXV_MOUNTAINCAR, 1> mountaincar;
+    RolloutLds<MXV_MOUNTAINCAR_CONT, 1> mountaincar_cont;
+    __device__ MixedLds() {}
+};
+
+__global__ void __launch_bounds__(kWave) mixed_rollout_kernel(const MixedArgs m) {
+    __shared__ MixedLds lds;
+    unsigned sidx = 0;
+#pragma unroll
+    for (int i = 1; i < MXV_MAX_MIXED; ++i)
+        if (i < m.count && blockIdx.x >= m.first_block[i]) sidx = (unsigned)i;
+    const StepArgs &a = m.seg[sidx];
+    const unsigned bid = blockIdx.x - m.first_block[sidx], nblk = m.first_block[sidx + 1] - m.first_block[sidx];
+    switch (m.kind[sidx]) {   // wave-uniform: one body per workgroup
+        case MXV_CARTPOLE:  // SAFE: a segment may have had its state injected
+            rollout_body_v3<MXV_CARTPOLE, true, 1, true, 0>(a, bid, nblk, lds.cartpole);
+            break;
+        case MXV_PENDULUM: rollout_body_v3<MXV_PENDULUM, true, 1, true, 0>(a, bid, nblk, lds.pendulum); break;
+        case MXV_ACROBOT: rollout_body_v3<MXV_ACROBOT, true, 1, true, 0>(a, bid, nblk, lds.acrobot); break;
+        case MXV_MOUNTAINCAR: rollout_body_v3<MXV_MOUNTAINCAR, true, 1, true, 0>(a, bid, nblk, lds.mountaincar); break;
+        default: rollout_body_v3<MXV_MOUNTAINCAR_CONT, true, 1, true, 0>(a, bid, nblk, lds.mountaincar_cont); break;
     }
 }
 
@@ -997,6 +1054,11 @@ hipError_t launch_sample(int env_id, int default_params, const SampleArgs &a, hi
         case MXV_MOUNTAINCAR_CONT: return launch_sample_env<MXV_MOUNTAINCAR_CONT>(default_params, a, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream) {
+    hipLaunchKernelGGL(mixed_rollout_kernel, dim3(m.first_block[m.count]), dim3(kWave), 0, stream, m);
+    return hipGetLastError();
 }
 
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream) {

@@ -43,6 +43,14 @@ struct StepArgs {
     EnvParams P;
 };
 
+// One launch over several homogeneous segments (mixed_rollout_kernel): segment i owns workgroups [first_block[i], first_block[i+1]).
+struct MixedArgs {
+    StepArgs seg[MXV_MAX_MIXED];
+    uint32_t first_block[MXV_MAX_MIXED + 1];
+    int32_t kind[MXV_MAX_MIXED];   // env kind of each segment
+    int32_t count;
+};
+
 struct ResetArgs {
     double *state;
     int32_t *elapsed;
@@ -143,6 +151,7 @@ constexpr int kBlock = 256;
 hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream);
 hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
 hipError_t launch_sample(int env_id, int param_mode, const SampleArgs &a, hipStream_t stream);
+hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream);
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);
 
 }  // namespace mxv

@@ -162,6 +162,23 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
 int mxv_rollout_tape(mxv_handle *h, int32_t K, int32_t per_step, const void *actions_tape_dev,
                      float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev,
                      float *final_obs_dev);
+/* Heterogeneous dispatch (BASELINE.json configs[4]: mixed batch {CartPole, Pendulum, Acrobot, MountainCar}).  The reference has
+ * no mixed vector env (gym/vector/vector_env.py:20-23; SyncVectorEnv requires identical sub-env spaces, sync_vector_env.py:
+ * 220-234): a mixed batch IS a set of homogeneous vector envs, here one handle per segment on one device.  This call advances
+ * all of them by K sampled steps in ONE kernel launch (a block -> segment table; every wave runs the rollout body of its
+ * segment's env kind), bit-identical to calling mxv_rollout(FUSED) on each handle.  outs[i] = the output pointers of handles[i]
+ * (meaning of mxv_rollout's; any but obs may be NULL).  The launch goes to handles[0]'s stream; the other handles' streams are
+ * ordered around it on the GPU.  MXV_ERR_UNSUPPORTED if a segment runs non-default physics attributes / without autoreset. */
+#define MXV_MAX_MIXED 8
+typedef struct mxv_step_outputs {
+    void *actions_out;
+    float *obs;
+    void *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    float *final_obs;
+} mxv_step_outputs;
+int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int32_t K, int32_t per_step, const mxv_step_outputs *outs);
 /* action_space.sample() for the NEXT step index without stepping. */
 int mxv_sample_actions(mxv_handle *h, void *actions_out_dev);
 
