@@ -36,7 +36,7 @@ EXPORTS = (
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
-    "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
+    "mxv_rollout_mixed", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -130,6 +130,7 @@ def _load():
         "mxv_set_state": ([vp, vp, vp], C.c_int),
         "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
+        "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
         "mxv_comm_init": ([vp, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_comm_destroy": ([vp], C.c_int),
@@ -551,6 +552,34 @@ class Handle:
         s = C.c_void_p()
         self._check(lib.mxv_comm_stream(self._h, C.byref(s)))
         return s.value or 0
+
+
+class StepOutputs(C.Structure):
+    """mxv_step_outputs (include/mxv.h): the output pointers of one segment of a mixed-batch launch."""
+    _fields_ = [("actions_out", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
+                ("truncated", C.c_void_p), ("final_obs", C.c_void_p)]
+
+
+MAX_MIXED = 8
+
+
+def rollout_mixed(handles, K: int, outs, per_step: bool = True):
+    """mxv_rollout_mixed: K sampled steps of several homogeneous handles (one device) in ONE kernel launch.  outs[i] = dict
+    with obs (required) / reward / terminated / truncated / actions / final_obs device tensors of handles[i]."""
+    n = len(handles)
+    assert 1 <= n <= MAX_MIXED and len(outs) == n
+    hs = (C.c_void_p * n)(*[h._h for h in handles])
+    arr = (StepOutputs * n)()
+    for i, o in enumerate(outs):
+        arr[i].actions_out = _ptr(o.get("actions"))
+        arr[i].obs = _ptr(o["obs"])
+        arr[i].reward = _ptr(o.get("reward"))
+        arr[i].terminated = _ptr(o.get("terminated"))
+        arr[i].truncated = _ptr(o.get("truncated"))
+        arr[i].final_obs = _ptr(o.get("final_obs"))
+    rc = lib.mxv_rollout_mixed(C.cast(hs, C.c_void_p), n, int(K), int(bool(per_step)), C.cast(arr, C.c_void_p))
+    if rc != OK:
+        raise MxvError(rc, (lib.mxv_last_error(handles[0]._h) or b"").decode())
 
 
 def comm_unique_id() -> bytes:

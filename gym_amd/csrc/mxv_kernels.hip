@@ -444,9 +444,26 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
     char *p_term = reinterpret_cast<char *>(a.terminated);
     char *p_trunc = reinterpret_cast<char *>(a.truncated);
     char *p_fin = FULL ? nullptr : reinterpret_cast<char *>(a.final_obs);
-    const int64_t slice = a.slice;
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
+    uint32_t lo[E];  // index of the lane's env slot inside one step's slice of every output array
+#if MXV_EXP_TILE_MAJOR  // measurement only: trajectories laid out [N/TILE][K][TILE] — every wave streams through its own region
+    const int64_t slice = a.slice ? TILE : 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) lo[j] = a.slice ? (uint32_t)(j * kWave + lane) : le[j];
+    if (a.slice) {
+        const int64_t base = tile0 * (int64_t)a.K;
+        p_obs += base * (int64_t)(O * sizeof(float));
+        if (p_rew) p_rew += base * rew_b;
+        if (p_act) p_act += base * act_b;
+        if (p_term) p_term += base;
+        if (p_trunc) p_trunc += base;
+    }
+#else
+    const int64_t slice = a.slice;
+#pragma unroll
+    for (int j = 0; j < E; ++j) lo[j] = le[j];
+#endif
 
     settle_entry_loads();
     for (int step = 0; step < a.K; ++step) {
@@ -461,7 +478,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if (!valid[j]) continue;
-                char *q = p_act + le[j] * act_b;
+                char *q = p_act + lo[j] * act_b;
                 if constexpr (NA > 0) {
                     if (act_i32)
                         *reinterpret_cast<int32_t *>(q) = ai[j];
@@ -489,8 +506,8 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             for (int j = 0; j < E; ++j) {
                 er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
                 if (pend[j]) {
-                    if (p_epr) p_epr[le[j]] = er[j];
-                    if (p_epl) p_epl[le[j]] = el[j];
+                    if (p_epr) p_epr[lo[j]] = er[j];
+                    if (p_epl) p_epl[lo[j]] = el[j];
                     er[j] = 0.0f;
                 }
             }
@@ -500,15 +517,15 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         for (int j = 0; j < E; ++j) {
             if (!valid[j]) continue;
             if (FULL || p_rew != nullptr) {
-                char *q = p_rew + le[j] * rew_b;
+                char *q = p_rew + lo[j] * rew_b;
                 if (rew_f32)
                     *reinterpret_cast<float *>(q) = (float)rew[j];
                 else
                     *reinterpret_cast<double *>(q) = rew[j];
             }
-            if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
-            if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
-            if (!FULL && pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);
+            if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[lo[j]] = term[j] ? 1 : 0;
+            if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[lo[j]] = trunc[j] ? 1 : 0;
+            if (!FULL && pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), lo[j], obs[j]);
         }
 
         // ---- autoreset (sync_vector_env.py:152-156): finished envs take their ready-made entry ----
@@ -545,7 +562,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         }
 #pragma unroll
         for (int j = 0; j < E; ++j)
-            if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
+            if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), lo[j], obs[j]);
 
         // ---- look-ahead pass: refill the empty reset slots j of this wave, every PERIOD steps per slot ----
 #pragma unroll

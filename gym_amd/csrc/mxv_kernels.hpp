@@ -125,6 +125,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_SMALL_E1
 #define MXV_ROLLOUT_SMALL_E1 1
 #endif
+// measurement hook: 1 = the fused rollout writes its trajectories tile-major ([N/TILE][K][TILE]) instead of step-major ([K][N])
+#ifndef MXV_EXP_TILE_MAJOR
+#define MXV_EXP_TILE_MAJOR 0
+#endif
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8

@@ -5,10 +5,12 @@ gym/vector/vector_env.py:20-23, and SyncVectorEnv raises on mismatched sub-env s
 gym/vector/sync_vector_env.py:220-234).  The only consistent definition — and the one the parity tests use — is the
 concatenation of homogeneous segments, each equal to its own `SyncVectorEnv`.
 
-Dispatch: one engine (= one C-ABI handle, one HIP stream) per segment per GPU.  The segments' kernels are
-launched back to back on their own streams, so the four grids run concurrently and fill the chip together —
-"heterogeneous dispatch" is stream-level concurrency, not a mega-kernel with a per-lane switch (which would
-serialise the four code paths inside every wave).  Across GPUs each segment is sharded like ShardedRollout
+Dispatch: one engine (= one C-ABI handle) per segment per GPU, and ONE kernel launch for all of them
+(`mxv_rollout_mixed`, include/mxv.h): a block -> segment table sends every workgroup (= one wave) to the rollout body of
+its segment's env kind, so waves stay homogeneous — no per-lane switch that would serialise the four code paths — while
+the four small grids fill the chip as one.  Bit-identical to launching the segments one by one (`single_launch=False`:
+back-to-back launches on the segments' own streams, also the fallback when a segment runs non-default physics
+attributes, and what a non-HIP engine factory gets).  Across GPUs each segment is sharded like ShardedRollout
 shards a homogeneous env: rank r owns the r-th contiguous slice of EVERY segment, so all ranks carry the same mix
 and the same load; Philox streams use the segment-global env index, hence results do not depend on the number of GPUs.
 """
@@ -26,7 +28,7 @@ class MixedRollout:
 
     def __init__(self, total_envs: int, ids: Sequence[str] = DEFAULT_MIX, *, rank: Optional[int] = None,
                  world_size: Optional[int] = None, device: Optional[int] = None, seed: int = 0, action_seed: int = 0,
-                 group=None, engine_factory: Optional[Callable] = None, **engine_kwargs):
+                 group=None, engine_factory: Optional[Callable] = None, single_launch: bool = True, **engine_kwargs):
         ids = list(ids)
         if total_envs % len(ids) != 0:
             raise ValueError(f"num_envs={total_envs} must be divisible by the number of env kinds ({len(ids)})")
@@ -45,16 +47,51 @@ class MixedRollout:
         first = next(iter(self.segments.values()))
         self.rank, self.world_size = first.rank, first.world_size
         self.local_envs = sum(sr.local_envs for sr in self.segments.values())
+        # one launch for all segments needs the HIP engine's handles
+        self.single_launch = bool(single_launch) and engine_factory is None and len(ids) <= 8
+        self._traj = {}
+
+    def _launch_all(self, K: int, outs: dict, per_step: bool) -> bool:
+        """All segments in one kernel launch; False if a segment needs its own kernel (the caller falls back)."""
+        from . import _native
+
+        engines = [sr.engine for sr in self.segments.values()]
+        for e in engines:
+            e._attach_episode_outputs(None)
+        try:
+            _native.rollout_mixed([e.handle for e in engines], K, [outs[k] for k in self.segments], per_step=per_step)
+        except _native.MxvError as err:
+            if err.code == _native.ERR_UNSUPPORTED:
+                return False
+            raise
+        return True
 
     def reset(self, seed: Optional[int] = None):
         return {k: sr.reset(seed=None if seed is None else seed + 1000003 * s)
                 for s, (k, sr) in enumerate(self.segments.items())}
 
     def rollout(self, K: int, **kw):
-        """K vector steps of every segment; launches are asynchronous and overlap across the segments' streams."""
+        """K vector steps of every segment; the output tensors hold the last step (the "final tensors" of the chunk)."""
+        if self.single_launch and K > 1 and not kw:
+            outs = {k: dict(obs=sr.engine.obs, reward=sr.engine.reward, terminated=sr.engine.terminated,
+                            truncated=sr.engine.truncated) for k, sr in self.segments.items()}
+            if self._launch_all(K, outs, per_step=False):
+                for sr in self.segments.values():
+                    e = sr.engine
+                    e._last = (e.obs, e.reward, e.terminated, e.truncated)
+                return {k: sr.engine._last for k, sr in self.segments.items()}
         return {k: sr.rollout(K, **kw) for k, sr in self.segments.items()}
 
     def rollout_per_step(self, K: int, out: Optional[dict] = None, **kw):
+        """K vector steps of every segment into per-segment [K, N_local, ...] trajectory tensors."""
+        if self.single_launch and K > 1 and kw.get("mode", "fused") == "fused" and kw.get("record_actions", True):
+            if out is None:
+                out = self._traj.get(K) or self._traj.setdefault(K, self.trajectory_buffers(K))
+            if all("ep_return" not in o for o in out.values()) and self._launch_all(K, out, per_step=True):
+                for k, sr in self.segments.items():
+                    o = out[k]
+                    sr.engine._last = (o["obs"][K - 1], o["reward"][K - 1], o["terminated"][K - 1], o["truncated"][K - 1])
+                return out
         return {k: sr.rollout_per_step(K, out=None if out is None else out[k], **kw) for k, sr in self.segments.items()}
 
     def trajectory_buffers(self, K: int):

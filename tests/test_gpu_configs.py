@@ -51,16 +51,19 @@ def _oracle_follow(name, seg_seed, seg_action_seed, env_offset, n, traj, horizon
             assert ulps32(traj["obs"][k], robs).max() <= MAX_OBS_ULPS, (name, k)
 
 
+@pytest.mark.parametrize("single_launch", [True, False])
 @pytest.mark.parametrize("rank,world", [(0, 1), (3, 8), (7, 8)])
-def test_config5_mixed_batch_segments_equal_homogeneous_engines_and_the_oracle(rank, world):
-    """configs[4] per GPU: total 2^17 * world envs -> four segments of 2^15 envs each on this rank."""
+def test_config5_mixed_batch_segments_equal_homogeneous_engines_and_the_oracle(rank, world, single_launch):
+    """configs[4] per GPU: total 2^17 * world envs -> four segments of 2^15 envs each on this rank; dispatched as ONE kernel
+    launch (mxv_rollout_mixed: block -> segment table) or as four launches on four streams."""
     import torch
 
     from gym_amd.mixed import DEFAULT_MIX, MixedRollout
     from gym_amd.rollout import DeviceRollout
 
     total, K, seed, action_seed = (1 << 17) * world, 24, 11, 12
-    mixed = MixedRollout(total, rank=rank, world_size=world, device=0, seed=seed, action_seed=action_seed)
+    mixed = MixedRollout(total, rank=rank, world_size=world, device=0, seed=seed, action_seed=action_seed,
+                         single_launch=single_launch)
     assert list(mixed.segments) == list(DEFAULT_MIX) and mixed.local_envs == 1 << 17
     mixed.reset(seed=seed)
     out = mixed.rollout_per_step(K)
@@ -88,5 +91,52 @@ def test_config5_mixed_batch_segments_equal_homogeneous_engines_and_the_oracle(r
                        horizon=K if name in ("CartPole", "MountainCar") else 10)
     done = sum(int((o["terminated"] | o["truncated"]).sum()) for o in out.values())
     assert done > 0          # CartPole episodes end inside 24 steps
+    # a second chunk (final-tensor mode) keeps the segments in step with stand-alone engines
+    fin = mixed.rollout(9)
+    mixed.synchronize()
+    for s, env_id in enumerate(DEFAULT_MIX):
+        sr = mixed.segments[env_id]
+        solo = DeviceRollout(env_id, sr.local_envs, env_offset=sr.env_offset, seed=seed + 1000003 * s,
+                             action_seed=action_seed + 1000003 * s)
+        solo.reset(seed=seed + 1000003 * s)
+        solo.rollout_per_step(K)
+        want = solo.rollout(9)
+        solo.synchronize()
+        for x, y in zip(fin[env_id], want):
+            assert torch.equal(x, y), env_id
+        assert sr.engine.handle.get_counters()[0] == K + 9
+        solo.close()
     mixed.close()
+    torch.cuda.synchronize()
+
+
+def test_mixed_single_launch_falls_back_for_non_default_attributes_and_handles_ragged_segments():
+    """A segment with a physics attribute set (set_attr) cannot run the constants-folded bodies of the mixed kernel:
+    MixedRollout then launches the segments one by one — same results.  Segment sizes that are not multiples of the wave."""
+    import torch
+
+    from gym_amd.mixed import MixedRollout
+
+    ids = ("CartPole-v1", "MountainCarContinuous-v0", "Pendulum-v1")
+    total = 3 * 1000                      # 1000 envs per segment: 15 full waves + a ragged one
+    outs = {}
+    for single in (True, False):
+        for tweak in (False, True):
+            m = MixedRollout(total, ids, device=0, seed=5, action_seed=6, single_launch=single)
+            if tweak:
+                h = m.segments["Pendulum-v1"].engine.handle
+                p = h.get_params()
+                p[3] = 9.81
+                h.set_params(p)
+            m.reset(seed=5)
+            o = m.rollout_per_step(40)
+            m.synchronize()
+            outs[(single, tweak)] = {k: {kk: vv.cpu().numpy().copy() for kk, vv in v.items()} for k, v in o.items()}
+            m.close()
+    for tweak in (False, True):
+        a, b = outs[(True, tweak)], outs[(False, tweak)]
+        for k in a:
+            for kk in a[k]:
+                assert np.array_equal(a[k][kk], b[k][kk]), (tweak, k, kk)
+    assert not np.array_equal(outs[(True, False)]["Pendulum-v1"]["obs"], outs[(True, True)]["Pendulum-v1"]["obs"])
     torch.cuda.synchronize()

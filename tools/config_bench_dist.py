@@ -84,10 +84,13 @@ def main():
     sr.close()
     del traj
 
-    mr = MixedRollout((1 << 17) * world, DEFAULT_MIX, rank=rank, world_size=world, device=local, seed=0, action_seed=1)
+    single = not os.environ.get("MXV_MIXED_MULTI_LAUNCH")   # A/B hook: one launch per segment on its own stream (round-1 dispatch)
+    mr = MixedRollout((1 << 17) * world, DEFAULT_MIX, rank=rank, world_size=world, device=local, seed=0, action_seed=1,
+                      single_launch=single)
     mr.reset(seed=0)
     timed(mr, mr.trajectory_buffers(chunk), (1 << 17) * world,
-          "config5: " + "+".join(DEFAULT_MIX) + ", 2^15 envs of each kind per GPU, 4 streams, gather per chunk", {})
+          "config5: " + "+".join(DEFAULT_MIX) + ", 2^15 envs of each kind per GPU, "
+          + ("ONE launch (block -> segment table)" if single else "4 launches on 4 streams") + ", gather per chunk", {})
     mr.close()
     if world > 1:
         dist.barrier()
