@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened with dlopen() by mxv_comm_init (no link-time dependency)
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -974,10 +975,12 @@ extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int3
         a.truncated = outs[i].truncated;
         a.final_obs = outs[i].final_obs;
         m.kind[i] = h->cfg.env_id;
-        m.first_block[i] = blocks;
-        blocks += (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup
+        m.blocks[i] = (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup
+        m.chunks[i] = m.chunks_sorted[i] = (m.blocks[i] + 7) / 8;
+        blocks += 8 * m.chunks[i];
     }
-    m.first_block[count] = blocks;
+    m.grid = blocks;
+    std::sort(m.chunks_sorted, m.chunks_sorted + count);
     // the launch goes to the first handle's stream; the other handles' streams are ordered before and after it on the GPU
     for (int i = 1; i < count; ++i) {
         mxv_handle *h = handles[i];

@@ -60,7 +60,9 @@ def test_action_frequencies_and_independence_at_2_pow_20():
     K = 96                                              # three 32-step bit blocks for Discrete(2)
     r = DeviceRollout("CartPole-v1", N, seed=1, action_seed=2, env_offset=1 << 21)
     r.reset(seed=1)
-    a = r.rollout_per_step(K)["actions"].cpu().numpy().astype(np.int8)
+    out = r.rollout_per_step(K)
+    r.synchronize()                                     # the outputs are ready on the ENGINE's stream
+    a = out["actions"].cpu().numpy().astype(np.int8)
     r.close()
     tot = a.size
     assert set(np.unique(a)) == {0, 1}
@@ -80,7 +82,9 @@ def test_action_frequencies_and_independence_at_2_pow_20():
     for env_id, n_act in (("Acrobot-v1", 3), ("MountainCar-v0", 3)):
         r = DeviceRollout(env_id, N, seed=3, action_seed=4)
         r.reset(seed=3)
-        a = r.rollout_per_step(24)["actions"].cpu().numpy()
+        out = r.rollout_per_step(24)
+        r.synchronize()
+        a = out["actions"].cpu().numpy()
         r.close()
         counts = np.bincount(a.ravel(), minlength=n_act)
         assert counts.size == n_act and stats.chisquare(counts).pvalue > 1e-6, env_id
@@ -92,7 +96,9 @@ def test_action_frequencies_and_independence_at_2_pow_20():
     for env_id, lim in (("Pendulum-v1", 2.0), ("MountainCarContinuous-v0", 1.0)):
         r = DeviceRollout(env_id, N, seed=5, action_seed=6)
         r.reset(seed=5)
-        a = r.rollout_per_step(8)["actions"].cpu().numpy().astype(np.float64)
+        out = r.rollout_per_step(8)
+        r.synchronize()
+        a = out["actions"].cpu().numpy().astype(np.float64)
         r.close()
         assert a.min() >= -lim and a.max() <= lim
         assert _ks_uniform(a.ravel()[: 1 << 22], -lim, lim) > 1e-6, env_id
