@@ -94,6 +94,10 @@ def cpu_baseline(sample_steps: int):
         "cores": cores if value >= single else 1,
         "kind": "port",
         "single_core_value": single,
+        "reference_python": {"value": 8.0e4, "unit": "env-steps/s/core", "kind": "reference",
+                             "note": "gym.vector.SyncVectorEnv(CartPole-v1) itself, measured in the build container (BASELINE.md §2); "
+                                     "/root/reference does not exist on the GPU box, so it cannot be re-timed beside this line — the C port "
+                                     "above is the reference's arithmetic without the Python interpreter"},
         "sample": f"{ENV_ID}, Philox actions + autoreset, gcc -O2 C port of the reference's step loop: 1 thread, 2^20 envs x "
                   f"{sample_steps} steps ({dt1:.1f} s); {cores} threads x {shard} envs x {steps_all} steps ({dt_all:.1f} s incl. "
                   "thread start-up and resets); the Python reference itself measured 8.0e4 env-steps/s/core (BASELINE.md §2)",

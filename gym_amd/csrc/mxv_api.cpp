@@ -255,8 +255,9 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     // from reset(options={"low","high"}) beyond that break the induction exactly like an injected state does: the next
     // fused launch takes the SAFE instantiation (every such env terminates in its first step and autoresets with the
     // default bounds, so one launch is enough).
-    if (h->cfg.env_id == MXV_CARTPOLE && std::fmax(std::fabs(b[0]), std::fabs(b[1])) > 0.78539816339744830962)
-        h->state_injected = true;
+    const double widest = std::fmax(std::fabs(b[0]), std::fabs(b[1]));
+    if ((h->cfg.env_id == MXV_CARTPOLE && widest > 0.78539816339744830962) || widest > 65536.0)
+        h->state_injected = true;  // (other kinds: the unguarded medium-range sin/cos of the fused rollout, mx_sincos<false>)
     return MXV_OK;
 }
 
@@ -975,12 +976,10 @@ extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int3
         a.truncated = outs[i].truncated;
         a.final_obs = outs[i].final_obs;
         m.kind[i] = h->cfg.env_id;
-        m.blocks[i] = (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup
-        m.chunks[i] = m.chunks_sorted[i] = (m.blocks[i] + 7) / 8;
-        blocks += 8 * m.chunks[i];
+        m.first_block[i] = blocks;
+        blocks += (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup
     }
-    m.grid = blocks;
-    std::sort(m.chunks_sorted, m.chunks_sorted + count);
+    m.first_block[count] = blocks;
     // the launch goes to the first handle's stream; the other handles' streams are ordered before and after it on the GPU
     for (int i = 1; i < count; ++i) {
         mxv_handle *h = handles[i];

@@ -246,15 +246,61 @@ __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) 
     *cs = t + __fma_rn(z, z * c, (1.0 - t) - hz);
 }
 
-// General-range sin/cos = ocml's sincos (Cody-Waite below 2^21-ish, Payne-Hanek above; documented <= 2 ulp).  A
-// hand-written fdlibm-style medium-range reduction with FMA tails (< 0.78 ulp, validated against mpmath) was built
-// and measured in round 1: it was 5-15 % SLOWER than ocml inside the Acrobot and MountainCar kernels (its quadrant
-// selects and cancellation branch cost more than ocml's), so it was dropped; profiles/r01_trig_ab.txt keeps the A/B.
-__device__ __forceinline__ void mx_sincos(double x, double *sn, double *cs) { sincos(x, sn, cs); }
-__device__ __forceinline__ double mx_cos(double x) { return cos(x); }
+// General-range sin/cos.  ocml's sincos costs ~80 VALU instructions per call on gfx950 (a 3-term Cody-Waite reduction kept in
+// double-double, ~20 v_mov to materialise polynomial coefficients next to v_fmac, a Payne-Hanek branch for |x| >= 2^30) and
+// Acrobot calls it eight times per step — two thirds of the most VALU-bound kernel of the engine (917 VALU instructions per
+// env-step at 82 % of the VALU issue rate, profiles/r02e_rooflines.jsonl).  mx_sincos is the medium-range version the dynamics
+// need: k = rint(x * 2/pi); r = x - k*pi/2 with pi/2 split 33 + 33 + 53 bits (k * P1 and, once r is small, k * P2 are exact, so
+// cancellation near multiples of pi/2 costs no accuracy: three FMAs); the fdlibm kernel polynomials of sincos_kernel on
+// |r| <= pi/4; quadrant swap and signs from k.  Error <= 1.5 ulp over |x| <= 40 including 3e6 arguments within 5e-7 of a
+// multiple of pi/2 (ocml documents 2 ulp; checked on the CPU against 80-bit sinl/cosl with the same FMA arithmetic,
+// tools/fast_sincos_check.c), ~35 instructions.  |x| >= 2^19 (k * P1 no longer exact; never produced by these dynamics) goes to
+// ocml.  As everywhere in this file, what happens inside a libm-like helper is the library's business: the reference's own
+// sin/cos are glibc's resp. NumPy's SIMD loops, which differ from each other in the last bit too.
+#ifndef MXV_FAST_TRIG
+#define MXV_FAST_TRIG 1  // A/B hook: 0 = ocml's sincos / cos everywhere
+#endif
+__device__ __forceinline__ void sincos_medium(double x, double *sn, double *cs) {
+    const double k = rint(x * 6.36619772367581382433e-01);        // 2/pi
+    double r = __fma_rn(-k, 1.5707963267341256, x);               // pi/2, first 33 bits: exact product for |k| < 2^20
+    r = __fma_rn(-k, 6.077100506303966e-11, r);                   // next 33 bits
+    r = __fma_rn(-k, 2.0222662487959506e-21, r);                  // the following 53
+    double s, c;
+    sincos_kernel(r, &s, &c);
+    const uint32_t q = (uint32_t)(int)k;
+    const bool swap = (q & 1u) != 0u;
+    const double ss = swap ? c : s, cc = swap ? s : c;
+    // sin changes sign in quadrants 2, 3; cos in quadrants 1, 2
+    *sn = __hiloint2double(__double2hiint(ss) ^ (int)((q & 2u) << 30), __double2loint(ss));
+    *cs = __hiloint2double(__double2hiint(cc) ^ (int)(((q + 1u) & 2u) << 30), __double2loint(cc));
+}
+// GUARD = false: the caller knows |x| < 2^19 (the fused rollout on states the dynamics themselves produced: Acrobot wraps its
+// angles to [-pi, pi] and bounds the velocities, MountainCar's argument is 3 * position, a time-limited Pendulum turns at most
+// 0.4 rad per step) — no range check and none of ocml's code or registers in the kernel.  mxv_set_state and unusual reset
+// bounds break that knowledge for one launch, which then takes the guarded instantiation (see launch_step_env, SAFE).
+template <bool GUARD = true>
+__device__ __forceinline__ void mx_sincos(double x, double *sn, double *cs) {
+#if MXV_FAST_TRIG
+    if (!GUARD || fabs(x) < 524288.0)
+        sincos_medium(x, sn, cs);
+    else
+#endif
+        sincos(x, sn, cs);
+}
+template <bool GUARD = true>
+__device__ __forceinline__ double mx_cos(double x) {
+#if MXV_FAST_TRIG
+    double s, c;
+    mx_sincos<GUARD>(x, &s, &c);
+    return c;
+#else
+    return cos(x);
+#endif
+}
+template <bool GUARD = true>
 __device__ __forceinline__ double mx_sin(double x) {
     double s, c;
-    sincos(x, &s, &c);  // the sine of sincos, so that a cached sine (Pendulum aux) and a fresh one are the same bits
+    mx_sincos<GUARD>(x, &s, &c);  // the sine of sincos, so that a cached sine (Pendulum aux) and a fresh one are the same bits
     return s;
 }
 
@@ -293,6 +339,7 @@ template <>
 struct Env<MXV_CARTPOLE> {
     static constexpr int S = 4, O = 4, NA = 2;
     static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    template <bool GUARD = true>
     __device__ __forceinline__ static void prime(const double *s, double *aux) {}
     // SAFE = false (rollout fast path, default parameters only): the caller guarantees |theta| <= pi/4 on entry, which
     // holds inductively after reset() under autoreset (an env leaves (-0.2095, 0.2095) only in the step that ends it);
@@ -336,6 +383,7 @@ struct Env<MXV_CARTPOLE> {
         obs[0] = (float)x; obs[1] = (float)x_dot; obs[2] = (float)theta; obs[3] = (float)theta_dot;  // :188
         return (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);          // :162-167
     }
+    template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {  // :207
         obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
     }
@@ -365,11 +413,13 @@ template <>
 struct Env<MXV_PENDULUM> {
     static constexpr int S = 2, O = 3, NA = 0;
     static constexpr int AUX = 1;  // fp64 values derived from the state that a fused rollout carries across steps
-    __device__ __forceinline__ static void prime(const double *s, double *aux) { aux[0] = mx_sin(s[0]); }
+    template <bool GUARD = true>
+    __device__ __forceinline__ static void prime(const double *s, double *aux) { aux[0] = mx_sin<GUARD>(s[0]); }
     // aux[0] = sin(theta): `sin(th)` of step t+1 (:131) is the sine _get_obs took at the end of step t (:162)
+    template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux) {  // :161-163
         double sn, cs;
-        mx_sincos(s[0], &sn, &cs);
+        mx_sincos<GUARD>(s[0], &sn, &cs);
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
         aux[0] = sn;
     }
@@ -395,7 +445,7 @@ struct Env<MXV_PENDULUM> {
         const double newth = th + newthdot * dt;                           // :133
         s[0] = newth; s[1] = newthdot;
         reward = -costs;                                                   // :139
-        observe(s, obs, aux);
+        observe<SAFE>(s, obs, aux);
         return false;
     }
     // high = (x_init, y_init), low = -high; np_random.uniform(low, high) :141-154
@@ -430,9 +480,10 @@ template <>
 struct Env<MXV_ACROBOT> {
     static constexpr int S = 4, O = 6, NA = 3;
     static constexpr int AUX = 4;  // sin(theta1), cos(theta1), sin(theta2), cos(theta2) of the current state
+    template <bool GUARD = true>
     __device__ __forceinline__ static void prime(const double *s, double *aux) {
-        mx_sincos(s[0], &aux[0], &aux[1]);
-        mx_sincos(s[1], &aux[2], &aux[3]);
+        mx_sincos<GUARD>(s[0], &aux[0], &aux[1]);
+        mx_sincos<GUARD>(s[1], &aux[2], &aux[3]);
     }
     // sc = sin/cos of sa[0], sa[1]
     template <int DEF>
@@ -487,10 +538,11 @@ struct Env<MXV_ACROBOT> {
         const double t = (m > x) ? m : x;
         return (M < t) ? M : t;
     }
+    template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux = nullptr) {  // :225-230
         double s0, c0, s1, c1;
-        mx_sincos(s[0], &s0, &c0);
-        mx_sincos(s[1], &s1, &c1);
+        mx_sincos<GUARD>(s[0], &s0, &c0);
+        mx_sincos<GUARD>(s[1], &s1, &c1);
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
         if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
@@ -512,18 +564,18 @@ struct Env<MXV_ACROBOT> {
         dsdt(P, y0, aux, torque, k1);  // :453  (the augmented torque component has derivative 0.0: it stays `torque`)
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k1[k];
-        mx_sincos(y[0], &sc[0], &sc[1]);
-        mx_sincos(y[1], &sc[2], &sc[3]);
+        mx_sincos<SAFE>(y[0], &sc[0], &sc[1]);
+        mx_sincos<SAFE>(y[1], &sc[2], &sc[3]);
         dsdt(P, y, sc, torque, k2);   // :454
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k2[k];
-        mx_sincos(y[0], &sc[0], &sc[1]);
-        mx_sincos(y[1], &sc[2], &sc[3]);
+        mx_sincos<SAFE>(y[0], &sc[0], &sc[1]);
+        mx_sincos<SAFE>(y[1], &sc[2], &sc[3]);
         dsdt(P, y, sc, torque, k3);   // :455
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt * k3[k];
-        mx_sincos(y[0], &sc[0], &sc[1]);
-        mx_sincos(y[1], &sc[2], &sc[3]);
+        mx_sincos<SAFE>(y[0], &sc[0], &sc[1]);
+        mx_sincos<SAFE>(y[1], &sc[2], &sc[3]);
         dsdt(P, y, sc, torque, k4);   // :456
         const double dt6 = dt / 6.0;
         double ns[4];
@@ -534,8 +586,8 @@ struct Env<MXV_ACROBOT> {
         s[2] = bound(ns[2], -P.get(8, 4 * kPi), P.get(8, 4 * kPi));  // :215
         s[3] = bound(ns[3], -P.get(9, 9 * kPi), P.get(9, 9 * kPi));  // :216
         double s0, c0, s1, c1;
-        mx_sincos(s[0], &s0, &c0);
-        mx_sincos(s[1], &s1, &c1);
+        mx_sincos<SAFE>(s[0], &s0, &c0);
+        mx_sincos<SAFE>(s[1], &s1, &c1);
         // cos(s[1] + s[0]) :235 from the same four values
         const double t21 = s[1] + s[0];
         const double cos21 = __fma_rn(two_sum_residual(s[1], s[0], t21), __fma_rn(s0, c1, c0 * s1), __fma_rn(c0, c1, -(s0 * s1)));
@@ -560,7 +612,9 @@ template <>
 struct Env<MXV_MOUNTAINCAR> {
     static constexpr int S = 2, O = 2, NA = 3;
     static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    template <bool GUARD = true>
     __device__ __forceinline__ static void prime(const double *s, double *aux) {}
+    template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
@@ -571,7 +625,7 @@ struct Env<MXV_MOUNTAINCAR> {
         const double goal_position = P.get(3, 0.5), goal_velocity = P.get(4, 0.0);
         const double force = P.get(5, 0.001), gravity = P.get(6, 0.0025);
         double position = s[0], velocity = s[1];
-        velocity = velocity + ((double)(ai - 1) * force + mx_cos(3 * position) * (-gravity));  // :133
+        velocity = velocity + ((double)(ai - 1) * force + mx_cos<SAFE>(3 * position) * (-gravity));  // :133
         if (velocity < -max_speed) velocity = -max_speed;                                  // np.clip :134
         if (velocity > max_speed) velocity = max_speed;
         position = position + velocity;                                                    // :135
@@ -597,7 +651,9 @@ template <>
 struct Env<MXV_MOUNTAINCAR_CONT> {
     static constexpr int S = 2, O = 2, NA = 0;
     static constexpr int AUX = 0;  // fp64 values derived from the state that a fused rollout carries across steps
+    template <bool GUARD = true>
     __device__ __forceinline__ static void prime(const double *s, double *aux) {}
+    template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
@@ -617,7 +673,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
         bool term;
         if (fresh) {
             double position = s[0], velocity = s[1];
-            const double g = 0.0025 * mx_cos(3 * position);  // :148
+            const double g = 0.0025 * mx_cos<SAFE>(3 * position);  // :148
             const double inc = clipped ? (force_py * power - g) : (double)(fp - (float)g);
             velocity = velocity + inc;
             if (velocity > max_speed) velocity = max_speed;    // :149-152
@@ -632,7 +688,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
         } else {
             float position = (float)s[0], velocity = (float)s[1];
             const float three_p = 3.0f * position;            // int * np.float32 -> float32
-            const double g = 0.0025 * mx_cos((double)three_p);
+            const double g = 0.0025 * mx_cos<SAFE>((double)three_p);
             const float inc = clipped ? (float)(force_py * power - g) : (fp - (float)g);
             velocity = velocity + inc;
             if (velocity > (float)max_speed) velocity = (float)max_speed;

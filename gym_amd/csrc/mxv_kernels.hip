@@ -391,7 +391,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
         el[j] = a.elapsed[le[j]];
         ep[j] = a.episodes[le[j]];
-        EV::prime(s[j], aux[j]);
+        EV::template prime<SAFE>(s[j], aux[j]);
     }
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
 #pragma unroll
@@ -420,12 +420,12 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             const uint64_t seed = a.seeds ? landed(a.seeds[le[j]]) : a.base_seed + a.env0 + (uint64_t)le[j];
             const U4 w = episode_reset_words(seed, ep[j]);
             Entry r;
-            EV::reset(w, a.b0, a.b1, r.s);
+            EV::reset(w, a.b0, a.b1, r.s);  // autoresets draw inside the env's default bounds: arguments far inside the unguarded range
             if constexpr (EV::AUX > 0) {
-                EV::observe(r.s, r.o, r.x);
+                EV::template observe<false>(r.s, r.o, r.x);
             } else {
                 double none[1];
-                EV::observe(r.s, r.o, none);
+                EV::template observe<false>(r.s, r.o, none);
             }
             lds_res[j * kWave + lane] = r;
         }
@@ -617,55 +617,18 @@ union MixedLds {
     __device__ MixedLds() {}
 };
 
-// Block -> (segment, block of the segment).  Handing each segment a contiguous range of block ids would put eight consecutive
-// workgroups of ONE kind on a CU: the CUs that draw the Acrobot range run two of its VALU-bound waves per SIMD while the CUs
-// with the light kinds idle (measured: 3.27 us per mixed step against 2.62 us for four separate launches, whose grids each
-// spread over all CUs).  So the table interleaves: block ids are taken in chunks of 8 (one block per XCD: the hardware deals
-// ids round-robin over the 8 XCDs, and a segment-local id must keep its XCD for xcd_contiguous_tile), chunk c goes round-robin
-// to the segments that still have chunks left, and the order inside a round is rotated by the round index so that no CU keeps
-// drawing the same kind.  Closed form over the segment sizes sorted ascending (<= MXV_MAX_MIXED scalar iterations).
-__device__ __forceinline__ bool mixed_block_to_segment(const MixedArgs &m, unsigned b, unsigned &sidx, unsigned &local) {
-    const unsigned c = b / kXcds, r = b % kXcds;
-    unsigned pos = 0, base_round = 0, round = 0, idx = 0, active = 1;
-    bool found = false;
-#pragma unroll
-    for (int l = 0; l < MXV_MAX_MIXED; ++l) {
-        if (l >= m.count || found) continue;
-        const unsigned act = (unsigned)(m.count - l);
-        const unsigned rounds_here = m.chunks_sorted[l] - (l ? m.chunks_sorted[l - 1] : 0u);
-        const unsigned span = rounds_here * act;
-        if (c < pos + span) {
-            round = base_round + (c - pos) / act;
-            idx = (c - pos) % act;
-            active = act;
-            found = true;
-        } else {
-            pos += span;
-            base_round += rounds_here;
-        }
-    }
-    if (!found) return false;
-    const unsigned want = (idx + round) % active;  // rotate the order of the kinds from round to round
-    unsigned seen = 0;
-    sidx = 0;
-#pragma unroll
-    for (int i = 0; i < MXV_MAX_MIXED; ++i) {
-        if (i >= m.count) continue;
-        if (m.chunks[i] > round) {
-            if (seen == want) sidx = (unsigned)i;
-            ++seen;
-        }
-    }
-    local = round * kXcds + r;
-    return local < m.blocks[sidx];
-}
-
+// Block -> segment: segment i owns the contiguous block range [first_block[i], first_block[i+1]).  (An interleaved table — chunks of
+// 8 blocks dealt round-robin to the segments, order rotated per round — was measured too: 4.52 us per mixed step against 3.27 us
+// for the contiguous ranges, profiles/r02e_mixed_dispatch_interleaved.jsonl.  The hardware deals consecutive workgroups over the
+// SIMDs, so what matters is WHICH two waves end up sharing a SIMD: the interleaving paired Acrobot waves with each other.)
 __global__ void __launch_bounds__(kWave) mixed_rollout_kernel(const MixedArgs m) {
     __shared__ MixedLds lds;
-    unsigned sidx, bid;
-    if (!mixed_block_to_segment(m, blockIdx.x, sidx, bid)) return;
+    unsigned sidx = 0;
+#pragma unroll
+    for (int i = 1; i < MXV_MAX_MIXED; ++i)
+        if (i < m.count && blockIdx.x >= m.first_block[i]) sidx = (unsigned)i;
     const StepArgs &a = m.seg[sidx];
-    const unsigned nblk = m.blocks[sidx];
+    const unsigned bid = blockIdx.x - m.first_block[sidx], nblk = m.first_block[sidx + 1] - m.first_block[sidx];
     switch (m.kind[sidx]) {   // wave-uniform: one body per workgroup
         case MXV_CARTPOLE:  // SAFE: a segment may have had its state injected
             rollout_body_v3<MXV_CARTPOLE, true, 1, true, 0>(a, bid, nblk, lds.cartpole);
@@ -1015,8 +978,11 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
     if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise) {
-        bool fast = false;
-        if constexpr (ENV == MXV_CARTPOLE) fast = def && !a.state_injected;  // see Env<MXV_CARTPOLE>::step, SAFE
+        // SAFE = false: the state obeys the invariants the dynamics maintain (CartPole: |theta| <= pi/4; the others: trig arguments
+        // below 2^19), so sin/cos need no range check.  A state injection (mxv_set_state) or unusual explicit-reset bounds break
+        // that for one launch; an unlimited Pendulum can turn without bound.
+        const bool bounded = ENV != MXV_PENDULUM || (a.max_steps > 0 && a.max_steps < 1000000);
+        const bool fast = def && !a.state_injected && bounded && MXV_FAST_TRIG;
         auto go = [&](auto er_tag) {
             constexpr int ER = decltype(er_tag)::value;
             const int64_t rtile = (int64_t)ER * kWave;
@@ -1024,7 +990,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
             if (!def) {
                 launch_rollout<ENV, false, ER, true>(rgrid, stream, a);
             } else if (fast) {
-                if constexpr (ENV == MXV_CARTPOLE) launch_rollout<ENV, true, ER, false>(rgrid, stream, a);
+                launch_rollout<ENV, true, ER, false>(rgrid, stream, a);
             } else {
                 launch_rollout<ENV, true, ER, true>(rgrid, stream, a);
             }
@@ -1115,7 +1081,7 @@ hipError_t launch_sample(int env_id, int default_params, const SampleArgs &a, hi
 }
 
 hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream) {
-    hipLaunchKernelGGL(mixed_rollout_kernel, dim3(m.grid), dim3(kWave), 0, stream, m);
+    hipLaunchKernelGGL(mixed_rollout_kernel, dim3(m.first_block[m.count]), dim3(kWave), 0, stream, m);
     return hipGetLastError();
 }
 

@@ -43,16 +43,12 @@ struct StepArgs {
     EnvParams P;
 };
 
-// One launch over several homogeneous segments (mixed_rollout_kernel).  Segment i has blocks[i] workgroups = chunks[i] chunks of
-// 8; the grid's block ids are dealt to the segments chunk by chunk, round-robin (see mixed_block_to_segment).
+// One launch over several homogeneous segments (mixed_rollout_kernel): segment i owns workgroups [first_block[i], first_block[i+1]).
 struct MixedArgs {
     StepArgs seg[MXV_MAX_MIXED];
-    uint32_t blocks[MXV_MAX_MIXED];         // workgroups (= waves = 64 envs) of each segment
-    uint32_t chunks[MXV_MAX_MIXED];         // ceil(blocks / 8)
-    uint32_t chunks_sorted[MXV_MAX_MIXED];  // the same values in ascending order
-    int32_t kind[MXV_MAX_MIXED];            // env kind of each segment
+    uint32_t first_block[MXV_MAX_MIXED + 1];
+    int32_t kind[MXV_MAX_MIXED];   // env kind of each segment
     int32_t count;
-    uint32_t grid;                          // 8 * sum(chunks)
 };
 
 struct ResetArgs {

@@ -5,12 +5,18 @@ gym/vector/vector_env.py:20-23, and SyncVectorEnv raises on mismatched sub-env s
 gym/vector/sync_vector_env.py:220-234).  The only consistent definition — and the one the parity tests use — is the
 concatenation of homogeneous segments, each equal to its own `SyncVectorEnv`.
 
-Dispatch: one engine (= one C-ABI handle) per segment per GPU, and ONE kernel launch for all of them
-(`mxv_rollout_mixed`, include/mxv.h): a block -> segment table sends every workgroup (= one wave) to the rollout body of
-its segment's env kind, so waves stay homogeneous — no per-lane switch that would serialise the four code paths — while
-the four small grids fill the chip as one.  Bit-identical to launching the segments one by one (`single_launch=False`:
-back-to-back launches on the segments' own streams, also the fallback when a segment runs non-default physics
-attributes, and what a non-HIP engine factory gets).  Across GPUs each segment is sharded like ShardedRollout
+Dispatch: one engine (= one C-ABI handle, one HIP stream) per segment per GPU.  Two ways to run a chunk of K steps, bit-identical:
+  * `single_launch=False` (default): the segments' fused rollouts are launched back to back on their own streams; the four
+    grids run concurrently.  2.62 us per mixed step at configs[4]'s per-GPU share (4 x 2^15 envs) = 5.0e10 env-steps/s — 94 % of
+    the floor set by the Acrobot segment alone (2.47 us: 512 latency-bound RK4 waves, one per SIMD).
+  * `single_launch=True`: ONE kernel for all segments (`mxv_rollout_mixed`, include/mxv.h): a block -> segment table sends every
+    workgroup (= one wave) to the rollout body of its segment's env kind, so waves stay homogeneous (no per-lane switch that
+    would serialise the code paths).  Measured SLOWER on the MI355X: 3.27 us with contiguous block ranges, 4.52 us with the
+    ranges interleaved (profiles/r02d_mixed_dispatch_contiguous.jsonl, r02e_mixed_dispatch_interleaved.jsonl): inside one grid the
+    hardware deals consecutive workgroups over the SIMDs, which pairs waves of the same segment — two VALU-bound Acrobot waves —
+    on one SIMD, while separate grids interleave kinds.  Kept as an option (one launch instead of four matters when launches
+    are the bottleneck: short chunks, many small segments).
+Across GPUs each segment is sharded like ShardedRollout
 shards a homogeneous env: rank r owns the r-th contiguous slice of EVERY segment, so all ranks carry the same mix
 and the same load; Philox streams use the segment-global env index, hence results do not depend on the number of GPUs.
 """
@@ -28,7 +34,7 @@ class MixedRollout:
 
     def __init__(self, total_envs: int, ids: Sequence[str] = DEFAULT_MIX, *, rank: Optional[int] = None,
                  world_size: Optional[int] = None, device: Optional[int] = None, seed: int = 0, action_seed: int = 0,
-                 group=None, engine_factory: Optional[Callable] = None, single_launch: bool = True, **engine_kwargs):
+                 group=None, engine_factory: Optional[Callable] = None, single_launch: bool = False, **engine_kwargs):
         ids = list(ids)
         if total_envs % len(ids) != 0:
             raise ValueError(f"num_envs={total_envs} must be divisible by the number of env kinds ({len(ids)})")
