@@ -592,8 +592,19 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 }
 
 
+// ... and the waves per SIMD it may NOT exceed.  The default-parameter kernels are pinned to exactly 4: a shard of 2^19 / 2^20
+// envs is a whole number of 4-wave rounds (8192 or 16384 single-wave workgroups on 1024 SIMDs), and a kernel that fits 5 waves
+// (Pendulum: 87 VGPRs) runs 3.2 rounds' worth of work in 4 rounds, the last one a fifth full: measured 6.4 instead of 5.9 us per
+// 2^20-env Pendulum step when the medium-range sincos shrank the kernel to 5 waves (profiles/r02f_fast_trig_ab.jsonl).
+template <int ENV, bool DEF, bool SAFE>
+constexpr int rollout_max_waves() {
+    return rollout_min_waves<ENV, DEF, SAFE>() == 1 ? 8 : rollout_min_waves<ENV, DEF, SAFE>();
+}
+
 template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
-__global__ void __launch_bounds__(kWave, (rollout_min_waves<ENV, DEF, SAFE>())) rollout_kernel_v3(const StepArgs a) {
+__global__ void __launch_bounds__(kWave)
+    __attribute__((amdgpu_waves_per_eu(rollout_min_waves<ENV, DEF, SAFE>(), rollout_max_waves<ENV, DEF, SAFE>())))
+    rollout_kernel_v3(const StepArgs a) {
     __shared__ RolloutLds<ENV, E> lds;
     rollout_body_v3<ENV, DEF, E, SAFE, OUT>(a, blockIdx.x, gridDim.x, lds);
 }
@@ -954,8 +965,14 @@ void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
     if constexpr (use_rollout_v2<ENV>())
         hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE, OUT>), dim3((grid + MXV_ROLLOUT_V2_WAVES - 1) / MXV_ROLLOUT_V2_WAVES),
                            dim3(kWave * MXV_ROLLOUT_V2_WAVES), 0, stream, a);
-    else
-        hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), 0, stream, a);
+    else {
+        // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
+        // rollout_max_waves) is its LDS footprint: padded with unused dynamic LDS to 9.5 KiB per single-wave workgroup, 16 of
+        // them fill the CU's 160 KiB and a 17th does not fit.
+        constexpr size_t kLdsPerWorkgroup = 9728, kStatic = sizeof(RolloutLds<ENV, ER>);
+        const size_t pad = (rollout_min_waves<ENV, DEF, SAFE>() == 4 && kStatic < kLdsPerWorkgroup) ? kLdsPerWorkgroup - kStatic : 0;
+        hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), pad, stream, a);
+    }
 }
 template <int ENV, bool DEF, int ER, bool SAFE>
 void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {

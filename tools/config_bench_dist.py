@@ -84,7 +84,7 @@ def main():
     sr.close()
     del traj
 
-    single = not os.environ.get("MXV_MIXED_MULTI_LAUNCH")   # A/B hook: one launch per segment on its own stream (round-1 dispatch)
+    single = bool(os.environ.get("MXV_MIXED_SINGLE_LAUNCH"))   # A/B hook: all segments in ONE launch (mxv_rollout_mixed) instead of one launch per segment on its own stream
     mr = MixedRollout((1 << 17) * world, DEFAULT_MIX, rank=rank, world_size=world, device=local, seed=0, action_seed=1,
                       single_launch=single)
     mr.reset(seed=0)
