@@ -36,7 +36,7 @@ EXPORTS = (
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
-    "mxv_rollout_mixed", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
+    "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -131,11 +131,12 @@ def _load():
         "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
+        "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
         "mxv_comm_init": ([vp, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_comm_destroy": ([vp], C.c_int),
         "mxv_allgather_outputs": ([vp] * 9, C.c_int),
-        "mxv_allgather_wait": ([vp, C.c_int32], C.c_int),
+        "mxv_allgather_wait": ([vp, C.c_int32, C.c_int32], C.c_int),
         "mxv_comm_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_get_episodes": ([vp, vp], C.c_int),
         "mxv_set_episodes": ([vp, vp], C.c_int),
@@ -528,6 +529,10 @@ class Handle:
     def set_stream(self, stream_ptr: int):
         self._check(lib.mxv_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def set_final_snapshot(self, obs=None, reward=None, terminated=None, truncated=None):
+        """Every following K-step rollout also writes its last step's outputs into these device buffers (None: detach)."""
+        self._check(lib.mxv_set_final_snapshot(self._h, _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated)))
+
     # -- collectives of a sharded vector env (RCCL behind the C ABI) ------------------------------------------------
     def comm_init(self, rank: int, world: int, unique_id: bytes):
         assert len(unique_id) == COMM_ID_BYTES
@@ -544,8 +549,9 @@ class Handle:
         self._check(lib.mxv_allgather_outputs(self._h, _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated),
                                               _ptr(all_obs), _ptr(all_reward), _ptr(all_terminated), _ptr(all_truncated)))
 
-    def allgather_wait(self, host_sync: bool = False):
-        self._check(lib.mxv_allgather_wait(self._h, int(bool(host_sync))))
+    def allgather_wait(self, host_sync: bool = False, age: int = 0):
+        """Wait for the last gather (age 0) or the one before (age 1); on the handle's stream, or on the host with host_sync."""
+        self._check(lib.mxv_allgather_wait(self._h, int(age), int(bool(host_sync))))
 
     @property
     def comm_stream(self) -> int:

@@ -115,8 +115,12 @@ struct mxv_handle {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_outputs = nullptr, ev_gathered = nullptr;
-    bool gather_pending = false;
+    hipEvent_t ev_outputs = nullptr, ev_gathered[2] = {nullptr, nullptr};  // completion of the last two gathers (ring)
+    uint64_t gathers = 0;                                                    // gathers issued so far
+    // optional second destination of a fused rollout's final tensors (mxv_set_final_snapshot)
+    float *snap_obs = nullptr;
+    void *snap_reward = nullptr;
+    uint8_t *snap_term = nullptr, *snap_trunc = nullptr;
     hipEvent_t ev_mixed = nullptr;  // orders this handle's stream against a mixed-batch launch issued on another handle's stream
     std::string error;
 
@@ -194,6 +198,9 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.ep_acc = h->ep_acc;
     a.ep_return_out = h->ep_acc ? h->ep_return_out : nullptr;
     a.ep_length_out = h->ep_acc ? h->ep_length_out : nullptr;
+    a.snap_obs = nullptr;   // only the K-step calls deposit a snapshot (fused_launch, mxv_rollout_mixed)
+    a.snap_reward = nullptr;
+    a.snap_terminated = a.snap_truncated = nullptr;
     a.P = h->P;
 }
 
@@ -466,6 +473,19 @@ int rollout_checks(mxv_handle *h, int32_t K, const float *obs_dev) {
     return use_device(h);
 }
 
+// Launch paths whose kernel does not write the snapshot itself: copy the last step's outputs (device to device, same stream).
+int copy_final_snapshot(mxv_handle *h, int32_t K, int32_t per_step, const float *obs, const void *reward, const uint8_t *term,
+                        const uint8_t *trunc) {
+    const size_t n = (size_t)h->cfg.num_envs, last = per_step ? (size_t)(K - 1) * n : 0;
+    MXV_HIP(h, hipMemcpyAsync(h->snap_obs, obs + last * h->O, n * h->O * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (h->snap_reward && reward)
+        MXV_HIP(h, hipMemcpyAsync(h->snap_reward, (const char *)reward + last * h->reward_bytes(), n * h->reward_bytes(),
+                                  hipMemcpyDeviceToDevice, h->stream));
+    if (h->snap_term && term) MXV_HIP(h, hipMemcpyAsync(h->snap_term, term + last, n, hipMemcpyDeviceToDevice, h->stream));
+    if (h->snap_trunc && trunc) MXV_HIP(h, hipMemcpyAsync(h->snap_trunc, trunc + last, n, hipMemcpyDeviceToDevice, h->stream));
+    return MXV_OK;
+}
+
 // One launch, K steps, env state in registers between steps.
 int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions_tape, void *actions_out, float *obs,
                  void *reward, uint8_t *term, uint8_t *trunc, float *final_obs) {
@@ -481,9 +501,17 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
+    const bool in_kernel = h->snap_obs && launch_step_is_rollout(h->param_mode(), a);
+    if (in_kernel) {
+        a.snap_obs = h->snap_obs;
+        a.snap_reward = h->snap_reward;
+        a.snap_terminated = h->snap_term;
+        a.snap_truncated = h->snap_trunc;
+    }
     MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream));
     h->state_injected = false;
     h->t += (uint64_t)K;
+    if (h->snap_obs && !in_kernel) return copy_final_snapshot(h, K, per_step, obs, reward, term, trunc);
     return MXV_OK;
 }
 
@@ -550,6 +578,18 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
     }
     h->state_injected = false;
     h->t += (uint64_t)K;
+    if (h->snap_obs) return copy_final_snapshot(h, K, per_step, obs_dev, reward_dev, terminated_dev, truncated_dev);
+    return MXV_OK;
+}
+
+int mxv_set_final_snapshot(mxv_handle *h, float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (!obs_dev && (reward_dev || terminated_dev || truncated_dev))
+        return fail(h, MXV_ERR_INVALID_ARG, "mxv_set_final_snapshot: the observation buffer is required (NULL everything to detach)");
+    h->snap_obs = obs_dev;
+    h->snap_reward = reward_dev;
+    h->snap_term = terminated_dev;
+    h->snap_trunc = truncated_dev;
     return MXV_OK;
 }
 
@@ -975,6 +1015,10 @@ extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int3
         a.terminated = outs[i].terminated;
         a.truncated = outs[i].truncated;
         a.final_obs = outs[i].final_obs;
+        a.snap_obs = h->snap_obs;
+        a.snap_reward = h->snap_reward;
+        a.snap_terminated = h->snap_term;
+        a.snap_truncated = h->snap_trunc;
         m.kind[i] = h->cfg.env_id;
         m.first_block[i] = blocks;
         blocks += (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup
@@ -1087,7 +1131,9 @@ int mxv_comm_init(mxv_handle *h, int32_t rank, int32_t world, const void *unique
     MXV_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
     MXV_HIP(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
     MXV_HIP(h, hipEventCreateWithFlags(&h->ev_outputs, hipEventDisableTiming));
-    MXV_HIP(h, hipEventCreateWithFlags(&h->ev_gathered, hipEventDisableTiming));
+    MXV_HIP(h, hipEventCreateWithFlags(&h->ev_gathered[0], hipEventDisableTiming));
+    MXV_HIP(h, hipEventCreateWithFlags(&h->ev_gathered[1], hipEventDisableTiming));
+    h->gathers = 0;
     return MXV_OK;
 }
 
@@ -1099,12 +1145,15 @@ int mxv_comm_destroy(mxv_handle *h) {
     (void)rccl().CommDestroy(h->comm);
     h->comm = nullptr;
     if (h->ev_outputs) (void)hipEventDestroy(h->ev_outputs);
-    if (h->ev_gathered) (void)hipEventDestroy(h->ev_gathered);
+    for (hipEvent_t &e : h->ev_gathered) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    h->ev_outputs = h->ev_gathered = nullptr;
+    h->ev_outputs = nullptr;
     h->comm_stream = nullptr;
     h->comm_world = 0;
-    h->gather_pending = false;
+    h->gathers = 0;
     return MXV_OK;
 }
 
@@ -1132,21 +1181,21 @@ int mxv_allgather_outputs(mxv_handle *h, const float *obs_dev, const void *rewar
     const ncclResult_t e = api.GroupEnd();
     if (r != ncclSuccess || e != ncclSuccess)
         return fail(h, MXV_ERR_HIP, "ncclAllGather: %s", api.GetErrorString(r != ncclSuccess ? r : e));
-    MXV_HIP(h, hipEventRecord(h->ev_gathered, h->comm_stream));
-    h->gather_pending = true;
+    MXV_HIP(h, hipEventRecord(h->ev_gathered[h->gathers & 1], h->comm_stream));
+    h->gathers += 1;
     return MXV_OK;
 }
 
-int mxv_allgather_wait(mxv_handle *h, int32_t host_sync) {
+int mxv_allgather_wait(mxv_handle *h, int32_t age, int32_t host_sync) {
     MXV_CHECK_HANDLE(h);
-    if (!h->gather_pending) return MXV_OK;
+    if (age < 0 || age > 1) return fail(h, MXV_ERR_INVALID_ARG, "mxv_allgather_wait: age must be 0 (last gather) or 1 (the one before)");
+    if (h->gathers <= (uint64_t)age) return MXV_OK;  // no such gather yet
     if (int rc = use_device(h)) return rc;
-    if (host_sync) {
-        MXV_HIP(h, hipEventSynchronize(h->ev_gathered));
-        h->gather_pending = false;
-    } else {
-        MXV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered, 0));
-    }
+    hipEvent_t ev = h->ev_gathered[(h->gathers - 1 - (uint64_t)age) & 1];
+    if (host_sync)
+        MXV_HIP(h, hipEventSynchronize(ev));
+    else
+        MXV_HIP(h, hipStreamWaitEvent(h->stream, ev, 0));
     return MXV_OK;
 }
 

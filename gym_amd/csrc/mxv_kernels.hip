@@ -563,6 +563,23 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 #pragma unroll
         for (int j = 0; j < E; ++j)
             if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), lo[j], obs[j]);
+        // ---- the chunk's FINAL tensors once more, into the caller's snapshot (what a sharded vector env all-gathers while the
+        //      next chunk runs: written here, no copy kernels between rollout and gather) ----
+        if (step + 1 == a.K && a.snap_obs != nullptr) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if (!valid[j]) continue;
+                store_obs<O>(a.snap_obs, le[j], obs[j]);
+                if (a.snap_reward != nullptr) {
+                    if (rew_f32)
+                        static_cast<float *>(a.snap_reward)[le[j]] = (float)rew[j];
+                    else
+                        static_cast<double *>(a.snap_reward)[le[j]] = rew[j];
+                }
+                if (a.snap_terminated != nullptr) a.snap_terminated[le[j]] = term[j] ? 1 : 0;
+                if (a.snap_truncated != nullptr) a.snap_truncated[le[j]] = trunc[j] ? 1 : 0;
+            }
+        }
 
         // ---- look-ahead pass: refill the empty reset slots j of this wave, every PERIOD steps per slot ----
 #pragma unroll
@@ -651,254 +668,6 @@ __global__ void __launch_bounds__(kWave) mixed_rollout_kernel(const MixedArgs m)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// rollout_kernel_v2 (A/B alternative of rollout_kernel_v3 for the envs with word-per-step actions; MXV_ROLLOUT_IMPL = 2):
-// same contract, tile and store pattern, resets drawn INSIDE the step by the owning lane.
-// A finished env is reset by ITS OWN lane (key and counter come from registers; the new state, aux values and observation
-// never leave the lane), and the lanes without a finished env draw the action words of future steps, ranked among
-// themselves with mbcnt: the k-th free lane draws group k % NACT of step filled + k / NACT.  Which lane evaluates
-// Philox(g, t) does not change its value, so the RNG contract and every output bit are those of rollout_kernel.
-// What is left in LDS is the 1-KiB ring of action words: per wave-step ONE LDS round trip (the ring read, prefetched
-// one step ahead) instead of three (ring read, compacted-list read, reset-entry read), 1 KiB instead of 9.7 KiB per
-// workgroup.  A lane with two finished envs (E = 2: ~0.2 % of wave-steps) or a wave without enough free lanes for a
-// forced refill (every Pendulum env truncating at step 200) takes extra passes.
-// ------------------------------------------------------------------------------------------------------------
-template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, int WAVES = MXV_ROLLOUT_V2_WAVES>
-__global__ void __launch_bounds__(kWave * WAVES, MXV_ROLLOUT_MIN_WAVES) rollout_kernel_v2(const StepArgs a) {
-    using EV = Env<ENV>;
-    constexpr int S = EV::S, O = EV::O, NA = EV::NA;
-    constexpr int TILE = E * kWave;
-    constexpr int NACT = TILE / 4;        // lanes that draw the action words of ONE step
-    constexpr int H = kWave / NACT;       // steps of action words one full call produces = depth of the ring
-    static_assert(NACT <= kWave, "E must be <= 4");
-    static_assert(!action_bits<ENV>(), "bit-sliced Discrete(2) actions are served by rollout_kernel_v3 only");
-    constexpr int AUXN = EV::AUX > 0 ? EV::AUX : 1;
-    // WAVES waves per workgroup, each an independent tile with a private ring (no barrier anywhere): a workgroup only groups
-    // WAVES consecutive tiles onto one CU so that their stores of a step land next to each other
-    __shared__ uint32_t lds_ring[WAVES][H * TILE];  // ring of action words: slot (q % H) holds step q of this launch
-    uint32_t *lds_act = lds_ring[threadIdx.x / kWave];
-
-    const int lane = threadIdx.x % kWave;
-    const uint32_t tile = xcd_contiguous_tile(blockIdx.x, gridDim.x) * WAVES + threadIdx.x / kWave;
-    const int64_t tile0 = (int64_t)tile * TILE;
-    const int64_t n = a.n;
-    const Par<DEF> P(a.P);
-    const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0);
-    // OUT != 0: every per-step output array is present, no final_obs, no episode statistics, dtypes fixed (1: float64 rewards
-    // + int64 actions, 2: float32 + int32) — the trajectory-recording launch.  The ~25 wave-uniform branches and ~60 scalar
-    // instructions per step that the optional outputs cost fold away at compile time.
-    constexpr bool FULL = OUT != 0;
-    const bool act_i32 = FULL ? (OUT == 2) : ((a.flags & MXV_FLAG_ACTION_I32) != 0);
-    const bool rew_f32 = FULL ? (OUT == 2) : ((a.flags & MXV_FLAG_REWARD_F32) != 0);
-    const bool ep_on = !FULL && a.ep_acc != nullptr;
-    const uint64_t group0 = (a.env0 + (uint64_t)tile0) >> 2;
-
-    double s[E][S], aux[E][AUXN];
-    int32_t el[E];
-    bool valid[E];
-    uint32_t le[E];  // env index inside the shard (fits 32 bits: mxv_create caps num_envs)
-    uint64_t seed[E];
-    uint32_t ep[E];  // reset ordinal = index of the env's next draw from the reset stream
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int64_t e = tile0 + j * kWave + lane;
-        valid[j] = e < n;
-        le[j] = (uint32_t)(valid[j] ? e : 0);
-#pragma unroll
-        for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
-        el[j] = a.elapsed[le[j]];
-        ep[j] = a.episodes[le[j]];
-        seed[j] = a.seeds ? landed(a.seeds[le[j]]) : a.base_seed + a.env0 + (uint64_t)le[j];
-        EV::prime(s[j], aux[j]);
-    }
-    float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
-#pragma unroll
-    for (int j = 0; j < E; ++j) er[j] = ep_on ? a.ep_acc[le[j]] : 0.0f;
-    float *p_epr = FULL ? nullptr : a.ep_return_out;
-    int32_t *p_epl = FULL ? nullptr : a.ep_length_out;
-
-    // action words of the first min(H, K) steps: lane L draws group L % NACT of step L / NACT
-    int filled = a.K < H ? a.K : H;  // steps [0, filled) of this launch have their action words in the ring
-    if (lane < filled * NACT) {
-        const U4 w = env_action_words<ENV>(a.action_seed, t0 + (uint64_t)(lane / NACT), group0 + (uint64_t)(lane % NACT));
-        reinterpret_cast<uint4 *>(lds_act)[lane] = make_uint4(w.x, w.y, w.z, w.w);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t word[E];  // this step's action words (read one step ahead)
-#pragma unroll
-    for (int j = 0; j < E; ++j) word[j] = lds_act[j * kWave + lane];
-
-    char *p_obs = reinterpret_cast<char *>(a.obs);
-    char *p_rew = reinterpret_cast<char *>(a.reward);
-    char *p_act = reinterpret_cast<char *>(a.actions_out);
-    char *p_term = reinterpret_cast<char *>(a.terminated);
-    char *p_trunc = reinterpret_cast<char *>(a.truncated);
-    char *p_fin = FULL ? nullptr : reinterpret_cast<char *>(a.final_obs);
-    const int64_t slice = a.slice;
-    const uint32_t rew_b = rew_f32 ? 4u : 8u;
-    const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
-
-    settle_entry_loads();
-    for (int step = 0; step < a.K; ++step) {
-        const uint64_t t = t0 + (uint64_t)step;
-
-        // ---- this step's actions ----
-        int ai[E];
-        float af[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], t, ai[j], af[j]);
-        if (FULL || p_act != nullptr) {
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                if (!valid[j]) continue;
-                char *q = p_act + le[j] * act_b;
-                if constexpr (NA > 0) {
-                    if (act_i32)
-                        *reinterpret_cast<int32_t *>(q) = ai[j];
-                    else
-                        *reinterpret_cast<int64_t *>(q) = (int64_t)ai[j];
-                } else {
-                    *reinterpret_cast<float *>(q) = af[j];
-                }
-            }
-        }
-
-        // ---- dynamics + TimeLimit, E independent chains ----
-        float obs[E][O];
-        double rew[E];
-        bool term[E], trunc[E], pend[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            term[j] = EV::template step<DEF, SAFE>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
-            el[j] += 1;                                              // time_limit.py:51
-            trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
-            pend[j] = valid[j] && (term[j] || trunc[j]);
-        }
-        if (ep_on) {  // record_episode_statistics.py:119-143
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
-                if (pend[j]) {
-                    if (p_epr) p_epr[le[j]] = er[j];
-                    if (p_epl) p_epl[le[j]] = el[j];
-                    er[j] = 0.0f;
-                }
-            }
-        }
-        // outputs that do not depend on the reset go out first: reward, flags, info["final_observation"]
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            if (!valid[j]) continue;
-            if (FULL || p_rew != nullptr) {
-                char *q = p_rew + le[j] * rew_b;
-                if (rew_f32)
-                    *reinterpret_cast<float *>(q) = (float)rew[j];
-                else
-                    *reinterpret_cast<double *>(q) = rew[j];
-            }
-            if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[le[j]] = term[j] ? 1 : 0;
-            if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[le[j]] = trunc[j] ? 1 : 0;
-            if (!FULL && pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), le[j], obs[j]);
-        }
-
-        // ---- masked Philox passes: every lane with a finished env resets it (sync_vector_env.py:152-156); the free
-        //      lanes draw action words of future steps.  Normally exactly one pass, or none at all. ----
-        while (true) {
-            int jsel = -1;
-#pragma unroll
-            for (int j = E - 1; j >= 0; --j)
-                if (pend[j]) jsel = j;
-            const bool resets = jsel >= 0;
-            const uint64_t busy = __ballot(resets);
-            const bool must = (filled == step + 1) && (step + 1 < a.K);      // the next step has no action words yet
-            if (busy == 0 && !must) break;
-            // ring capacity: this step's slot is consumed, so steps (step, step + H] fit
-            const int horizon = (a.K < step + 1 + H) ? a.K : step + 1 + H;
-            const int room = horizon - filled;
-            const int nfree = kWave - (int)__popcll(busy);
-            int nfit = nfree / NACT;                                         // future steps the free lanes can draw
-            nfit = nfit < room ? nfit : room;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(~busy >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)~busy, 0u));
-            const bool is_act = !resets && (int)rank < nfit * NACT;
-            if (resets || is_act) {
-                U4 c;
-                uint64_t key;
-                const int q = filled + (int)rank / NACT;                     // launch-relative step drawn by an action lane
-                if (is_act) {
-                    const uint64_t g = group0 + (uint64_t)(rank % NACT), tq = t0 + (uint64_t)q;
-                    c.x = (uint32_t)g; c.y = (uint32_t)(g >> 32); c.z = (uint32_t)tq;
-                    c.w = ((uint32_t)(tq >> 32) & 0x0fffffffu) | (kStreamAction << 28);
-                    key = a.action_seed;
-                } else {
-                    key = seed[0];
-                    uint32_t kk = ep[0];
-#pragma unroll
-                    for (int j = 1; j < E; ++j) {
-                        key = (j == jsel) ? seed[j] : key;
-                        kk = (j == jsel) ? ep[j] : kk;
-                    }
-                    c.x = kk; c.y = 0u; c.z = 0u; c.w = (kStreamReset << 28);
-                }
-                const U4 w = philox4x32_10_vkey(c, (uint32_t)key, (uint32_t)(key >> 32));
-                if (is_act) {
-                    reinterpret_cast<uint4 *>(lds_act)[(q % H) * NACT + rank % NACT] = make_uint4(w.x, w.y, w.z, w.w);
-                } else {
-                    double ns[S], naux[AUXN];
-                    float nobs[O];
-                    EV::reset(w, a.b0, a.b1, ns);
-                    EV::observe(ns, nobs, naux);
-#pragma unroll
-                    for (int j = 0; j < E; ++j)
-                        if (j == jsel) {
-#pragma unroll
-                            for (int k = 0; k < EV::AUX; ++k) aux[j][k] = naux[k];
-#pragma unroll
-                            for (int k = 0; k < S; ++k) s[j][k] = ns[k];
-#pragma unroll
-                            for (int k = 0; k < O; ++k) obs[j][k] = nobs[k];
-                            el[j] = 0;  // time_limit.py:67
-                            ep[j] += 1;
-                            pend[j] = false;
-                        }
-                }
-            }
-            filled += nfit;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-
-        // ---- next step's action words (LDS latency hides behind the observation stores) ----
-        if (step + 1 < a.K) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int j = 0; j < E; ++j) word[j] = lds_act[((step + 1) % H) * TILE + j * kWave + lane];
-        }
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), le[j], obs[j]);
-
-        // ---- advance the scalar output bases to the next trajectory slice ----
-        p_obs += slice * (int64_t)(O * sizeof(float));
-        if (FULL || p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
-        if (FULL || p_act != nullptr) p_act += slice * (int64_t)act_b;
-        if (FULL || p_term != nullptr) p_term += slice;
-        if (FULL || p_trunc != nullptr) p_trunc += slice;
-        if (!FULL && p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
-        if (!FULL && p_epr != nullptr) p_epr += slice;
-        if (!FULL && p_epl != nullptr) p_epl += slice;
-    }
-
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        if (!valid[j]) continue;
-#pragma unroll
-        for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
-        a.elapsed[le[j]] = el[j];
-        a.episodes[le[j]] = ep[j];
-        if (ep_on) a.ep_acc[le[j]] = er[j];
-    }
-}
-
 // Explicit reset (SyncVectorEnv.reset_wait, sync_vector_env.py:90-129): one env per lane.
 template <int ENV>
 __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
@@ -955,24 +724,14 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
 
 __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
-// rollout_kernel_v3 by default; MXV_ROLLOUT_IMPL = 2 builds the envs with word-per-step actions on rollout_kernel_v2 (A/B hook).
-template <int ENV>
-constexpr bool use_rollout_v2() {
-    return MXV_ROLLOUT_IMPL == 2 && !action_bits<ENV>();
-}
 template <int ENV, bool DEF, int ER, bool SAFE, int OUT>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
-    if constexpr (use_rollout_v2<ENV>())
-        hipLaunchKernelGGL((rollout_kernel_v2<ENV, DEF, ER, SAFE, OUT>), dim3((grid + MXV_ROLLOUT_V2_WAVES - 1) / MXV_ROLLOUT_V2_WAVES),
-                           dim3(kWave * MXV_ROLLOUT_V2_WAVES), 0, stream, a);
-    else {
-        // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
-        // rollout_max_waves) is its LDS footprint: padded with unused dynamic LDS to 9.5 KiB per single-wave workgroup, 16 of
-        // them fill the CU's 160 KiB and a 17th does not fit.
-        constexpr size_t kLdsPerWorkgroup = 9728, kStatic = sizeof(RolloutLds<ENV, ER>);
-        const size_t pad = (rollout_min_waves<ENV, DEF, SAFE>() == 4 && kStatic < kLdsPerWorkgroup) ? kLdsPerWorkgroup - kStatic : 0;
-        hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), pad, stream, a);
-    }
+    // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
+    // rollout_max_waves) is its LDS footprint: padded with unused dynamic LDS to 9.5 KiB per single-wave workgroup, 16 of
+    // them fill the CU's 160 KiB and a 17th does not fit.
+    constexpr size_t kLdsPerWorkgroup = 9728, kStatic = sizeof(RolloutLds<ENV, ER>);
+    const size_t pad = (rollout_min_waves<ENV, DEF, SAFE>() == 4 && kStatic < kLdsPerWorkgroup) ? kLdsPerWorkgroup - kStatic : 0;
+    hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), pad, stream, a);
 }
 template <int ENV, bool DEF, int ER, bool SAFE>
 void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
@@ -994,7 +753,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
     const bool def = pm == PM_DEFAULT;
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
-    if (a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise) {
+    if (launch_step_is_rollout(pm, a)) {
         // SAFE = false: the state obeys the invariants the dynamics maintain (CartPole: |theta| <= pi/4; the others: trig arguments
         // below 2^19), so sin/cos need no range check.  A state injection (mxv_set_state) or unusual explicit-reset bounds break
         // that for one launch; an unlimited Pendulum can turn without bound.
@@ -1059,6 +818,12 @@ hipError_t launch_sample_env(int pm, const SampleArgs &a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Sampled actions + autoreset, several steps per launch: the fused fast path (rollout_kernel_v3).  Everything else — caller
+// actions, single steps, per-env parameters, torque noise, no autoreset — runs step_kernel.
+bool launch_step_is_rollout(int pm, const StepArgs &a) {
+    return a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise;
+}
 
 hipError_t launch_step(int env_id, int default_params, const StepArgs &a, hipStream_t stream) {
     switch (env_id) {

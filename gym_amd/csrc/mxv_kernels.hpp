@@ -40,6 +40,11 @@ struct StepArgs {
     float *ep_acc;           // [N] running episode return, float32 like the reference's accumulator
     float *ep_return_out;    // [N] / [K][N]: episode return, written only where terminated | truncated
     int32_t *ep_length_out;  // [N] / [K][N]: episode length, written only where terminated | truncated
+    // optional second destination of the LAST step's outputs of a fused rollout (mxv_set_final_snapshot), [N] each
+    float *snap_obs;
+    void *snap_reward;
+    uint8_t *snap_terminated;
+    uint8_t *snap_truncated;
     EnvParams P;
 };
 
@@ -116,11 +121,6 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_MIN_WAVES
 #define MXV_MIN_WAVES 1
 #endif
-// fused-rollout implementation: 3 (default) = rollout_kernel_v3 (next-reset entries precomputed off the critical path, bit-sliced
-// Discrete(2) actions); 2 = rollout_kernel_v2 (owner-lane resets inside the step; not for Discrete(2) envs) — A/B hook
-#ifndef MXV_ROLLOUT_IMPL
-#define MXV_ROLLOUT_IMPL 3
-#endif
 // 1: shards smaller than one E-env-per-lane wave per SIMD run the fused rollout with one env per lane (A/B hook)
 #ifndef MXV_ROLLOUT_SMALL_E1
 #define MXV_ROLLOUT_SMALL_E1 1
@@ -132,10 +132,6 @@ constexpr int rollout_envs_per_lane(int env_id) {
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8
-#endif
-// waves (= independent tiles) per workgroup of rollout_kernel_v2
-#ifndef MXV_ROLLOUT_V2_WAVES
-#define MXV_ROLLOUT_V2_WAVES 1
 #endif
 // rollout_kernel's minimum waves per SIMD (tuning hook; 1 = let the register allocator decide: 113 VGPRs = 4 waves for CartPole)
 #ifndef MXV_ROLLOUT_MIN_WAVES
@@ -153,6 +149,8 @@ constexpr int kBlock = 256;
 
 // param_mode: PM_DEFAULT / PM_BROADCAST / PM_PER_ENV (mxv_device.hpp)
 hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream);
+// true if launch_step(a) runs the fused rollout kernel, which also writes StepArgs::snap_* (other launches: the caller copies)
+bool launch_step_is_rollout(int param_mode, const StepArgs &a);
 hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
 hipError_t launch_sample(int env_id, int param_mode, const SampleArgs &a, hipStream_t stream);
 hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream);

@@ -54,6 +54,9 @@ class GatheredOutputs:
         off, nb, dt, shape = o._layout[i]
         return [o._recv[r, off:off + nb].view(dt).view(shape) for r in range(o.world_size)]
 
+    def __repr__(self):
+        return f"GatheredOutputs(world={self._o.world_size}, envs={self._o.total_envs}, comm={self._o.comm!r})"
+
     def full(self, i: int) -> torch.Tensor:
         if self._o.comm == "mxv":      # received in place: [world][N_local, ...] IS the concatenation
             return self._o._mxv_recv[i]
@@ -105,11 +108,21 @@ class ShardedRollout:
         self.engine = engine_factory(id, self.local_envs, env_offset=self.env_offset, seed=seed,
                                      action_seed=action_seed, **engine_kwargs)
         self._pending = None
-        self._send = None
         self._recv = None
         self._mxv_recv = None
+        self._layout = None
+        # Snapshots of the chunk's final tensors, TWO sets used alternately: the fused rollout kernel deposits the last step's
+        # outputs into the armed set itself (mxv_set_final_snapshot), the gather reads it while the next chunk — armed with the
+        # other set — already runs.  Engines without that hook (the oracle stand-in of the CPU tests) get copies instead.
+        self._snap = None
+        self._works = [None, None]
+        self._cur = 0
+        self._cur_written = False     # the most recent rollout deposited its finals into set _cur
+        self._cur_gathered = True     # set _cur has been handed to a gather since it was written (=> the next rollout flips sets)
+        handle = getattr(self.engine, "handle", None)
+        self._in_kernel = handle is not None and hasattr(handle, "set_final_snapshot")
+        self._force_collective = False   # measurement hook (tools/chunk_overhead.py): issue the real collective at world size 1 too
         if comm == "mxv":
-            handle = getattr(self.engine, "handle", None)
             if handle is None or not hasattr(handle, "comm_init"):
                 raise TypeError("comm='mxv' needs the HIP engine (gym_amd.rollout.DeviceRollout): the collective lives in libmxv.so")
             from . import _native
@@ -129,11 +142,128 @@ class ShardedRollout:
 
     def rollout(self, K: int, **kw):
         """K vector steps of the local shard (no communication); outputs = the last step."""
+        self._arm(K)
         return self.engine.rollout(K, **kw)
 
     def rollout_per_step(self, K: int, **kw):
         """K vector steps of the local shard into [K, N_local, ...] trajectory tensors (no communication)."""
+        self._arm(K)
         return self.engine.rollout_per_step(K, **kw)
+
+    # -- snapshots --------------------------------------------------------------------------------------
+    def _snapshots(self):
+        """The two snapshot sets (allocated on first use; shapes and dtypes of the engine's final tensors).  torch transport:
+        each set is ONE packed buffer (obs | reward | terminated | truncated, sections aligned to 256 B) so that the four
+        logical gathers travel as one all-gather; mxv transport: four tensors, gathered as one grouped RCCL launch."""
+        if self._snap is None:
+            finals = self.engine.final_tensors()
+            self._layout, off = [], 0
+            for t in finals:
+                nbytes = t.numel() * t.element_size()
+                self._layout.append((off, nbytes, t.dtype, tuple(t.shape)))
+                off = (off + nbytes + 255) // 256 * 256
+            self._shard_bytes = off
+            with self._stream_ctx():
+                dev = finals[0].device
+                self._snap = []
+                for _ in range(2):
+                    if self.comm == "mxv":
+                        self._snap.append({"views": [torch.empty_like(t) for t in finals]})
+                    else:
+                        send = torch.empty(off, dtype=torch.uint8, device=dev)
+                        self._snap.append({"send": send, "views": [send[o:o + nb].view(dt).view(shape)
+                                                                   for o, nb, dt, shape in self._layout]})
+                if self.comm == "mxv":
+                    self._mxv_recv = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                                      for t in finals]
+                else:
+                    self._recv = torch.empty((self.world_size, off), dtype=torch.uint8, device=dev)
+        return self._snap
+
+    def _wait_set(self, idx: int):
+        """Order the engine's stream after the gather that last read snapshot set `idx` (GPU-side; the host does not block)."""
+        if self.comm == "mxv":
+            # sets alternate per gather: the last gather read set _cur, the one before it the other set
+            self.engine.handle.allgather_wait(host_sync=False, age=0 if idx == self._cur else 1)
+        elif self._works[idx] is not None:
+            with self._stream_ctx():
+                self._works[idx].wait()
+            self._works[idx] = None
+
+    def _arm(self, K: int = 2):
+        """Called before every rollout: pick the snapshot set this rollout deposits its final tensors into."""
+        if not self._in_kernel:
+            self._cur_written = False
+            return
+        snap = self._snapshots()
+        if self._cur_gathered:                      # the current set is (or was) being read by a gather: use the other one
+            nxt = 1 - self._cur
+            self._wait_set(nxt)                     # ... once the gather that read IT (two gathers ago) is done
+            self._cur = nxt
+            self._cur_gathered = False
+            self.engine.handle.set_final_snapshot(*snap[nxt]["views"])
+        self._cur_written = True
+
+    def gather_async(self):
+        """Start the all-gather of the latest chunk's final tensors; returns immediately (the next rollout overlaps it)."""
+        snap = self._snapshots()
+        if not self._cur_written:                   # no in-kernel snapshot of the latest outputs: copy them
+            if self._cur_gathered:
+                nxt = 1 - self._cur
+                self._wait_set(nxt)
+                self._cur = nxt
+            else:
+                self._wait_set(self._cur)
+            with self._stream_ctx():
+                for dst, src in zip(snap[self._cur]["views"], self.engine.final_tensors()):
+                    dst.copy_(src, non_blocking=True)
+        cur = snap[self._cur]
+        if self.comm == "mxv":
+            self.engine.handle.allgather_outputs(*cur["views"], *self._mxv_recv)
+            self._pending = "mxv"
+        else:
+            with self._stream_ctx():               # the collective is ordered after the engine's stream (where the snapshot was written)
+                if self.world_size == 1 and not self._force_collective:
+                    self._recv.view(-1).copy_(cur["send"], non_blocking=True)
+                    self._works[self._cur] = None
+                else:
+                    self._works[self._cur] = dist.all_gather_into_tensor(self._recv.view(-1), cur["send"], group=self.group,
+                                                                         async_op=True)
+            self._pending = "torch"
+        self._cur_gathered = True
+        self._cur_written = False
+
+    def wait_gather(self):
+        """GatheredOutputs of the last gather_async (unpacks to the full (N_total, ...) obs / reward / terminated /
+        truncated), or None.  Orders the engine's stream after the gather; valid until the next gather_async()."""
+        if self._pending is None:
+            return None
+        if self._pending == "mxv":
+            self.engine.handle.allgather_wait(host_sync=False, age=0)
+        elif self._works[self._cur] is not None:
+            with self._stream_ctx():
+                self._works[self._cur].wait()
+            self._works[self._cur] = None
+        self._pending = None
+        return GatheredOutputs(self)
+
+    def gather(self):
+        self.gather_async()
+        return self.wait_gather()
+
+    def synchronize(self):
+        self.wait_gather()
+        for i in (0, 1):
+            if self._works[i] is not None:
+                self._works[i].wait()
+                self._works[i] = None
+        self.engine.synchronize()
+
+    def close(self):
+        self.wait_gather()
+        close = getattr(self.engine, "close", None)
+        if close:
+            close()
 
     def make_normalizer(self, obs_dim: Optional[int] = None, **kw):
         """RunningNormalizer (NormalizeObservation / NormalizeReward) over the LOGICAL vector env: the
@@ -148,82 +278,3 @@ class ShardedRollout:
             kw.setdefault("stream", getattr(self.engine, "stream", None))
         return RunningNormalizer(self.local_envs, obs_dim, world_size=self.world_size, total_envs=self.total_envs,
                                  group=self.group, **kw)
-
-    def _buffers(self):
-        """One packed send buffer (this rank's snapshot of obs | reward | terminated | truncated, every section
-        aligned to 256 B) and one [world][bytes] receive buffer: the four logical gathers travel as ONE RCCL
-        all-gather (one launch, one large message per peer instead of four, two of them tiny)."""
-        if self._send is None:
-            finals = self.engine.final_tensors()
-            self._layout = []
-            off = 0
-            for t in finals:
-                nbytes = t.numel() * t.element_size()
-                self._layout.append((off, nbytes, t.dtype, tuple(t.shape)))
-                off = (off + nbytes + 255) // 256 * 256
-            self._shard_bytes = off
-            with self._stream_ctx():
-                dev = finals[0].device
-                self._send = torch.empty(off, dtype=torch.uint8, device=dev)
-                self._recv = torch.empty((self.world_size, off), dtype=torch.uint8, device=dev)
-            self._send_views = [self._send[o:o + nb].view(dt).view(shape) for o, nb, dt, shape in self._layout]
-        return self._send, self._recv
-
-    def _gather_async_mxv(self):
-        finals = self.engine.final_tensors()
-        if self._mxv_recv is None:
-            with self._stream_ctx():
-                self._mxv_send = [torch.empty_like(t) for t in finals]
-                self._mxv_recv = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                                  for t in finals]
-        h = self.engine.handle
-        h.allgather_wait(host_sync=False)          # the previous gather must have read its snapshot before it is overwritten
-        with self._stream_ctx():
-            for dst, src in zip(self._mxv_send, finals):
-                dst.copy_(src, non_blocking=True)
-        h.allgather_outputs(*self._mxv_send, *self._mxv_recv)
-        self._pending = "mxv"
-
-    def gather_async(self):
-        """Snapshot the current output tensors and start their all-gather; returns immediately."""
-        if self.comm == "mxv":
-            return self._gather_async_mxv()
-        self.wait_gather()
-        send, recv = self._buffers()
-        with self._stream_ctx():
-            for dst, src in zip(self._send_views, self.engine.final_tensors()):
-                dst.copy_(src, non_blocking=True)
-            if self.world_size == 1:
-                recv.view(-1).copy_(send, non_blocking=True)
-                self._pending = []
-            else:
-                self._pending = [dist.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)]
-
-    def wait_gather(self):
-        """GatheredOutputs of the last gather_async (unpacks to the full (N_total, ...) obs / reward / terminated /
-        truncated), or None."""
-        if self._pending is None:
-            return None
-        if self._pending == "mxv":
-            self.engine.handle.allgather_wait(host_sync=False)   # the engine's stream is ordered after the gather
-            self._pending = None
-            return GatheredOutputs(self)
-        with self._stream_ctx():
-            for w in self._pending:
-                w.wait()
-        self._pending = None
-        return GatheredOutputs(self)
-
-    def gather(self):
-        self.gather_async()
-        return self.wait_gather()
-
-    def synchronize(self):
-        self.wait_gather()
-        self.engine.synchronize()
-
-    def close(self):
-        self.wait_gather()
-        close = getattr(self.engine, "close", None)
-        if close:
-            close()

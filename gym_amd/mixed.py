@@ -62,6 +62,8 @@ class MixedRollout:
         from . import _native
 
         engines = [sr.engine for sr in self.segments.values()]
+        for sr in self.segments.values():
+            sr._arm(K)                      # the segments' final-tensor snapshots for the gather (ShardedRollout)
         for e in engines:
             e._attach_episode_outputs(None)
         try:

@@ -162,6 +162,12 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
 int mxv_rollout_tape(mxv_handle *h, int32_t K, int32_t per_step, const void *actions_tape_dev,
                      float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev,
                      float *final_obs_dev);
+/* Second destination for the FINAL tensors of every following mxv_rollout / mxv_rollout_tape / mxv_rollout_mixed call: the
+ * last of the K steps also writes its obs / reward / terminated / truncated (the handle's dtypes, [N] each; reward .. truncated
+ * may be NULL) into these device buffers — by the fused kernel itself, or by device-to-device copies on the handle's stream
+ * for the other launch modes.  This is the snapshot a sharded vector env hands to mxv_allgather_outputs while the next chunk
+ * runs: no copy kernels between rollout and gather, and the trajectory tensors may be reused at once.  NULL obs detaches. */
+int mxv_set_final_snapshot(mxv_handle *h, float *obs_dev, void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev);
 /* Heterogeneous dispatch (BASELINE.json configs[4]: mixed batch {CartPole, Pendulum, Acrobot, MountainCar}).  The reference has
  * no mixed vector env (gym/vector/vector_env.py:20-23; SyncVectorEnv requires identical sub-env spaces, sync_vector_env.py:
  * 220-234): a mixed batch IS a set of homogeneous vector envs, here one handle per segment on one device.  This call advances
@@ -409,9 +415,10 @@ int mxv_comm_destroy(mxv_handle *h);
 int mxv_allgather_outputs(mxv_handle *h, const float *obs_dev, const void *reward_dev, const uint8_t *terminated_dev,
                           const uint8_t *truncated_dev, float *all_obs_dev, void *all_reward_dev, uint8_t *all_terminated_dev,
                           uint8_t *all_truncated_dev);
-/* host_sync == 0: the handle's stream waits (on the GPU) for the last gather — order later work after it without blocking the
- * host; host_sync != 0: block the host until the gathered tensors are complete. */
-int mxv_allgather_wait(mxv_handle *h, int32_t host_sync);
+/* Wait for the last gather (age 0) or the one before it (age 1: what a caller that alternates between two snapshot buffers
+ * needs before it lets a rollout overwrite the older one — the younger gather keeps overlapping).  host_sync == 0: the handle's
+ * stream waits on the GPU, the host does not block; host_sync != 0: block the host until those gathered tensors are complete. */
+int mxv_allgather_wait(mxv_handle *h, int32_t age, int32_t host_sync);
 /* the hipStream_t the gathers run on (NULL before mxv_comm_init) */
 int mxv_comm_stream(mxv_handle *h, void **stream);
 

@@ -59,6 +59,7 @@ def test_native_comm_through_the_plain_c_abi():
     h.step_sampled(obs, rew, term, trunc)
     h.allgather_outputs(obs, rew, term, None, all_obs, all_rew, all_term, None)     # truncated skipped (NULL pair)
     h.allgather_wait(host_sync=True)
+    h.allgather_wait(host_sync=True, age=1)          # no such gather yet: a no-op
     h.sync()
     assert torch.equal(all_obs, obs) and torch.equal(all_rew, rew) and torch.equal(all_term, term)
     assert float(all_rew.min()) == -1.0 and float(all_rew.max()) <= 0.0
@@ -67,3 +68,68 @@ def test_native_comm_through_the_plain_c_abi():
     with pytest.raises(_native.MxvError):
         h.comm_init(1, 1, uid)                         # rank outside the world
     h.close()
+
+
+@pytest.mark.parametrize("mode", ["fused", "eager", "graph"])
+def test_final_snapshot_is_the_last_step_of_every_launch_mode(mode):
+    """mxv_set_final_snapshot: the last of the K steps also lands in the caller's snapshot buffers — written by the fused kernel
+    itself, copied on the handle's stream for the per-step launch modes — for [K][N] trajectories and final-tensor mode alike."""
+    import torch
+
+    from gym_amd.rollout import DeviceRollout
+
+    n, K = 5000, 19
+    r = DeviceRollout("Acrobot-v1", n, seed=2, action_seed=3, max_episode_steps=11)
+    r.reset(seed=2)
+    dev = r.device
+    snap = [torch.full((n, 6), -7.0, dtype=torch.float32, device=dev), torch.full((n,), -7.0, dtype=torch.float64, device=dev),
+            torch.full((n,), 9, dtype=torch.uint8, device=dev), torch.full((n,), 9, dtype=torch.uint8, device=dev)]
+    torch.cuda.synchronize()
+    r.handle.set_final_snapshot(*snap)
+    out = r.rollout_per_step(K, mode=mode)
+    r.synchronize()
+    for s, key in zip(snap, ("obs", "reward", "terminated", "truncated")):
+        assert torch.equal(s, out[key][K - 1]), (mode, key)
+    fin = r.rollout(K, mode=mode)
+    r.synchronize()
+    for s, t in zip(snap, fin):
+        assert torch.equal(s, t), mode
+    r.handle.set_final_snapshot()                         # detach: later rollouts leave the buffers alone
+    keep = [s.clone() for s in snap]
+    r.rollout(K, mode=mode)
+    r.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(keep, snap))
+    r.close()
+
+
+def test_gathers_alternate_snapshot_sets_and_survive_back_to_back_chunks():
+    """ShardedRollout deposits the final tensors of chunk i into snapshot set i % 2 from inside the rollout kernel and gathers
+    it while chunk i+1 (armed with the other set) runs: many chunks issued without any host synchronisation must gather, every
+    time, exactly the final tensors of their own chunk — for both transports, and when several rollouts precede a gather."""
+    import torch
+
+    from gym_amd.distributed import ShardedRollout
+
+    n, K, chunks = 1 << 15, 16, 12
+    for comm in ("torch", "mxv"):
+        sr = ShardedRollout("CartPole-v1", n, rank=0, world_size=1, device=0, seed=5, action_seed=6, comm=comm)
+        ref = ShardedRollout("CartPole-v1", n, rank=0, world_size=1, device=0, seed=5, action_seed=6, comm="torch")
+        sr.reset(seed=5), ref.reset(seed=5)
+        got = []
+        for c in range(chunks):
+            sr.rollout_per_step(K)
+            if c % 3 == 2:
+                sr.rollout(K)                               # two rollouts before this gather: the same set is written twice
+            sr.gather_async()
+            g = sr.wait_gather()                            # GPU-side ordering only; the host runs ahead
+            with torch.cuda.stream(sr.engine.stream):
+                got.append([t.clone() for t in g])
+        sr.synchronize()
+        for c in range(chunks):
+            ref.engine.rollout_per_step(K)
+            if c % 3 == 2:
+                ref.engine.rollout(K)
+            ref.engine.synchronize()
+            for x, y in zip(got[c], ref.engine.final_tensors()):
+                assert torch.equal(x, y), (comm, c)
+        sr.close(), ref.close()
