@@ -113,7 +113,7 @@ class ShardedRollout:
         self._layout = None
         # Snapshots of the chunk's final tensors, TWO sets used alternately: the fused rollout kernel deposits the last step's
         # outputs into the armed set itself (mxv_set_final_snapshot), the gather reads it while the next chunk — armed with the
-        # other set — already runs.  Engines without that hook (the oracle stand-in of the CPU tests) get copies instead.
+        # other set — already runs.  Engines without that hook (the CPU stand-in of the gloo tests) get copies instead.
         self._snap = None
         self._works = [None, None]
         self._cur = 0
