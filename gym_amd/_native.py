@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -243,6 +244,32 @@ def _ptr(x):
     return x.data_ptr()  # torch tensor
 
 
+class _ArrayPool:
+    """Recycles the host arrays the NumPy adapter returns.  SyncVectorEnv(copy=True) hands the caller a fresh array per call
+    (`deepcopy(self.observations)`, gym/vector/sync_vector_env.py:163); allocating one with np.empty means a fresh anonymous
+    mapping per step for anything above glibc's mmap threshold — 42 MB of page faults and kernel page zeroing per step at 2^20
+    CartPole envs, which is what made that loop 2-3 ms per step (the DMA itself is 0.9 ms).  The pool keeps a few arrays per
+    (shape, dtype) and hands one out again ONLY when nobody but the pool references it any more (sys.getrefcount: the caller
+    dropped it and every view of it), so the contract the caller sees is unchanged — an array it got is never overwritten while
+    it can still see it — and the pages stay mapped.  If the caller keeps everything, the pool just grows to `limit` and further
+    arrays are plain np.empty."""
+
+    def __init__(self, limit: int = 6):
+        self._free = {}
+        self._limit = limit
+
+    def take(self, shape, dtype) -> np.ndarray:
+        key = (tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape, np.dtype(dtype).str)
+        lst = self._free.setdefault(key, [])
+        for a in lst:
+            if sys.getrefcount(a) == 3:   # the list, the loop variable, getrefcount's argument: nobody else
+                return a
+        a = np.empty(shape, dtype=dtype)
+        if len(lst) < self._limit:
+            lst.append(a)
+        return a
+
+
 class _DestroyLater:
     """Owns the mxv_destroy of a handle whose pinned I/O block is referenced by NumPy views."""
 
@@ -367,14 +394,22 @@ class Handle:
         self._check(lib.mxv_reset_host(self._h, _ptr(m), bp, obs.ctypes.data))
         return obs
 
-    def step_host(self, actions, want_final=True):
+    def step_host(self, actions, want_final=True, pooled=False):
+        """One vector step through host arrays.  pooled=True (the NumPy adapter): outputs come from the handle's array pool
+        (see _ArrayPool) and `final_obs` rows of envs that did not finish hold stale data instead of zeros."""
         n, O = self.num_envs, self.O
         a = np.ascontiguousarray(actions, dtype=self.action_dtype).reshape(n)
-        obs = np.empty((n, O), dtype=np.float32)
-        rew = np.empty(n, dtype=self.reward_dtype)
-        term = np.empty(n, dtype=np.uint8)
-        trunc = np.empty(n, dtype=np.uint8)
-        fin = np.zeros((n, O), dtype=np.float32) if want_final else None
+        if pooled:
+            pool = self.__dict__.setdefault("_pool", _ArrayPool())
+            obs, rew = pool.take((n, O), np.float32), pool.take((n,), self.reward_dtype)
+            term, trunc = pool.take((n,), np.uint8), pool.take((n,), np.uint8)
+            fin = pool.take((n, O), np.float32) if want_final else None
+        else:
+            obs = np.empty((n, O), dtype=np.float32)
+            rew = np.empty(n, dtype=self.reward_dtype)
+            term = np.empty(n, dtype=np.uint8)
+            trunc = np.empty(n, dtype=np.uint8)
+            fin = np.zeros((n, O), dtype=np.float32) if want_final else None
         self._check(lib.mxv_step_host(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                       trunc.ctypes.data, _ptr(fin)))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin

@@ -107,6 +107,9 @@ struct mxv_handle {
     size_t io_total = 0, io_out_off = 0, io_out_bytes = 0, io_act_bytes = 0;
     int32_t *hm_err = nullptr;
     bool hostmap = false;       // the kernels address the pinned block directly
+    // large envs: info["final_observation"] travels as packed (index, row) pairs of the finished envs only (compact_final_kernel)
+    char *fin_dev = nullptr;    // device: count (256 B) | idx int32[N] | rows float[N][O]
+    char *fin_host = nullptr;   // pinned mirror
     // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
     using GraphKey = std::tuple<int, int, void *, void *, void *, void *, void *, void *>;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -271,7 +274,8 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
 // Up to this size the step kernels address the pinned block directly; above it they use device staging.
 constexpr size_t kHostMapLimit = 2 * 1024 * 1024;
 
-// Layout of one I/O block (pinned and device copies share it): actions | obs | final_obs | reward | term | trunc | mask | err
+// Layout of one I/O block (pinned and device copies share it): actions | final_obs | obs | reward | term | trunc | mask | err
+// (final_obs sits outside the contiguous per-step output region obs .. trunc: for large envs it is not copied densely)
 int ensure_staging(mxv_handle *h, bool want_pinned = false) {
     const size_t n = (size_t)h->cfg.num_envs;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -279,8 +283,8 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
     if (!h->st_obs) {
         h->io_total = b_act + 2 * b_obs + b_rew + 3 * b_flag + 256;
         h->io_act_bytes = n * h->action_bytes();
-        h->io_out_off = b_act;
-        h->io_out_bytes = 2 * b_obs + b_rew + 2 * b_flag;
+        h->io_out_off = b_act + b_obs;
+        h->io_out_bytes = b_obs + b_rew + 2 * b_flag;
         h->hostmap = h->io_total <= kHostMapLimit;
         if (h->hostmap) {
             MXV_HIP(h, hipHostMalloc(&h->hm_block, h->io_total, hipHostMallocDefault));
@@ -289,8 +293,8 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
         }
         char *p = (char *)(h->hostmap ? h->hm_block : h->dv_block);
         h->st_actions = p; p += b_act;
-        h->st_obs = (float *)p; p += b_obs;
         h->st_final = (float *)p; p += b_obs;
+        h->st_obs = (float *)p; p += b_obs;
         h->st_reward = p; p += b_rew;
         h->st_term = (uint8_t *)p; p += b_flag;
         h->st_trunc = (uint8_t *)p; p += b_flag;
@@ -298,6 +302,10 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
         if (h->hostmap) {
             h->hm_err = (int32_t *)p;
             *h->hm_err = 0;
+        } else {
+            const size_t fin_bytes = 256 + n * sizeof(int32_t) + n * h->O * sizeof(float);
+            MXV_HIP(h, hipMalloc((void **)&h->fin_dev, fin_bytes));
+            MXV_HIP(h, hipHostMalloc((void **)&h->fin_host, fin_bytes, hipHostMallocDefault));
         }
     }
     if (want_pinned && !h->hm_block) {  // large env: pinned mirror of the device block for the zero-copy calls
@@ -305,6 +313,40 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
         h->hm_err = (int32_t *)((char *)h->hm_block + h->io_total - 256);
         *h->hm_err = 0;
     }
+    return MXV_OK;
+}
+
+// Large envs: pack the final_obs rows of the envs that finished this step on the device, bring (count | indices) and the rows
+// over in two small DMAs — speculatively the first eighth of the capacity, the rest only if more envs finished — and scatter
+// them into the caller's dense [N][O] array (rows of other envs untouched, as the dense copy left them).  Synchronises.
+int fetch_final_rows(mxv_handle *h, float *final_host) {
+    const size_t n = (size_t)h->cfg.num_envs, O = (size_t)h->O;
+    int32_t *d_count = (int32_t *)h->fin_dev, *d_idx = (int32_t *)(h->fin_dev + 256);
+    float *d_rows = (float *)(h->fin_dev + 256 + n * sizeof(int32_t));
+    int32_t *p_count = (int32_t *)h->fin_host, *p_idx = (int32_t *)(h->fin_host + 256);
+    float *p_rows = (float *)(h->fin_host + 256 + n * sizeof(int32_t));
+    MXV_HIP(h, hipMemsetAsync(d_count, 0, sizeof(int32_t), h->stream));
+    CompactArgs c{};
+    c.terminated = h->st_term;
+    c.truncated = h->st_trunc;
+    c.final_obs = h->st_final;
+    c.count = d_count;
+    c.idx = d_idx;
+    c.rows = d_rows;
+    c.n = (int64_t)n;
+    MXV_HIP(h, launch_compact_final(h->O, c, h->stream));
+    const size_t first = std::min(n, std::max<size_t>(1024, n / 8));
+    MXV_HIP(h, hipMemcpyAsync(p_count, d_count, 256 + first * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipMemcpyAsync(p_rows, d_rows, first * O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t count = (size_t)*p_count;
+    if (count > first) {
+        MXV_HIP(h, hipMemcpyAsync(p_idx + first, d_idx + first, (count - first) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipMemcpyAsync(p_rows + first * O, d_rows + first * O, (count - first) * O * sizeof(float), hipMemcpyDeviceToHost,
+                                  h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    for (size_t i = 0; i < count; ++i) std::memcpy(final_host + (size_t)p_idx[i] * O, p_rows + i * O, O * sizeof(float));
     return MXV_OK;
 }
 
@@ -403,6 +445,8 @@ int mxv_destroy(mxv_handle *h) {
     if (h->ev_mixed) (void)hipEventDestroy(h->ev_mixed);
     free_graphs(h);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
+    if (h->fin_host) (void)hipHostFree(h->fin_host);
+    if (h->fin_dev) (void)hipFree(h->fin_dev);
     void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -691,9 +735,11 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
         MXV_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
     if (truncated_host)
         MXV_HIP(h, hipMemcpyAsync(truncated_host, h->st_trunc, n, hipMemcpyDeviceToHost, h->stream));
-    if (final_obs_host)
-        MXV_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * h->O * sizeof(float), hipMemcpyDeviceToHost,
-                                  h->stream));
+    if (final_obs_host && terminated_host && truncated_host) {
+        if (int rc = fetch_final_rows(h, final_obs_host)) return rc;   // packed rows of the finished envs only
+    } else if (final_obs_host) {
+        MXV_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
     int rc = check_latched(h);  // synchronises
     if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
     return rc;
@@ -720,9 +766,14 @@ int mxv_host_io(mxv_handle *h, void **actions, float **obs, void **reward, uint8
 namespace {
 
 int mapped_finish(mxv_handle *h, bool stepped) {
-    if (!h->hostmap)  // one DMA copy brings obs | final_obs | reward | terminated | truncated into the pinned mirror
+    if (!h->hostmap) {  // one DMA copy brings obs | reward | terminated | truncated into the pinned mirror ...
         MXV_HIP(h, hipMemcpyAsync((char *)h->hm_block + h->io_out_off, (char *)h->dv_block + h->io_out_off, h->io_out_bytes,
                                   hipMemcpyDeviceToHost, h->stream));
+        if (stepped) {  // ... and the final_obs rows of the finished envs follow packed
+            float *fin_pinned = (float *)((char *)h->hm_block + ((char *)h->st_final - (char *)h->dv_block));
+            if (int rc = fetch_final_rows(h, fin_pinned)) return rc;
+        }
+    }
     MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     if (*h->hm_err != 0) {

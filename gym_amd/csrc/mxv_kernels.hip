@@ -724,6 +724,27 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
 
 __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
+// info["final_observation"] for a host caller: of the dense [N][O] final_obs rows only those of the envs that finished this step
+// (terminated | truncated: ~5 % of a random-policy CartPole batch) are meaningful.  Instead of sending the whole array over PCIe
+// every step, pack (env index, row) pairs of the finished envs: one ballot + one atomic per wave; the host scatters them back.
+template <int O>
+__global__ void __launch_bounds__(kBlock) compact_final_kernel(const CompactArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool done = e < a.n && (a.terminated[e] | a.truncated[e]) != 0;
+    const uint64_t m = __ballot(done);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x % kWave;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((unsigned long long)m) - 1u) base = (uint32_t)atomicAdd(a.count, (int32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, __ffsll((unsigned long long)m) - 1);
+    if (done) {
+        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        a.idx[slot] = (int32_t)e;
+#pragma unroll
+        for (int k = 0; k < O; ++k) a.rows[(size_t)slot * O + k] = a.final_obs[(size_t)e * O + k];
+    }
+}
+
 template <int ENV, bool DEF, int ER, bool SAFE, int OUT>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
     // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
@@ -864,6 +885,18 @@ hipError_t launch_sample(int env_id, int default_params, const SampleArgs &a, hi
 
 hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream) {
     hipLaunchKernelGGL(mixed_rollout_kernel, dim3(m.first_block[m.count]), dim3(kWave), 0, stream, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_final(int obs_dim, const CompactArgs &a, hipStream_t stream) {
+    const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    switch (obs_dim) {
+        case 2: hipLaunchKernelGGL(compact_final_kernel<2>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(compact_final_kernel<3>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(compact_final_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(compact_final_kernel<6>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -125,7 +125,7 @@ class FakeHandle:
     def reset_host(self, mask=None, bounds=None):
         return self.o.reset(mask=mask, bounds=bounds)
 
-    def step_host(self, actions, want_final=True):
+    def step_host(self, actions, want_final=True, pooled=False):
         obs, rew, term, trunc, fin, _ = self.o.step(actions)
         return obs, rew, term, trunc, fin
 
