@@ -38,7 +38,7 @@ EXPORTS = (
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
-    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -133,6 +133,8 @@ def _load():
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
+        "mxv_final_packed": ([vp, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
+        "mxv_final_packed_view": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
         "mxv_comm_init": ([vp, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_comm_destroy": ([vp], C.c_int),
@@ -403,7 +405,7 @@ class Handle:
             pool = self.__dict__.setdefault("_pool", _ArrayPool())
             obs, rew = pool.take((n, O), np.float32), pool.take((n,), self.reward_dtype)
             term, trunc = pool.take((n,), np.uint8), pool.take((n,), np.uint8)
-            fin = pool.take((n, O), np.float32) if want_final else None
+            fin = pool.take((n, O), np.float32) if want_final and not getattr(self, "_packed_final", False) else None
         else:
             obs = np.empty((n, O), dtype=np.float32)
             rew = np.empty(n, dtype=self.reward_dtype)
@@ -436,6 +438,26 @@ class Handle:
 
     def step_mapped(self):
         self._check(lib.mxv_step_mapped(self._h))
+
+    def final_packed(self, enable: bool = True) -> bool:
+        """Ask the host step calls to leave info["final_observation"] rows packed (see include/mxv.h); False for small envs."""
+        ok = C.c_int32()
+        self._check(lib.mxv_final_packed(self._h, int(bool(enable)), C.byref(ok)))
+        self._packed_final = bool(ok.value) and bool(enable)
+        if self._packed_final and getattr(self, "_packed_views", None) is None:
+            pc, pi, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            self._check(lib.mxv_final_packed_view(self._h, C.byref(pc), C.byref(pi), C.byref(pr)))
+            n, O = self.num_envs, self.O
+            self._packed_views = (np.frombuffer((C.c_char * 4).from_address(pc.value), dtype=np.int32, count=1),
+                                  np.frombuffer((C.c_char * (4 * n)).from_address(pi.value), dtype=np.int32, count=n),
+                                  np.frombuffer((C.c_char * (4 * n * O)).from_address(pr.value), dtype=np.float32, count=n * O).reshape(n, O))
+        return self._packed_final
+
+    def final_packed_rows(self):
+        """(indices, rows) of the envs that finished the LAST host step — copies (the library's buffer is overwritten by the next)."""
+        cnt, idx, rows = self._packed_views
+        c = int(cnt[0])
+        return idx[:c].copy(), rows[:c].copy()
 
     def reset_mapped(self, bounds=None):
         b, bp = self._bounds(bounds)

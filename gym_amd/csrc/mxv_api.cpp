@@ -110,6 +110,7 @@ struct mxv_handle {
     // large envs: info["final_observation"] travels as packed (index, row) pairs of the finished envs only (compact_final_kernel)
     char *fin_dev = nullptr;    // device: count (256 B) | idx int32[N] | rows float[N][O]
     char *fin_host = nullptr;   // pinned mirror
+    bool fin_packed = false;    // mxv_final_packed: host step calls leave the rows packed (no scatter into a dense array)
     // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
     using GraphKey = std::tuple<int, int, void *, void *, void *, void *, void *, void *>;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -346,7 +347,10 @@ int fetch_final_rows(mxv_handle *h, float *final_host) {
                                   h->stream));
         MXV_HIP(h, hipStreamSynchronize(h->stream));
     }
-    for (size_t i = 0; i < count; ++i) std::memcpy(final_host + (size_t)p_idx[i] * O, p_rows + i * O, O * sizeof(float));
+    // scattering ~5 % of 2^20 rows into a dense array is 0.5 ms of cache misses: callers that can consume the packed pairs
+    // (mxv_final_packed) skip it
+    if (final_host)
+        for (size_t i = 0; i < count; ++i) std::memcpy(final_host + (size_t)p_idx[i] * O, p_rows + i * O, O * sizeof(float));
     return MXV_OK;
 }
 
@@ -707,7 +711,7 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     } restore{h, keep_r, keep_l};
     if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, reward_host ? h->st_reward : nullptr,
                          terminated_host ? h->st_term : nullptr, truncated_host ? h->st_trunc : nullptr,
-                         final_obs_host ? h->st_final : nullptr))
+                         (final_obs_host || h->fin_packed) ? h->st_final : nullptr))
         return rc;
     if (h->hostmap) {  // outputs are already in host memory once the stream drains; one 4-byte copy fetches the error latch
         MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -735,8 +739,10 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
         MXV_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
     if (truncated_host)
         MXV_HIP(h, hipMemcpyAsync(truncated_host, h->st_trunc, n, hipMemcpyDeviceToHost, h->stream));
-    if (final_obs_host && terminated_host && truncated_host) {
-        if (int rc = fetch_final_rows(h, final_obs_host)) return rc;   // packed rows of the finished envs only
+    if (h->fin_packed && terminated_host && truncated_host) {
+        if (int rc = fetch_final_rows(h, nullptr)) return rc;          // left packed for mxv_final_packed_view
+    } else if (final_obs_host && terminated_host && truncated_host) {
+        if (int rc = fetch_final_rows(h, final_obs_host)) return rc;   // packed rows of the finished envs only, scattered here
     } else if (final_obs_host) {
         MXV_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     }
@@ -771,7 +777,7 @@ int mapped_finish(mxv_handle *h, bool stepped) {
                                   hipMemcpyDeviceToHost, h->stream));
         if (stepped) {  // ... and the final_obs rows of the finished envs follow packed
             float *fin_pinned = (float *)((char *)h->hm_block + ((char *)h->st_final - (char *)h->dv_block));
-            if (int rc = fetch_final_rows(h, fin_pinned)) return rc;
+            if (int rc = fetch_final_rows(h, h->fin_packed ? nullptr : fin_pinned)) return rc;
         }
     }
     MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -856,6 +862,25 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
     MXV_CHECK_HANDLE(h);
     h->t = t;
     h->r = r;
+    return MXV_OK;
+}
+
+int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_staging(h)) return rc;
+    const bool ok = !h->hostmap;  // small envs: the kernel writes final_obs straight into the pinned block, nothing to pack
+    h->fin_packed = ok && enable != 0;
+    if (supported) *supported = ok ? 1 : 0;
+    return MXV_OK;
+}
+
+int mxv_final_packed_view(mxv_handle *h, const int32_t **count, const int32_t **idx, const float **rows) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->fin_host) return fail(h, MXV_ERR_INVALID_ARG, "mxv_final_packed_view: packed final rows exist for large envs only (see mxv_final_packed)");
+    if (count) *count = (const int32_t *)h->fin_host;
+    if (idx) *idx = (const int32_t *)(h->fin_host + 256);
+    if (rows) *rows = (const float *)(h->fin_host + 256 + (size_t)h->cfg.num_envs * sizeof(int32_t));
     return MXV_OK;
 }
 

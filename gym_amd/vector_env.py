@@ -286,6 +286,8 @@ class HipVectorEnv(VectorEnv):
         self._actions = None
         self._was_reset = False
         self._per_env = False  # True while sub-envs hold differing physics attributes (set_attr with a list)
+        # large envs: info["final_observation"] rows arrive packed (indices + rows of the finished envs), never as a dense array
+        self._packed = bool(getattr(self._handle, "final_packed", lambda on: False)(True))
         allowed = CTOR_KWARGS.get(self.kind, {})
         for k, v in kwargs.items():
             if k == "render_mode" and v is None:
@@ -461,6 +463,9 @@ class HipVectorEnv(VectorEnv):
             # and the object arrays cost 0.5 ms per step at 2^20 envs, and most training loops never look at them.
             state = {}
 
+            if self._packed:            # (index, row) pairs packed by the device; the library's buffer is overwritten next step
+                state["idx"], state["rows"] = self._handle.final_packed_rows()
+
             def finished():
                 if "idx" not in state:
                     state["idx"] = np.flatnonzero(done)
@@ -525,6 +530,7 @@ class HipVectorEnv(VectorEnv):
                                       env_offset=snap["env_offset"], seed=snap["base_seed"], action_seed=snap["action_seed"],
                                       flags=snap["flags"])
         self._handle.restore(snap)
+        self._packed = bool(self._handle.final_packed(True))
 
     # -- escape hatch for device-resident use ----------------------------------------------------------
     @property

@@ -206,6 +206,18 @@ int mxv_host_io(mxv_handle *h, void **actions, float **obs, void **reward, uint8
 int mxv_step_mapped(mxv_handle *h);
 int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host);
 
+/* info["final_observation"] for host callers of LARGE vector envs (step I/O above 2 MiB).  Only the rows of the envs that finished a
+ * step mean anything (sync_vector_env.py:152-156), typically a few percent of the batch, so the host calls never move the dense
+ * [N][O] array over PCIe: the device packs (env index, row) pairs (one ballot + one atomic per wave), two small DMAs bring
+ * them over, and by default the library scatters them into the caller's dense final_obs array — 0.5 ms of cache misses per step
+ * at 2^20 envs.  mxv_final_packed(h, 1, &supported) skips the scatter: after every mxv_step_host / mxv_step_mapped the pairs
+ * of THAT step are read through mxv_final_packed_view (pointers into the library's pinned buffer, valid until the next step:
+ * *count pairs, idx[i] = env index, rows[i*O .. i*O+O) = its terminal observation; order unspecified); final_obs_host is then
+ * ignored and the mapped block's final_obs region is not updated.  supported = 0 for small envs (nothing to pack: the kernel
+ * writes the pinned block itself); the dense path stays in force there. */
+int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported);
+int mxv_final_packed_view(mxv_handle *h, const int32_t **count, const int32_t **idx, const float **rows);
+
 /* -- state access (parity hook + checkpoint/resume) ---------------------------------------------- */
 /* state_soa_host: double[S][N]; elapsed_host: int32[N]; either may be NULL.  Synchronises. */
 int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host);

@@ -492,6 +492,11 @@ def test_large_env_final_observations_travel_packed(mode, limit):
         robs, rrew, rterm, rtrunc, rfin, rmask = o.step(a)
         assert np.array_equal(term, rterm) and np.array_equal(trunc, rtrunc)
         done = term | trunc
+        if mode == "copy":
+            kept.append((obs, obs.copy(), rew, rew.copy()))     # a fresh array per call: later steps must not touch these
+        if not done.any():
+            assert not infos
+            continue
         assert np.array_equal(infos["_final_observation"], done) and np.array_equal(infos["_final_info"], done)
         fo = infos["final_observation"]
         idx = np.flatnonzero(done)
@@ -499,8 +504,6 @@ def test_large_env_final_observations_travel_packed(mode, limit):
         got = np.stack([fo[i] for i in idx])
         assert ulps32(got, rfin[idx]).max() <= MAX_OBS_ULPS
         assert all(fo[i] is None for i in np.flatnonzero(~done)[:1000])
-        if mode == "copy":
-            kept.append((obs, obs.copy(), rew, rew.copy()))     # a fresh array per call: later steps must not touch these
     for o1, o2, r1, r2 in kept:
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2)
     assert len({id(k[0]) for k in kept}) == len(kept)
