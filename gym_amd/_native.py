@@ -38,7 +38,7 @@ EXPORTS = (
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
-    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_host_register", "mxv_host_unregister",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -133,8 +133,6 @@ def _load():
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
-        "mxv_host_register": ([vp, u64], C.c_int),
-        "mxv_host_unregister": ([vp], C.c_int),
         "mxv_final_packed": ([vp, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
         "mxv_final_packed_view": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
@@ -258,12 +256,9 @@ class _ArrayPool:
     it can still see it — and the pages stay mapped.  If the caller keeps everything, the pool just grows to `limit` and further
     arrays are plain np.empty."""
 
-    PIN_ABOVE = 1 << 20   # arrays this large are page-locked once (hipHostRegister): their D2H copies become direct DMA
-
     def __init__(self, limit: int = 6):
         self._free = {}
         self._limit = limit
-        self._pinned = []
 
     def take(self, shape, dtype) -> np.ndarray:
         key = (tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape, np.dtype(dtype).str)
@@ -274,18 +269,7 @@ class _ArrayPool:
         a = np.empty(shape, dtype=dtype)
         if len(lst) < self._limit:
             lst.append(a)
-            if a.nbytes >= self.PIN_ABOVE and os.environ.get("MXV_POOL_PIN", "1") != "0":
-                a.fill(0)       # touch the pages before pinning them
-                if lib.mxv_host_register(a.ctypes.data, a.nbytes) == OK:
-                    self._pinned.append(a)
         return a
-
-    def close(self):
-        """Unpin before the arrays can be freed (the pool is the last owner of the ones nobody else holds)."""
-        for a in self._pinned:
-            lib.mxv_host_unregister(a.ctypes.data)
-        self._pinned = []
-        self._free = {}
 
 
 class _DestroyLater:
@@ -341,9 +325,6 @@ class Handle:
         return np.float32 if self.flags & FLAG_REWARD_F32 else np.float64
 
     def close(self):
-        pool = self.__dict__.pop("_pool", None)
-        if pool is not None:
-            pool.close()
         if getattr(self, "_h", None) is not None and self._h:
             keep = getattr(self, "_io_keep", None)
             if keep is not None:

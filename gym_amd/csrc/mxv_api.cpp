@@ -865,26 +865,6 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
     return MXV_OK;
 }
 
-int mxv_host_register(void *host_ptr, uint64_t bytes) {
-    if (!host_ptr || bytes == 0) return fail(nullptr, MXV_ERR_INVALID_ARG, "mxv_host_register: NULL pointer or zero size");
-    const hipError_t e = hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(nullptr, MXV_ERR_HIP, "hipHostRegister: %s", hipGetErrorString(e));
-    }
-    return MXV_OK;
-}
-
-int mxv_host_unregister(void *host_ptr) {
-    if (!host_ptr) return MXV_OK;
-    const hipError_t e = hipHostUnregister(host_ptr);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(nullptr, MXV_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
-    }
-    return MXV_OK;
-}
-
 int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported) {
     MXV_CHECK_HANDLE(h);
     if (int rc = use_device(h)) return rc;

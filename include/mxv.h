@@ -206,12 +206,6 @@ int mxv_host_io(mxv_handle *h, void **actions, float **obs, void **reward, uint8
 int mxv_step_mapped(mxv_handle *h);
 int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host);
 
-/* Page-lock a caller-owned host buffer that is passed to the *_host calls again and again (the NumPy adapter recycles its output
- * arrays): the per-array copies of mxv_step_host then run as direct DMA instead of being staged.  Thin wrappers of
- * hipHostRegister / hipHostUnregister; unregister before the memory is freed. */
-int mxv_host_register(void *host_ptr, uint64_t bytes);
-int mxv_host_unregister(void *host_ptr);
-
 /* info["final_observation"] for host callers of LARGE vector envs (step I/O above 2 MiB).  Only the rows of the envs that finished a
  * step mean anything (sync_vector_env.py:152-156), typically a few percent of the batch, so the host calls never move the dense
  * [N][O] array over PCIe: the device packs (env index, row) pairs (one ballot + one atomic per wave), two small DMAs bring
