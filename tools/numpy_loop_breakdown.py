@@ -27,6 +27,9 @@ for n in (1 << 16, 1 << 20):
     out[f"step_host_fresh_arrays_{n}"] = t(lambda: h.step_host(a, want_final=True))
     out[f"step_host_pooled_{n}"] = t(lambda: h.step_host(a, want_final=True, pooled=True))
     out[f"step_host_pooled_nofinal_{n}"] = t(lambda: h.step_host(a, want_final=False, pooled=True))
+    h.final_packed(True)
+    out[f"step_host_pooled_packed_final_{n}"] = t(lambda: (h.step_host(a, want_final=True, pooled=True), h.final_packed_rows()))
+    h.final_packed(False)
     io = h.host_io()
     h.reset_mapped()
     io["actions"][:] = a
