@@ -283,6 +283,12 @@ def main():
     # repeats of the timed region: a pure function of the arguments (every rank must issue the same launches and collectives)
     nominal_ms_per_step = 6.0e-3 * local_envs / ENVS_TOTAL
     repeats = args.repeats if args.repeats > 0 else max(1, int(-(-args.min_timed_ms // max(args.steps * nominal_ms_per_step, 1e-9))))
+    if args.repeats <= 0 and repeats > 1 and mode == "fused":
+        # whole launches only: round up so that repeats * steps is a multiple of the chunk (20 steps x 512 = 40 launches of 256)
+        import math
+
+        unit = args.chunk // math.gcd(args.steps, args.chunk)
+        repeats = -(-repeats // unit) * unit
     timed_steps = args.steps * repeats
 
     ev0 = torch.cuda.Event(enable_timing=True)
