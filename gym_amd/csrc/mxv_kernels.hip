@@ -465,9 +465,24 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
     for (int j = 0; j < E; ++j) lo[j] = le[j];
 #endif
 
+#if MXV_EXP_STATE_IN_LDS  // measurement only (north_star: "integration ... staged in LDS"): the fp64 state lives in LDS between steps
+    __shared__ double lds_state[E * S * kWave];
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+#pragma unroll
+        for (int k = 0; k < S; ++k) lds_state[(j * S + k) * kWave + lane] = s[j][k];
+#endif
+
     settle_entry_loads();
     for (int step = 0; step < a.K; ++step) {
         const uint64_t t = t0 + (uint64_t)step;
+#if MXV_EXP_STATE_IN_LDS
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[j][k] = lds_state[(j * S + k) * kWave + lane];
+#endif
 
         // ---- this step's actions ----
         int ai[E];
@@ -581,6 +596,13 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             }
         }
 
+#if MXV_EXP_STATE_IN_LDS
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+#pragma unroll
+            for (int k = 0; k < S; ++k) lds_state[(j * S + k) * kWave + lane] = s[j][k];
+        asm volatile("" ::: "memory");
+#endif
         // ---- look-ahead pass: refill the empty reset slots j of this wave, every PERIOD steps per slot ----
 #pragma unroll
         for (int j = 0; j < E; ++j)

@@ -138,6 +138,11 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_EXP_TILE_MAJOR
 #define MXV_EXP_TILE_MAJOR 0
 #endif
+// measurement hook: 1 = the fused rollout keeps the fp64 env state in LDS between steps (read at the top of a step, written back at its
+// end) instead of registers — the "staged in LDS" reading of north_star, for the A/B in profiles/
+#ifndef MXV_EXP_STATE_IN_LDS
+#define MXV_EXP_STATE_IN_LDS 0
+#endif
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8
