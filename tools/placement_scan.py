@@ -80,7 +80,7 @@ def main():
     while time.perf_counter() - t0 < 0.25:
         r.rollout_per_step(K, out=views(packed()))
         r.synchronize()
-    probe = [timed(views(packed(start=s * GiB))) for s in (0, 1, 2, 3)]
+    probe = [timed(views(packed(start=s * GiB))) for s in (0, 1, 2, 3, 0, 1)]
     kind = "fast" if min(probe) < 6.2 else "slow"
     print(json.dumps({"box": kind, "probe_us_per_step": probe}), flush=True)
     if kind == "slow" and not args.force:
@@ -96,9 +96,17 @@ def main():
     layouts["order reward obs actions"] = packed(perm=["reward", "obs", "actions", "terminated", "truncated"])
     layouts["order actions last, flags between"] = packed(perm=["obs", "terminated", "reward", "truncated", "actions"])
     rng = random.Random(1)
-    for i in range(8):   # random 4-KiB-aligned placements of the five tensors anywhere in the block (non-overlapping by construction)
-        slots = rng.sample(range(0, 13), 5)
-        layouts[f"random {i}"] = {name: s * GiB * 1 + rng.randrange(0, 1 << 18) * 4096 % (GiB // 4) for name, s in zip(order, slots)}
+    for i in range(8):   # random order, random 4-KiB-aligned gaps (the five tensors are 8.5 GiB; up to 5 GiB of gaps in the 14-GiB block)
+        perm = order[:]
+        rng.shuffle(perm)
+        cuts = sorted(rng.randrange(0, 5 * GiB // 4096) for _ in range(5))
+        gaps = [cuts[0]] + [cuts[j] - cuts[j - 1] for j in range(1, 5)]
+        offs, off = {}, 0
+        for name, g in zip(perm, gaps):
+            off += g * 4096
+            offs[name] = off
+            off += sizes[name]
+        layouts[f"random {i}"] = offs
     names = list(layouts)
     res = {k: [] for k in names}
     for rep in range(2):
