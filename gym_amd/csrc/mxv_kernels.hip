@@ -608,6 +608,9 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         for (int j = 0; j < E; ++j)
             if ((step & (PERIOD - 1)) == j * (PERIOD / E) && __any(need[j])) fill_entries(j);
 
+#if MXV_EXP_SLEEP > 0  // measurement only: pace the wave (units of 64 clocks) — does a slower issue rate help the write path?
+        __builtin_amdgcn_s_sleep(MXV_EXP_SLEEP);
+#endif
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
         if (FULL || p_rew != nullptr) p_rew += slice * (int64_t)rew_b;

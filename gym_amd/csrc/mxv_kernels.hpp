@@ -143,6 +143,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_EXP_STATE_IN_LDS
 #define MXV_EXP_STATE_IN_LDS 0
 #endif
+// measurement hook: s_sleep of this many 64-clock units at the end of every step of the fused rollout (0 = none)
+#ifndef MXV_EXP_SLEEP
+#define MXV_EXP_SLEEP 0
+#endif
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8
