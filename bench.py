@@ -55,6 +55,20 @@ def algorithmic_bytes_per_env_step(mode: str, chunk: float) -> float:
     return 8 * S_DIM + 4 * O_DIM + 4 + 4 + 2 + 8
 
 
+def timed_repeats(steps: int, chunk: int, local_envs: int, min_timed_ms: float, mode: str = "fused") -> int:
+    """How often the `steps`-step timed region is repeated inside one bracket: a pure function of the arguments (every rank must
+    issue the same launches and collectives), from a nominal 6 us per 2^20-env step, rounded up so that repeats * steps is a
+    whole number of chunk-step launches (20 steps x 512 = 40 launches of 256)."""
+    import math
+
+    nominal_ms_per_step = 6.0e-3 * local_envs / ENVS_TOTAL
+    repeats = max(1, math.ceil(min_timed_ms / max(steps * nominal_ms_per_step, 1e-9)))
+    if repeats > 1 and mode == "fused":
+        unit = chunk // math.gcd(steps, chunk)
+        repeats = -(-repeats // unit) * unit
+    return repeats
+
+
 def cpu_baseline(sample_steps: int):
     """C port of the reference (oracle/classic_control.c, kind "port") on the host cores, same workload, bounded sample:
     first one thread (2^20 envs x sample_steps steps), then one thread per host core over equal env shards (the port has no
@@ -280,15 +294,7 @@ def main():
         sr.gather()
     fence()
 
-    # repeats of the timed region: a pure function of the arguments (every rank must issue the same launches and collectives)
-    nominal_ms_per_step = 6.0e-3 * local_envs / ENVS_TOTAL
-    repeats = args.repeats if args.repeats > 0 else max(1, int(-(-args.min_timed_ms // max(args.steps * nominal_ms_per_step, 1e-9))))
-    if args.repeats <= 0 and repeats > 1 and mode == "fused":
-        # whole launches only: round up so that repeats * steps is a multiple of the chunk (20 steps x 512 = 40 launches of 256)
-        import math
-
-        unit = args.chunk // math.gcd(args.steps, args.chunk)
-        repeats = -(-repeats // unit) * unit
+    repeats = args.repeats if args.repeats > 0 else timed_repeats(args.steps, args.chunk, local_envs, args.min_timed_ms, mode)
     timed_steps = args.steps * repeats
 
     ev0 = torch.cuda.Event(enable_timing=True)

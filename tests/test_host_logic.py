@@ -224,3 +224,19 @@ def test_plugin_registers_with_the_live_reference_registry():
             with pytest.raises(_native.MxvError) as ei:   # reached mxv_create: no device here, and no CPU fallback
                 gym.make(env_id, num_envs=8)
             assert "no HIP device" in str(ei.value) or ei.value.code == _native.ERR_HIP
+
+
+def test_bench_accounting_is_a_pure_function_of_the_arguments():
+    """bench.py: algorithmic bytes per env-step and the repeat count of a short timed region — the driver runs
+    `--steps 20 --warmup 5`, every rank must derive the same launches from the arguments alone."""
+    import bench
+
+    assert bench.algorithmic_bytes_per_env_step("fused", 256) == pytest.approx(4 * 4 + 4 + 4 + 2 + 16 * 4 / 256) == pytest.approx(26.25)
+    assert bench.algorithmic_bytes_per_env_step("fused", 20) == pytest.approx(29.2)
+    assert bench.algorithmic_bytes_per_env_step("eager", 1) == 66
+    r = bench.timed_repeats(20, 256, 1 << 20, 60.0)
+    assert r == 512 and (r * 20) % 256 == 0 and r * 20 * 6e-3 >= 60.0          # 40 whole launches of 256 steps, >= 60 ms nominal
+    assert bench.timed_repeats(20480, 256, 1 << 20, 60.0) == 1                  # the default run is long enough as it is
+    r8 = bench.timed_repeats(20, 256, 1 << 17, 60.0)                            # an 8-GPU strong-scaling shard: 8x shorter steps
+    assert r8 >= 8 * 500 and (r8 * 20) % 256 == 0
+    assert bench.timed_repeats(20, 256, 1 << 20, 60.0, mode="eager") == 500
