@@ -121,23 +121,54 @@ class DeviceRollout:
                 self.handle.set_episode_outputs(*tgt)
                 self._ep_attached = tgt[0]
 
-    def trajectory_buffers(self, K: int, want_final: bool = False):
+    def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "separate", seed: int = 0):
         """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk).  want_final adds
         `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
-        of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content."""
+        of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content.
+
+        layout="separate": one allocation per tensor.  layout="spread": all tensors carved out of ONE allocation in shuffled order
+        at irregular offsets (pseudo-random gaps of up to ~60 % of the tensors' size in total, 4-KiB aligned, fixed by `seed`):
+        on the boxes where placement matters the speed mode of the write-bound rollout is a function of the ADDRESSES — packed
+        back to back (which is also what consecutive separate allocations are) can hit the slow mode, eight of eight such
+        irregular layouts measured fast (profiles/r02q_placement_scan_one_allocation.jsonl)."""
         n, dev = self.num_envs, self.device
+        specs = []
+        if want_final:
+            specs.append(("final_obs", (K, n, self.O), torch.float32, True))
+        if getattr(self, "episode_stats", False):
+            specs += [("ep_return", (K, n), torch.float32, True), ("ep_length", (K, n), torch.int32, True)]
+        specs += [("obs", (K, n, self.O), torch.float32, False), ("reward", (K, n), self.reward_dtype, False),
+                  ("terminated", (K, n), torch.uint8, False), ("truncated", (K, n), torch.uint8, False),
+                  ("actions", (K, n), self.action_dtype, False)]
         with torch.cuda.stream(self.stream):
-            extra = {}
-            if want_final:
-                extra["final_obs"] = torch.zeros((K, n, self.O), dtype=torch.float32, device=dev)
-            if getattr(self, "episode_stats", False):
-                extra.update(ep_return=torch.zeros((K, n), dtype=torch.float32, device=dev),
-                             ep_length=torch.zeros((K, n), dtype=torch.int32, device=dev))
-            return dict(**extra, obs=torch.empty((K, n, self.O), dtype=torch.float32, device=dev),
-                        reward=torch.empty((K, n), dtype=self.reward_dtype, device=dev),
-                        terminated=torch.empty((K, n), dtype=torch.uint8, device=dev),
-                        truncated=torch.empty((K, n), dtype=torch.uint8, device=dev),
-                        actions=torch.empty((K, n), dtype=self.action_dtype, device=dev))
+            if layout == "separate":
+                return {name: (torch.zeros if zero else torch.empty)(shape, dtype=dt, device=dev) for name, shape, dt, zero in specs}
+            if layout != "spread":
+                raise ValueError(f"layout must be 'separate' or 'spread', got {layout!r}")
+            import math
+            import random
+
+            rng = random.Random(0x5EED + 7919 * seed)
+            order = list(range(len(specs)))
+            rng.shuffle(order)
+            nbytes = [math.prod(shape) * torch.empty((), dtype=dt).element_size() for _, shape, dt, _ in specs]
+            total = sum(nbytes)
+            cuts = sorted(rng.uniform(0.0, 0.6) * total for _ in order)
+            gaps = [cuts[0]] + [b - a for a, b in zip(cuts, cuts[1:])]
+            offs, off = {}, 0
+            for i, g in zip(order, gaps):
+                off = (int(off + g) + 4095) // 4096 * 4096
+                offs[i] = off
+                off += nbytes[i]
+            block = torch.empty(off + 4096, dtype=torch.uint8, device=dev)
+            base = (-block.data_ptr()) % 4096
+            out = {}
+            for i, (name, shape, dt, zero) in enumerate(specs):
+                t = block[base + offs[i]: base + offs[i] + nbytes[i]].view(dt).view(shape)
+                if zero:
+                    t.zero_()
+                out[name] = t
+            return out
 
     def tuned_trajectory_buffers(self, K: int, candidates: int = 8, launches: int = 6, want_final: bool = False,
                                  mixes: Optional[int] = None):
@@ -159,8 +190,11 @@ class DeviceRollout:
         per_step = self.num_envs * (4 * self.O * (2 if want_final else 1) + self.reward.element_size()
                                     + self.actions.element_size() + 2)
         free, _ = torch.cuda.mem_get_info(self.device)
-        candidates = max(1, min(int(candidates), int(0.8 * free) // max(1, K * per_step)))  # never tune the device out of memory
-        sets = [self.trajectory_buffers(K, want_final=want_final) for _ in range(candidates)]
+        candidates = max(1, min(int(candidates), int(0.8 * free) // max(1, int(1.3 * K * per_step))))  # never tune the device out of memory
+        # the last quarter of the candidates are single-allocation "spread" layouts (see trajectory_buffers): evidence for a rule
+        n_spread = candidates // 4
+        kinds = ["separate"] * (candidates - n_spread) + ["spread"] * n_spread
+        sets = [self.trajectory_buffers(K, want_final=want_final, layout=kind, seed=i) for i, kind in enumerate(kinds)]
 
         def timed(traj, warm):
             for _ in range(warm):
@@ -205,7 +239,7 @@ class DeviceRollout:
         if running is not None:
             self.handle.set_running_returns(running)
         torch.cuda.empty_cache()
-        return best, {"candidates": len(times), "us_per_step": [round(x, 3) for x in times],
+        return best, {"candidates": len(times), "kinds": kinds, "us_per_step": [round(x, 3) for x in times],
                       "mixes_us_per_step": [round(x, 3) for x in mix_times], "chosen_us_per_step": round(best_us, 3)}
 
     # -- checkpoint / resume -------------------------------------------------------------------------

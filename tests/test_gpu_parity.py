@@ -497,3 +497,35 @@ def test_tuned_trajectory_buffers_leave_results_unchanged():
         r.close()
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_spread_layout_buffers_give_identical_trajectories():
+    """trajectory_buffers(layout="spread"): all output tensors carved out of ONE allocation at irregular offsets (the placement
+    experiment's fast family) — a placement choice only: same shapes, dtypes and bits as separate allocations,
+    non-overlapping, also with final observations and episode statistics; the tuner reports which kind each candidate was."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    n, K = 1 << 14, 24
+    outs = []
+    for layout in ("separate", "spread"):
+        r = DeviceRollout("CartPole-v1", n, seed=3, action_seed=4)
+        r.enable_episode_stats()
+        r.reset(seed=3)
+        traj = r.trajectory_buffers(K, want_final=True, layout=layout, seed=5)
+        if layout == "spread":
+            spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in traj.values())
+            assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and all(s[0] % 4096 == 0 for s in spans)
+            assert len({t.untyped_storage().data_ptr() for t in traj.values()}) == 1
+        r.rollout_per_step(K, out=traj)
+        r.synchronize()
+        outs.append({k: v.cpu().numpy().copy() for k, v in traj.items()})
+        r.close()
+    assert set(outs[0]) == set(outs[1]) == {"obs", "reward", "terminated", "truncated", "actions", "final_obs", "ep_return", "ep_length"}
+    for k in outs[0]:
+        assert outs[0][k].dtype == outs[1][k].dtype and np.array_equal(outs[0][k], outs[1][k]), k
+    r = DeviceRollout("CartPole-v1", 1 << 16, seed=1, action_seed=2)
+    r.reset(seed=1)
+    traj, report = r.tuned_trajectory_buffers(16, candidates=8, launches=2)
+    assert report["kinds"] == ["separate"] * 6 + ["spread"] * 2 and len(report["us_per_step"]) == 8
+    r.close()
