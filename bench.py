@@ -358,7 +358,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "rollout_kernel<CartPole>" if mode == "fused" else "step_kernel<CartPole>",
+                "kernel": "rollout_kernel_v3<CartPole>" if mode == "fused" else "step_kernel<CartPole>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
