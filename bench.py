@@ -372,6 +372,20 @@ def main():
                 "avg_launch_us": launch_ms * 1e3,
             },
         }
+        if mode == "fused" and not args.compact_outputs and local_envs % 1024 == 0:
+            # what THIS box sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
+            # the very tensors the timed region wrote: boxes of this pool differ by 20 % here, so the kernel's time
+            # is printed next to the box's own ceiling for it
+            from gym_amd import _native
+            torch.cuda.synchronize()
+            probe_us = _native.write_probe(local_rank, local_envs, args.chunk, 20, traj["obs"], traj["reward"], traj["actions"],
+                                           traj["terminated"], traj["truncated"])
+            real_b = 34.0 * local_envs
+            out["roofline"]["write_probe"] = {
+                "what": "same store pattern, no physics (mxv_write_probe), same tensors",
+                "us_per_step": probe_us, "real_GBs": real_b / probe_us / 1e3,
+                "kernel_us_per_step": launch_ms * 1e3 / steps_per_launch,
+                "kernel_over_probe": launch_ms * 1e3 / steps_per_launch / probe_us}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_steps)
 

@@ -38,7 +38,7 @@ EXPORTS = (
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
-    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_write_probe",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -133,6 +133,7 @@ def _load():
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
+        "mxv_write_probe": ([C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
         "mxv_final_packed": ([vp, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
         "mxv_final_packed_view": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
@@ -643,6 +644,16 @@ def rollout_mixed(handles, K: int, outs, per_step: bool = True):
     rc = lib.mxv_rollout_mixed(C.cast(hs, C.c_void_p), n, int(K), int(bool(per_step)), C.cast(arr, C.c_void_p))
     if rc != OK:
         raise MxvError(rc, (lib.mxv_last_error(handles[0]._h) or b"").decode())
+
+
+def write_probe(device, num_envs, K, launches, obs, reward, actions, terminated, truncated) -> float:
+    """mxv_write_probe: us per vector step of the rollout's store pattern alone into the given [K][N] device tensors."""
+    us = C.c_double()
+    rc = lib.mxv_write_probe(int(device), int(num_envs), int(K), int(launches), _ptr(obs), _ptr(reward), _ptr(actions),
+                             _ptr(terminated), _ptr(truncated), C.byref(us))
+    if rc != OK:
+        raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
+    return us.value
 
 
 def comm_unique_id() -> bytes:

@@ -865,6 +865,35 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
     return MXV_OK;
 }
 
+int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev, double *reward_dev, int64_t *actions_dev,
+                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step) {
+    if (!obs_dev || !reward_dev || !actions_dev || !terminated_dev || !truncated_dev || !us_per_step || K < 1 || launches < 1 ||
+        num_envs < 1024 || num_envs % 1024 != 0)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "mxv_write_probe: [K][num_envs] buffers of all five outputs, num_envs a multiple of 1024");
+    MXV_HIP(nullptr, hipSetDevice(device));
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    MXV_HIP(nullptr, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    MXV_HIP(nullptr, hipEventCreate(&e0));
+    MXV_HIP(nullptr, hipEventCreate(&e1));
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < 2 && err == hipSuccess; ++i)
+        err = launch_write_probe(obs_dev, reward_dev, actions_dev, terminated_dev, truncated_dev, num_envs, K, s);
+    if (err == hipSuccess) err = hipEventRecord(e0, s);
+    for (int i = 0; i < launches && err == hipSuccess; ++i)
+        err = launch_write_probe(obs_dev, reward_dev, actions_dev, terminated_dev, truncated_dev, num_envs, K, s);
+    if (err == hipSuccess) err = hipEventRecord(e1, s);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    if (err != hipSuccess) return fail(nullptr, MXV_ERR_HIP, "mxv_write_probe: %s", hipGetErrorString(err));
+    *us_per_step = (double)ms * 1e3 / ((double)launches * K);
+    return MXV_OK;
+}
+
 int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported) {
     MXV_CHECK_HANDLE(h);
     if (int rc = use_device(h)) return rc;

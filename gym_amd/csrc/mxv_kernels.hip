@@ -925,6 +925,37 @@ hipError_t launch_compact_final(int obs_dim, const CompactArgs &a, hipStream_t s
     return hipGetLastError();
 }
 
+// Diagnostic: the store pattern of the fused CartPole rollout with the physics removed (tools/wbench5.hip, M = 0) — one wave per
+// workgroup, two envs per lane, XCD-contiguous tiles, the five output streams with the reference's dtypes.  What THIS box sustains
+// for the pattern; bench.py prints it next to the kernel's own time (boxes differ by 20 %).
+__global__ void __launch_bounds__(kWave, 4) write_probe_kernel(float4 *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc,
+                                                               int64_t n, int K) {
+    const unsigned tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    const int64_t e0 = (int64_t)tile * 128 + lane, e1 = e0 + 64;
+    float x = (float)lane;
+    for (int k = 0; k < K; ++k) {
+        const int64_t so = (int64_t)k * n;
+        x = x * 1.0001f + 0.5f;
+        act[so + e0] = k & 1;
+        act[so + e1] = (k >> 1) & 1;
+        rew[so + e0] = 1.0;
+        rew[so + e1] = 1.0;
+        term[so + e0] = x > 1e30f;
+        term[so + e1] = 0;
+        trunc[so + e0] = 0;
+        trunc[so + e1] = 0;
+        obs[so + e0] = make_float4(x, x + 1, 0.f, 1.f);
+        obs[so + e1] = make_float4(x + 2, x, 1.f, 0.f);
+    }
+}
+
+hipError_t launch_write_probe(float *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t n, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(write_probe_kernel, dim3((unsigned)(n / 128)), dim3(kWave), 0, stream, reinterpret_cast<float4 *>(obs), rew, act, term,
+                       trunc, n, K);
+    return hipGetLastError();
+}
+
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream) {
     hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, stream, dst, value);
     return hipGetLastError();

@@ -173,6 +173,7 @@ hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
 hipError_t launch_sample(int env_id, int param_mode, const SampleArgs &a, hipStream_t stream);
 hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream);
 hipError_t launch_compact_final(int obs_dim, const CompactArgs &a, hipStream_t stream);
+hipError_t launch_write_probe(float *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t n, int K, hipStream_t stream);
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);
 
 }  // namespace mxv

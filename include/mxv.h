@@ -434,6 +434,15 @@ int mxv_allgather_wait(mxv_handle *h, int32_t age, int32_t host_sync);
 /* the hipStream_t the gathers run on (NULL before mxv_comm_init) */
 int mxv_comm_stream(mxv_handle *h, void **stream);
 
+/* -- diagnostics ------------------------------------------------------------------------------------------------------------------
+ * What this GPU sustains for the store pattern of the fused CartPole rollout with the physics removed (one wave per workgroup, two
+ * envs per lane, XCD-aware tiles; obs float32 [K][N][4], reward float64 [K][N], actions int64 [K][N], two flag bytes [K][N]: 34 B
+ * per env-step): microseconds per vector step, averaged over `launches` K-step launches into the caller's [K][num_envs] buffers
+ * (contents destroyed).  MI355X boxes differ by 20 % on this pattern; bench.py prints the figure next to the
+ * kernel's own time so that a number can be read against the box it was taken on.  Synchronises. */
+int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev, double *reward_dev, int64_t *actions_dev,
+                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step);
+
 /* -- stream / sync -------------------------------------------------------------------------------- */
 /* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last
  * sync saw an out-of-range action (and clears the latch). */

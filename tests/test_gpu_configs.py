@@ -140,3 +140,25 @@ def test_mixed_single_launch_falls_back_for_non_default_attributes_and_handles_r
                 assert np.array_equal(a[k][kk], b[k][kk]), (tweak, k, kk)
     assert not np.array_equal(outs[(True, False)]["Pendulum-v1"]["obs"], outs[(True, True)]["Pendulum-v1"]["obs"])
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_write_probe_reports_a_plausible_store_rate():
+    """mxv_write_probe (include/mxv.h): the rollout's store pattern alone; 34 B/env-step must land between 0.5 and 8 TB/s."""
+    import torch
+
+    from gym_amd import _native
+
+    n, K = 1 << 18, 16
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((K, n, 4), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, n), dtype=torch.float64, device=dev)
+    act = torch.empty((K, n), dtype=torch.int64, device=dev)
+    te = torch.empty((K, n), dtype=torch.uint8, device=dev)
+    tr = torch.empty((K, n), dtype=torch.uint8, device=dev)
+    us = _native.write_probe(0, n, K, 10, obs, rew, act, te, tr)
+    gbs = 34.0 * n / us / 1e3
+    assert 500.0 < gbs < 8000.0, (us, gbs)
+    assert float(rew.min()) == 1.0 and float(rew.max()) == 1.0 and int(tr.max()) == 0 and int(act.max()) == 1
+    with pytest.raises(_native.MxvError):
+        _native.write_probe(0, 1000, K, 1, obs, rew, act, te, tr)
