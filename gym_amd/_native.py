@@ -38,7 +38,8 @@ EXPORTS = (
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
-    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_write_probe",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_write_probe", "mxv_host_alloc", "mxv_host_free",
+                "mxv_host_block_layout", "mxv_step_host_block",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -134,6 +135,10 @@ def _load():
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
         "mxv_write_probe": ([C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
+        "mxv_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),
+        "mxv_host_free": ([vp], C.c_int),
+        "mxv_host_block_layout": ([vp] + [C.POINTER(C.c_size_t)] * 6, C.c_int),
+        "mxv_step_host_block": ([vp, vp, vp, C.c_int32], C.c_int),
         "mxv_final_packed": ([vp, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
         "mxv_final_packed_view": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
@@ -271,6 +276,47 @@ class _ArrayPool:
         if len(lst) < self._limit:
             lst.append(a)
         return a
+
+
+class _PinnedBlock:
+    """One mxv_host_alloc block; freed when the last NumPy view of it is gone."""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        rc = lib.mxv_host_alloc(nbytes, C.byref(p))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        try:
+            lib.mxv_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+class _BlockPool:
+    """Pinned output blocks of the NumPy adapter (mxv_step_host_block): the caller gets VIEWS of one block per step; a block is
+    handed out again only when no array derived from it is alive any more (every view holds a reference to the block's byte
+    array, so sys.getrefcount sees them) — the same "never overwritten while the caller can see it" contract as _ArrayPool.
+    A caller that keeps everything makes the pool grow to `limit` blocks; take() then returns None and the step falls back to
+    separate, unpinned arrays."""
+
+    def __init__(self, nbytes: int, limit: int = 6):
+        self._nbytes, self._limit, self._raw = nbytes, limit, []
+
+    def take(self):
+        for raw in self._raw:
+            if sys.getrefcount(raw) == 3:   # the list, the loop variable, getrefcount's argument
+                return raw
+        if len(self._raw) >= self._limit:
+            return None
+        blk = _PinnedBlock(self._nbytes)
+        buf = (C.c_char * self._nbytes).from_address(blk.ptr)
+        buf._keepalive = blk
+        raw = np.frombuffer(buf, dtype=np.uint8)
+        self._raw.append(raw)
+        return raw
 
 
 class _DestroyLater:
@@ -416,6 +462,33 @@ class Handle:
         self._check(lib.mxv_step_host(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                       trunc.ctypes.data, _ptr(fin)))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin
+
+    def step_host_block(self, actions, want_final=True):
+        """One vector step whose outputs are views of ONE pooled, pinned host block filled by a single DMA
+        (mxv_step_host_block); -> obs, reward, terminated, truncated, final_obs (None when the rows are packed or not wanted).
+        Falls back to step_host(pooled=True) when the caller holds on to every block of the pool."""
+        n, O = self.num_envs, self.O
+        lay = getattr(self, "_block_layout", None)
+        if lay is None:
+            v = [C.c_size_t() for _ in range(6)]
+            self._check(lib.mxv_host_block_layout(self._h, *[C.byref(x) for x in v]))
+            lay = self._block_layout = tuple(x.value for x in v)
+            self._block_pool = _BlockPool(lay[0])
+        raw = self._block_pool.take()
+        if raw is None:
+            return self.step_host(actions, want_final=want_final, pooled=True)
+        a = np.ascontiguousarray(actions, dtype=self.action_dtype).reshape(n)
+        self._check(lib.mxv_step_host_block(self._h, a.ctypes.data, raw.ctypes.data, int(bool(want_final))))
+        _, o_fin, o_obs, o_rew, o_te, o_tr = lay
+        rb = np.dtype(self.reward_dtype).itemsize
+        obs = raw[o_obs:o_obs + 4 * n * O].view(np.float32).reshape(n, O)
+        rew = raw[o_rew:o_rew + rb * n].view(self.reward_dtype)
+        term = raw[o_te:o_te + n].view(np.bool_)
+        trunc = raw[o_tr:o_tr + n].view(np.bool_)
+        fin = None
+        if want_final and not getattr(self, "_packed_final", False):
+            fin = raw[o_fin:o_fin + 4 * n * O].view(np.float32).reshape(n, O)
+        return obs, rew, term, trunc, fin
 
     def host_io(self):
         """NumPy views of the pinned, device-mapped I/O block (zero-copy stepping): dict(actions, obs, reward, terminated,

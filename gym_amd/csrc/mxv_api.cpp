@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -110,6 +111,7 @@ struct mxv_handle {
     // large envs: info["final_observation"] travels as packed (index, row) pairs of the finished envs only (compact_final_kernel)
     char *fin_dev = nullptr;    // device: count (256 B) | idx int32[N] | rows float[N][O]
     char *fin_host = nullptr;   // pinned mirror
+    size_t fin_last = 0;        // finished envs of the previous host step (sizes the speculative DMA)
     bool fin_packed = false;    // mxv_final_packed: host step calls leave the rows packed (no scatter into a dense array)
     // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
     using GraphKey = std::tuple<int, int, void *, void *, void *, void *, void *, void *>;
@@ -305,7 +307,7 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
             *h->hm_err = 0;
         } else {
             const size_t fin_bytes = 256 + n * sizeof(int32_t) + n * h->O * sizeof(float);
-            MXV_HIP(h, hipMalloc((void **)&h->fin_dev, fin_bytes));
+            MXV_HIP(h, hipMalloc((void **)&h->fin_dev, fin_bytes + (size_t)compact_chunks((int64_t)n) * sizeof(int32_t)));  // + chunk counts
             MXV_HIP(h, hipHostMalloc((void **)&h->fin_host, fin_bytes, hipHostMallocDefault));
         }
     }
@@ -317,30 +319,55 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
     return MXV_OK;
 }
 
+// Actions of a host step, caller's (pageable) array -> device staging.  One plain hipMemcpyAsync: the runtime stages pageable
+// memory through its own pinned buffers, and does it better than a hand-rolled version — copying 1-MiB slices into a pinned
+// buffer of the library's and queueing one DMA per slice (so that slice k's DMA overlaps slice k+1's memcpy) made the 2^20-env
+// CartPole step 130 us SLOWER (1054 vs 917 us, profiles/r03g_upload_ab.txt).
+int upload_actions(mxv_handle *h, const void *actions_host) {
+    const size_t bytes = (size_t)h->cfg.num_envs * h->action_bytes();
+    if (h->hostmap)
+        std::memcpy(h->st_actions, actions_host, bytes);
+    else
+        MXV_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, bytes, hipMemcpyHostToDevice, h->stream));
+    return MXV_OK;
+}
+
 // Large envs: pack the final_obs rows of the envs that finished this step on the device, bring (count | indices) and the rows
 // over in two small DMAs — speculatively the first eighth of the capacity, the rest only if more envs finished — and scatter
 // them into the caller's dense [N][O] array (rows of other envs untouched, as the dense copy left them).  Synchronises.
-int fetch_final_rows(mxv_handle *h, float *final_host) {
+int queue_final_rows(mxv_handle *h, size_t *first_out) {
     const size_t n = (size_t)h->cfg.num_envs, O = (size_t)h->O;
     int32_t *d_count = (int32_t *)h->fin_dev, *d_idx = (int32_t *)(h->fin_dev + 256);
     float *d_rows = (float *)(h->fin_dev + 256 + n * sizeof(int32_t));
-    int32_t *p_count = (int32_t *)h->fin_host, *p_idx = (int32_t *)(h->fin_host + 256);
+    int32_t *p_count = (int32_t *)h->fin_host;
     float *p_rows = (float *)(h->fin_host + 256 + n * sizeof(int32_t));
-    MXV_HIP(h, hipMemsetAsync(d_count, 0, sizeof(int32_t), h->stream));
     CompactArgs c{};
     c.terminated = h->st_term;
     c.truncated = h->st_trunc;
     c.final_obs = h->st_final;
     c.count = d_count;
+    c.chunk_counts = (int32_t *)(h->fin_dev + 256 + n * sizeof(int32_t) + n * O * sizeof(float));
     c.idx = d_idx;
     c.rows = d_rows;
     c.n = (int64_t)n;
     MXV_HIP(h, launch_compact_final(h->O, c, h->stream));
-    const size_t first = std::min(n, std::max<size_t>(1024, n / 8));
+    // speculative size of the first DMA: what finished last step plus a margin (episode ends arrive at a smooth rate)
+    const size_t first = std::min(n, std::max<size_t>(1024, h->fin_last + h->fin_last / 4 + 1024));
     MXV_HIP(h, hipMemcpyAsync(p_count, d_count, 256 + first * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     MXV_HIP(h, hipMemcpyAsync(p_rows, d_rows, first * O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    *first_out = first;
+    return MXV_OK;
+}
+
+// After the stream drained: fetch what the speculative DMA missed, scatter if asked.
+int finish_final_rows(mxv_handle *h, size_t first, float *final_host) {
+    const size_t n = (size_t)h->cfg.num_envs, O = (size_t)h->O;
+    int32_t *d_idx = (int32_t *)(h->fin_dev + 256);
+    float *d_rows = (float *)(h->fin_dev + 256 + n * sizeof(int32_t));
+    int32_t *p_count = (int32_t *)h->fin_host, *p_idx = (int32_t *)(h->fin_host + 256);
+    float *p_rows = (float *)(h->fin_host + 256 + n * sizeof(int32_t));
     const size_t count = (size_t)*p_count;
+    h->fin_last = count;
     if (count > first) {
         MXV_HIP(h, hipMemcpyAsync(p_idx + first, d_idx + first, (count - first) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         MXV_HIP(h, hipMemcpyAsync(p_rows + first * O, d_rows + first * O, (count - first) * O * sizeof(float), hipMemcpyDeviceToHost,
@@ -352,6 +379,13 @@ int fetch_final_rows(mxv_handle *h, float *final_host) {
     if (final_host)
         for (size_t i = 0; i < count; ++i) std::memcpy(final_host + (size_t)p_idx[i] * O, p_rows + i * O, O * sizeof(float));
     return MXV_OK;
+}
+
+int fetch_final_rows(mxv_handle *h, float *final_host) {
+    size_t first = 0;
+    if (int rc = queue_final_rows(h, &first)) return rc;
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return finish_final_rows(h, first, final_host);
 }
 
 void free_graphs(mxv_handle *h) {
@@ -695,10 +729,7 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     if (int rc = use_device(h)) return rc;
     if (int rc = ensure_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
-    if (h->hostmap)
-        std::memcpy(h->st_actions, actions_host, n * h->action_bytes());
-    else
-        MXV_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * h->action_bytes(), hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_actions(h, actions_host)) return rc;
     float *keep_r = h->ep_return_out;
     int32_t *keep_l = h->ep_length_out;
     if (h->ep_acc) {  // host callers read the statistics of this step with mxv_episode_stats_host()
@@ -732,6 +763,12 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
         }
         return MXV_OK;
     }
+    // the packed final rows go first: their DMAs target pinned memory and are truly asynchronous, the copies into the caller's
+    // (pageable) arrays below are not
+    const bool packed = (h->fin_packed || final_obs_host) && terminated_host && truncated_host;
+    size_t first = 0;
+    if (packed)
+        if (int rc = queue_final_rows(h, &first)) return rc;
     MXV_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (reward_host)
         MXV_HIP(h, hipMemcpyAsync(reward_host, h->st_reward, n * h->reward_bytes(), hipMemcpyDeviceToHost, h->stream));
@@ -739,14 +776,84 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
         MXV_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
     if (truncated_host)
         MXV_HIP(h, hipMemcpyAsync(truncated_host, h->st_trunc, n, hipMemcpyDeviceToHost, h->stream));
-    if (h->fin_packed && terminated_host && truncated_host) {
-        if (int rc = fetch_final_rows(h, nullptr)) return rc;          // left packed for mxv_final_packed_view
-    } else if (final_obs_host && terminated_host && truncated_host) {
-        if (int rc = fetch_final_rows(h, final_obs_host)) return rc;   // packed rows of the finished envs only, scattered here
-    } else if (final_obs_host) {
+    if (!packed && final_obs_host)
         MXV_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    }
     int rc = check_latched(h);  // synchronises
+    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
+    if (rc == MXV_OK && packed)                   // packed rows of the finished envs: left packed (mxv_final_packed_view) or scattered
+        rc = finish_final_rows(h, first, h->fin_packed ? nullptr : final_obs_host);
+    return rc;
+}
+
+int mxv_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr || bytes == 0) return fail(nullptr, MXV_ERR_INVALID_ARG, "mxv_host_alloc: NULL pointer or zero size");
+    MXV_HIP(nullptr, hipHostMalloc(ptr, bytes, hipHostMallocPortable));
+    return MXV_OK;
+}
+
+int mxv_host_free(void *ptr) {
+    if (ptr) MXV_HIP(nullptr, hipHostFree(ptr));
+    return MXV_OK;
+}
+
+int mxv_host_block_layout(mxv_handle *h, size_t *bytes, size_t *final_obs_off, size_t *obs_off, size_t *reward_off,
+                          size_t *terminated_off, size_t *truncated_off) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_staging(h)) return rc;
+    const char *base = (const char *)h->st_final;
+    if (bytes) *bytes = (size_t)((const char *)h->st_mask - base);
+    if (final_obs_off) *final_obs_off = 0;
+    if (obs_off) *obs_off = (size_t)((const char *)h->st_obs - base);
+    if (reward_off) *reward_off = (size_t)((const char *)h->st_reward - base);
+    if (terminated_off) *terminated_off = (size_t)((const char *)h->st_term - base);
+    if (truncated_off) *truncated_off = (size_t)((const char *)h->st_trunc - base);
+    return MXV_OK;
+}
+
+int mxv_step_host_block(mxv_handle *h, const void *actions_host, void *block_host, int32_t want_final) {
+    MXV_CHECK_HANDLE(h);
+    if (!actions_host || !block_host) return fail(h, MXV_ERR_INVALID_ARG, "actions/block pointer is NULL");
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_staging(h)) return rc;
+    if (int rc = upload_actions(h, actions_host)) return rc;
+    float *keep_r = h->ep_return_out;
+    int32_t *keep_l = h->ep_length_out;
+    if (h->ep_acc) {
+        h->ep_return_out = h->st_ep_r;
+        h->ep_length_out = h->st_ep_l;
+    }
+    struct Restore {
+        mxv_handle *h; float *r; int32_t *l;
+        ~Restore() { h->ep_return_out = r; h->ep_length_out = l; }
+    } restore{h, keep_r, keep_l};
+    if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, h->st_reward, h->st_term, h->st_trunc, want_final ? h->st_final : nullptr))
+        return rc;
+    const bool packed = want_final && h->fin_packed && !h->hostmap;
+    const bool dense_final = want_final && !packed;
+    const char *src = (const char *)(dense_final ? (void *)h->st_final : (void *)h->st_obs);
+    const size_t off = (size_t)(src - (const char *)h->st_final), len = (size_t)((const char *)h->st_mask - src);
+    size_t first = 0;
+    int rc;
+    if (h->hostmap) {
+        MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+        std::memcpy((char *)block_host + off, src, len);
+        rc = MXV_OK;
+        if (*h->hm_err != 0) {
+            const int32_t e = *h->hm_err;
+            *h->hm_err = 0;
+            MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+            rc = (e & 1) ? fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA)
+                         : fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
+        }
+    } else {
+        if (packed)
+            if (int rc2 = queue_final_rows(h, &first)) return rc2;
+        MXV_HIP(h, hipMemcpyAsync((char *)block_host + off, src, len, hipMemcpyDeviceToHost, h->stream));   // ONE DMA: obs .. truncated
+        rc = check_latched(h);  // synchronises
+        if (rc == MXV_OK && packed) rc = finish_final_rows(h, first, nullptr);
+    }
     if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
     return rc;
 }

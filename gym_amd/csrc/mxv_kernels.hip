@@ -751,22 +751,75 @@ __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
 
 // info["final_observation"] for a host caller: of the dense [N][O] final_obs rows only those of the envs that finished this step
 // (terminated | truncated: ~5 % of a random-policy CartPole batch) are meaningful.  Instead of sending the whole array over PCIe
-// every step, pack (env index, row) pairs of the finished envs: one ballot + one atomic per wave; the host scatters them back.
+// every step, pack (env index, row) pairs of the finished envs IN ASCENDING ENV ORDER (= np.flatnonzero(terminated | truncated)):
+// two small kernels over chunks of kCompactChunk envs — count per chunk, then every chunk's workgroup sums the counts of the
+// chunks before it and writes its pairs at the right offset.  No atomics: a first version took one returning atomicAdd per wave on
+// a single counter, 16 384 same-address atomics at 2^20 envs = 163 us for a 5-us job (profiles/r03d_numpy_loop_trace.md).
+constexpr int kCompactChunk = 4096, kCompactIters = kCompactChunk / kBlock, kCompactWaves = kBlock / kWave;
+
+__device__ __forceinline__ bool compact_done(const CompactArgs &a, int64_t e) {
+    return e < a.n && (a.terminated[e] | a.truncated[e]) != 0;
+}
+
+__global__ void __launch_bounds__(kBlock) final_count_kernel(const CompactArgs a) {
+    __shared__ int32_t part[kCompactWaves];
+    const int64_t e0 = (int64_t)blockIdx.x * kCompactChunk + threadIdx.x;
+    int32_t c = 0;
+#pragma unroll 4
+    for (int i = 0; i < kCompactIters; ++i) c += (int32_t)__popcll(__ballot(compact_done(a, e0 + (int64_t)i * kBlock)));
+    if (threadIdx.x % kWave == 0) part[threadIdx.x / kWave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t t = 0;
+        for (int w = 0; w < kCompactWaves; ++w) t += part[w];
+        a.chunk_counts[blockIdx.x] = t;
+    }
+}
+
 template <int O>
-__global__ void __launch_bounds__(kBlock) compact_final_kernel(const CompactArgs a) {
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool done = e < a.n && (a.terminated[e] | a.truncated[e]) != 0;
-    const uint64_t m = __ballot(done);
-    if (m == 0) return;
-    const uint32_t lane = threadIdx.x % kWave;
-    uint32_t base = 0;
-    if (lane == (uint32_t)__ffsll((unsigned long long)m) - 1u) base = (uint32_t)atomicAdd(a.count, (int32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, __ffsll((unsigned long long)m) - 1);
-    if (done) {
-        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        a.idx[slot] = (int32_t)e;
+__global__ void __launch_bounds__(kBlock) final_pack_kernel(const CompactArgs a) {
+    static_assert(kCompactIters * kCompactWaves == kWave, "one lane per (iteration, wave) cell in the prefix below");
+    __shared__ int32_t cell[kWave];      // finished envs per (iteration, wave) of this chunk, in env order
+    __shared__ int32_t red[kCompactWaves];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    const int64_t e0 = (int64_t)blockIdx.x * kCompactChunk + threadIdx.x;
+    // offset of this chunk = finished envs in all chunks before it
+    int32_t before = 0;
+    for (unsigned c = threadIdx.x; c < blockIdx.x; c += kBlock) before += a.chunk_counts[c];
 #pragma unroll
-        for (int k = 0; k < O; ++k) a.rows[(size_t)slot * O + k] = a.final_obs[(size_t)e * O + k];
+    for (int d = kWave / 2; d > 0; d >>= 1) before += __shfl_xor(before, d);
+    if (lane == 0) red[wave] = before;
+    uint64_t masks[kCompactIters];
+#pragma unroll
+    for (int i = 0; i < kCompactIters; ++i) {
+        masks[i] = __ballot(compact_done(a, e0 + (int64_t)i * kBlock));
+        if (lane == 0) cell[i * kCompactWaves + wave] = (int32_t)__popcll(masks[i]);
+    }
+    __syncthreads();
+    int32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactWaves; ++w) base += red[w];
+    // exclusive prefix over the 64 cells (lane l owns cell l)
+    const int32_t mine = cell[lane];
+    int32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const int32_t excl = incl - mine;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kWave - 1) *a.count = base + incl;   // lane 63 of wave 0: the chunk's total
+#pragma unroll
+    for (int i = 0; i < kCompactIters; ++i) {
+        const uint64_t m = masks[i];
+        const int32_t off = __shfl(excl, i * kCompactWaves + wave);
+        if ((m >> lane) & 1) {
+            const int64_t e = e0 + (int64_t)i * kBlock;
+            const uint32_t slot = (uint32_t)(base + off) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            a.idx[slot] = (int32_t)e;
+#pragma unroll
+            for (int k = 0; k < O; ++k) a.rows[(size_t)slot * O + k] = a.final_obs[(size_t)e * O + k];
+        }
     }
 }
 
@@ -913,13 +966,16 @@ hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream) {
     return hipGetLastError();
 }
 
+int64_t compact_chunks(int64_t n) { return (n + kCompactChunk - 1) / kCompactChunk; }
+
 hipError_t launch_compact_final(int obs_dim, const CompactArgs &a, hipStream_t stream) {
-    const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
+    const unsigned grid = (unsigned)compact_chunks(a.n);
+    hipLaunchKernelGGL(final_count_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
     switch (obs_dim) {
-        case 2: hipLaunchKernelGGL(compact_final_kernel<2>, dim3(grid), dim3(kBlock), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(compact_final_kernel<3>, dim3(grid), dim3(kBlock), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL(compact_final_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, a); break;
-        case 6: hipLaunchKernelGGL(compact_final_kernel<6>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(final_pack_kernel<2>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(final_pack_kernel<3>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(final_pack_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(final_pack_kernel<6>, dim3(grid), dim3(kBlock), 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -73,7 +73,8 @@ struct ResetArgs {
 struct CompactArgs {
     const uint8_t *terminated, *truncated;  // [N]
     const float *final_obs;                 // [N][O] dense (rows of finished envs valid)
-    int32_t *count;                         // zeroed before the launch
+    int32_t *count;                         // total, written by the launch
+    int32_t *chunk_counts;                  // [compact_chunks(N)] scratch
     int32_t *idx;                           // [N] packed env indices
     float *rows;                            // [N][O] packed rows
     int64_t n;
@@ -172,6 +173,7 @@ bool launch_step_is_rollout(int param_mode, const StepArgs &a);
 hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
 hipError_t launch_sample(int env_id, int param_mode, const SampleArgs &a, hipStream_t stream);
 hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream);
+int64_t compact_chunks(int64_t n);
 hipError_t launch_compact_final(int obs_dim, const CompactArgs &a, hipStream_t stream);
 hipError_t launch_write_probe(float *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t n, int K, hipStream_t stream);
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);

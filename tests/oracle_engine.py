@@ -129,5 +129,8 @@ class FakeHandle:
         obs, rew, term, trunc, fin, _ = self.o.step(actions)
         return obs, rew, term, trunc, fin
 
+    def step_host_block(self, actions, want_final=True):
+        return self.step_host(actions, want_final=want_final)
+
     def close(self):
         self.closed = True

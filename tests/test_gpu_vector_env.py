@@ -427,11 +427,12 @@ def test_set_attr_per_env_values_like_the_reference_test():
 
 
 @pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1"])
-@pytest.mark.parametrize("n", [8, 50000])
+@pytest.mark.parametrize("n", [8, 20000, 50000])
 def test_copy_false_and_zero_copy_equal_the_copying_path(env_id, n):
     """SyncVectorEnv(copy=False) (sync_vector_env.py:61-63,163): the returned observations are the internal buffer — here a
     view of the pinned, device-mapped I/O block the kernel writes over PCIe.  Same numbers as copy=True, step for step; the
-    observation array is reused, rewards/flags are fresh unless zero_copy=True; views stay valid after close()."""
+    observation array is reused, rewards/flags are fresh unless zero_copy=True; views stay valid after close().  Above 2 MiB of
+    step I/O (n = 50000) every mode returns arrays the caller owns (views of a pooled pinned block, one DMA per step)."""
     import gym_amd
 
     envs = [gym_amd.make(env_id, n), gym_amd.make(env_id, n, copy=False), gym_amd.make(env_id, n, zero_copy=True)]
@@ -439,6 +440,8 @@ def test_copy_false_and_zero_copy_equal_the_copying_path(env_id, n):
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
     envs[0].action_space.seed(1)
     prev_obs_id = outs[1].__array_interface__["data"][0]
+    shared = not envs[1]._packed
+    assert shared == (n <= 20000)
     ndone = 0
     for t in range(30):
         a = envs[0].action_space.sample()
@@ -446,7 +449,8 @@ def test_copy_false_and_zero_copy_equal_the_copying_path(env_id, n):
         for r in res[1:]:
             for x, y in zip(res[0][:4], r[:4]):
                 assert x.dtype == y.dtype and np.array_equal(x, y)
-        assert res[1][0].__array_interface__["data"][0] == prev_obs_id          # the same buffer every step
+        if shared:
+            assert res[1][0].__array_interface__["data"][0] == prev_obs_id      # the same buffer every step
         done = res[0][2] | res[0][3]
         if done.any():
             for r in res[1:]:
@@ -457,10 +461,14 @@ def test_copy_false_and_zero_copy_equal_the_copying_path(env_id, n):
     if env_id == "CartPole-v1":
         assert ndone > 0
     rew_copy, rew_view = res[1][1], res[2][1]
+    kept = [(x, x.copy()) for r in res[1:] for x in r[:4]]
     envs[1].step(a)
     envs[2].step(a)
-    assert rew_copy is not envs[1]._io()["reward"]                              # copy=False: rewards are copies
-    assert rew_view.__array_interface__["data"][0] == envs[2]._io()["reward"].__array_interface__["data"][0]
+    if shared:
+        assert rew_copy is not envs[1]._io()["reward"]                          # copy=False: rewards are copies
+        assert rew_view.__array_interface__["data"][0] == envs[2]._io()["reward"].__array_interface__["data"][0]
+    else:
+        assert all(np.array_equal(x, y) for x, y in kept)                       # owned arrays: the next step left them alone
     obs_view = res[2][0]
     for e in envs:
         e.close()
@@ -508,3 +516,49 @@ def test_large_env_final_observations_travel_packed(mode, limit):
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2)
     assert len({id(k[0]) for k in kept}) == len(kept)
     env.close()
+
+
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous"])
+@pytest.mark.parametrize("n,packed", [(64, False), (150_000, False), (150_000, True)])
+def test_one_dma_block_step_equals_per_array_step(name, n, packed):
+    """mxv_step_host_block (one pooled pinned block per step, a single DMA) against mxv_step_host (four copies into separate
+    arrays) on twin handles: identical outputs; packed final rows arrive in ascending env order (= np.flatnonzero of the done
+    mask) and equal the dense rows; a block is never handed out again while the caller holds an array of it, and is once dropped."""
+    from gym_amd import _native
+
+    kind = getattr(_native, name.upper().replace("MOUNTAINCARCONTINUOUS", "MOUNTAINCAR_CONT"))
+    limit = 9
+    h = _native.Handle(kind, n, limit, seed=3, action_seed=4)
+    g = _native.Handle(kind, n, limit, seed=3, action_seed=4)
+    h.reset_host()
+    g.reset_host()
+    if packed:
+        assert h.final_packed(True)
+    rng = np.random.default_rng(5)
+    held, seen_ptrs, ndone = [], set(), 0
+    for t in range(24):
+        a = rng.integers(0, h.NA, n) if h.NA > 0 else rng.uniform(-2.5, 2.5, n).astype(np.float32)
+        obs, rew, term, trunc, fin = h.step_host_block(a, want_final=True)
+        o2, r2, te2, tr2, f2 = g.step_host(a, want_final=True)
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(term, te2) and np.array_equal(trunc, tr2)
+        assert obs.dtype == np.float32 and rew.dtype == r2.dtype and term.dtype == np.bool_
+        done = term | trunc
+        ndone += int(done.sum())
+        if packed:
+            assert fin is None
+            idx, rows = h.final_packed_rows()
+            assert np.array_equal(idx, np.flatnonzero(done))
+            assert np.array_equal(rows, f2[idx])
+        else:
+            assert np.array_equal(fin[done], f2[done])
+        if t < 3:
+            held.append((obs, obs.copy(), rew, rew.copy(), term, term.copy()))
+        seen_ptrs.add(obs.ctypes.data)
+    assert ndone >= 2 * n              # TimeLimit 9: every env finished at least twice in 24 steps
+    for o1, o1c, r1, r1c, t1, t1c in held:
+        assert np.array_equal(o1, o1c) and np.array_equal(r1, r1c) and np.array_equal(t1, t1c)
+    assert len({x[0].ctypes.data for x in held}) == 3
+    assert len(seen_ptrs) <= 6          # blocks are recycled (3 held + the ones in flight), not allocated per step
+    del held, obs, rew, term, trunc, fin
+    h.close()
+    g.close()

@@ -34,7 +34,7 @@ def loop(env_id, n, steps, keep=False, **kw):
 
 
 for env_id in ("CartPole-v1", "Pendulum-v1"):
-    for n, steps in ((8, 2000), (4096, 1000), (65536, 300), (1 << 20, 40)):
+    for n, steps in ((8, 2000), (4096, 1000), (65536, 300), (1 << 20, 200)):
         for label, kw, keep in (("copy=True", {}, False), ("copy=True, caller keeps 4 results", {}, True), ("copy=False", dict(copy=False), False),
                                 ("zero_copy=True", dict(zero_copy=True), False)):
             us = loop(env_id, n, steps, keep=keep, **kw)
