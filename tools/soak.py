@@ -57,6 +57,34 @@ def main():
         hb.close()
         total += 4099 * 200
         print(f"ok Blackjack-v1 seed={seed}", flush=True)
+    # long horizons: the fused rollout (rollout_kernel_v3: K steps per launch, ready-made resets in LDS, look-ahead refills) against
+    # one launch per step (step_kernel), bit for bit over thousands of steps — every output of every step, then state, elapsed
+    # steps, reset ordinals and counters
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    for name in ENV_NAMES:
+        for n, chunks, K, limit in ((6000, 8, 256, None), (70001, 3, 192, 40)):
+            kw = {} if limit is None else dict(max_episode_steps=limit)
+            a = DeviceRollout(GYM_IDS[name], n, seed=91, action_seed=92, env_offset=3 << 20, **kw)
+            b = DeviceRollout(GYM_IDS[name], n, seed=91, action_seed=92, env_offset=3 << 20, **kw)
+            a.reset(seed=91), b.reset(seed=91)
+            dones = 0
+            for c in range(chunks):
+                fa = a.rollout_per_step(K, mode="fused")
+                fb = b.rollout_per_step(K, mode="eager")
+                a.synchronize(), b.synchronize()
+                for key in ("obs", "reward", "terminated", "truncated", "actions"):
+                    assert torch.equal(fa[key], fb[key]), (name, n, c, key)
+                dones += int((fa["terminated"] | fa["truncated"]).sum())
+            for x, y in zip(a.handle.get_state(), b.handle.get_state()):
+                assert np.array_equal(x, y), (name, n)
+            assert np.array_equal(a.handle.get_episodes(), b.handle.get_episodes())
+            assert a.handle.get_counters() == b.handle.get_counters()
+            a.close(), b.close()
+            total += n * chunks * K
+            print(f"ok fused==per-step {name:22s} n={n:<6d} steps={chunks * K:<5d} limit={limit} dones={dones}", flush=True)
     print(f"soak passed: {total:.3e} env-steps compared in {time.time() - t0:.0f} s")
 
 
