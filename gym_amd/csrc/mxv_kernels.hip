@@ -347,7 +347,7 @@ struct RolloutLds {
 
 // The kernel body as a device function of (arguments, workgroup index, workgroups of this segment, LDS): rollout_kernel_v3 runs
 // it for one homogeneous vector env, mixed_rollout_kernel for the segment a workgroup belongs to.
-template <int ENV, bool DEF, int E, bool SAFE, int OUT>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT, bool TAPE = false>
 __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigned bid, const unsigned nblk, RolloutLds<ENV, E> &lds) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -408,10 +408,44 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
     uint32_t word[E];
-    draw_units(0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (!TAPE) {
+        draw_units(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int j = 0; j < E; ++j) word[j] = lds_act[j * kWave + lane];
+        for (int j = 0; j < E; ++j) word[j] = lds_act[j * kWave + lane];
+    }
+    // TAPE: the actions come from the caller's [K][act_slice] tape (mxv_rollout_tape) instead of the Philox stream.  A load inside
+    // the loop shares the in-order vmcnt counter with the stores: consumed in the step that issues it (step_kernel's way), it
+    // drains every store of the wave once per step — 12.5 instead of 5.7 us per 2^20-env CartPole step.  So the tape is read ONE
+    // STEPS AHEAD into registers (two register sets, the loop unrolled by two), and the loop is arranged so that the compiler can
+    // wait for that load with vmcnt(N > 0) — "everything older than the last two steps' stores" — instead of vmcnt(0): the load
+    // is unconditional (row clamped to the last one; a conditional load goes through temporaries and a copy behind s_waitcnt
+    // vmcnt(0) at the join) and no store of a step sits behind an exec-mask branch (ALLV below).  One step ahead is not enough
+    // for the light kernels: a read issued into write-saturated HBM takes longer than their 1.5-us wave-step.
+    const uint32_t tape_b = NA > 0 ? (act_i32 ? 4u : 8u) : 4u;
+    const char *const p_tape = reinterpret_cast<const char *>(a.actions);
+    struct TapeRegs {
+        int64_t i[E];
+        float f[E];
+    } tape_even, tape_odd;  // the tape rows of the next even / odd step
+    auto load_tape = [&](int step, TapeRegs &r) {
+        const char *base = p_tape + (int64_t)min(step, a.K - 1) * a.act_slice * (int64_t)tape_b;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const char *q = base + le[j] * tape_b;
+            if constexpr (NA > 0)
+                r.i[j] = act_i32 ? (int64_t) * reinterpret_cast<const int32_t *>(q) : *reinterpret_cast<const int64_t *>(q);
+            else
+                r.f[j] = *reinterpret_cast<const float *>(q);
+        }
+    };
+    bool bad[E];  // TAPE: the tape held an action outside [0, NA) for this env: error latched, state never written back
+#pragma unroll
+    for (int j = 0; j < E; ++j) bad[j] = false;
+    if constexpr (TAPE) {
+        load_tape(0, tape_even);
+        load_tape(1, tape_odd);
+    }
 
     // ---- reset entries: need[j] = this lane's slot j holds no entry (an i1 per lane: lives in an SGPR pair) ----
     bool need[E];
@@ -474,7 +508,11 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 #endif
 
     settle_entry_loads();
-    for (int step = 0; step < a.K; ++step) {
+    // The loop exists twice in a tape-driven kernel: ALLV = every env slot of the wave is a real env (all tiles but possibly the
+    // last), so no store sits behind an exec-mask branch — the compiler can then prove how many stores follow a tape load on
+    // every path and waits for the load with s_waitcnt vmcnt(N > 0) instead of draining the wave's stores.
+    auto one_step = [&](const int step, auto allv_tag, TapeRegs &tape) __attribute__((always_inline)) {
+        constexpr bool ALLV = decltype(allv_tag)::value;
         const uint64_t t = t0 + (uint64_t)step;
 #if MXV_EXP_STATE_IN_LDS
         asm volatile("" ::: "memory");
@@ -487,12 +525,32 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         // ---- this step's actions ----
         int ai[E];
         float af[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], t, ai[j], af[j]);
-        if (FULL || p_act != nullptr) {
+        if constexpr (TAPE) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                if (!valid[j]) continue;
+                if constexpr (NA > 0) {
+                    const int64_t v = tape.i[j];
+                    const bool oob = v < 0 || v >= NA;
+                    if ((ALLV || valid[j]) && oob && !bad[j]) {  // Discrete.contains (cartpole.py:131-132): latch the error; the env's
+                        atomicOr(a.err, 1);                      // state is never written back (its outputs are garbage from here on)
+                        bad[j] = true;
+                    }
+                    ai[j] = oob ? 0 : (int)v;
+                    af[j] = 0.0f;
+                } else {
+                    ai[j] = 0;
+                    af[j] = tape.f[j];
+                }
+            }
+            load_tape(step + 2, tape);
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) action_from_word<ENV, DEF>(P, word[j], t, ai[j], af[j]);
+        }
+        if (TAPE ? (!FULL && p_act != nullptr) : (FULL || p_act != nullptr)) {  // a tape-driven trajectory launch records no actions
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if (!ALLV && !valid[j]) continue;
                 char *q = p_act + lo[j] * act_b;
                 if constexpr (NA > 0) {
                     if (act_i32)
@@ -514,7 +572,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             term[j] = EV::template step<DEF, SAFE>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
-            pend[j] = valid[j] && (term[j] || trunc[j]);
+            pend[j] = (ALLV || valid[j]) && (term[j] || trunc[j]);
         }
         if (ep_on) {  // record_episode_statistics.py:119-143
 #pragma unroll
@@ -530,7 +588,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         // outputs that do not depend on the reset go out first: reward, flags, info["final_observation"]
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            if (!valid[j]) continue;
+            if (!ALLV && !valid[j]) continue;
             if (FULL || p_rew != nullptr) {
                 char *q = p_rew + lo[j] * rew_b;
                 if (rew_f32)
@@ -566,7 +624,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         }
 
         // ---- next step's action words (LDS latency hides behind the observation stores) ----
-        if (step + 1 < a.K) {
+        if (!TAPE && step + 1 < a.K) {
             const uint64_t q0 = (t >> SH) - u0, q1 = ((t + 1) >> SH) - u0;
             if (SH == 0 || q1 != q0) {
                 if (q1 % H == 0) draw_units(q1);
@@ -577,13 +635,13 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         }
 #pragma unroll
         for (int j = 0; j < E; ++j)
-            if (valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), lo[j], obs[j]);
+            if (ALLV || valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), lo[j], obs[j]);
         // ---- the chunk's FINAL tensors once more, into the caller's snapshot (what a sharded vector env all-gathers while the
         //      next chunk runs: written here, no copy kernels between rollout and gather) ----
         if (step + 1 == a.K && a.snap_obs != nullptr) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                if (!valid[j]) continue;
+                if (!ALLV && !valid[j]) continue;
                 store_obs<O>(a.snap_obs, le[j], obs[j]);
                 if (a.snap_reward != nullptr) {
                     if (rew_f32)
@@ -614,17 +672,38 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
         if (FULL || p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
-        if (FULL || p_act != nullptr) p_act += slice * (int64_t)act_b;
+        if (TAPE ? (!FULL && p_act != nullptr) : (FULL || p_act != nullptr)) p_act += slice * (int64_t)act_b;
         if (FULL || p_term != nullptr) p_term += slice;
         if (FULL || p_trunc != nullptr) p_trunc += slice;
         if (!FULL && p_fin != nullptr) p_fin += slice * (int64_t)(O * sizeof(float));
         if (!FULL && p_epr != nullptr) p_epr += slice;
         if (!FULL && p_epl != nullptr) p_epl += slice;
+    };
+    if constexpr (TAPE) {
+        // two steps per iteration, each with its own tape registers: a row requested at the top of step s is consumed at the top
+        // of step s + 2, with two steps' stores provably issued in between
+        auto run_pairs = [&](auto allv_tag) __attribute__((always_inline)) {
+            int step = 0;
+            for (; step + 1 < a.K; step += 2) {
+                one_step(step, allv_tag, tape_even);
+                one_step(step + 1, allv_tag, tape_odd);
+            }
+            if (step < a.K) one_step(step, allv_tag, tape_even);
+        };
+        bool allv = true;
+#pragma unroll
+        for (int j = 0; j < E; ++j) allv = allv && __all(valid[j]);
+        if (allv)
+            run_pairs(std::true_type{});
+        else
+            run_pairs(std::false_type{});
+    } else {
+        for (int step = 0; step < a.K; ++step) one_step(step, std::false_type{}, tape_even);
     }
 
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        if (!valid[j]) continue;
+        if (!valid[j] || bad[j]) continue;
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
         a.elapsed[le[j]] = el[j];
@@ -643,12 +722,12 @@ constexpr int rollout_max_waves() {
     return rollout_min_waves<ENV, DEF, SAFE>() == 1 ? 8 : rollout_min_waves<ENV, DEF, SAFE>();
 }
 
-template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, bool TAPE = false>
 __global__ void __launch_bounds__(kWave)
     __attribute__((amdgpu_waves_per_eu(rollout_min_waves<ENV, DEF, SAFE>(), rollout_max_waves<ENV, DEF, SAFE>())))
     rollout_kernel_v3(const StepArgs a) {
     __shared__ RolloutLds<ENV, E> lds;
-    rollout_body_v3<ENV, DEF, E, SAFE, OUT>(a, blockIdx.x, gridDim.x, lds);
+    rollout_body_v3<ENV, DEF, E, SAFE, OUT, TAPE>(a, blockIdx.x, gridDim.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -823,27 +902,35 @@ __global__ void __launch_bounds__(kBlock) final_pack_kernel(const CompactArgs a)
     }
 }
 
-template <int ENV, bool DEF, int ER, bool SAFE, int OUT>
+template <int ENV, bool DEF, int ER, bool SAFE, int OUT, bool TAPE = false>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
     // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
     // rollout_max_waves) is its LDS footprint: padded with unused dynamic LDS to 9.5 KiB per single-wave workgroup, 16 of
     // them fill the CU's 160 KiB and a 17th does not fit.
     constexpr size_t kLdsPerWorkgroup = 9728, kStatic = sizeof(RolloutLds<ENV, ER>);
     const size_t pad = (rollout_min_waves<ENV, DEF, SAFE>() == 4 && kStatic < kLdsPerWorkgroup) ? kLdsPerWorkgroup - kStatic : 0;
-    hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT>), dim3(grid), dim3(kWave), pad, stream, a);
+    hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT, TAPE>), dim3(grid), dim3(kWave), pad, stream, a);
 }
 template <int ENV, bool DEF, int ER, bool SAFE>
 void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
-    // the trajectory-recording shape (all outputs, no final_obs / statistics) has its own straight-line instantiations
+    // the trajectory-recording shape (all outputs, no final_obs / statistics) has its own straight-line instantiations; a
+    // tape-driven launch of that shape records everything but the actions (the caller holds them)
+    const bool tape = a.actions != nullptr;
     int out = 0;
-    if (DEF && a.reward && a.actions_out && a.terminated && a.truncated && !a.final_obs && !a.ep_acc) {
+    if (DEF && a.reward && (tape ? !a.actions_out : a.actions_out != nullptr) && a.terminated && a.truncated && !a.final_obs && !a.ep_acc) {
         const int f = a.flags & (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32);
         out = f == 0 ? 1 : (f == (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32) ? 2 : 0);
     }
     if constexpr (DEF) {
-        if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a);
-        if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a);
+        if (tape) {
+            if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, true>(grid, stream, a);
+            if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, true>(grid, stream, a);
+        } else {
+            if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a);
+            if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a);
+        }
     }
+    if (tape) return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a);
     launch_rollout_out<ENV, DEF, ER, SAFE, 0>(grid, stream, a);
 }
 
@@ -918,10 +1005,11 @@ hipError_t launch_sample_env(int pm, const SampleArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-// Sampled actions + autoreset, several steps per launch: the fused fast path (rollout_kernel_v3).  Everything else — caller
-// actions, single steps, per-env parameters, torque noise, no autoreset — runs step_kernel.
+// Sampled actions or an action tape + autoreset, several steps per launch: the fused fast path (rollout_kernel_v3).  Everything
+// else — single steps with caller actions, per-env parameters, torque noise, no autoreset — runs step_kernel.
 bool launch_step_is_rollout(int pm, const StepArgs &a) {
-    return a.actions == nullptr && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise;
+    const bool sampled_or_tape = a.actions == nullptr || a.act_slice != 0;
+    return sampled_or_tape && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise;
 }
 
 hipError_t launch_step(int env_id, int default_params, const StepArgs &a, hipStream_t stream) {

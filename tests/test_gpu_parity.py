@@ -529,3 +529,89 @@ def test_spread_layout_buffers_give_identical_trajectories():
     traj, report = r.tuned_trajectory_buffers(16, candidates=8, launches=2)
     assert report["kinds"] == ["separate"] * 6 + ["spread"] * 2 and len(report["us_per_step"]) == 8
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_tape_driven_rollout_equals_stepping_with_the_same_actions(name, compact):
+    """mxv_rollout_tape runs rollout_kernel_v3 with the action words replaced by a caller's [K][N] tape, read two steps ahead
+    (loop unrolled by two, a second loop instantiation for waves whose env slots are all real).  Against one step_kernel launch
+    per step fed the same rows: every output of every step, final observations, then state / elapsed steps / reset ordinals,
+    bit for bit — over launches with even, odd and one-step-pair K, a tiny TimeLimit (ready-made reset entries run out), n not a
+    multiple of the tile (the last wave takes the other loop), and both dtype sets."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    n, limit = 5000 + 77, 6
+    kw = dict(seed=41, action_seed=42, env_offset=1 << 21, max_episode_steps=limit, reward_f32=compact, action_i32=compact)
+    src = DeviceRollout(GYM_IDS[name], n, **kw)     # only produces action rows (its own Philox stream)
+    a = DeviceRollout(GYM_IDS[name], n, **kw)
+    b = DeviceRollout(GYM_IDS[name], n, **kw)
+    for r in (src, a, b):
+        r.reset(seed=41)
+    ndone = 0
+    for K in (2, 9, 64, 33):
+        rows = src.rollout_per_step(K, mode="fused")["actions"]
+        src.synchronize()                      # the rows are written on src's stream; clone() runs on torch's current one
+        tape = rows.clone()
+        out = a.rollout_tape(tape, out=a.trajectory_buffers(K, want_final=True))
+        a.synchronize()
+        for k in range(K):
+            o, r, te, tr = b.step(tape[k], want_final=True)
+            b.synchronize()
+            assert torch.equal(out["obs"][k], o) and torch.equal(out["reward"][k], r), (name, K, k)
+            assert torch.equal(out["terminated"][k], te) and torch.equal(out["truncated"][k], tr), (name, K, k)
+            done = (te | tr).bool()
+            assert torch.equal(out["final_obs"][k][done], b.final_obs[done]), (name, K, k)
+            ndone += int(done.sum())
+        for x, y in zip(a.handle.get_state(), b.handle.get_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.handle.get_episodes(), b.handle.get_episodes())
+        assert a.handle.get_counters() == b.handle.get_counters()
+    assert ndone >= 10 * n
+    # the trajectory shape without final observations (the straight-line instantiation) gives the same numbers
+    rows = src.rollout_per_step(16, mode="fused")["actions"]
+    src.synchronize()
+    tape = rows.clone()
+    st = a.handle.snapshot()
+    full = a.rollout_tape(tape, out=a.trajectory_buffers(16, want_final=True))
+    a.synchronize()
+    b.handle.restore(st)
+    plain = b.rollout_tape(tape)
+    b.synchronize()
+    for key in ("obs", "reward", "terminated", "truncated"):
+        assert torch.equal(full[key], plain[key]), key
+    for r in (src, a, b):
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["CartPole", "Acrobot", "MountainCar"])
+def test_tape_with_an_out_of_range_action_latches_the_error_and_leaves_that_env_alone(name):
+    """Discrete.contains (cartpole.py:131-132) inside a tape: the launch latches the error (raised at the next synchronisation,
+    as for a single step), the offending env's state is not written back, every other env is stepped as if nothing happened."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    n, K, victim = 1000, 12, 333
+    a = DeviceRollout(GYM_IDS[name], n, seed=51, action_seed=52)
+    b = DeviceRollout(GYM_IDS[name], n, seed=51, action_seed=52)
+    a.reset(seed=51), b.reset(seed=51)
+    rows = b.rollout_per_step(K, mode="fused")["actions"]
+    b.synchronize()
+    tape = rows.clone()
+    st0, el0 = a.handle.get_state()
+    bad = tape.clone()
+    bad[5, victim] = 7
+    out = a.rollout_tape(bad)
+    with pytest.raises(AssertionError):
+        a.synchronize()
+    st1, el1 = a.handle.get_state()
+    stb, elb = b.handle.get_state()
+    keep = np.arange(n) != victim
+    assert np.array_equal(st1[:, keep], stb[:, keep]) and np.array_equal(el1[keep], elb[keep])
+    assert np.array_equal(st1[:, victim], st0[:, victim]) and el1[victim] == el0[victim]
+    a.close(), b.close()

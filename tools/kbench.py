@@ -45,6 +45,15 @@ def main():
                 def go(k):
                     for _ in range(k):
                         r.step(acts, want_final=False)
+            elif base == "tape":     # K steps per launch, actions read from a caller-provided [K][N] tape
+                seed_run = r.rollout_per_step(K, mode="fused")
+                r.synchronize()
+                tape = seed_run["actions"].clone()
+                tout = {k: seed_run[k] for k in ("obs", "reward", "terminated", "truncated")}
+
+                def go(k):
+                    for _ in range(k // K):
+                        r.rollout_tape(tape, out=tout)
             elif base.endswith("-final"):  # outputs of every step overwrite one buffer ("final tensors" mode)
                 def go(k, m=base[:-6]):
                     for _ in range(k // K):
