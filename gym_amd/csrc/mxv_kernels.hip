@@ -697,6 +697,15 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             run_pairs(std::true_type{});
         else
             run_pairs(std::false_type{});
+    } else if constexpr (FULL && MXV_EXP_ALLV_FUSED) {   // measurement: the branch-free stores for the sampled trajectory kernels too
+        bool allv = true;
+#pragma unroll
+        for (int j = 0; j < E; ++j) allv = allv && __all(valid[j]);
+        if (allv) {
+            for (int step = 0; step < a.K; ++step) one_step(step, std::true_type{}, tape_even);
+        } else {
+            for (int step = 0; step < a.K; ++step) one_step(step, std::false_type{}, tape_even);
+        }
     } else {
         for (int step = 0; step < a.K; ++step) one_step(step, std::false_type{}, tape_even);
     }

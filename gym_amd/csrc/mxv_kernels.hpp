@@ -145,6 +145,9 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #define MXV_EXP_STATE_IN_LDS 0
 #endif
 // measurement hook: s_sleep of this many 64-clock units at the end of every step of the fused rollout (0 = none)
+#ifndef MXV_EXP_ALLV_FUSED
+#define MXV_EXP_ALLV_FUSED 0
+#endif
 #ifndef MXV_EXP_SLEEP
 #define MXV_EXP_SLEEP 0
 #endif
