@@ -931,15 +931,13 @@ void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
         out = f == 0 ? 1 : (f == (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32) ? 2 : 0);
     }
     if constexpr (DEF) {
-        if (tape) {
+        if (tape) {  // (tapes exist for default parameters only, launch_step_is_rollout; the compact dtypes take the generic body)
             if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, true>(grid, stream, a);
-            if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, true>(grid, stream, a);
-        } else {
-            if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a);
-            if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a);
+            return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a);
         }
+        if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a);
+        if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a);
     }
-    if (tape) return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a);
     launch_rollout_out<ENV, DEF, ER, SAFE, 0>(grid, stream, a);
 }
 
@@ -1014,10 +1012,11 @@ hipError_t launch_sample_env(int pm, const SampleArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-// Sampled actions or an action tape + autoreset, several steps per launch: the fused fast path (rollout_kernel_v3).  Everything
-// else — single steps with caller actions, per-env parameters, torque noise, no autoreset — runs step_kernel.
+// Sampled actions, or an action tape with the default physics parameters, + autoreset, several steps per launch: the fused fast
+// path (rollout_kernel_v3).  Everything else — single steps with caller actions, tapes with changed parameters, per-env
+// parameters, torque noise, no autoreset — runs step_kernel.
 bool launch_step_is_rollout(int pm, const StepArgs &a) {
-    const bool sampled_or_tape = a.actions == nullptr || a.act_slice != 0;
+    const bool sampled_or_tape = a.actions == nullptr || (a.act_slice != 0 && pm == PM_DEFAULT);
     return sampled_or_tape && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise;
 }
 
