@@ -39,7 +39,7 @@ EXPORTS = (
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_write_probe", "mxv_host_alloc", "mxv_host_free",
-                "mxv_host_block_layout", "mxv_step_host_block",
+                "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -135,6 +135,7 @@ def _load():
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
         "mxv_write_probe": ([C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
+        "mxv_wait_stream": ([vp, vp], C.c_int),
         "mxv_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),
         "mxv_host_free": ([vp], C.c_int),
         "mxv_host_block_layout": ([vp] + [C.POINTER(C.c_size_t)] * 6, C.c_int),
@@ -650,6 +651,10 @@ class Handle:
 
     def sync(self):
         self._check(lib.mxv_sync(self._h))
+
+    def wait_stream(self, stream_ptr: int):
+        """mxv_wait_stream: the handle's stream waits (on the GPU) for everything queued on hipStream_t `stream_ptr` so far."""
+        self._check(lib.mxv_wait_stream(self._h, C.c_void_p(stream_ptr)))
 
     @property
     def stream(self) -> int:

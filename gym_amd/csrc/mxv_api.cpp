@@ -127,6 +127,7 @@ struct mxv_handle {
     float *snap_obs = nullptr;
     void *snap_reward = nullptr;
     uint8_t *snap_term = nullptr, *snap_trunc = nullptr;
+    hipEvent_t ev_wait = nullptr;   // mxv_wait_stream
     hipEvent_t ev_mixed = nullptr;  // orders this handle's stream against a mixed-batch launch issued on another handle's stream
     std::string error;
 
@@ -481,6 +482,7 @@ int mxv_destroy(mxv_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)mxv_comm_destroy(h);
     if (h->ev_mixed) (void)hipEventDestroy(h->ev_mixed);
+    if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
     free_graphs(h);
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     if (h->fin_host) (void)hipHostFree(h->fin_host);
@@ -1175,6 +1177,16 @@ int mxv_get_stream(mxv_handle *h, void **stream) {
     MXV_CHECK_HANDLE(h);
     if (!stream) return fail(h, MXV_ERR_INVALID_ARG, "stream pointer is NULL");
     *stream = (void *)h->stream;
+    return MXV_OK;
+}
+
+int mxv_wait_stream(mxv_handle *h, void *other_stream) {
+    MXV_CHECK_HANDLE(h);
+    if ((hipStream_t)other_stream == h->stream) return MXV_OK;
+    if (int rc = use_device(h)) return rc;
+    if (!h->ev_wait) MXV_HIP(h, hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming));
+    MXV_HIP(h, hipEventRecord(h->ev_wait, (hipStream_t)other_stream));
+    MXV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_wait, 0));
     return MXV_OK;
 }
 

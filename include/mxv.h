@@ -465,6 +465,10 @@ int mxv_sync(mxv_handle *h);
 /* The hipStream_t the handle launches on (created non-blocking by mxv_create) / adopt an external one. */
 int mxv_get_stream(mxv_handle *h, void **stream);
 int mxv_set_stream(mxv_handle *h, void *stream);
+/* GPU-side ordering, no host wait: everything queued on `other_stream` (a hipStream_t; NULL = the default stream) so far
+ * completes before anything the handle launches from now on — what a learner whose policy produced the actions on its own
+ * stream calls before mxv_step (one event record + one stream wait; a no-op if it IS the handle's stream). */
+int mxv_wait_stream(mxv_handle *h, void *other_stream);
 
 #ifdef __cplusplus
 }

@@ -162,3 +162,41 @@ def test_write_probe_reports_a_plausible_store_rate():
     assert float(rew.min()) == 1.0 and float(rew.max()) == 1.0 and int(tr.max()) == 0 and int(act.max()) == 1
     with pytest.raises(_native.MxvError):
         _native.write_probe(0, 1000, K, 1, obs, rew, act, te, tr)
+
+
+@pytest.mark.gpu
+def test_step_orders_itself_after_the_callers_stream():
+    """DeviceRollout.step(actions): the policy wrote `actions` on the caller's CURRENT torch stream; the engine launches on its
+    own stream and must wait for that work on the GPU (mxv_wait_stream, include/mxv.h) without a host synchronisation.  The
+    tensor holds an out-of-range action until a delayed copy on a side stream replaces it: a step that did not wait would read
+    the 7 and latch Discrete.contains' error."""
+    import torch
+
+    from gym_amd.rollout import DeviceRollout
+
+    n = 1 << 16
+    r = DeviceRollout("CartPole-v1", n, seed=1, action_seed=2)
+    g = DeviceRollout("CartPole-v1", n, seed=1, action_seed=2)
+    r.reset(seed=1), g.reset(seed=1)
+    good = g.sample_actions().clone()
+    g.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(5):
+        acts = torch.full((n,), 7, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(20_000_000)        # ~10 ms of GPU time before the real actions land
+            acts.copy_(good)
+            o, rew, te, tr = r.step(acts, want_final=False)
+        r.synchronize()                          # raises AssertionError if the kernel saw a 7
+        o2, rew2, te2, tr2 = g.step(good, want_final=False)
+        g.synchronize()
+        assert torch.equal(o, o2) and torch.equal(te, te2)
+    # and the other direction: ready() makes the caller's stream wait for the engine's outputs
+    with torch.cuda.stream(side):
+        o, rew, te, tr = r.step(good)
+        r.ready()
+        total = float(rew.sum())
+    side.synchronize()
+    assert total == float(n)
+    r.close(), g.close()
