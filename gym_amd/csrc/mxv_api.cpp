@@ -111,6 +111,7 @@ struct mxv_handle {
     // large envs: info["final_observation"] travels as packed (index, row) pairs of the finished envs only (compact_final_kernel)
     char *fin_dev = nullptr;    // device: count (256 B) | idx int32[N] | rows float[N][O]
     char *fin_host = nullptr;   // pinned mirror
+    bool err_in_block = false;  // host steps of a small env: the kernel raises the error word in the pinned I/O block itself
     size_t fin_last = 0;        // finished envs of the previous host step (sizes the speculative DMA)
     bool fin_packed = false;    // mxv_final_packed: host step calls leave the rows packed (no scatter into a dense array)
     // hipGraph cache of mxv_rollout: key = (K, per_step, output pointers)
@@ -180,13 +181,29 @@ int check_latched(mxv_handle *h) {
     return MXV_OK;
 }
 
+// Host steps of a small env (the kernel reads and writes the pinned I/O block over PCIe): the error word lives in that block too,
+// so the call is one launch and one synchronisation — no 4-byte copy to fetch a device-side latch (a quarter of the 17 us).
+struct ErrInBlock {
+    mxv_handle *h;
+    explicit ErrInBlock(mxv_handle *hh) : h(hh) { h->err_in_block = h->hostmap; }
+    ~ErrInBlock() { h->err_in_block = false; }
+};
+
+int take_block_error(mxv_handle *h) {  // after the stream drained
+    const int32_t e = *h->hm_err;
+    if (e == 0) return MXV_OK;
+    *h->hm_err = 0;
+    if (e & 1) return fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA);
+    return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
+}
+
 void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.state = h->state;
     a.elapsed = h->elapsed;
     a.episodes = h->episodes;
     a.seeds = h->seeds;
     a.t_dev = nullptr;
-    a.err = h->err;
+    a.err = h->err_in_block ? h->hm_err : h->err;
     a.n = h->cfg.num_envs;
     a.env0 = (uint64_t)h->cfg.env_offset;
     a.base_seed = h->base_seed;
@@ -742,28 +759,23 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
         mxv_handle *h; float *r; int32_t *l;
         ~Restore() { h->ep_return_out = r; h->ep_length_out = l; }
     } restore{h, keep_r, keep_l};
-    if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, reward_host ? h->st_reward : nullptr,
-                         terminated_host ? h->st_term : nullptr, truncated_host ? h->st_trunc : nullptr,
-                         (final_obs_host || h->fin_packed) ? h->st_final : nullptr))
-        return rc;
-    if (h->hostmap) {  // outputs are already in host memory once the stream drains; one 4-byte copy fetches the error latch
-        MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    {
+        ErrInBlock guard(h);
+        if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, reward_host ? h->st_reward : nullptr,
+                             terminated_host ? h->st_term : nullptr, truncated_host ? h->st_trunc : nullptr,
+                             (final_obs_host || h->fin_packed) ? h->st_final : nullptr))
+            return rc;
+    }
+    if (h->hostmap) {  // outputs and the error word are already in host memory once the stream drains
         MXV_HIP(h, hipStreamSynchronize(h->stream));
         std::memcpy(obs_host, h->st_obs, n * h->O * sizeof(float));
         if (reward_host) std::memcpy(reward_host, h->st_reward, n * h->reward_bytes());
         if (terminated_host) std::memcpy(terminated_host, h->st_term, n);
         if (truncated_host) std::memcpy(truncated_host, h->st_trunc, n);
         if (final_obs_host) std::memcpy(final_obs_host, h->st_final, n * h->O * sizeof(float));
-        if (*h->hm_err != 0) {
-            const int32_t e = *h->hm_err;
-            *h->hm_err = 0;
-            MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
-            h->t -= 1;  // the reference raises before stepping anything further
-            if (e & 1)
-                return fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA);
-            return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
-        }
-        return MXV_OK;
+        const int rc = take_block_error(h);
+        if (rc != MXV_OK) h->t -= 1;  // the reference raises before stepping anything further
+        return rc;
     }
     // the packed final rows go first: their DMAs target pinned memory and are truly asynchronous, the copies into the caller's
     // (pageable) arrays below are not
@@ -829,8 +841,11 @@ int mxv_step_host_block(mxv_handle *h, const void *actions_host, void *block_hos
         mxv_handle *h; float *r; int32_t *l;
         ~Restore() { h->ep_return_out = r; h->ep_length_out = l; }
     } restore{h, keep_r, keep_l};
-    if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, h->st_reward, h->st_term, h->st_trunc, want_final ? h->st_final : nullptr))
-        return rc;
+    {
+        ErrInBlock guard(h);
+        if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, h->st_reward, h->st_term, h->st_trunc, want_final ? h->st_final : nullptr))
+            return rc;
+    }
     const bool packed = want_final && h->fin_packed && !h->hostmap;
     const bool dense_final = want_final && !packed;
     const char *src = (const char *)(dense_final ? (void *)h->st_final : (void *)h->st_obs);
@@ -838,17 +853,9 @@ int mxv_step_host_block(mxv_handle *h, const void *actions_host, void *block_hos
     size_t first = 0;
     int rc;
     if (h->hostmap) {
-        MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         MXV_HIP(h, hipStreamSynchronize(h->stream));
         std::memcpy((char *)block_host + off, src, len);
-        rc = MXV_OK;
-        if (*h->hm_err != 0) {
-            const int32_t e = *h->hm_err;
-            *h->hm_err = 0;
-            MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
-            rc = (e & 1) ? fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA)
-                         : fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
-        }
+        rc = take_block_error(h);
     } else {
         if (packed)
             if (int rc2 = queue_final_rows(h, &first)) return rc2;
@@ -889,17 +896,16 @@ int mapped_finish(mxv_handle *h, bool stepped) {
             if (int rc = fetch_final_rows(h, h->fin_packed ? nullptr : fin_pinned)) return rc;
         }
     }
-    MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    MXV_HIP(h, hipStreamSynchronize(h->stream));
-    if (*h->hm_err != 0) {
-        const int32_t e = *h->hm_err;
-        *h->hm_err = 0;
-        MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
-        if (stepped) h->t -= 1;  // the reference raises before stepping anything further
-        if (e & 1) return fail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains assert)", h->NA);
-        return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
+    if (!h->hostmap) {  // (a small env's kernel raised the word in the pinned block itself: see ErrInBlock)
+        MXV_HIP(h, hipMemcpyAsync(h->hm_err, h->err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+        if (*h->hm_err != 0) MXV_HIP(h, hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+    } else {
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
     }
-    return MXV_OK;
+    const int rc = take_block_error(h);
+    if (rc != MXV_OK && stepped) h->t -= 1;  // the reference raises before stepping anything further
+    return rc;
 }
 
 }  // namespace
@@ -922,7 +928,10 @@ int mxv_step_mapped(mxv_handle *h) {
         mxv_handle *h; float *r; int32_t *l;
         ~Restore() { h->ep_return_out = r; h->ep_length_out = l; }
     } restore{h, keep_r, keep_l};
-    if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, h->st_reward, h->st_term, h->st_trunc, h->st_final)) return rc;
+    {
+        ErrInBlock guard(h);
+        if (int rc = do_step(h, h->st_actions, nullptr, h->st_obs, h->st_reward, h->st_term, h->st_trunc, h->st_final)) return rc;
+    }
     return mapped_finish(h, true);
 }
 

@@ -21,6 +21,10 @@ namespace mxv {
 
 namespace {
 
+// The error word only ever receives single-bit codes, so a plain store does what an atomic OR would — and it also works when the
+// word lives in pinned host memory (host steps of small envs, mxv_api.cpp: ErrInBlock), where a PCIe atomic might not.
+__device__ __forceinline__ void raise_error(int32_t *err, int32_t bit) { *reinterpret_cast<volatile int32_t *>(err) = bit; }
+
 template <int O>
 __device__ __forceinline__ void store_obs(float *base, int64_t e, const float *o) {
     if constexpr (O == 4) {
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                                           : static_cast<const int64_t *>(a.actions)[ec];
                     // Discrete.contains (cartpole.py:131-132): out of range -> latch, leave the env untouched
                     if (valid[j] && (v < 0 || v >= NA)) {
-                        atomicOr(a.err, 1);
+                        raise_error(a.err, 1);
                         valid[j] = false;
                     }
                     ai[j] = (int)v;
@@ -532,7 +536,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
                     const int64_t v = tape.i[j];
                     const bool oob = v < 0 || v >= NA;
                     if ((ALLV || valid[j]) && oob && !bad[j]) {  // Discrete.contains (cartpole.py:131-132): latch the error; the env's
-                        atomicOr(a.err, 1);                      // state is never written back (its outputs are garbage from here on)
+                        raise_error(a.err, 1);                      // state is never written back (its outputs are garbage from here on)
                         bad[j] = true;
                     }
                     ai[j] = oob ? 0 : (int)v;
