@@ -445,6 +445,10 @@ int mxv_create(const mxv_config *cfg, mxv_handle **out) {
     if (cfg->env_id < 0 || cfg->env_id >= MXV_NUM_ENV_KINDS)
         return fail(nullptr, MXV_ERR_INVALID_ARG, "unknown env_id %d", cfg->env_id);
     if (cfg->num_envs <= 0) return fail(nullptr, MXV_ERR_INVALID_ARG, "num_envs must be positive (got %lld)", (long long)cfg->num_envs);
+    // the fused kernels address one step's slice of every output array with 32-bit byte offsets (16 B per env at most)
+    if (cfg->num_envs > MXV_MAX_NUM_ENVS)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "num_envs %lld exceeds the per-handle maximum of %lld: shard the vector env (env_offset)",
+                    (long long)cfg->num_envs, (long long)MXV_MAX_NUM_ENVS);
     if (cfg->env_offset < 0 || cfg->env_offset % MXV_ENV_ALIGN != 0)
         return fail(nullptr, MXV_ERR_INVALID_ARG, "env_offset must be a non-negative multiple of %d", MXV_ENV_ALIGN);
     int ndev = 0;

@@ -78,6 +78,7 @@ enum {
 
 #define MXV_MAX_PARAMS 12
 #define MXV_ENV_ALIGN 4 /* env_offset must be a multiple of this (Philox action groups of 4 envs) */
+#define MXV_MAX_NUM_ENVS (1LL << 28) /* envs per handle (268 M); larger vector envs are shards: one handle per env_offset range */
 
 /*
  * Physics parameter vector P[MXV_MAX_PARAMS] (fp64) = the attributes the reference's env objects hold

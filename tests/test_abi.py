@@ -66,7 +66,8 @@ def test_no_device_fails_loudly_no_cpu_fallback():
 def test_bad_config_rejected_before_touching_a_device():
     from gym_amd import _native
 
-    for kw in (dict(env_id=7, num_envs=8), dict(env_id=0, num_envs=0), dict(env_id=0, num_envs=8, env_offset=3)):
+    for kw in (dict(env_id=7, num_envs=8), dict(env_id=0, num_envs=0), dict(env_id=0, num_envs=8, env_offset=3),
+               dict(env_id=0, num_envs=(1 << 28) + 4)):      # MXV_MAX_NUM_ENVS: the fused kernels' 32-bit slice offsets
         with pytest.raises(_native.MxvError) as ei:
             _native.Handle(kw["env_id"], kw["num_envs"], 500, env_offset=kw.get("env_offset", 0))
         assert ei.value.code == _native.ERR_INVALID_ARG
