@@ -200,3 +200,65 @@ def test_step_orders_itself_after_the_callers_stream():
     side.synchronize()
     assert total == float(n)
     r.close(), g.close()
+
+
+@pytest.mark.gpu
+def test_largest_vector_env_a_handle_accepts():
+    """MXV_MAX_NUM_ENVS = 2^28 envs in one handle (29 GB of state + two steps of trajectories on a 288-GB MI355X): the fused
+    kernel's 32-bit per-slice byte offsets at their largest.  The last 4096 envs must equal a 4096-env shard created at
+    env_offset 2^28 - 4096 (shard invariance), bit for bit, and one env more is refused."""
+    import torch
+
+    from gym_amd import _native
+    from gym_amd.rollout import DeviceRollout
+
+    n, tail, K = 1 << 28, 4096, 3
+    if torch.cuda.mem_get_info(0)[0] < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free HBM")
+    with pytest.raises(_native.MxvError):
+        _native.Handle(_native.CARTPOLE, n + 4, 500)
+    big = DeviceRollout("CartPole-v1", n, seed=5, action_seed=6, max_episode_steps=2)
+    small = DeviceRollout("CartPole-v1", tail, seed=5, action_seed=6, max_episode_steps=2, env_offset=n - tail)
+    big.reset(seed=5), small.reset(seed=5)
+    a = big.rollout_per_step(K, mode="fused")
+    b = small.rollout_per_step(K, mode="fused")
+    big.synchronize(), small.synchronize()
+    for key in ("obs", "reward", "terminated", "truncated", "actions"):
+        assert torch.equal(a[key][:, n - tail:], b[key]), key
+    assert int(a["truncated"][1].sum()) == n          # TimeLimit 2: every env is truncated at its second step
+    # the tape path and a single step at the same size
+    tape = a["actions"]
+    st = big.handle.get_episodes()
+    assert int(st.min()) >= 1
+    out = big.rollout_tape(tape[:2].contiguous())
+    o, r, te, tr = small.step(tape[0, n - tail:].contiguous(), want_final=False)
+    big.synchronize(), small.synchronize()
+    assert torch.equal(out["obs"][0, n - tail:], o) and torch.equal(out["terminated"][0, n - tail:], te)
+    del a, b, out, tape
+    big.close(), small.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous"])
+def test_ragged_sizes_from_one_env_up(name):
+    """Vector envs of 1, 2, 3, 5, 63, 64, 65, 127, 129 and 257 envs (partial waves, partial tiles, a tile boundary inside): the fused
+    rollout equals one launch per step bit for bit and follows the oracle twin."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    for n in (1, 2, 3, 5, 63, 64, 65, 127, 129, 257):
+        a = DeviceRollout(GYM_IDS[name], n, seed=61, action_seed=62, max_episode_steps=7)
+        b = DeviceRollout(GYM_IDS[name], n, seed=61, action_seed=62, max_episode_steps=7)
+        a.reset(seed=61), b.reset(seed=61)
+        fa = a.rollout_per_step(23, mode="fused", out=a.trajectory_buffers(23, want_final=True))
+        fb = b.rollout_per_step(23, mode="eager", out=b.trajectory_buffers(23, want_final=True))
+        a.synchronize(), b.synchronize()
+        for key in ("obs", "reward", "terminated", "truncated", "actions"):
+            assert torch.equal(fa[key], fb[key]), (name, n, key)
+        done = (fa["terminated"] | fa["truncated"]).bool()
+        assert torch.equal(fa["final_obs"][done], fb["final_obs"][done]), (name, n)
+        assert int(done.sum()) >= 3 * n
+        a.close(), b.close()
+        assert _rollout_compare(name, n=n, steps=16, seed=63, limit=5) >= 3 * n
