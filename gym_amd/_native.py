@@ -102,12 +102,39 @@ class MxvError(RuntimeError):
         self.message = message
 
 
+def _share_torch_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under torch/lib and
+    name them WITHOUT version suffix in their NEEDED entries, so they do not match a system runtime that is already loaded:
+    `import gym_amd; env = gym_amd.make(...); import torch` would put two runtimes into the process and
+    torch.cuda.is_available() turns False (seen on the MI355X box: NormalizeObservation created after a NumPy-only loop).
+    The other order works — libmxv's NEEDED libamdhip64.so.7 matches the soname of torch's copy once that is loaded — so,
+    when torch is installed (not imported: only located), its bundled runtime is loaded first and libmxv binds to it.
+    MXV_SYSTEM_HIP=1 keeps the system runtime (then do not use torch.cuda in the same process)."""
+    if os.environ.get("MXV_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if not os.path.exists(path):
+                return
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass   # a torch without a usable bundled runtime: fall through to the system one
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or gym_amd/csrc/build.sh). gym_amd has no CPU fallback."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
     sig = {

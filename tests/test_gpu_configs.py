@@ -262,3 +262,17 @@ def test_ragged_sizes_from_one_env_up(name):
         assert int(done.sum()) >= 3 * n
         a.close(), b.close()
         assert _rollout_compare(name, n=n, steps=16, seed=63, limit=5) >= 3 * n
+
+
+@pytest.mark.gpu
+def test_gym_amd_first_torch_second_share_one_hip_runtime():
+    """A fresh interpreter that creates and steps a NumPy vector env BEFORE importing torch: torch.cuda must still see the GPU
+    afterwards and the torch-backed wrappers must work (gym_amd/_native.py: _share_torch_hip_runtime; with the system runtime
+    loaded first, PyTorch-ROCm brings its bundled second runtime into the process and loses the device)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "import_order.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok: gym_amd first" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
