@@ -38,7 +38,7 @@ EXPORTS = (
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
-    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_write_probe", "mxv_host_alloc", "mxv_host_free",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_host_alloc", "mxv_host_free",
                 "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -168,6 +168,7 @@ def _load():
         "mxv_host_block_layout": ([vp] + [C.POINTER(C.c_size_t)] * 6, C.c_int),
         "mxv_step_host_block": ([vp, vp, vp, C.c_int32], C.c_int),
         "mxv_final_packed": ([vp, C.c_int32, C.POINTER(C.c_int32)], C.c_int),
+        "mxv_final_packed_stats_view": ([vp, C.POINTER(vp), C.POINTER(vp)], C.c_int),
         "mxv_final_packed_view": ([vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),
         "mxv_comm_unique_id": ([vp], C.c_int),
         "mxv_comm_init": ([vp, C.c_int32, C.c_int32, vp], C.c_int),
@@ -560,6 +561,20 @@ class Handle:
         cnt, idx, rows = self._packed_views
         c = int(cnt[0])
         return idx[:c].copy(), rows[:c].copy()
+
+    def final_packed_stats(self):
+        """(indices, episode returns float32, episode lengths int32) of the envs that finished the LAST host step — copies.
+        Needs episode statistics on and packed final rows (large envs)."""
+        if getattr(self, "_packed_stats_views", None) is None:
+            pr, pl = C.c_void_p(), C.c_void_p()
+            self._check(lib.mxv_final_packed_stats_view(self._h, C.byref(pr), C.byref(pl)))
+            n = self.num_envs
+            self._packed_stats_views = (np.frombuffer((C.c_char * (4 * n)).from_address(pr.value), dtype=np.float32, count=n),
+                                        np.frombuffer((C.c_char * (4 * n)).from_address(pl.value), dtype=np.int32, count=n))
+        cnt, idx, _ = self._packed_views
+        c = int(cnt[0])
+        r, l = self._packed_stats_views
+        return idx[:c].copy(), r[:c].copy(), l[:c].copy()
 
     def reset_mapped(self, bounds=None):
         b, bp = self._bounds(bounds)

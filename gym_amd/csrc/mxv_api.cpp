@@ -292,6 +292,21 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     return MXV_OK;
 }
 
+// Packed record of the envs that finished a host step (device buffer and its pinned mirror share the offsets):
+//   count (256 B) | idx int32[N] | rows float[N][O] | ep_return float[N] | ep_length int32[N]      (+ device only: chunk counts)
+struct FinLayout {
+    size_t idx, rows, ep_r, ep_l, host_bytes, chunks, dev_bytes;
+    FinLayout(size_t n, size_t O) {
+        idx = 256;
+        rows = idx + n * sizeof(int32_t);
+        ep_r = rows + n * O * sizeof(float);
+        ep_l = ep_r + n * sizeof(float);
+        host_bytes = ep_l + n * sizeof(int32_t);
+        chunks = host_bytes;
+        dev_bytes = chunks + (size_t)compact_chunks((int64_t)n) * sizeof(int32_t);
+    }
+};
+
 // Up to this size the step kernels address the pinned block directly; above it they use device staging.
 constexpr size_t kHostMapLimit = 2 * 1024 * 1024;
 
@@ -324,9 +339,9 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
             h->hm_err = (int32_t *)p;
             *h->hm_err = 0;
         } else {
-            const size_t fin_bytes = 256 + n * sizeof(int32_t) + n * h->O * sizeof(float);
-            MXV_HIP(h, hipMalloc((void **)&h->fin_dev, fin_bytes + (size_t)compact_chunks((int64_t)n) * sizeof(int32_t)));  // + chunk counts
-            MXV_HIP(h, hipHostMalloc((void **)&h->fin_host, fin_bytes, hipHostMallocDefault));
+            const FinLayout L(n, (size_t)h->O);
+            MXV_HIP(h, hipMalloc((void **)&h->fin_dev, L.dev_bytes));
+            MXV_HIP(h, hipHostMalloc((void **)&h->fin_host, L.host_bytes, hipHostMallocDefault));
         }
     }
     if (want_pinned && !h->hm_block) {  // large env: pinned mirror of the device block for the zero-copy calls
@@ -350,29 +365,35 @@ int upload_actions(mxv_handle *h, const void *actions_host) {
     return MXV_OK;
 }
 
-// Large envs: pack the final_obs rows of the envs that finished this step on the device, bring (count | indices) and the rows
-// over in two small DMAs — speculatively the first eighth of the capacity, the rest only if more envs finished — and scatter
-// them into the caller's dense [N][O] array (rows of other envs untouched, as the dense copy left them).  Synchronises.
+// Large envs: pack the final_obs rows (and, with episode statistics on, the return and length) of the envs that finished this
+// step on the device — ascending env order — and bring count | indices, rows and statistics over in small DMAs sized
+// speculatively from the previous step's count; the rest follows only if more envs finished.
 int queue_final_rows(mxv_handle *h, size_t *first_out) {
     const size_t n = (size_t)h->cfg.num_envs, O = (size_t)h->O;
-    int32_t *d_count = (int32_t *)h->fin_dev, *d_idx = (int32_t *)(h->fin_dev + 256);
-    float *d_rows = (float *)(h->fin_dev + 256 + n * sizeof(int32_t));
-    int32_t *p_count = (int32_t *)h->fin_host;
-    float *p_rows = (float *)(h->fin_host + 256 + n * sizeof(int32_t));
+    const FinLayout L(n, O);
+    const bool stats = h->ep_acc != nullptr;
     CompactArgs c{};
     c.terminated = h->st_term;
     c.truncated = h->st_trunc;
     c.final_obs = h->st_final;
-    c.count = d_count;
-    c.chunk_counts = (int32_t *)(h->fin_dev + 256 + n * sizeof(int32_t) + n * O * sizeof(float));
-    c.idx = d_idx;
-    c.rows = d_rows;
+    c.count = (int32_t *)h->fin_dev;
+    c.chunk_counts = (int32_t *)(h->fin_dev + L.chunks);
+    c.idx = (int32_t *)(h->fin_dev + L.idx);
+    c.rows = (float *)(h->fin_dev + L.rows);
+    c.ep_return_in = stats ? h->st_ep_r : nullptr;
+    c.ep_length_in = stats ? h->st_ep_l : nullptr;
+    c.ep_return = (float *)(h->fin_dev + L.ep_r);
+    c.ep_length = (int32_t *)(h->fin_dev + L.ep_l);
     c.n = (int64_t)n;
     MXV_HIP(h, launch_compact_final(h->O, c, h->stream));
     // speculative size of the first DMA: what finished last step plus a margin (episode ends arrive at a smooth rate)
     const size_t first = std::min(n, std::max<size_t>(1024, h->fin_last + h->fin_last / 4 + 1024));
-    MXV_HIP(h, hipMemcpyAsync(p_count, d_count, 256 + first * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    MXV_HIP(h, hipMemcpyAsync(p_rows, d_rows, first * O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipMemcpyAsync(h->fin_host, h->fin_dev, 256 + first * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipMemcpyAsync(h->fin_host + L.rows, h->fin_dev + L.rows, first * O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (stats) {
+        MXV_HIP(h, hipMemcpyAsync(h->fin_host + L.ep_r, h->fin_dev + L.ep_r, first * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipMemcpyAsync(h->fin_host + L.ep_l, h->fin_dev + L.ep_l, first * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
     *first_out = first;
     return MXV_OK;
 }
@@ -380,16 +401,23 @@ int queue_final_rows(mxv_handle *h, size_t *first_out) {
 // After the stream drained: fetch what the speculative DMA missed, scatter if asked.
 int finish_final_rows(mxv_handle *h, size_t first, float *final_host) {
     const size_t n = (size_t)h->cfg.num_envs, O = (size_t)h->O;
-    int32_t *d_idx = (int32_t *)(h->fin_dev + 256);
-    float *d_rows = (float *)(h->fin_dev + 256 + n * sizeof(int32_t));
-    int32_t *p_count = (int32_t *)h->fin_host, *p_idx = (int32_t *)(h->fin_host + 256);
-    float *p_rows = (float *)(h->fin_host + 256 + n * sizeof(int32_t));
-    const size_t count = (size_t)*p_count;
+    const FinLayout L(n, O);
+    const int32_t *p_idx = (const int32_t *)(h->fin_host + L.idx);
+    const float *p_rows = (const float *)(h->fin_host + L.rows);
+    const size_t count = (size_t) * (const int32_t *)h->fin_host;
     h->fin_last = count;
     if (count > first) {
-        MXV_HIP(h, hipMemcpyAsync(p_idx + first, d_idx + first, (count - first) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        MXV_HIP(h, hipMemcpyAsync(p_rows + first * O, d_rows + first * O, (count - first) * O * sizeof(float), hipMemcpyDeviceToHost,
-                                  h->stream));
+        const size_t more = count - first;
+        auto tail = [&](size_t off, size_t elem) {
+            return hipMemcpyAsync(h->fin_host + off + first * elem, h->fin_dev + off + first * elem, more * elem, hipMemcpyDeviceToHost,
+                                  h->stream);
+        };
+        MXV_HIP(h, tail(L.idx, sizeof(int32_t)));
+        MXV_HIP(h, tail(L.rows, O * sizeof(float)));
+        if (h->ep_acc) {
+            MXV_HIP(h, tail(L.ep_r, sizeof(float)));
+            MXV_HIP(h, tail(L.ep_l, sizeof(int32_t)));
+        }
         MXV_HIP(h, hipStreamSynchronize(h->stream));
     }
     // scattering ~5 % of 2^20 rows into a dense array is 0.5 ms of cache misses: callers that can consume the packed pairs
@@ -1029,9 +1057,19 @@ int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported) {
 int mxv_final_packed_view(mxv_handle *h, const int32_t **count, const int32_t **idx, const float **rows) {
     MXV_CHECK_HANDLE(h);
     if (!h->fin_host) return fail(h, MXV_ERR_INVALID_ARG, "mxv_final_packed_view: packed final rows exist for large envs only (see mxv_final_packed)");
+    const FinLayout L((size_t)h->cfg.num_envs, (size_t)h->O);
     if (count) *count = (const int32_t *)h->fin_host;
-    if (idx) *idx = (const int32_t *)(h->fin_host + 256);
-    if (rows) *rows = (const float *)(h->fin_host + 256 + (size_t)h->cfg.num_envs * sizeof(int32_t));
+    if (idx) *idx = (const int32_t *)(h->fin_host + L.idx);
+    if (rows) *rows = (const float *)(h->fin_host + L.rows);
+    return MXV_OK;
+}
+
+int mxv_final_packed_stats_view(mxv_handle *h, const float **ep_return, const int32_t **ep_length) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->fin_host) return fail(h, MXV_ERR_INVALID_ARG, "mxv_final_packed_stats_view: packed records exist for large envs only (see mxv_final_packed)");
+    const FinLayout L((size_t)h->cfg.num_envs, (size_t)h->O);
+    if (ep_return) *ep_return = (const float *)(h->fin_host + L.ep_r);
+    if (ep_length) *ep_length = (const int32_t *)(h->fin_host + L.ep_l);
     return MXV_OK;
 }
 

@@ -911,6 +911,10 @@ __global__ void __launch_bounds__(kBlock) final_pack_kernel(const CompactArgs a)
             a.idx[slot] = (int32_t)e;
 #pragma unroll
             for (int k = 0; k < O; ++k) a.rows[(size_t)slot * O + k] = a.final_obs[(size_t)e * O + k];
+            if (a.ep_return_in != nullptr) {   // RecordEpisodeStatistics: return and length of the episode that just ended
+                a.ep_return[slot] = a.ep_return_in[e];
+                a.ep_length[slot] = a.ep_length_in[e];
+            }
         }
     }
 }

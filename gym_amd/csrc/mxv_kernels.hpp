@@ -77,6 +77,10 @@ struct CompactArgs {
     int32_t *chunk_counts;                  // [compact_chunks(N)] scratch
     int32_t *idx;                           // [N] packed env indices
     float *rows;                            // [N][O] packed rows
+    const float *ep_return_in;              // [N] dense episode statistics of this step (valid at finished envs) or nullptr
+    const int32_t *ep_length_in;
+    float *ep_return;                       // [N] packed
+    int32_t *ep_length;
     int64_t n;
 };
 

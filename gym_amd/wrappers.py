@@ -18,7 +18,7 @@ from typing import List
 
 import numpy as np
 
-from .vector_env import HipVectorEnv, LazyInfos
+from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
 __all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward"]
 
@@ -102,6 +102,10 @@ class RecordEpisodeStatistics(_VectorWrapper):
         observations, rewards, terminateds, truncateds, infos = self.env.step(action)
         assert isinstance(infos, dict), (f"`info` dtype is {type(infos)} while supported dtype is `dict`. This may be "
                                          "due to usage of other wrappers in the wrong order.")
+        base = self.env.unwrapped
+        if getattr(base, "_packed", False) and not self._host_returns and isinstance(infos, LazyInfos):
+            self._step_packed(base, infos)
+            return observations, rewards, terminateds, truncateds, infos
         done = terminateds | truncateds
         if self._host_returns:
             self._acc += rewards   # float32 array += float64 rewards, like the reference's accumulator
@@ -124,6 +128,31 @@ class RecordEpisodeStatistics(_VectorWrapper):
             self.length_queue.extend(l[idx].tolist())
             self.episode_count += int(idx.size)
         return observations, rewards, terminateds, truncateds, infos
+
+    def _step_packed(self, base, infos):
+        """Large vector envs: the device packed (env index, episode return, episode length) of the envs that finished this step
+        next to their final observations (mxv_final_packed_stats_view) — a few percent of N.  The queues and the count are
+        updated from those; the dense float64 arrays of infos["episode"] (add_vector_episode_statistics, :10-37: length N, zero
+        where no episode ended) are built on first access only — three 8-MB arrays per step at 2^20 envs that most loops read
+        only through the `_episode` mask."""
+        if "_final_observation" not in infos:      # nobody finished
+            return
+        done = dict.__getitem__(infos, "_final_observation")
+        idx, r, l = base.handle.final_packed_stats()
+        t = round(time.perf_counter() - self.t0, 6)
+        n = self.num_envs
+
+        def build_episode():
+            er, el, et = np.zeros(n), np.zeros(n), np.zeros(n)
+            er[idx], el[idx], et[idx] = r, l, t
+            return {"r": er, "l": el, "t": et}
+
+        dict.__setitem__(infos, "episode", _Pending(build_episode))
+        dict.__setitem__(infos, "_episode", _Pending(done.copy))
+        keep = self.return_queue.maxlen      # a bounded deque only ever sees the last `maxlen` of them anyway
+        self.return_queue.extend((r if keep is None else r[-keep:]).tolist())
+        self.length_queue.extend((l if keep is None else l[-keep:]).tolist())
+        self.episode_count += int(idx.size)
 
 
 class VectorListInfo(_VectorWrapper):

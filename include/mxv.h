@@ -218,6 +218,11 @@ int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host);
  * writes the pinned block itself); the dense path stays in force there. */
 int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported);
 int mxv_final_packed_view(mxv_handle *h, const int32_t **count, const int32_t **idx, const float **rows);
+/* With episode statistics enabled (mxv_episode_stats), the packed record of a host step also carries what
+ * RecordEpisodeStatistics reports for the finished envs (record_episode_statistics.py:124-143): ep_return[i] / ep_length[i] =
+ * return (float32 accumulator) and length of the episode that ended at env idx[i] — instead of two dense [N] arrays
+ * (mxv_episode_stats_host) of which a few percent mean anything.  Same lifetime as the other views. */
+int mxv_final_packed_stats_view(mxv_handle *h, const float **ep_return, const int32_t **ep_length);
 
 /* One-DMA form of mxv_step_host: the step's outputs land in ONE caller-supplied host block
  *     final_obs float32 [N][O] | obs float32 [N][O] | reward | terminated uint8 [N] | truncated uint8 [N]

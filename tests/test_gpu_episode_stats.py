@@ -201,3 +201,53 @@ def test_vector_list_info_and_wrong_wrapping_order():
     with pytest.raises(TypeError):  # the reference asserts at step time (test_wrong_wrapping_order); here at construction
         gym_amd.RecordEpisodeStatistics(wrong)
     wrong.close()
+
+
+@pytest.mark.parametrize("deque_size", [100, 7])
+def test_large_env_statistics_travel_packed_and_equal_the_dense_path(deque_size):
+    """Above 2 MiB of step I/O RecordEpisodeStatistics reads (env index, return, length) of the finished envs from the packed
+    record of the step (mxv_final_packed_stats_view) and builds infos["episode"] lazily.  Same wrapper output as the dense
+    path (mxv_episode_stats_host + np.where over N, what small envs use), step for step: arrays, mask, queues, count —
+    also through VectorListInfo."""
+    import gym_amd
+
+    n, limit = 120_000, 9
+    env = gym_amd.RecordEpisodeStatistics(gym_amd.make("CartPole-v1", num_envs=n, max_episode_steps=limit), deque_size=deque_size)
+    assert env.unwrapped._packed
+    env.reset(seed=21)
+    env.action_space.seed(22)
+    want_r, want_l, count = [], [], 0
+    for t in range(30):
+        obs, rew, term, trunc, infos = env.step(env.action_space.sample())
+        done = term | trunc
+        if not done.any():
+            assert "episode" not in infos
+            continue
+        r, l = env.unwrapped.handle.episode_stats_host()        # dense [N] staging of the same step
+        ep = infos["episode"]
+        assert np.array_equal(infos["_episode"], done) and infos["_episode"] is not done
+        assert ep["r"].dtype == ep["l"].dtype == ep["t"].dtype == np.float64 and ep["r"].shape == (n,)
+        assert np.array_equal(ep["r"], np.where(done, r, 0).astype(np.float64))
+        assert np.array_equal(ep["l"], np.where(done, l, 0).astype(np.float64))
+        assert np.array_equal(ep["t"] > 0, done)
+        idx = np.flatnonzero(done)
+        want_r += r[idx].tolist()
+        want_l += l[idx].tolist()
+        count += idx.size
+        assert env.episode_count == count
+        assert list(env.return_queue) == want_r[-deque_size:] and list(env.length_queue) == want_l[-deque_size:]
+    assert count > 2 * n
+    env.close()
+    # VectorListInfo on top: the per-env dicts carry the same numbers
+    env = gym_amd.VectorListInfo(gym_amd.RecordEpisodeStatistics(gym_amd.make("CartPole-v1", num_envs=n, max_episode_steps=3)))
+    env.reset(seed=1)
+    env.action_space.seed(2)
+    for t in range(3):
+        obs, rew, term, trunc, infos = env.step(env.action_space.sample())
+    r, l = env.unwrapped.handle.episode_stats_host()
+    done = term | trunc
+    assert done.all() and isinstance(infos, list) and len(infos) == n
+    for i in (0, 1, n // 2, n - 1):
+        assert infos[i]["episode"]["r"] == float(r[i]) and infos[i]["episode"]["l"] == float(l[i]) == 3.0
+        assert infos[i]["final_observation"].shape == (4,)
+    env.close()
