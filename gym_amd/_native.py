@@ -39,7 +39,7 @@ EXPORTS = (
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_host_alloc", "mxv_host_free",
-                "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream",
+                "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream", "mxv_staging_view",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -163,6 +163,7 @@ def _load():
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
         "mxv_write_probe": ([C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
         "mxv_wait_stream": ([vp, vp], C.c_int),
+        "mxv_staging_view": ([vp] + [C.POINTER(vp)] * 4, C.c_int),
         "mxv_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),
         "mxv_host_free": ([vp], C.c_int),
         "mxv_host_block_layout": ([vp] + [C.POINTER(C.c_size_t)] * 6, C.c_int),
@@ -346,6 +347,12 @@ class _BlockPool:
         raw = np.frombuffer(buf, dtype=np.uint8)
         self._raw.append(raw)
         return raw
+
+
+def pinned_pool(nbytes: int, limit: int = 6) -> "_BlockPool":
+    """A pool of pinned host blocks of `nbytes` (see _BlockPool): take() returns a uint8 array (or None when the caller holds
+    every block), recycled once no view of it is alive."""
+    return _BlockPool(nbytes, limit)
 
 
 class _DestroyLater:
@@ -561,6 +568,13 @@ class Handle:
         cnt, idx, rows = self._packed_views
         c = int(cnt[0])
         return idx[:c].copy(), rows[:c].copy()
+
+    def staging_view(self):
+        """mxv_staging_view: (obs, reward, terminated, truncated) addresses of the last host step's outputs as the GPU sees them
+        (ints, valid until the next host call)."""
+        p = [C.c_void_p() for _ in range(4)]
+        self._check(lib.mxv_staging_view(self._h, *[C.byref(x) for x in p]))
+        return tuple(x.value for x in p)
 
     def final_packed_stats(self):
         """(indices, episode returns float32, episode lengths int32) of the envs that finished the LAST host step — copies.

@@ -831,6 +831,16 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     return rc;
 }
 
+int mxv_staging_view(mxv_handle *h, const float **obs, const void **reward, const uint8_t **terminated, const uint8_t **truncated) {
+    MXV_CHECK_HANDLE(h);
+    if (!h->st_obs) return fail(h, MXV_ERR_INVALID_ARG, "mxv_staging_view: no host step or reset has run on this handle yet");
+    if (obs) *obs = h->st_obs;
+    if (reward) *reward = h->st_reward;
+    if (terminated) *terminated = h->st_term;
+    if (truncated) *truncated = h->st_trunc;
+    return MXV_OK;
+}
+
 int mxv_host_alloc(size_t bytes, void **ptr) {
     if (!ptr || bytes == 0) return fail(nullptr, MXV_ERR_INVALID_ARG, "mxv_host_alloc: NULL pointer or zero size");
     MXV_HIP(nullptr, hipHostMalloc(ptr, bytes, hipHostMallocPortable));

@@ -129,6 +129,29 @@ class RunningNormalizer:
                                       self.total_envs)
         return out
 
+    # -- the same two maps fed from raw device addresses (one step, HIP backend): what the NumPy wrappers use to normalise the
+    #    outputs of a host step where they still sit in device-visible memory (mxv_staging_view) -----------------------------
+    def normalize_obs_at(self, x_ptr: int, out: torch.Tensor) -> torch.Tensor:
+        """x: float32 [N, O] at device address x_ptr -> out (float64 or float32 [N, O] device tensor)."""
+        assert out.is_contiguous() and out.numel() == self.num_envs * self.obs_dim
+        with self._ctx():
+            sums = torch.empty((1, 2 * self.obs_dim), dtype=torch.float64, device=out.device)
+            self.backend.obs.obs_sums(1, x_ptr, sums)
+            self.backend.obs.obs_apply(1, x_ptr, out, out.dtype == torch.float32, self.obs_epsilon, self._all_sums(sums),
+                                       self.world_size, self.total_envs)
+        return out
+
+    def normalize_rewards_at(self, r_ptr: int, te_ptr: int, tr_ptr: int, out: torch.Tensor) -> torch.Tensor:
+        """reward [N] of out's dtype at r_ptr, uint8 flags at te_ptr / tr_ptr -> out ([N] device tensor)."""
+        assert out.is_contiguous() and out.numel() == self.num_envs and out.dtype in (torch.float64, torch.float32)
+        f32 = out.dtype == torch.float32
+        with self._ctx():
+            sums = torch.empty((1, 2), dtype=torch.float64, device=out.device)
+            self.backend.rew.reward_sums(1, r_ptr, f32, te_ptr, tr_ptr, self.gamma, sums)
+            self.backend.rew.reward_apply(1, r_ptr, f32, out, self.reward_epsilon, self._all_sums(sums), self.world_size,
+                                          self.total_envs)
+        return out
+
     # -- the wrappers' attributes (normalize.py:64-70,117-125) ---------------------------------------------------------
     @property
     def obs_rms(self):

@@ -233,6 +233,12 @@ int mxv_final_packed_stats_view(mxv_handle *h, const float **ep_return, const in
  * being reused only once the caller dropped every array of it.  want_final = 0: final_obs is not produced.  want_final != 0:
  * with mxv_final_packed enabled the rows of the finished envs are left packed (mxv_final_packed_view) and the block's
  * final_obs region is not written; otherwise the dense rows are part of the same DMA.  Synchronises; errors as mxv_step_host. */
+/* Where the outputs of the LAST host step (or host reset: obs only) still sit in memory the GPU can read — the device staging
+ * of a large env, the pinned block of a small one — as addresses valid on the handle's device until the next host call.  What a
+ * device-side consumer of a host loop starts from (NormalizeObservation / NormalizeReward stacked on the NumPy adapter
+ * normalise these instead of uploading the arrays the step just downloaded).  obs float32 [N][O], reward in the handle's
+ * reward dtype, flags uint8 [N]; any out-pointer may be NULL. */
+int mxv_staging_view(mxv_handle *h, const float **obs, const void **reward, const uint8_t **terminated, const uint8_t **truncated);
 int mxv_host_alloc(size_t bytes, void **ptr);
 int mxv_host_free(void *ptr);
 int mxv_host_block_layout(mxv_handle *h, size_t *bytes, size_t *final_obs_off, size_t *obs_off, size_t *reward_off,
