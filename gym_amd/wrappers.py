@@ -188,21 +188,6 @@ class VectorListInfo(_VectorWrapper):
         return list_info
 
 
-class _TorchPickle:
-    """Mixin of the Normalize* wrappers: the cached torch module handle is dropped when pickling and re-imported after."""
-
-    def __getstate__(self):
-        d = dict(self.__dict__)
-        d.pop("_torch", None)
-        return d
-
-    def __setstate__(self, d):
-        import torch
-
-        self.__dict__.update(d)
-        self._torch = torch
-
-
 def _hip_base(env, who: str) -> HipVectorEnv:
     base = getattr(env, "unwrapped", env)
     if not isinstance(base, HipVectorEnv):
