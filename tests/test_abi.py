@@ -30,6 +30,14 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in _native.lib.mxv_version()
 
 
+def test_every_exported_symbol_is_mapped_to_a_reference_interface_in_the_integration_notes():
+    """INTEGRATION.md is the drop-in contract: each entry point of include/mxv.h appears there next to the reference
+    interface (file:line) it replaces, or is marked as having no reference analogue."""
+    notes = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [sym for sym in _declared_symbols() if sym not in notes]
+    assert not missing, missing
+
+
 def test_static_tables_match_oracle():
     from gym_amd import _native
 
