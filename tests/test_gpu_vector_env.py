@@ -562,3 +562,38 @@ def test_one_dma_block_step_equals_per_array_step(name, n, packed):
     del held, obs, rew, term, trunc, fin
     h.close()
     g.close()
+
+
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Acrobot-v1", "MountainCar-v0"])
+def test_large_env_discrete_actions_cross_the_link_narrowed(env_id):
+    """int64 actions of a large env are narrowed to one byte on the host while being range-checked (mxv_api.cpp:
+    upload_actions): same trajectories as a twin fed int32 actions (never narrowed), and an out-of-range value anywhere —
+    negative, 2^40 + 1 (low byte valid!), NA — still raises Discrete.contains' AssertionError with the engine usable afterwards."""
+    import gym_amd
+    from gym_amd import _native
+
+    n = 1 << 17
+    a = _native.Handle(getattr(_native, {"CartPole-v1": "CARTPOLE", "Acrobot-v1": "ACROBOT", "MountainCar-v0": "MOUNTAINCAR"}[env_id]),
+                       n, 30, seed=3, action_seed=4)
+    b = _native.Handle(a.env_id, n, 30, seed=3, action_seed=4, flags=_native.FLAG_ACTION_I32)
+    a.reset_host(), b.reset_host()
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        act = rng.integers(0, a.NA, n)
+        ra = a.step_host_block(act, want_final=False)
+        rb = b.step_host_block(act.astype(np.int32), want_final=False)
+        for x, y in zip(ra[:4], rb[:4]):
+            assert np.array_equal(x, y)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    a.close(), b.close()
+    env = gym_amd.make(env_id, num_envs=n)
+    env.reset(seed=0)
+    good = np.zeros(n, dtype=np.int64)
+    for bad_value in (-1, (1 << 40) + 1, env.single_action_space.n):
+        bad = good.copy()
+        bad[n - 7] = bad_value
+        with pytest.raises(AssertionError):
+            env.step(bad)
+        env.step(good)
+    env.close()
