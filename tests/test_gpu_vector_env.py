@@ -565,10 +565,10 @@ def test_one_dma_block_step_equals_per_array_step(name, n, packed):
 
 
 @pytest.mark.parametrize("env_id", ["CartPole-v1", "Acrobot-v1", "MountainCar-v0"])
-def test_large_env_discrete_actions_cross_the_link_narrowed(env_id):
-    """int64 actions of a large env are narrowed to one byte on the host while being range-checked (mxv_api.cpp:
-    upload_actions): same trajectories as a twin fed int32 actions (never narrowed), and an out-of-range value anywhere —
-    negative, 2^40 + 1 (low byte valid!), NA — still raises Discrete.contains' AssertionError with the engine usable afterwards."""
+def test_large_env_discrete_action_dtypes_and_out_of_range_values(env_id):
+    """int64 and int32 actions of a large env give the same trajectories, and an out-of-range value anywhere — negative,
+    2^40 + 1 (a valid low byte: catches any narrowing of the upload), NA — raises Discrete.contains' AssertionError with the
+    engine usable afterwards."""
     import gym_amd
     from gym_amd import _native
 
