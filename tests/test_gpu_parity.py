@@ -615,3 +615,45 @@ def test_tape_with_an_out_of_range_action_latches_the_error_and_leaves_that_env_
     assert np.array_equal(st1[:, keep], stb[:, keep]) and np.array_equal(el1[keep], elb[keep])
     assert np.array_equal(st1[:, victim], st0[:, victim]) and el1[victim] == el0[victim]
     a.close(), b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("autoreset", [True, False])
+@pytest.mark.parametrize("params", ["default", "broadcast", "per_env"])
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum", "Acrobot"])
+def test_tape_dispatch_matrix_equals_stepping(name, params, autoreset):
+    """mxv_rollout_tape takes the fused rollout kernel only for default physics parameters with autoreset; changed parameters
+    (one value for all envs, or one per env) and MXV_FLAG_NO_AUTORESET run step_kernel's K-loop.  Whichever kernel serves it, a
+    tape gives what K single steps with the same rows give, bit for bit."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from helpers import GYM_IDS
+
+    n, K = 3000, 21
+    kw = dict(seed=71, action_seed=72, max_episode_steps=8, autoreset=autoreset)
+    src = DeviceRollout(GYM_IDS[name], n, seed=71, action_seed=72)
+    a, b = DeviceRollout(GYM_IDS[name], n, **kw), DeviceRollout(GYM_IDS[name], n, **kw)
+    for r in (a, b):
+        if params == "broadcast":
+            p = r.handle.get_params()
+            p[0] *= 1.07                    # gravity (CartPole, Acrobot's g analogue) / max_speed ... any attribute: only != default matters
+            r.handle.set_params(p)
+        elif params == "per_env":
+            t = r.handle.get_params_per_env()
+            t[0] *= np.linspace(0.9, 1.1, n)
+            r.handle.set_params_per_env(t)
+    src.reset(seed=71), a.reset(seed=71), b.reset(seed=71)
+    rows = src.rollout_per_step(K, mode="fused")["actions"]
+    src.synchronize()
+    tape = rows.clone()
+    out = a.rollout_tape(tape, out=a.trajectory_buffers(K, want_final=True))
+    a.synchronize()
+    for k in range(K):
+        o, r, te, tr = b.step(tape[k], want_final=True)
+        b.synchronize()
+        assert torch.equal(out["obs"][k], o) and torch.equal(out["reward"][k], r), (k,)
+        assert torch.equal(out["terminated"][k], te) and torch.equal(out["truncated"][k], tr), (k,)
+    for x, y in zip(a.handle.get_state(), b.handle.get_state()):
+        assert np.array_equal(x, y)
+    for r in (src, a, b):
+        r.close()
