@@ -964,19 +964,27 @@ class Tab:
         self._check(lib.mxv_tab_reset_host(self._h, _ptr(m), obs.ctypes.data))
         return obs
 
-    def step_host(self, actions, uniforms=None):
+    def step_host(self, actions, uniforms=None, pooled=False):
         """-> obs i64[N], reward f64[N], terminated bool[N], truncated bool[N], prob f64[N], final_obs i64[N], final_prob f64[N]
-        (final_* valid where terminated | truncated).  uniforms: None or float64 [2][N] (transition, autoreset)."""
+        (final_* valid where terminated | truncated).  uniforms: None or float64 [2][N] (transition, autoreset).
+        pooled=True (the NumPy adapter): the arrays come from a recycling pool (_ArrayPool: no fresh mappings per step) and
+        final_* hold stale values, not zeros, where no episode ended."""
         n = self.num_envs
         a = np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
         u = None if uniforms is None else np.ascontiguousarray(uniforms, dtype=np.float64).reshape(2, n)
-        obs = np.empty(n, np.int64)
-        rew = np.empty(n, np.float64)
-        term = np.empty(n, np.uint8)
-        trunc = np.empty(n, np.uint8)
-        prob = np.empty(n, np.float64)
-        fin = np.zeros(n, np.int64)
-        fprob = np.zeros(n, np.float64)
+        if pooled:
+            pool = self.__dict__.setdefault("_pool", _ArrayPool(limit=12))
+            obs, rew, prob = pool.take((n,), np.int64), pool.take((n,), np.float64), pool.take((n,), np.float64)
+            term, trunc = pool.take((n,), np.uint8), pool.take((n,), np.uint8)
+            fin, fprob = pool.take((n,), np.int64), pool.take((n,), np.float64)
+        else:
+            obs = np.empty(n, np.int64)
+            rew = np.empty(n, np.float64)
+            term = np.empty(n, np.uint8)
+            trunc = np.empty(n, np.uint8)
+            prob = np.empty(n, np.float64)
+            fin = np.zeros(n, np.int64)
+            fprob = np.zeros(n, np.float64)
         self._check(lib.mxv_tab_step_host(self._h, a.ctypes.data, _ptr(u), obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                           trunc.ctypes.data, prob.ctypes.data, fin.ctypes.data, fprob.ctypes.data))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), prob, fin, fprob
@@ -1086,16 +1094,22 @@ class Blackjack:
         self._check(lib.mxv_bj_reset_host(self._h, _ptr(c), obs.ctypes.data))
         return obs
 
-    def step_host(self, actions, cards=None):
-        """-> obs i64[3][N], reward f64[N], terminated bool[N], truncated bool[N], final_obs i64[3][N]."""
+    def step_host(self, actions, cards=None, pooled=False):
+        """-> obs i64[3][N], reward f64[N], terminated bool[N], truncated bool[N], final_obs i64[3][N] (pooled: see Tab.step_host)."""
         n = self.num_envs
         a = np.ascontiguousarray(actions, dtype=np.int64).reshape(n)
         c = None if cards is None else np.ascontiguousarray(cards, dtype=np.int8).reshape(n, BJ_MAX_DRAWS)
-        obs = np.empty((3, n), np.int64)
-        rew = np.empty(n, np.float64)
-        term = np.empty(n, np.uint8)
-        trunc = np.empty(n, np.uint8)
-        fin = np.zeros((3, n), np.int64)
+        if pooled:
+            pool = self.__dict__.setdefault("_pool", _ArrayPool(limit=12))
+            obs, fin = pool.take((3, n), np.int64), pool.take((3, n), np.int64)
+            rew = pool.take((n,), np.float64)
+            term, trunc = pool.take((n,), np.uint8), pool.take((n,), np.uint8)
+        else:
+            obs = np.empty((3, n), np.int64)
+            rew = np.empty(n, np.float64)
+            term = np.empty(n, np.uint8)
+            trunc = np.empty(n, np.uint8)
+            fin = np.zeros((3, n), np.int64)
         self._check(lib.mxv_bj_step_host(self._h, a.ctypes.data, _ptr(c), obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                          trunc.ctypes.data, fin.ctypes.data))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin

@@ -386,7 +386,7 @@ class HipTabularVectorEnv(VectorEnv):
         if not self._was_reset:
             raise error.ResetNeeded("Cannot call env.step() before calling env.reset()")
         try:
-            obs, rew, term, trunc, prob, fin, fprob = self._handle.step_host(actions)
+            obs, rew, term, trunc, prob, fin, fprob = self._handle.step_host(actions, pooled=True)
         except _native.MxvError as e:
             if e.code == _native.ERR_INVALID_ACTION:
                 bad = actions[(actions < 0) | (actions >= self.mdp.num_actions)]
@@ -647,7 +647,7 @@ class HipBlackjackVectorEnv(VectorEnv):
         if not self._was_reset:
             raise error.ResetNeeded("Cannot call env.step() before calling env.reset()")
         try:
-            cols, rew, term, trunc, fin = self._handle.step_host(actions)
+            cols, rew, term, trunc, fin = self._handle.step_host(actions, pooled=True)
         except _native.MxvError as e:
             if e.code == _native.ERR_INVALID_ACTION:
                 raise AssertionError(f"{actions!r} ({type(actions)}) invalid") from None   # blackjack.py:122
