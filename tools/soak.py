@@ -85,6 +85,51 @@ def main():
             a.close(), b.close()
             total += n * chunks * K
             print(f"ok fused==per-step {name:22s} n={n:<6d} steps={chunks * K:<5d} limit={limit} dones={dones}", flush=True)
+    # randomized shapes: sampled rollout (fused) == one launch per step (eager) == tape-driven rollout fed the recorded actions,
+    # every output of every step and the final state, over random env kinds, sizes, chunk lengths, time limits, shard offsets
+    # and dtype sets
+    rng = np.random.default_rng(20260923)
+    for case in range(int(os.environ.get("SOAK_RANDOM_CASES", "80"))):
+        name = ENV_NAMES[int(rng.integers(len(ENV_NAMES)))]
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 1000, 4097])) if rng.random() < 0.5 else int(rng.integers(1, 6000))
+        K = int(rng.integers(1, 90))
+        limit = None if rng.random() < 0.3 else int(rng.integers(1, 30))
+        off = int(rng.integers(0, 1 << 34)) * 4
+        compact = bool(rng.random() < 0.3)
+        kw = dict(seed=int(rng.integers(1 << 30)), action_seed=int(rng.integers(1 << 30)), env_offset=off, reward_f32=compact,
+                  action_i32=compact)
+        if limit is not None:
+            kw["max_episode_steps"] = limit
+        envs = [DeviceRollout(GYM_IDS[name], n, **kw) for _ in range(3)]
+        for e in envs:
+            e.reset(seed=kw["seed"])
+        for rep in range(2):
+            want_final = bool(rng.random() < 0.5)
+            fa = envs[0].rollout_per_step(K, mode="fused", out=envs[0].trajectory_buffers(K, want_final=want_final))
+            fb = envs[1].rollout_per_step(K, mode="eager", out=envs[1].trajectory_buffers(K, want_final=want_final))
+            envs[0].synchronize(), envs[1].synchronize()
+            keys = ["obs", "reward", "terminated", "truncated", "actions"]
+            for key in keys:
+                assert torch.equal(fa[key], fb[key]), (case, name, n, K, limit, key)
+            done = (fa["terminated"] | fa["truncated"]).bool()
+            if want_final:
+                assert torch.equal(fa["final_obs"][done], fb["final_obs"][done]), (case, name, "final_obs")
+            if K > 1:
+                fc = envs[2].rollout_tape(fa["actions"].clone(), out=envs[2].trajectory_buffers(K, want_final=want_final))
+            else:
+                o, r, te, tr = envs[2].step(fa["actions"][0].clone(), want_final=want_final)
+                fc = {"obs": o[None], "reward": r[None], "terminated": te[None], "truncated": tr[None]}
+            envs[2].synchronize()
+            for key in keys[:4]:
+                assert torch.equal(fa[key], fc[key]), (case, name, n, K, limit, "tape", key)
+        for other in envs[1:]:
+            for x, y in zip(envs[0].handle.get_state(), other.handle.get_state()):
+                assert np.array_equal(x, y), (case, name)
+            assert np.array_equal(envs[0].handle.get_episodes(), other.handle.get_episodes())
+        for e in envs:
+            e.close()
+        total += 2 * 3 * n * K
+    print(f"ok randomized fused == per-step == tape: {case + 1} cases", flush=True)
     print(f"soak passed: {total:.3e} env-steps compared in {time.time() - t0:.0f} s")
 
 
