@@ -9,13 +9,13 @@ between the NumPy contract of the reference and the engine's buffers.
 from __future__ import annotations
 
 import os
-from typing import Any, Iterable, List, Optional, Union
+from typing import List, Optional, Union
 
 import numpy as np
 
 from . import _native, error
 from .registration import (CTOR_KWARGS, ENUM_PARAMS, PARAM_NAMES, PENDULUM, single_spaces, spec as _spec)
-from .spaces import Box, Discrete, batch_space
+from .spaces import Discrete, batch_space
 
 __all__ = ["VectorEnv", "HipVectorEnv", "make"]
 
