@@ -124,8 +124,9 @@ def measure_variant(args, ShardedRollout, torch):
                         action_seed=1, reward_f32=True, action_i32=True)
     eng = sr.engine
     sr.reset(seed=0)
+    placement = None
     if args.placement_candidates > 1:
-        traj, _ = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
+        traj, placement = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
     else:
         traj = eng.trajectory_buffers(args.chunk)
     launches = max(8, args.steps // args.chunk // 4)
@@ -144,7 +145,8 @@ def measure_variant(args, ShardedRollout, torch):
     b = algorithmic_bytes_per_env_step("fused", args.chunk)
     steps_s = ENVS_TOTAL * args.chunk / (ms * 1e-3)
     return {"value": steps_s, "unit": "env-steps/s", "us_per_step": ms * 1e3 / args.chunk,
-            "outputs": "float32 rewards, int32 actions (26 real B/env-step)", "roofline_frac": steps_s * b / 1e9 / HBM_PEAK_GBS}
+            "outputs": "float32 rewards, int32 actions (26 real B/env-step)", "roofline_frac": steps_s * b / 1e9 / HBM_PEAK_GBS,
+            "placement_candidates_us_per_step": None if placement is None else placement.get("us_per_step")}
 
 
 def read_traffic(mode: str, steps_per_launch: float, envs: int, compact: bool):
