@@ -12,9 +12,13 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+// MAP 0: XCD-contiguous tiles (the engine's map: XCD x owns the x-th contiguous eighth of every row); 1: natural order (consecutive
+// tiles go to consecutive XCDs); 2: XCD x owns every eighth 16-tile group (32 KiB of obs)
+template <int MAP>
 __global__ void __launch_bounds__(64, 4) stores(float4 *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t row, int K) {
     const unsigned bid = blockIdx.x, ntiles = gridDim.x;
-    const unsigned tile = (bid % 8) * (ntiles / 8) + bid / 8;
+    const unsigned xcd = bid % 8, j = bid / 8;
+    const unsigned tile = MAP == 0 ? xcd * (ntiles / 8) + j : (MAP == 1 ? bid : ((j / 16) * 8 + xcd) * 16 + j % 16);
     const int lane = threadIdx.x;
     const int64_t e0 = (int64_t)tile * 128 + lane, e1 = e0 + 64;
     float x = (float)lane;
@@ -52,18 +56,23 @@ int main() {
             CK(hipMalloc(&act, K * row * 8));
             CK(hipMalloc(&term, K * row));
             CK(hipMalloc(&trunc, K * row));
-            float best = 1e9f;
-            for (int rep = 0; rep < 4; ++rep) {
-                CK(hipEventRecord(e0, s));
-                for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(stores, dim3(n / 128), dim3(64), 0, s, obs, rew, act, term, trunc, row, K);
-                CK(hipEventRecord(e1, s));
-                CK(hipEventSynchronize(e1));
-                float ms;
-                CK(hipEventElapsedTime(&ms, e0, e1));
-                if (rep > 0 && ms < best) best = ms;
-            }
-            printf("{\"round\": %d, \"pad_envs\": %lld, \"us_per_step\": %.3f, \"obs\": \"%p\", \"rew\": \"%p\", \"act\": \"%p\"}\n", round,
-                   (long long)pad, best * 1e3 / (4 * K), (void *)obs, (void *)rew, (void *)act);
+            float best[3] = {1e9f, 1e9f, 1e9f};
+            for (int rep = 0; rep < 3; ++rep)
+                for (int map = 0; map < 3; ++map) {
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 4; ++i) {
+                        if (map == 0) hipLaunchKernelGGL(stores<0>, dim3(n / 128), dim3(64), 0, s, obs, rew, act, term, trunc, row, K);
+                        if (map == 1) hipLaunchKernelGGL(stores<1>, dim3(n / 128), dim3(64), 0, s, obs, rew, act, term, trunc, row, K);
+                        if (map == 2) hipLaunchKernelGGL(stores<2>, dim3(n / 128), dim3(64), 0, s, obs, rew, act, term, trunc, row, K);
+                    }
+                    CK(hipEventRecord(e1, s));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep > 0 && ms < best[map]) best[map] = ms;
+                }
+            printf("{\"round\": %d, \"pad_envs\": %lld, \"us_per_step\": %.3f, \"natural_map\": %.3f, \"grouped_map\": %.3f, \"obs\": \"%p\"}\n", round,
+                   (long long)pad, best[0] * 1e3 / (4 * K), best[1] * 1e3 / (4 * K), best[2] * 1e3 / (4 * K), (void *)obs);
             fflush(stdout);
             CK(hipFree(obs)); CK(hipFree(rew)); CK(hipFree(act)); CK(hipFree(term)); CK(hipFree(trunc));
         }
