@@ -487,7 +487,8 @@ def test_tuned_trajectory_buffers_leave_results_unchanged():
         r.reset(seed=13)
         if tune:
             traj, report = r.tuned_trajectory_buffers(K, candidates=3, launches=2)
-            assert report["candidates"] == 3 and len(report["us_per_step"]) == 3 and len(report["mixes_us_per_step"]) == 6
+            nc = report["candidates"]           # 3, or up to 6 when none of the first three stood out (adaptive second batch)
+            assert 3 <= nc <= 6 and len(report["us_per_step"]) == nc == len(report["kinds"]) and len(report["mixes_us_per_step"]) == 2 * nc
             assert report["chosen_us_per_step"] > 0
         else:
             traj = r.trajectory_buffers(K)
@@ -527,7 +528,8 @@ def test_spread_layout_buffers_give_identical_trajectories():
     r = DeviceRollout("CartPole-v1", 1 << 16, seed=1, action_seed=2)
     r.reset(seed=1)
     traj, report = r.tuned_trajectory_buffers(16, candidates=8, launches=2)
-    assert report["kinds"] == ["separate"] * 6 + ["spread"] * 2 and len(report["us_per_step"]) == 8
+    assert report["kinds"][:8] == ["separate"] * 6 + ["spread"] * 2 and 8 <= len(report["us_per_step"]) <= 16
+    assert all(k == "separate" for k in report["kinds"][8:])
     r.close()
 
 
