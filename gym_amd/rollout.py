@@ -248,7 +248,8 @@ class DeviceRollout:
         def stands_out():   # both modes seen: some set is clearly faster than some other
             return len(times) > 1 and best_us <= 0.93 * max(times)
 
-        while len(sets) < max_candidates and not stands_out():   # nothing fast yet: new physical pages, one set at a time
+        big = K * per_step >= (1 << 30)   # the modes were only ever seen on sets of a GiB and more
+        while big and len(sets) < max_candidates and not stands_out():   # nothing fast yet: new physical pages, one set at a time
             traj = self.trajectory_buffers(K, want_final=want_final, layout="separate", seed=len(sets))
             sets.append(traj)
             kinds.append("separate")
