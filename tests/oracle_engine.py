@@ -134,3 +134,53 @@ class FakeHandle:
 
     def close(self):
         self.closed = True
+
+
+class PackedFakeHandle(FakeHandle):
+    """FakeHandle that behaves like the handle of a LARGE vector env: final_packed() is supported, host steps leave the final
+    observations (and, with episode statistics on, returns and lengths) of the finished envs as packed (index, row) records in
+    ascending env order and return no dense final array; the resets of the autoreset come from the oracle.  Exercises the
+    adapter's packed code paths (LazyInfos built from packed rows, RecordEpisodeStatistics._step_packed) without a device."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        from oracle.oracle import EpisodeStats
+
+        self._packed_on = False
+        self._stats = None
+        self._EpisodeStats = EpisodeStats
+        self._rec = (np.zeros(0, np.int32), np.zeros((0, self.O), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
+        self._dense_stats = None
+
+    def final_packed(self, enable=True):
+        self._packed_on = bool(enable)
+        return self._packed_on
+
+    def episode_stats(self, enable=True):
+        self._stats = self._EpisodeStats(self.num_envs) if enable else None
+
+    def reset_host(self, mask=None, bounds=None):
+        if self._stats is not None and mask is None:
+            self._stats.reset()
+        return super().reset_host(mask=mask, bounds=bounds)
+
+    def step_host_block(self, actions, want_final=True):
+        obs, rew, term, trunc, fin, _ = self.o.step(actions)
+        done = term | trunc
+        idx = np.flatnonzero(done).astype(np.int32)
+        r = l = None
+        if self._stats is not None:
+            r, l, _ = self._stats.step(rew, term, trunc)
+            self._dense_stats = (r, l)
+        self._rec = (idx, fin[idx].copy(), None if r is None else r[idx].copy(), None if l is None else l[idx].copy())
+        return obs, rew, term, trunc, (None if self._packed_on else fin)
+
+    def final_packed_rows(self):
+        return self._rec[0].copy(), self._rec[1].copy()
+
+    def final_packed_stats(self):
+        return self._rec[0].copy(), self._rec[2].copy(), self._rec[3].copy()
+
+    def episode_stats_host(self, want_running=False):
+        r, l = self._dense_stats
+        return (r, l, self._stats.returns.copy()) if want_running else (r, l)

@@ -240,3 +240,83 @@ def test_bench_accounting_is_a_pure_function_of_the_arguments():
     r8 = bench.timed_repeats(20, 256, 1 << 17, 60.0)                            # an 8-GPU strong-scaling shard: 8x shorter steps
     assert r8 >= 8 * 500 and (r8 * 20) % 256 == 0
     assert bench.timed_repeats(20, 256, 1 << 20, 60.0, mode="eager") == 500
+
+
+def test_array_pool_recycles_only_what_nobody_references():
+    """_ArrayPool (gym_amd/_native.py): an array goes out again only when the caller dropped it and every view of it."""
+    from gym_amd._native import _ArrayPool
+
+    pool = _ArrayPool(limit=2)
+    a = pool.take((1000, 4), np.float32)
+    b = pool.take((1000, 4), np.float32)
+    assert a is not b and a.shape == (1000, 4) and a.dtype == np.float32
+    ida, idb = id(a), id(b)
+    view = a[10:20]
+    del a
+    c = pool.take((1000, 4), np.float32)          # a is still visible through `view`; b is held: a third array (unpooled: limit 2)
+    assert id(c) not in (ida, idb)
+    del view, c
+    d = pool.take((1000, 4), np.float32)
+    assert id(d) == ida                           # now a is free again
+    e = pool.take((1000,), np.float32)            # another shape: its own list
+    assert e.shape == (1000,)
+    del b
+    f = pool.take((1000, 4), np.float32)
+    assert id(f) == idb
+
+
+def test_large_env_adapter_paths_on_a_packed_stand_in(monkeypatch):
+    """HipVectorEnv + RecordEpisodeStatistics + VectorListInfo over a handle that reports packed final records (what a large
+    vector env does on the device): infos built from the packed rows equal what the dense path builds, step for step."""
+    from oracle_engine import FakeHandle, PackedFakeHandle
+
+    import gym_amd
+    from gym_amd import _native
+
+    n = 64
+    monkeypatch.setattr(_native, "Handle", PackedFakeHandle)
+    packed = gym_amd.RecordEpisodeStatistics(gym_amd.make("CartPole-v1", num_envs=n, max_episode_steps=7), deque_size=5)
+    assert packed.unwrapped._packed
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    dense = gym_amd.make("CartPole-v1", num_envs=n, max_episode_steps=7)
+    assert not dense._packed
+    packed.reset(seed=3), dense.reset(seed=3)
+    dense.action_space.seed(4)
+    from oracle.oracle import EpisodeStats
+
+    stats = EpisodeStats(n)
+    want_r, want_l, count = [], [], 0
+    for t in range(40):
+        a = dense.action_space.sample()
+        o1, r1, te1, tr1, i1 = packed.step(a)
+        o2, r2, te2, tr2, i2 = dense.step(a)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(te1, te2) and np.array_equal(tr1, tr2)
+        er, el, done = stats.step(r2, te2, tr2)
+        if not done.any():
+            assert "episode" not in i1 and "final_observation" not in i1
+            continue
+        assert set(i1) == set(i2) | {"episode", "_episode"}
+        f1, f2 = i1["final_observation"], i2["final_observation"]
+        for i in range(n):
+            assert (f1[i] is None) == (f2[i] is None) == (not done[i])
+            if done[i]:
+                assert np.array_equal(f1[i], f2[i])
+        assert np.array_equal(i1["_final_observation"], done) and np.array_equal(i1["_final_info"], done)
+        ep = i1["episode"]
+        assert np.array_equal(ep["r"], er.astype(np.float64)) and np.array_equal(ep["l"], el.astype(np.float64))
+        assert np.array_equal(i1["_episode"], done) and np.array_equal(ep["t"] > 0, done)
+        idx = np.flatnonzero(done)
+        want_r += er[idx].tolist()
+        want_l += el[idx].tolist()
+        count += idx.size
+        assert packed.episode_count == count
+        assert list(packed.return_queue) == want_r[-5:] and list(packed.length_queue) == want_l[-5:]
+        assert dict(i1).keys() == i1.keys() and isinstance(dict(i1)["episode"], dict)   # placeholders resolve on every way out
+    assert count > n
+    # VectorListInfo over the packed path
+    monkeypatch.setattr(_native, "Handle", PackedFakeHandle)
+    env = gym_amd.VectorListInfo(gym_amd.RecordEpisodeStatistics(gym_amd.make("CartPole-v1", num_envs=8, max_episode_steps=2)))
+    env.reset(seed=1)
+    env.step(np.zeros(8, dtype=np.int64))
+    infos = env.step(np.zeros(8, dtype=np.int64))[4]
+    assert isinstance(infos, list) and all(d["episode"]["l"] == 2.0 and d["final_observation"].shape == (4,) for d in infos)
