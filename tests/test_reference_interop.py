@@ -15,14 +15,16 @@ import pytest
 from test_host_logic import _ref_gym
 
 
-@pytest.fixture()
-def hip(monkeypatch):
+@pytest.fixture(params=["dense", "packed"])
+def hip(monkeypatch, request):
+    """The engine handle replaced by the oracle-backed stand-in; "packed" = the stand-in of a LARGE vector env (final
+    observations arrive as packed records, infos are built lazily from them)."""
     gym = _ref_gym()
-    from oracle_engine import FakeHandle
+    from oracle_engine import FakeHandle, PackedFakeHandle
 
     from gym_amd import _native, plugin
 
-    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    monkeypatch.setattr(_native, "Handle", PackedFakeHandle if request.param == "packed" else FakeHandle)
     plugin.register_envs(gym)
     return gym
 
