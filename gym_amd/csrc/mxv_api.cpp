@@ -1035,10 +1035,9 @@ int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launche
     MXV_HIP(nullptr, hipSetDevice(device));
     hipStream_t s = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    MXV_HIP(nullptr, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    MXV_HIP(nullptr, hipEventCreate(&e0));
-    MXV_HIP(nullptr, hipEventCreate(&e1));
-    hipError_t err = hipSuccess;
+    hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
     for (int i = 0; i < 2 && err == hipSuccess; ++i)
         err = launch_write_probe(obs_dev, reward_dev, actions_dev, terminated_dev, truncated_dev, num_envs, K, s);
     if (err == hipSuccess) err = hipEventRecord(e0, s);
@@ -1048,9 +1047,9 @@ int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launche
     if (err == hipSuccess) err = hipEventSynchronize(e1);
     float ms = 0.0f;
     if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipStreamDestroy(s);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
     if (err != hipSuccess) return fail(nullptr, MXV_ERR_HIP, "mxv_write_probe: %s", hipGetErrorString(err));
     *us_per_step = (double)ms * 1e3 / ((double)launches * K);
     return MXV_OK;
