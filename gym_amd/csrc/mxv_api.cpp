@@ -108,7 +108,7 @@ struct mxv_handle {
     size_t io_total = 0, io_out_off = 0, io_out_bytes = 0, io_act_bytes = 0;
     int32_t *hm_err = nullptr;
     bool hostmap = false;       // the kernels address the pinned block directly
-    // large envs: info["final_observation"] travels as packed (index, row) pairs of the finished envs only (compact_final_kernel)
+    // large envs: info["final_observation"] travels as packed (index, row) pairs of the finished envs only (final_count_kernel + final_pack_kernel)
     char *fin_dev = nullptr;    // device: count (256 B) | idx int32[N] | rows float[N][O]
     char *fin_host = nullptr;   // pinned mirror
     bool err_in_block = false;  // host steps of a small env: the kernel raises the error word in the pinned I/O block itself

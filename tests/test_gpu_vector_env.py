@@ -479,7 +479,7 @@ def test_copy_false_and_zero_copy_equal_the_copying_path(env_id, n):
 @pytest.mark.parametrize("limit", [3, 40])
 def test_large_env_final_observations_travel_packed(mode, limit):
     """Above 2 MiB of step I/O the adapter no longer copies the dense final_obs array over PCIe: the device packs (index, row)
-    pairs of the envs that finished (compact_final_kernel) and the library scatters them on the host.  TimeLimit 3: a third of
+    pairs of the envs that finished (final_count_kernel + final_pack_kernel) and the library scatters them on the host.  TimeLimit 3: a third of
     the 200 000 envs finish per step — more than the speculative first transfer holds (n / 8), so the second one runs;
     TimeLimit 40: a few percent.  Every info["final_observation"] row must be the terminal observation the oracle computes, for
     the copying adapter (pooled arrays) and for the views of the pinned block alike; arrays the caller keeps stay intact."""
