@@ -52,6 +52,9 @@ class OracleEngine:
         obs, rew, term, trunc, fin, fmask = self.o.step(actions)
         return obs, rew, term, trunc, fin
 
+    def set_params(self, p):
+        self.o.P[:] = p
+
 
 class HipEngine:
     """The product path: every call goes through the C ABI (ctypes -> libmxv.so -> HIP kernels)."""
@@ -71,6 +74,9 @@ class HipEngine:
 
     def step(self, actions):
         return self.h.step_host(actions, want_final=True)
+
+    def set_params(self, p):
+        self.h.set_params(p)
 
 
 # Tolerances of engine-vs-reference comparisons.  Integer/boolean outputs (terminated, truncated, elapsed,
@@ -130,6 +136,28 @@ def run_p1(engine_cls, name, strict, kind="p1"):
                truncated=np.zeros(n, dtype=bool), final_obs=g["obs"], state=g["state1"], elapsed=elapsed + 1)
     compare_step(f"{name} {kind.upper()}", got, ref, done, strict)
     return int(term.sum())
+
+
+def run_p1_variants(engine_cls, name, strict):
+    """Single raw-env steps with NON-DEFAULT physics attributes (golden <env>_p1_variants.npz, make_golden_variants.py: the
+    reference run with the attributes set on the raw env).  The engine gets the same parameter vector through its set_params."""
+    g = load_golden(name, "p1_variants")
+    V, n = g["action"].shape
+    total = 0
+    for v in range(V):
+        eng = engine_cls(name, n, 0, autoreset=False)
+        eng.set_params(g["params"][v])
+        elapsed = np.where(g["fresh"][v] == 1, 0, 5).astype(np.int32)
+        eng.set_state(g["state0"][v].T, elapsed)
+        obs, rew, term, trunc, fin = eng.step(g["action"][v])
+        st, el = eng.get_state()
+        done = np.zeros(n, dtype=bool)
+        got = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, final_obs=fin, state=st.T, elapsed=el)
+        ref = dict(obs=g["obs"][v], reward=g["reward"][v], terminated=g["terminated"][v].astype(bool),
+                   truncated=np.zeros(n, dtype=bool), final_obs=g["obs"][v], state=g["state1"][v], elapsed=elapsed + 1)
+        compare_step(f"{name} P1[variant {v}]", got, ref, done, strict)
+        total += int(term.sum())
+    return total
 
 
 def run_p2(engine_cls, name, tag, strict):

@@ -659,3 +659,14 @@ def test_tape_dispatch_matrix_equals_stepping(name, params, autoreset):
         assert np.array_equal(x, y)
     for r in (src, a, b):
         r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_non_default_physics_attributes_against_the_reference(name):
+    """<env>_p1_variants.npz (make_golden_variants.py: the live reference stepped with changed attributes — semi-implicit
+    CartPole, nips Acrobot, Pendulum g, goal_velocity, moved thresholds, masses, lengths, time steps): the device's
+    runtime-parameter kernels against the reference's own outputs, masks exact, observations within the usual bars."""
+    from helpers import run_p1_variants
+
+    run_p1_variants(HipEngine, name, strict=False)
