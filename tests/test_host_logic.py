@@ -320,3 +320,56 @@ def test_large_env_adapter_paths_on_a_packed_stand_in(monkeypatch):
     env.step(np.zeros(8, dtype=np.int64))
     infos = env.step(np.zeros(8, dtype=np.int64))[4]
     assert isinstance(infos, list) and all(d["episode"]["l"] == 2.0 and d["final_observation"].shape == (4,) for d in infos)
+
+
+@pytest.mark.parametrize("env_name", ["Acrobot-v1", "CartPole-v1", "MountainCar-v0", "MountainCarContinuous-v0"])
+def test_customizable_resets_like_the_reference_tests(env_name, monkeypatch):
+    """tests/envs/test_env_implementation.py:150-215 restated for the vector adapter (oracle-backed stand-in handle): reset
+    options low/high as floats or 0-d arrays bound every state component; strings, low > high, lists and 1-d arrays raise
+    ValueError (classic_control/utils.py:8-46); Pendulum takes x_init / y_init instead (pendulum.py:141-159)."""
+    from oracle_engine import FakeHandle
+
+    import gym_amd
+    from gym_amd import _native
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    for low_high in (None, (-0.4, 0.4), (np.array(-0.4), np.array(0.4))):
+        env = gym_amd.make(env_name, num_envs=16)
+        env.action_space.seed(0)
+        if low_high is None:
+            env.reset()
+        else:
+            low, high = low_high
+            env.reset(options={"low": low, "high": high})
+            st = env.handle.o.state
+            assert np.all((st >= low) & (st <= high))
+        env.step(env.action_space.sample())
+        env.close()
+    for low_high in (("x", "y"), (10.0, 8.0), ([-1.0, -1.0], [1.0, 1.0]), (np.array([-1.0, -1.0]), np.array([1.0, 1.0]))):
+        env = gym_amd.make(env_name, num_envs=4)
+        with pytest.raises(ValueError):
+            env.reset(options={"low": low_high[0], "high": low_high[1]})
+        env.close()
+
+
+def test_customizable_pendulum_resets_like_the_reference_test(monkeypatch):
+    from oracle_engine import FakeHandle
+
+    import gym_amd
+    from gym_amd import _native
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    for low_high in (None, (1.2, 1.0), (np.array(1.2), np.array(1.0))):
+        env = gym_amd.make("Pendulum-v1", num_envs=32)
+        env.action_space.seed(0)
+        if low_high is None:
+            env.reset()
+            st = env.handle.o.state
+            assert np.all(np.abs(st[0]) <= np.pi) and np.all(np.abs(st[1]) <= 1.0)
+        else:
+            x, y = low_high
+            env.reset(options={"x_init": x, "y_init": y})
+            st = env.handle.o.state
+            assert np.all(np.abs(st[0]) <= 1.2) and np.all(np.abs(st[1]) <= 1.0)
+        env.step(env.action_space.sample())
+        env.close()
