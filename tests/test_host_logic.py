@@ -373,3 +373,37 @@ def test_customizable_pendulum_resets_like_the_reference_test(monkeypatch):
             assert np.all(np.abs(st[0]) <= 1.2) and np.all(np.abs(st[1]) <= 1.0)
         env.step(env.action_space.sample())
         env.close()
+
+
+@pytest.mark.parametrize("env_name", ["Pendulum-v1", "MountainCarContinuous-v0"])
+def test_box_actions_out_of_bound_like_the_reference_test(env_name, monkeypatch):
+    """tests/envs/test_action_dim_check.py:90-136: a Box action beyond a bound has the effect of the action AT the bound (the envs
+    clip inside step); discrete envs reject out-of-range actions (:62-78)."""
+    from oracle_engine import FakeHandle
+
+    import gym_amd
+    from gym_amd import _native
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    n = 8
+    env, oob_env = gym_amd.make(env_name, num_envs=n), gym_amd.make(env_name, num_envs=n)
+    env.reset(seed=42), oob_env.reset(seed=42)
+    hi, lo = env.single_action_space.high, env.single_action_space.low
+    for bound, sign in ((hi, +1), (lo, -1)):
+        a = np.tile(bound, (n, 1)).astype(np.float32)
+        obs = env.step(a)[0]
+        oob_obs = oob_env.step(a + np.float32(sign * 100))[0]
+        if env_name == "Pendulum-v1":
+            assert np.all(obs == oob_obs)
+        else:
+            # MountainCarContinuous under NumPy 2 (NEP 50): `min(max(action[0], min_action), max_action)` hands back the float32
+            # action itself AT the bound but the Python-float bound beyond it, so `force * self.power` is a float32 product in one
+            # case and a float64 product in the other (continuous_mountain_car.py:146-148; SURVEY App. A.5): the reference — and
+            # therefore the oracle and the engine — may differ in the last float32 bit of the velocity between the two
+            np.testing.assert_allclose(obs, oob_obs, rtol=3e-7, atol=1e-9)
+    env.close(), oob_env.close()
+    disc = gym_amd.make("CartPole-v1", num_envs=4)
+    disc.reset(seed=0)
+    with pytest.raises(Exception):
+        disc.step(np.full(4, disc.single_action_space.n))
+    disc.close()
