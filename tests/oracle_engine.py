@@ -132,6 +132,15 @@ class FakeHandle:
     def step_host_block(self, actions, want_final=True):
         return self.step_host(actions, want_final=want_final)
 
+    def get_state(self):
+        return self.o.state.copy(), self.o.elapsed.copy()
+
+    def set_state(self, state=None, elapsed=None):
+        if state is not None:
+            self.o.state[:] = state
+        if elapsed is not None:
+            self.o.elapsed[:] = elapsed
+
     def close(self):
         self.closed = True
 

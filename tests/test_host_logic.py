@@ -407,3 +407,56 @@ def test_box_actions_out_of_bound_like_the_reference_test(env_name, monkeypatch)
     with pytest.raises(Exception):
         disc.step(np.full(4, disc.single_action_space.n))
     disc.close()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_adapter_error_and_time_limit_contract_on_the_stand_in(packed, monkeypatch):
+    """The ordering / error / TimeLimit contract of the NumPy adapter without a device (the same checks run against the HIP
+    engine in tests/test_gpu_vector_env.py): order_enforcing.py:33-37, seeding.py:21-22, cartpole.py:131-132,
+    async_vector_env.py's pending-call errors, time_limit.py:50-54 and tests/wrappers/test_time_limit.py:38-57."""
+    from oracle_engine import FakeHandle, PackedFakeHandle
+
+    import gym_amd
+    from gym_amd import _native, error
+
+    monkeypatch.setattr(_native, "Handle", PackedFakeHandle if packed else FakeHandle)
+    env = gym_amd.make("CartPole-v1", num_envs=8)
+    with pytest.raises(error.ResetNeeded):
+        env.step(np.zeros(8, dtype=np.int64))
+    with pytest.raises(error.Error):
+        env.reset(seed=-1)
+    obs, info = env.reset(seed=0)
+    assert info == {} and obs.shape == (8, 4)
+    with pytest.raises(AssertionError):
+        env.step(np.full(8, 2, dtype=np.int64))
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(8, dtype=np.float32))
+    with pytest.raises(error.NoAsyncCallError):
+        env.step_wait()
+    env.step_async(np.zeros(8, dtype=np.int64))
+    with pytest.raises(error.AlreadyPendingCallError):
+        env.step_async(np.zeros(8, dtype=np.int64))
+    env.step_wait()
+    env.step(np.ones(8, dtype=np.int64))
+    env.close()
+    with pytest.raises(error.ClosedEnvironmentError):
+        env.step(np.ones(8, dtype=np.int64))
+    with pytest.raises(error.UnregisteredEnv):
+        gym_amd.make("LunarLander-v2", num_envs=8)
+    with pytest.raises(TypeError):
+        gym_amd.make("CartPole-v1", num_envs=8, g=1.0)
+    # TimeLimit: truncation every third step; termination and truncation can coincide
+    env = gym_amd.make("CartPole-v1", num_envs=16, max_episode_steps=3)
+    env.reset(seed=0)
+    for k in range(1, 7):
+        _, _, term, trunc, infos = env.step(np.zeros(16, dtype=np.int64))
+        assert np.all(trunc == (k % 3 == 0))
+        if k % 3 == 0:
+            assert infos["_final_observation"].all() and all(o.shape == (4,) for o in infos["final_observation"])
+    st, el = env.handle.get_state()
+    st[0, :], st[1, :], el[:] = 2.399, 5.0, 2
+    env.handle.set_state(st, el)
+    _, _, term, trunc, infos = env.step(np.ones(16, dtype=np.int64))
+    assert term.all() and trunc.all() and infos["_final_observation"].all()
+    assert all(abs(o[0]) > 2.4 for o in infos["final_observation"])      # the terminal observation, not the reset one
+    env.close()
