@@ -19,6 +19,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <new>
 #include <string>
 
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
         if (a.actions) {
             act = a.actions[(int64_t)k * a.act_slice + e];
             if (act < 0 || act > 1) {  // `assert self.action_space.contains(action)` (:122)
-                atomicOr(a.err, 1);
+                *reinterpret_cast<volatile int32_t *>(a.err) = 1;  // single-bit code: a plain store (the word may live in pinned host memory)
                 continue;
             }
         } else {
@@ -226,6 +227,10 @@ struct mxv_bj {
     double *st_reward = nullptr;
     uint8_t *st_term = nullptr, *st_trunc = nullptr;
     int8_t *st_cards = nullptr;
+    // small vector envs: the staging arrays are slices of ONE pinned, device-mapped host block (see mxv_tab.hip)
+    char *hm_block = nullptr;
+    int32_t *hm_err = nullptr;
+    bool hostmap = false, err_in_block = false;
     std::string error;
 };
 
@@ -275,7 +280,7 @@ int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t a
     BjArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.actions = actions; a.actions_out = actions_out;
     a.cards = cards; a.obs = obs; a.reward = reward; a.terminated = term; a.truncated = trunc; a.final_obs = final_obs;
-    a.err = h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed;
+    a.err = h->err_in_block ? h->hm_err : h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed;
     a.action_seed = h->action_seed; a.t = h->t; a.max_steps = h->cfg.max_episode_steps; a.K = K;
     a.natural = h->cfg.natural; a.sab = h->cfg.sab; a.slice = slice; a.act_slice = act_slice;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock);
@@ -301,6 +306,25 @@ int bj_do_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int
 int bj_staging(mxv_bj *h) {
     if (h->st_obs) return MXV_OK;
     const size_t n = (size_t)h->cfg.num_envs;
+    {
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t b8 = up(n * 8), b24 = up(3 * n * 8), b1 = up(n), bc = up(n * MXV_BJ_MAX_DRAWS), total = 2 * b8 + 2 * b24 + 2 * b1 + bc + 256;
+        if (total <= (size_t)2 << 20) {
+            BJ_HIP(h, hipHostMalloc((void **)&h->hm_block, total, hipHostMallocDefault));
+            char *p = h->hm_block;
+            h->st_actions = (int64_t *)p; p += b8;
+            h->st_obs = (int64_t *)p; p += b24;
+            h->st_final = (int64_t *)p; p += b24;
+            h->st_reward = (double *)p; p += b8;
+            h->st_term = (uint8_t *)p; p += b1;
+            h->st_trunc = (uint8_t *)p; p += b1;
+            h->st_cards = (int8_t *)p; p += bc;
+            h->hm_err = (int32_t *)p;
+            *h->hm_err = 0;
+            h->hostmap = true;
+            return MXV_OK;
+        }
+    }
     BJ_HIP(h, hipMalloc((void **)&h->st_actions, n * 8));
     BJ_HIP(h, hipMalloc((void **)&h->st_obs, 3 * n * 8));
     BJ_HIP(h, hipMalloc((void **)&h->st_final, 3 * n * 8));
@@ -356,10 +380,16 @@ int mxv_bj_destroy(mxv_bj *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->seeds, h->st_actions, h->st_obs, h->st_final, h->st_reward, h->st_term,
-                    h->st_trunc, h->st_cards};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->seeds};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    if (h->hostmap) {
+        (void)hipHostFree(h->hm_block);
+    } else {
+        void *stage[] = {h->st_actions, h->st_obs, h->st_final, h->st_reward, h->st_term, h->st_trunc, h->st_cards};
+        for (void *p : stage)
+            if (p) (void)hipFree(p);
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MXV_OK;
@@ -411,6 +441,13 @@ int mxv_bj_reset_host(mxv_bj *h, const int8_t *cards_host, int64_t *obs_host) {
     BJ_HIP(h, hipSetDevice(h->cfg.device));
     if (int rc = bj_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
+    if (h->hostmap) {
+        if (cards_host) std::memcpy(h->st_cards, cards_host, n * 4);
+        if (int rc = bj_do_reset(h, nullptr, cards_host ? h->st_cards : nullptr, obs_host ? h->st_obs : nullptr)) return rc;
+        BJ_HIP(h, hipStreamSynchronize(h->stream));
+        if (obs_host) std::memcpy(obs_host, h->st_obs, 3 * n * 8);
+        return MXV_OK;
+    }
     if (cards_host) BJ_HIP(h, hipMemcpyAsync(h->st_cards, cards_host, n * 4, hipMemcpyHostToDevice, h->stream));
     if (int rc = bj_do_reset(h, nullptr, cards_host ? h->st_cards : nullptr, obs_host ? h->st_obs : nullptr)) return rc;
     if (obs_host) BJ_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, 3 * n * 8, hipMemcpyDeviceToHost, h->stream));
@@ -425,6 +462,27 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
     BJ_HIP(h, hipSetDevice(h->cfg.device));
     if (int rc = bj_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
+    if (h->hostmap) {   // one launch + one synchronisation: the kernel reads and writes the pinned block itself
+        std::memcpy(h->st_actions, actions_host, n * 8);
+        if (cards_host) std::memcpy(h->st_cards, cards_host, n * MXV_BJ_MAX_DRAWS);
+        h->err_in_block = true;
+        const int lrc = bj_launch(h, 1, 0, h->st_actions, 0, nullptr, cards_host ? h->st_cards : nullptr, h->st_obs, h->st_reward,
+                                  h->st_term, h->st_trunc, final_obs_host ? h->st_final : nullptr);
+        h->err_in_block = false;
+        if (lrc) return lrc;
+        BJ_HIP(h, hipStreamSynchronize(h->stream));
+        std::memcpy(obs_host, h->st_obs, 3 * n * 8);
+        if (reward_host) std::memcpy(reward_host, h->st_reward, n * 8);
+        if (terminated_host) std::memcpy(terminated_host, h->st_term, n);
+        if (truncated_host) std::memcpy(truncated_host, h->st_trunc, n);
+        if (final_obs_host) std::memcpy(final_obs_host, h->st_final, 3 * n * 8);
+        if (*h->hm_err != 0) {
+            *h->hm_err = 0;
+            h->t -= 1;
+            return bfail(h, MXV_ERR_INVALID_ACTION, "action outside {0, 1} (Discrete(2).contains assert, blackjack.py:122)");
+        }
+        return MXV_OK;
+    }
     BJ_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * 8, hipMemcpyHostToDevice, h->stream));
     if (cards_host) BJ_HIP(h, hipMemcpyAsync(h->st_cards, cards_host, n * MXV_BJ_MAX_DRAWS, hipMemcpyHostToDevice, h->stream));
     if (int rc = bj_launch(h, 1, 0, h->st_actions, 0, nullptr, cards_host ? h->st_cards : nullptr, h->st_obs, h->st_reward,

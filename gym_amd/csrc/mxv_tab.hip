@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
             if (!valid) continue;
             act = a.actions[(int64_t)k * a.act_slice + e];
             if (act < 0 || act >= a.A) {  // `assert self.action_space.contains(a)`-class error: latch, leave the env unstepped
-                atomicOr(a.err, 1);
+                *reinterpret_cast<volatile int32_t *>(a.err) = 1;  // single-bit code: a plain store (the word may live in pinned host memory)
                 continue;
             }
         } else {
@@ -274,6 +274,12 @@ struct mxv_tab {
     int64_t *st_actions = nullptr, *st_obs = nullptr, *st_final = nullptr;
     double *st_reward = nullptr, *st_prob = nullptr, *st_fprob = nullptr, *st_uniforms = nullptr;
     uint8_t *st_term = nullptr, *st_trunc = nullptr, *st_mask = nullptr;
+    // small vector envs (all host-step I/O <= 2 MiB): the staging arrays are slices of ONE pinned, device-mapped host block the
+    // kernel reads and writes over PCIe — a host step is one launch and one synchronisation instead of eight copies (the
+    // latency-bound regime: 8 FrozenLake envs 148 -> ~35 us per step; same scheme as mxv_api.cpp's I/O block)
+    char *hm_block = nullptr;
+    int32_t *hm_err = nullptr;
+    bool hostmap = false, err_in_block = false;
     std::string error;
 };
 
@@ -330,7 +336,7 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const int64_t *actions, int64_t
     a.actions = actions; a.actions_out = actions_out; a.uniforms = uniforms;
     a.obs = obs; a.reward_out = reward; a.terminated = term; a.truncated = trunc; a.prob_out = prob;
     a.final_obs = final_obs; a.final_prob = final_prob;
-    a.err = h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset;
+    a.err = h->err_in_block ? h->hm_err : h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset;
     a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->t;
     a.max_steps = h->cfg.max_episode_steps; a.K = K; a.slice = slice; a.act_slice = act_slice;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
@@ -360,6 +366,26 @@ int tab_do_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
 int tab_ensure_staging(mxv_tab *h) {
     if (h->st_obs) return MXV_OK;
     const size_t n = (size_t)h->cfg.num_envs;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b8 = up(n * 8), b1 = up(n), total = 6 * b8 + up(2 * n * 8) + 3 * b1 + 256;
+    if (total <= (size_t)2 << 20) {
+        TAB_HIP(h, hipHostMalloc((void **)&h->hm_block, total, hipHostMallocDefault));
+        char *p = h->hm_block;
+        h->st_actions = (int64_t *)p; p += b8;
+        h->st_obs = (int64_t *)p; p += b8;
+        h->st_final = (int64_t *)p; p += b8;
+        h->st_reward = (double *)p; p += b8;
+        h->st_prob = (double *)p; p += b8;
+        h->st_fprob = (double *)p; p += b8;
+        h->st_uniforms = (double *)p; p += up(2 * n * 8);
+        h->st_term = (uint8_t *)p; p += b1;
+        h->st_trunc = (uint8_t *)p; p += b1;
+        h->st_mask = (uint8_t *)p; p += b1;
+        h->hm_err = (int32_t *)p;
+        *h->hm_err = 0;
+        h->hostmap = true;
+        return MXV_OK;
+    }
     TAB_HIP(h, hipMalloc((void **)&h->st_actions, n * 8));
     TAB_HIP(h, hipMalloc((void **)&h->st_obs, n * 8));
     TAB_HIP(h, hipMalloc((void **)&h->st_final, n * 8));
@@ -459,10 +485,17 @@ int mxv_tab_destroy(mxv_tab *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->st_actions,
-                    h->st_obs, h->st_final, h->st_reward, h->st_prob, h->st_fprob, h->st_uniforms, h->st_term, h->st_trunc, h->st_mask};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    if (h->hostmap) {
+        (void)hipHostFree(h->hm_block);
+    } else {
+        void *stage[] = {h->st_actions, h->st_obs, h->st_final, h->st_reward, h->st_prob, h->st_fprob, h->st_uniforms, h->st_term,
+                         h->st_trunc, h->st_mask};
+        for (void *p : stage)
+            if (p) (void)hipFree(p);
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MXV_OK;
@@ -531,6 +564,13 @@ int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host) 
     TAB_HIP(h, hipSetDevice(h->cfg.device));
     if (int rc = tab_ensure_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
+    if (h->hostmap) {
+        if (mask_host) std::memcpy(h->st_mask, mask_host, n);
+        if (int rc = tab_do_reset(h, mask_host ? h->st_mask : nullptr, obs_host ? h->st_obs : nullptr)) return rc;
+        TAB_HIP(h, hipStreamSynchronize(h->stream));
+        if (obs_host) std::memcpy(obs_host, h->st_obs, n * 8);
+        return MXV_OK;
+    }
     if (mask_host) TAB_HIP(h, hipMemcpyAsync(h->st_mask, mask_host, n, hipMemcpyHostToDevice, h->stream));
     if (int rc = tab_do_reset(h, mask_host ? h->st_mask : nullptr, obs_host ? h->st_obs : nullptr)) return rc;
     if (obs_host) TAB_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * 8, hipMemcpyDeviceToHost, h->stream));
@@ -546,6 +586,31 @@ int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uni
     TAB_HIP(h, hipSetDevice(h->cfg.device));
     if (int rc = tab_ensure_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
+    if (h->hostmap) {
+        std::memcpy(h->st_actions, actions_host, n * 8);
+        if (uniforms_host) std::memcpy(h->st_uniforms, uniforms_host, 2 * n * 8);
+        h->err_in_block = true;
+        const int lrc = tab_launch(h, 1, 0, h->st_actions, 0, nullptr, uniforms_host ? h->st_uniforms : nullptr, h->st_obs,
+                                   reward_host ? h->st_reward : nullptr, terminated_host ? h->st_term : nullptr,
+                                   truncated_host ? h->st_trunc : nullptr, prob_host ? h->st_prob : nullptr,
+                                   final_obs_host ? h->st_final : nullptr, final_prob_host ? h->st_fprob : nullptr);
+        h->err_in_block = false;
+        if (lrc) return lrc;
+        TAB_HIP(h, hipStreamSynchronize(h->stream));
+        std::memcpy(obs_host, h->st_obs, n * 8);
+        if (reward_host) std::memcpy(reward_host, h->st_reward, n * 8);
+        if (terminated_host) std::memcpy(terminated_host, h->st_term, n);
+        if (truncated_host) std::memcpy(truncated_host, h->st_trunc, n);
+        if (prob_host) std::memcpy(prob_host, h->st_prob, n * 8);
+        if (final_obs_host) std::memcpy(final_obs_host, h->st_final, n * 8);
+        if (final_prob_host) std::memcpy(final_prob_host, h->st_fprob, n * 8);
+        if (*h->hm_err != 0) {
+            *h->hm_err = 0;
+            h->t -= 1;
+            return tfail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains)", h->cfg.num_actions);
+        }
+        return MXV_OK;
+    }
     TAB_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * 8, hipMemcpyHostToDevice, h->stream));
     if (uniforms_host) TAB_HIP(h, hipMemcpyAsync(h->st_uniforms, uniforms_host, 2 * n * 8, hipMemcpyHostToDevice, h->stream));
     if (int rc = tab_launch(h, 1, 0, h->st_actions, 0, nullptr, uniforms_host ? h->st_uniforms : nullptr, h->st_obs,
