@@ -220,7 +220,7 @@ class ShardedRollout:
         cur = snap[self._cur]
         if self.comm == "mxv":
             self.engine.handle.allgather_outputs(*cur["views"], *self._mxv_recv)
-            self._pending = "mxv"
+            self._pending = ("mxv", self._cur)
         else:
             with self._stream_ctx():               # the collective is ordered after the engine's stream (where the snapshot was written)
                 if self.world_size == 1 and not self._force_collective:
@@ -229,7 +229,9 @@ class ShardedRollout:
                 else:
                     self._works[self._cur] = dist.all_gather_into_tensor(self._recv.view(-1), cur["send"], group=self.group,
                                                                          async_op=True)
-            self._pending = "torch"
+            # the set index travels with the pending gather: a rollout issued between gather_async() and wait_gather() — the
+            # documented overlap pattern — flips _cur to the other set in _arm()
+            self._pending = ("torch", self._cur)
         self._cur_gathered = True
         self._cur_written = False
 
@@ -238,12 +240,13 @@ class ShardedRollout:
         truncated), or None.  Orders the engine's stream after the gather; valid until the next gather_async()."""
         if self._pending is None:
             return None
-        if self._pending == "mxv":
-            self.engine.handle.allgather_wait(host_sync=False, age=0)
-        elif self._works[self._cur] is not None:
+        kind, idx = self._pending
+        if kind == "mxv":
+            self.engine.handle.allgather_wait(host_sync=False, age=0)   # age counts gathers, not sets: 0 = the last one issued
+        elif self._works[idx] is not None:
             with self._stream_ctx():
-                self._works[self._cur].wait()
-            self._works[self._cur] = None
+                self._works[idx].wait()
+            self._works[idx] = None
         self._pending = None
         return GatheredOutputs(self)
 

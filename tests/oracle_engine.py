@@ -61,6 +61,41 @@ class OracleRollout:
         pass
 
 
+class _SnapshotHandle:
+    """The one hook of the HIP handle ShardedRollout looks for: a second destination for the final tensors of every rollout."""
+
+    def __init__(self):
+        self.views = None
+
+    def set_final_snapshot(self, obs, reward, terminated, truncated):
+        self.views = (obs, reward, terminated, truncated)
+
+
+class OracleRolloutInKernelSnapshot(OracleRollout):
+    """OracleRollout with the HIP engine's in-kernel final snapshot (mxv_set_final_snapshot): every rollout also deposits its
+    last step's outputs into the armed snapshot set, so ShardedRollout runs the two-set / flip-in-_arm control flow it
+    runs on the device — the path where a rollout issued between gather_async() and wait_gather() changes `_cur`."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.handle = _SnapshotHandle()
+
+    def _deposit(self):
+        if self.handle.views is not None:
+            for dst, src in zip(self.handle.views, self._last):
+                dst.copy_(src)
+
+    def rollout(self, K, **kw):
+        out = super().rollout(K, **kw)
+        self._deposit()
+        return out
+
+    def rollout_per_step(self, K, out=None, **kw):
+        res = super().rollout_per_step(K, out=out, **kw)
+        self._deposit()
+        return res
+
+
 class OracleNormBackend:
     """CPU stand-in for gym_amd.normalize.HipNormBackend (same methods, CPU torch tensors), backed by the oracle's
     restatement of the device definition (oracle/normalize.c, split sums/apply form): lets the product's

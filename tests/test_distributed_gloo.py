@@ -64,6 +64,28 @@ def _worker(rank, world, port, case, total, steps, q):
             if rank == 0:
                 q.put({k: [t.numpy().copy() for t in v] for k, v in got.items()})
             mr.close()
+        elif case.startswith("inkernel:"):
+            from gym_amd.distributed import ShardedRollout
+            from oracle_engine import OracleRolloutInKernelSnapshot
+
+            sr = ShardedRollout(case.split(":", 1)[1], total, engine_factory=OracleRolloutInKernelSnapshot, seed=11, action_seed=12)
+            assert sr._in_kernel
+            sr.reset(seed=11)
+            firsts = []
+            for chunk in range(4):                      # gather_async -> rollout -> wait_gather, several times: both sets, both orders
+                sr.rollout(steps)
+                sr.gather_async()
+                pend = sr._pending
+                sr.rollout(steps)                       # flips _cur to the other snapshot set
+                assert sr._cur != pend[1]
+                work = sr._works[pend[1]]
+                got = sr.wait_gather()
+                assert work is None or work.is_completed()   # the gather that was pending has been waited for, not the other set's
+                assert sr._works[pend[1]] is None
+                firsts.append([t.numpy().copy() for t in got])
+            if rank == 0:
+                q.put(firsts)
+            sr.close()
         else:
             from gym_amd.distributed import ShardedRollout
 
@@ -90,6 +112,15 @@ def _run(case, total, steps, world=2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, total, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
+    import time
+
+    deadline = time.time() + 300
+    while q.empty():                      # a worker that died never fills the queue: fail instead of blocking for ever
+        if any(p.exitcode not in (None, 0) for p in procs) or time.time() > deadline:
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"worker exit codes {[p.exitcode for p in procs]} before any result")
+        time.sleep(0.05)
     out = q.get()
     for p in procs:
         p.join(120)
@@ -120,6 +151,18 @@ def test_two_rank_sharding_equals_single_rank(env_id):
         for g, r in zip(got, ref):
             assert np.array_equal(g, r)  # global-index Philox streams: sharding is invisible in the results
     assert last[2].sum() + last[3].sum() >= 0 and not np.array_equal(first[0], last[0])
+
+
+def test_gather_async_then_rollout_then_wait_gather_waits_for_the_pending_gather():
+    """The documented overlap pattern on the in-kernel-snapshot path (what the HIP engine runs at world size > 1): the rollout
+    issued between gather_async() and wait_gather() flips the snapshot set; wait_gather must still wait for (and return) the
+    gather that was pending — the results are the odd chunks' finals of the unsharded run."""
+    total, steps = 128, 7
+    firsts = _run("inkernel:CartPole-v1", total, steps)
+    refs = _single("CartPole-v1", total, [steps] * 8, 11, 12)
+    for i, got in enumerate(firsts):
+        for g, r in zip(got, refs[2 * i]):
+            assert np.array_equal(g, r)
 
 
 def test_mixed_batch_two_ranks():
