@@ -48,6 +48,7 @@ EXPORTS = (
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_set_stream",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
+    "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error",
 )
 
 
@@ -93,6 +94,27 @@ class MxvBjConfig(C.Structure):
 
 
 BJ_MAX_DRAWS = 24
+PLACED_CHUNK_BYTES = 256 << 20
+PLACED_MIN_BYTES = 2 << 30
+PLACED_PLAIN, PLACED_WIDE_SEARCH = 1, 2
+
+
+class MxvPlacedInfo(C.Structure):
+    _fields_ = [
+        ("placed", C.c_int32),
+        ("balanced", C.c_int32),
+        ("chunks_created", C.c_int32),
+        ("chunks_kept", C.c_int32),
+        ("class_chunks", C.c_int32 * 2),
+        ("group0_class", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("same_class_us", C.c_double),
+        ("different_class_us", C.c_double),
+        ("seconds", C.c_double),
+        ("requested_bytes", C.c_size_t),
+        ("held_bytes", C.c_size_t),
+        ("peak_bytes", C.c_size_t),
+    ]
 
 
 class MxvError(RuntimeError):
@@ -236,6 +258,10 @@ def _load():
         "mxv_bj_get_counters": ([vp, vp, vp], C.c_int),
         "mxv_bj_sync": ([vp], C.c_int),
         "mxv_bj_set_stream": ([vp, vp], C.c_int),
+        "mxv_placed_alloc": ([i32, i32, vp, vp, i32, vp, C.POINTER(vp)], C.c_int),
+        "mxv_placed_free": ([vp], C.c_int),
+        "mxv_placed_info_get": ([vp, C.POINTER(MxvPlacedInfo)], C.c_int),
+        "mxv_placed_last_error": ([vp], C.c_char_p),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the .so does not export a declared symbol
@@ -788,6 +814,66 @@ def write_probe(device, num_envs, K, launches, obs, reward, actions, terminated,
     if rc != OK:
         raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
     return us.value
+
+
+class _PlacedArray:
+    """One tensor of a PlacedMemory as a __cuda_array_interface__ object (what torch.as_tensor turns into a zero-copy tensor;
+    the tensor keeps this object — and through it the whole PlacedMemory — alive)."""
+
+    def __init__(self, owner, ptr, shape, typestr):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class PlacedMemory:
+    """mxv_placed_alloc: device memory for a set of tensors whose long store streams must not share a physical memory class
+    (include/mxv.h "placed device memory").  specs: [(name, shape, numpy dtype, group)], group 0 / 1 = the two sides that are
+    kept apart (observations | rewards + actions), -1 = does not matter.  `pointers[name]` are device addresses;
+    `arrays()` gives __cuda_array_interface__ objects, `tensors(device)` torch tensors sharing the memory.  The memory lives
+    until close() or until the object and every tensor made from it are gone."""
+
+    def __init__(self, device: int, specs, *, flags: int = 0):
+        self.device = int(device)
+        self.specs = [(name, tuple(int(x) for x in shape), np.dtype(dt), int(group)) for name, shape, dt, group in specs]
+        n = len(self.specs)
+        nbytes = (C.c_size_t * n)(*[max(1, int(np.prod(shape)) * dt.itemsize) for _, shape, dt, _ in self.specs])
+        groups = (C.c_int32 * n)(*[g for *_, g in self.specs])
+        ptrs = (C.c_void_p * n)()
+        h = C.c_void_p()
+        rc = lib.mxv_placed_alloc(self.device, n, nbytes, groups, int(flags), ptrs, C.byref(h))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_placed_last_error(None) or b"").decode())
+        self._h = h
+        self.pointers = {name: int(ptrs[i]) for i, (name, *_rest) in enumerate(self.specs)}
+        info = MxvPlacedInfo()
+        lib.mxv_placed_info_get(self._h, C.byref(info))
+        self.info = {"placed": bool(info.placed), "balanced": bool(info.balanced), "chunks_created": info.chunks_created,
+                     "chunks_kept": info.chunks_kept, "class_chunks": [info.class_chunks[0], info.class_chunks[1]],
+                     "group0_class": info.group0_class, "same_class_us": round(info.same_class_us, 3),
+                     "different_class_us": round(info.different_class_us, 3), "seconds": round(info.seconds, 3),
+                     "requested_GiB": round(info.requested_bytes / 2**30, 3), "held_GiB": round(info.held_bytes / 2**30, 3),
+                     "peak_GiB": round(info.peak_bytes / 2**30, 3)}
+
+    def arrays(self) -> dict:
+        return {name: _PlacedArray(self, self.pointers[name], shape, dt.str) for name, shape, dt, _ in self.specs}
+
+    def tensors(self) -> dict:
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        return {name: torch.as_tensor(a, device=dev) for name, a in self.arrays().items()}
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.mxv_placed_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def comm_unique_id() -> bytes:
