@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # also fine: an external launcher is detected through WORLD_SIZE
 
 Workload = BASELINE.json configs[1]: CartPole-v1, num_envs = 2^20 (BASELINE.json's metric: the 2^20 logical envs are
 partitioned over the N GPUs, --scaling strong, the default; --scaling weak keeps 2^20 envs PER GPU), on-device autoreset,
-Philox-sampled actions, inputs/state resident in HBM.  A "step" is one vector step (SyncVectorEnv.step_wait) of
-every env of the job; EVERY step writes its observations, rewards, terminated/truncated flags and the sampled
-actions to its own slice of [chunk][N] trajectory tensors in HBM (nothing is skipped or overwritten in cache).
---mode fused (default) runs a chunk of --chunk steps as ONE kernel launch with the env state in registers;
---mode graph / eager launch the same kernel once per step.  At N > 1 every rank steps its shard of the logical
-envs with no data-path collective; the final obs/reward/terminated/truncated tensors of each --chunk steps are
-all-gathered over RCCL asynchronously (north_star: all-gather only for the final tensors).
+Philox-sampled actions, inputs/state resident in HBM.  A "step" is one vector step (SyncVectorEnv.step_wait,
+gym/vector/sync_vector_env.py:135-169) of every env of the job; EVERY step writes its observations, rewards,
+terminated/truncated flags and the sampled actions to its own slice of [chunk][N] trajectory tensors in HBM (nothing is skipped
+or overwritten in cache).  --mode fused (default) runs a chunk of --chunk steps as ONE kernel launch with the env state in
+registers; --mode graph / eager launch the same kernel once per step.  At N > 1 every rank steps its shard of the logical envs
+with no data-path collective; the final obs/reward/terminated/truncated tensors of each --chunk steps are all-gathered over
+RCCL asynchronously (north_star: all-gather only for the final tensors; the reference's np.stack, gym/vector/utils/numpy_utils.py:49-50).
 
 Timing.  The timed region is --steps vector steps, bracketed by barrier + synchronize.  When that is shorter than
 --min-timed-ms (a 20-step region is 0.12 ms: below the resolution of a host fence and of the clock ramp) the region is
@@ -24,15 +24,23 @@ The launch shape does not depend on --steps: the rollout always advances in --ch
 Rank 0 prints ONE JSON line.  `roofline` prices the step kernel against HBM: achieved = algorithmic bytes per
 launch (see algorithmic_bytes_per_env_step) / average launch duration measured with HIP events on
 the engine's stream over the timed region.  `cpu_baseline` (N=1 only) times the C port of the reference
-(oracle/, kind "port") on one host core over a bounded sample of the same workload.
+(oracle/, kind "port") on the host cores over a bounded sample of the same workload, and carries the reference itself
+(gym.vector.SyncVectorEnv, timed by tools/reference_baseline.py: the committed run, plus a live re-timing where
+/root/reference exists).  `config.work_check` lets a reader hold the timed region against the oracle
+(tests/test_gpu_bench_line.py does).  `variants` (N=1): the other BASELINE.json configs on one GPU and the
+learner-in-the-loop step(actions) path, each with its own roofline.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
-# the host driver supports dmabuf IPC only: RCCL / cross-process device memory needs this before the HIP runtime starts
+# The host driver of this pool supports dmabuf IPC only (task environment: the variable is exported on the GPU boxes; without it RCCL /
+# cross-process device memory fails with `hipIpcGetMemHandle: invalid argument`): set before the HIP runtime starts, never overridden.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,27 +48,28 @@ sys.path.insert(0, ROOT)
 
 ENVS_TOTAL = 1 << 20      # BASELINE.json metric: num_envs = 2^20
 ENV_ID = "CartPole-v1"
-S_DIM, O_DIM = 4, 4
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at the nominal 2.4 GHz
+DIMS = {"CartPole-v1": (4, 4), "Pendulum-v1": (2, 3), "Acrobot-v1": (4, 6), "MountainCar-v0": (2, 2), "MountainCarContinuous-v0": (2, 2)}  # (S, O)
+CHECK_ENVS = 4096         # work_check: the first CHECK_ENVS envs of rank 0's shard
 
 
-def algorithmic_bytes_per_env_step(mode: str, chunk: float) -> float:
-    """SURVEY.md §8(d).  One launch per step (eager/graph): read {state, action, counter} + write {state, obs,
+def algorithmic_bytes_per_env_step(mode: str, chunk: float, env_id: str = ENV_ID) -> float:
+    """SURVEY.md §8(d).  One launch per step (eager/graph/given actions): read {state, action, counter} + write {state, obs,
     reward, 2 flags, counter} at the fp32 contract = 8*S + 4*O + 4 + 4 + 2 + 8 = 66 B for CartPole.  Fused chunk of
     K steps with the state resident in registers: outputs only, 4*O + 4 + 4 + 2, plus the state round trip
     amortised over the chunk, 16*S/K — K being the steps the timed launches REALLY fused (bench passes the measured
     steps per launch, not the --chunk argument)."""
+    S, O = DIMS[env_id]
     if mode == "fused":
-        return 4 * O_DIM + 4 + 4 + 2 + 16.0 * S_DIM / chunk
-    return 8 * S_DIM + 4 * O_DIM + 4 + 4 + 2 + 8
+        return 4 * O + 4 + 4 + 2 + 16.0 * S / chunk
+    return 8 * S + 4 * O + 4 + 4 + 2 + 8
 
 
 def timed_repeats(steps: int, chunk: int, local_envs: int, min_timed_ms: float, mode: str = "fused") -> int:
     """How often the `steps`-step timed region is repeated inside one bracket: a pure function of the arguments (every rank must
     issue the same launches and collectives), from a nominal 6 us per 2^20-env step, rounded up so that repeats * steps is a
     whole number of chunk-step launches (20 steps x 512 = 40 launches of 256)."""
-    import math
-
     nominal_ms_per_step = 6.0e-3 * local_envs / ENVS_TOTAL
     repeats = max(1, math.ceil(min_timed_ms / max(steps * nominal_ms_per_step, 1e-9)))
     if repeats > 1 and mode == "fused":
@@ -69,11 +78,77 @@ def timed_repeats(steps: int, chunk: int, local_envs: int, min_timed_ms: float, 
     return repeats
 
 
+def spinup_steps(spinup_ms: float, chunk: int, local_envs: int) -> int:
+    """Untimed steps before the warm-up (clock ramp), a pure function of the arguments — a whole number of chunks worth about
+    spinup_ms at the nominal 6 us per 2^20-env step — so that the step index of the timed region, and with it
+    config.work_check, is reproducible."""
+    if spinup_ms <= 0:
+        return 0
+    nominal_ms_per_chunk = 6.0e-3 * max(local_envs, 1 << 17) / ENVS_TOTAL * chunk
+    return max(1, math.ceil(spinup_ms / nominal_ms_per_chunk)) * chunk
+
+
+def work_checksum(terminated, truncated, actions):
+    """64-bit checksum of a [K][n] block of flags and discrete actions: sum over (k, i) of (terminated + 2 truncated + 4 action) *
+    ((k * n + i) * 0x9E3779B97F4A7C15 + 1) mod 2^64.  Works on torch tensors (device) and NumPy arrays (the oracle side of
+    tests/test_gpu_bench_line.py) alike: int64 / uint64 arithmetic wraps."""
+    import numpy as np
+
+    if isinstance(terminated, np.ndarray):
+        K, n = terminated.shape
+        v = terminated.astype(np.uint64) + np.uint64(2) * truncated.astype(np.uint64) + np.uint64(4) * actions.astype(np.uint64)
+        idx = np.arange(K * n, dtype=np.uint64).reshape(K, n)
+        with np.errstate(over="ignore"):
+            w = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+            return int((v * w).sum(dtype=np.uint64))
+    import torch
+
+    K, n = terminated.shape
+    v = terminated.to(torch.int64) + 2 * truncated.to(torch.int64) + 4 * actions.to(torch.int64)
+    idx = torch.arange(K * n, dtype=torch.int64, device=terminated.device).reshape(K, n)
+    w = idx * (0x9E3779B97F4A7C15 - (1 << 64)) + 1      # the same constant as a wrapped int64
+    return int((v * w).sum().item()) % (1 << 64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baselines
+# ---------------------------------------------------------------------------------------------------------------------------
+def reference_python_baseline():
+    """The reference itself: gym.vector.SyncVectorEnv(CartPole-v1) under tools/reference_baseline.py.  The committed
+    run (profiles/reference_cpu_baseline.json: build container, host described in the file) is always reported; where the
+    reference tree exists (the build container — not the GPU box) the headline case is re-timed live beside it."""
+    out = {"kind": "reference", "unit": "env-steps/s/core"}
+    path = os.path.join(ROOT, "profiles", "reference_cpu_baseline.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        out.update({"value": j["headline"]["value"], "env_id": j["headline"]["env_id"], "num_envs": j["headline"]["num_envs"],
+                    "source": "profiles/reference_cpu_baseline.json (tools/reference_baseline.py, measured " + j.get("measured_at", "?") + ")",
+                    "host": j.get("host"), "single_core_all_sizes": j["single_core"].get("CartPole-v1"),
+                    "all_cores": j.get("all_cores")})
+    except (OSError, KeyError, ValueError) as e:
+        out.update({"value": None, "source": f"profiles/reference_cpu_baseline.json unreadable: {e}"})
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import reference_baseline as rb
+
+        if rb.reference_available():
+            live = rb.measure(quick=True)
+            out["live"] = {"value": live["headline"]["value"], "host": live["host"],
+                           "what": "re-timed in this process's host (CartPole-v1, n = 64, 1000 steps, best of 1)"}
+        else:
+            out["live"] = None   # no /root/reference here (GPU box): the committed run stands
+    except Exception as e:  # noqa: BLE001
+        out["live"] = {"error": str(e)[:200]}
+    return out
+
+
 def cpu_baseline(sample_steps: int):
     """C port of the reference (oracle/classic_control.c, kind "port") on the host cores, same workload, bounded sample:
     first one thread (2^20 envs x sample_steps steps), then one thread per host core over equal env shards (the port has no
     cross-env dependency, exactly like one SyncVectorEnv process per core for the reference).  `value` is the
-    all-core aggregate, `cores` the threads used; the single-thread rate is reported beside it."""
+    all-core aggregate, `cores` the threads used; the single-thread rate is reported beside it, and so is the Python
+    reference itself (reference_python_baseline)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle.oracle import OracleVecEnv
@@ -108,45 +183,185 @@ def cpu_baseline(sample_steps: int):
         "cores": cores if value >= single else 1,
         "kind": "port",
         "single_core_value": single,
-        "reference_python": {"value": 8.0e4, "unit": "env-steps/s/core", "kind": "reference",
-                             "note": "gym.vector.SyncVectorEnv(CartPole-v1) itself, measured in the build container (BASELINE.md §2); "
-                                     "/root/reference does not exist on the GPU box, so it cannot be re-timed beside this line — the C port "
-                                     "above is the reference's arithmetic without the Python interpreter"},
+        "reference_python": reference_python_baseline(),
         "sample": f"{ENV_ID}, Philox actions + autoreset, gcc -O2 C port of the reference's step loop: 1 thread, 2^20 envs x "
                   f"{sample_steps} steps ({dt1:.1f} s); {cores} threads x {shard} envs x {steps_all} steps ({dt_all:.1f} s incl. "
-                  "thread start-up and resets); the Python reference itself measured 8.0e4 env-steps/s/core (BASELINE.md §2)",
+                  "thread start-up and resets)",
     }
 
 
-def measure_variant(args, ShardedRollout, torch):
-    """Same workload, MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32 outputs; short (a tenth of the headline's steps)."""
-    sr = ShardedRollout(ENV_ID, ENVS_TOTAL, rank=0, world_size=1, device=torch.cuda.current_device(), seed=0,
-                        action_seed=1, reward_f32=True, action_i32=True)
-    eng = sr.engine
-    sr.reset(seed=0)
-    placement = None
-    if args.placement_candidates > 1:
-        traj, placement = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
-    else:
-        traj = eng.trajectory_buffers(args.chunk)
-    launches = max(8, args.steps // args.chunk // 4)
-    t_spin = time.perf_counter()  # same clock-ramp treatment as the headline: --spinup-ms of untimed work first
-    while (time.perf_counter() - t_spin) * 1e3 < max(args.spinup_ms, 1.0):
-        sr.rollout_per_step(args.chunk, mode="fused", out=traj, record_actions=True)
-        sr.synchronize()
+# ---------------------------------------------------------------------------------------------------------------------------
+# secondary measurements (N = 1)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _spin(fn, sync, ms):
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e3 < ms:
+        fn()
+        sync()
+
+
+def warm_until_stable(fn, sync, max_s=4.0, window_s=0.1, tol=0.01, min_s=0.6):
+    """Run fn until its rate has settled: successive windows of window_s agree within tol (and at least min_s have passed), or max_s.
+    A box that has been idle needs more than a second of load before its clocks, and with them the kernel's instruction stream, reach
+    their sustained state (the first process on a fresh box measured 6.4-6.5 us per step after 0.2 s of load, 5.8 after 3 s;
+    profiles/r3d_*).  Returns (seconds, calls)."""
+    t_start = time.perf_counter()
+    prev, calls = None, 0
+    while True:
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < window_s:
+            fn()
+            sync()
+            n += 1
+        calls += n
+        now = time.perf_counter()
+        rate = n / (now - t0)
+        if (prev is not None and abs(rate - prev) <= tol * rate and now - t_start >= min_s) or now - t_start >= max_s:
+            return now - t_start, calls
+        prev = rate
+
+
+def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin_ms=60.0, probe=True, valu_per_env_step=None):
+    """One env kind, fused trajectory launches on one GPU: us per step, env-steps/s, roofline on the algorithmic bytes, the
+    write probe of its own store pattern into the same tensors."""
+    from gym_amd import _native
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout(env_id, envs, seed=0, action_seed=1, reward_f32=compact, action_i32=compact)
+    r.reset(seed=0)
+    traj = r.trajectory_buffers(chunk)
+    placement = getattr(r, "last_placement", None) if sum(t.numel() * t.element_size() for t in traj.values()) >= _native.PLACED_MIN_BYTES else None
+    fn = lambda: r.rollout_per_step(chunk, out=traj)   # noqa: E731
+    _spin(fn, r.stream.synchronize, spin_ms)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(eng.stream)
+    ev0.record(r.stream)
     for _ in range(launches):
-        sr.rollout_per_step(args.chunk, mode="fused", out=traj, record_actions=True)
-    ev1.record(eng.stream)
-    sr.synchronize()
-    ms = ev0.elapsed_time(ev1) / launches
-    sr.close()
-    b = algorithmic_bytes_per_env_step("fused", args.chunk)
-    steps_s = ENVS_TOTAL * args.chunk / (ms * 1e-3)
-    return {"value": steps_s, "unit": "env-steps/s", "us_per_step": ms * 1e3 / args.chunk,
-            "outputs": "float32 rewards, int32 actions (26 real B/env-step)", "roofline_frac": steps_s * b / 1e9 / HBM_PEAK_GBS,
-            "placement_candidates_us_per_step": None if placement is None else placement.get("us_per_step")}
+        fn()
+    ev1.record(r.stream)
+    r.synchronize()
+    us = ev0.elapsed_time(ev1) / launches / chunk * 1e3
+    b = algorithmic_bytes_per_env_step("fused", chunk, env_id)
+    real_b = sum(t[0].numel() * t.element_size() for k, t in traj.items()) / envs
+    out = {"workload": f"{env_id}, num_envs={envs}, fused {chunk}-step launches, "
+                       + ("float32 rewards + int32 actions" if compact else "the reference's output dtypes"),
+           "value": envs / us * 1e6, "unit": "env-steps/s", "us_per_step": us,
+           "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / us / 1e3, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS, "stored_bytes_per_env_step": real_b}}
+    if valu_per_env_step:
+        rate = envs / us * 1e6 * valu_per_env_step / 64.0
+        out["roofline_valu"] = {"bound": "valu", "valu_instructions_per_env_step": valu_per_env_step, "achieved": rate,
+                                "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave64 VALU instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTR_PER_S,
+                                "source": "PMC SQ_INSTS_VALU, profiles/r02g_rooflines.jsonl"}
+    if probe:
+        torch.cuda.synchronize()
+        flags = (_native.FLAG_REWARD_F32 | _native.FLAG_ACTION_I32) if compact else 0
+        p = _native.write_probe_env(r.device.index, r.spec.kind, flags, envs, chunk, 8, traj["obs"], traj["reward"], traj["actions"],
+                                    traj["terminated"], traj["truncated"])
+        out["write_probe"] = {"us_per_step": p, "stored_GBs": real_b * envs / p / 1e3, "kernel_over_probe": us / p}
+    if placement is not None:
+        out["placement"] = placement
+    r.close()
+    del traj
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_mixed(torch, envs_per_segment, chunk, launches=8, spin_ms=60.0):
+    """BASELINE.json configs[4]'s per-GPU share: {CartPole, Pendulum, Acrobot, MountainCar} x envs_per_segment, four streams."""
+    from gym_amd.mixed import DEFAULT_MIX, MixedRollout
+
+    total = envs_per_segment * len(DEFAULT_MIX)
+    mr = MixedRollout(total, rank=0, world_size=1, seed=0, action_seed=1)
+    mr.reset(seed=0)
+    fn = lambda: mr.rollout(chunk)   # noqa: E731
+    _spin(fn, mr.synchronize, spin_ms)
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        fn()
+    mr.synchronize()
+    us = (time.perf_counter() - t0) / launches / chunk * 1e6
+    b = sum(algorithmic_bytes_per_env_step("fused", chunk, e) for e in DEFAULT_MIX) / len(DEFAULT_MIX)
+    mr.close()
+    return {"workload": f"mixed batch {list(DEFAULT_MIX)} x {envs_per_segment} envs each (configs[4]'s share of one of 8 GPUs), one stream per "
+                        f"segment, fused {chunk}-step launches, final tensors only",
+            "value": total / us * 1e6, "unit": "env-steps/s", "us_per_step": us,
+            "roofline": {"bound": "latency (512 single-wave Acrobot workgroups on 1024 SIMDs set the floor, DESIGN.md §4)",
+                         "algorithmic_bytes_per_env_step": b, "achieved": total * b / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": total * b / us / 1e3 / HBM_PEAK_GBS}}
+
+
+def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
+    """The learner-in-the-loop path: DeviceRollout.step(actions) with caller-provided actions, one launch per vector step
+    (gym/vector/sync_vector_env.py:131-169 with a policy in the loop).  halves = 2: the batch as two half-size engines (global env
+    indices unchanged: env_offset) on their own streams, stepped alternately — the double-buffered sampling pattern (the policy
+    works on one half while the other steps) that lets one half's launch overlap the other's tail."""
+    from gym_amd.rollout import DeviceRollout
+
+    n = envs // halves
+    eng = [DeviceRollout(ENV_ID, n, env_offset=i * n, seed=0, action_seed=1, reward_f32=compact, action_i32=compact) for i in range(halves)]
+    acts = []
+    for e in eng:
+        e.reset(seed=0)
+        with torch.cuda.stream(e.stream):
+            acts.append(e.sample_actions().clone())
+        e.synchronize()
+
+    def one():
+        for e, a in zip(eng, acts):
+            with torch.cuda.stream(e.stream):      # the caller works on the engine's stream: no cross-stream wait per step
+                e.step(a, want_final=False)
+
+    _spin(one, lambda: [e.stream.synchronize() for e in eng], 60.0)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in eng]
+    for e, (a0, _) in zip(eng, evs):
+        a0.record(e.stream)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    for e, (_, a1) in zip(eng, evs):
+        a1.record(e.stream)
+    for e in eng:
+        e.synchronize()
+    wall_us = (time.perf_counter() - t0) / steps * 1e6
+    gpu_us = max(a0.elapsed_time(a1) for a0, a1 in evs) / steps * 1e3
+    for e in eng:
+        e.close()
+    b = algorithmic_bytes_per_env_step("given", 1)
+    us = max(wall_us, gpu_us)
+    return {"halves": halves, "dtypes": "float32 rewards, int32 actions" if compact else "float64 rewards, int64 actions (the reference's)",
+            "us_per_step": us, "gpu_us_per_step": gpu_us, "value": envs / us * 1e6, "unit": "env-steps/s",
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / us / 1e3, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS}}
+
+
+def measure_step_kernel(torch, envs, launches=400, compact=False):
+    """The step kernel itself (HIP events around back-to-back launches are dominated by the inter-launch gap, so the kernel time
+    is taken with one event pair PER launch on a few launches and the minimum-gap figure is the loop's)."""
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout(ENV_ID, envs, seed=0, action_seed=1, reward_f32=compact, action_i32=compact)
+    r.reset(seed=0)
+    with torch.cuda.stream(r.stream):
+        a = r.sample_actions().clone()
+        for _ in range(200):
+            r.step(a, want_final=False)
+        r.stream.synchronize()
+        ts = []
+        for _ in range(launches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(r.stream)
+            r.step(a, want_final=False)
+            e1.record(r.stream)
+            ts.append((e0, e1))
+        r.stream.synchronize()
+    us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ts)
+    r.close()
+    med = us[len(us) // 2]
+    b = algorithmic_bytes_per_env_step("given", 1)
+    return {"us_per_launch_median": med, "us_per_launch_min": us[0],
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / med / 1e3, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": envs * b / med / 1e3 / HBM_PEAK_GBS},
+            "note": "event pair around single launches (includes the events' own ~1-2 us); rocprofv3 kernel time in profiles/"}
 
 
 def read_traffic(mode: str, steps_per_launch: float, envs: int, compact: bool):
@@ -173,7 +388,49 @@ def read_traffic(mode: str, steps_per_launch: float, envs: int, compact: bool):
     return None, "no committed PMC pass with this launch shape"
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment as torch.distributed.run would set them), wait, and fail fast and readably if
+    any rank dies or the job exceeds --launch-timeout.  Rank 0 prints the JSON line on the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MXV_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = next((c for c in codes if c), 0)
+            if rc:
+                print(f"bench.py: ranks exited with codes {codes}", file=sys.stderr, flush=True)
+            break
+        bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            why = f"rank {bad[0][0]} exited with code {bad[0][1]}" if bad else f"no result after {args.launch_timeout:.0f} s"
+            print(f"bench.py: {why}; stopping the other ranks", file=sys.stderr, flush=True)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = bad[0][1] if bad else 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20480)
@@ -190,23 +447,37 @@ def main():
                     help="the timed region is repeated back to back until it is nominally at least this long (see docstring)")
     ap.add_argument("--repeats", type=int, default=0, help="force the number of repeats of the timed region (0 = from --min-timed-ms)")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
-                    help="untimed device spin-up before the W warmup steps (DVFS: the GPU needs tens of ms of load to "
-                         "reach its sustained clocks; a 2000-step run is 13 ms); 0 disables; reported in config")
+                    help="nominal length of the untimed device spin-up before the W warmup steps (DVFS: the GPU needs tens of ms of "
+                         "load to reach its sustained clocks); converted to a fixed number of steps; 0 disables; reported in config")
+    ap.add_argument("--warm-max-s", type=float, default=4.0,
+                    help="upper bound of the rate-settling phase that precedes reset(seed=0) (an idle box needs > 1 s of load); 0 disables")
     ap.add_argument("--compact-outputs", action="store_true",
                     help="float32 rewards + int32 actions (MXV_FLAG_REWARD_F32|ACTION_I32: 26 real bytes per env-step "
                          "instead of 34); off by default: the headline keeps the reference's float64 / int64 dtypes")
-    ap.add_argument("--placement-candidates", type=int, default=8,
-                    help="> 1: time that many candidate sets of trajectory tensors before the run and keep the fastest")
+    ap.add_argument("--placement", default="sorted", choices=["sorted", "placed", "tuned", "first"],
+                    help="trajectory tensors: sorted = ordinary allocations sorted by measured HBM class (the product default, "
+                         "DeviceRollout.trajectory_buffers); placed = 256-MiB physical chunks of measured class mapped through the HIP "
+                         "virtual-memory API (mxv_placed_alloc); tuned = round 2's timing of --placement-candidates ordinary sets; "
+                         "first = the first ordinary allocation")
+    ap.add_argument("--placement-candidates", type=int, default=8, help="candidate sets of --placement tuned")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary compact-outputs measurement (N=1 only)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (N=1 only)")
     ap.add_argument("--comm", default="torch", choices=["torch", "mxv"],
                     help="transport of the per-chunk all-gather at N > 1: torch.distributed (packed all_gather_into_tensor) or the C "
                          "ABI's own RCCL collective (mxv_allgather_outputs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1.  nccl (= RCCL) is the product path; gloo exists to exercise the "
                          "multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices)")
-    args = ap.parse_args()
+    ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds the process group / first collective may take")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds a self-launched job may take in total")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -215,24 +486,46 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nnodes=1 "
-                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; gym_amd has no CPU fallback")
+    ndev = torch.cuda.device_count()
     if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()   # debug path: more ranks than GPUs
+        local_rank %= ndev   # debug path: more ranks than GPUs
+    elif local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank} but only {ndev} HIP device(s) are visible "
+                         f"(--gpus {args.gpus} with --backend nccl is one process per GPU; --backend gloo shares devices)")
     torch.cuda.set_device(local_rank)
+    comm_info = {"backend": None}
     if world > 1:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL's kernels run on high-priority streams: a chunk's all-gather gets CUs as soon as rollout waves retire instead of
         # queueing behind the next chunk's (long-running, chip-filling) rollout launch
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        to = datetime.timedelta(seconds=args.init_timeout)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=to)
+            else:
+                dist.init_process_group("gloo", timeout=to)
+            # first collective: how many ranks does the communicator really span?
+            one = torch.ones(1, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(one)
+            ranks_seen = int(one.item())
+        except Exception as e:  # noqa: BLE001
+            raise SystemExit(f"bench.py: rank {rank}/{world}: process group ({args.backend}, {os.environ.get('MASTER_ADDR')}:"
+                             f"{os.environ.get('MASTER_PORT')}) failed within {args.init_timeout:.0f} s: {e}")
+        comm_info = {"backend": args.backend, "ranks_seen": ranks_seen, "transport": args.comm,
+                     "launcher": "bench.py" if os.environ.get("MXV_BENCH_SELF_LAUNCHED") else "external (WORLD_SIZE was set)"}
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+            try:
+                comm_info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                comm_info["rccl_version"] = None
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: the communicator spans {ranks_seen} ranks, expected {world}")
 
     from gym_amd.distributed import ShardedRollout
 
@@ -247,16 +540,25 @@ def main():
     sr.reset(seed=0)
     # [chunk][N] obs / reward / flags / actions, reused every chunk
     placement = None
-    if mode == "fused" and args.placement_candidates > 1:
+    if mode == "fused" and args.placement == "tuned" and args.placement_candidates > 1:
         try:
             traj, placement = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
+            placement["kind"] = "tuned (timing of candidate sets)"
         except (RuntimeError, MemoryError) as e:   # e.g. out of device memory: measure on the first allocation instead
             torch.cuda.empty_cache()
-            traj, placement = eng.trajectory_buffers(args.chunk), {"error": f"placement tuning failed: {e}"[:300]}
+            traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"error": f"placement tuning failed: {e}"[:300]}
+    elif args.placement == "first":
+        traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"kind": "first ordinary allocation"}
     else:
-        traj = eng.trajectory_buffers(args.chunk)
+        big = local_envs * args.chunk * 34 >= (2 << 30)      # below 2 GiB (a 2^17-env shard is latency-bound): ordinary allocations
+        traj = eng.trajectory_buffers(args.chunk, layout=args.placement if big else "separate")
+        placement = dict(getattr(eng, "last_placement", None) or {}) if big else {"kind": "ordinary allocations (set below 2 GiB)"}
+        if big:
+            placement["kind"] = {"sorted": "sorted (ordinary allocations classified with mxv_hbm_pair_probe)",
+                                 "placed": "placed (mxv_placed_alloc)"}[args.placement]
     launches = [0]
     since_gather = [0]
+    issued = [0]
 
     def run(steps, gather=True):
         """`steps` vector steps as chunk-step launches; at N > 1 the final tensors are all-gathered (asynchronously, overlapping
@@ -267,6 +569,7 @@ def main():
             sr.rollout_per_step(k, mode=mode, out=traj, record_actions=True)
             launches[0] += 1 if mode == "fused" else k
             done += k
+            issued[0] += k
             since_gather[0] += k
             if world > 1 and gather and since_gather[0] >= args.chunk:
                 sr.gather_async()
@@ -278,18 +581,19 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # device spin-up: same workload, untimed, until --spinup-ms of wall time has passed; then W warmup steps
-    # (which also instantiate the hipGraph(s) and RCCL communicators used in the timed region)
-    # The spin-up is time-based, so its iteration count differs between ranks: it must not contain a collective (every rank
-    # has to issue the same sequence of them) — the all-gathers start with the warm-up, whose step count is fixed.
-    spin_steps = 0
-    if args.spinup_ms > 0:
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            run(args.chunk, gather=False)
-            sr.synchronize()
-            spin_steps += args.chunk
-    fence()   # ranks leave placement tuning and spin-up at different times
+    # Clock state first: the same workload until its rate has settled (time-based, so rank-dependent: no collective inside), THEN
+    # reset(seed=0) — which restarts the step index and every env's reset stream — so that everything from here on is a pure
+    # function of the arguments and config.work_check is reproducible.
+    warm_s, warm_calls = (0.0, 0)
+    if args.warm_max_s > 0:
+        warm_s, warm_calls = warm_until_stable(lambda: sr.rollout_per_step(args.chunk, mode=mode, out=traj, record_actions=True),
+                                               sr.synchronize, max_s=args.warm_max_s)
+    sr.reset(seed=0)
+    # device spin-up: a fixed number of untimed steps; then W warmup steps, which also instantiate the hipGraph(s) and RCCL communicators
+    # used in the timed region
+    spin = spinup_steps(args.spinup_ms, args.chunk, local_envs)
+    run(spin, gather=False)
+    fence()   # ranks leave placement and spin-up at different times
     since_gather[0] = 0
     run(max(args.warmup, 1))
     if world > 1:
@@ -311,15 +615,44 @@ def main():
     if world > 1:
         sr.wait_gather()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
 
     launch_ms = ev0.elapsed_time(ev1) / launches[0]  # avg step-kernel launch duration on the engine's stream
     steps_per_launch = timed_steps / launches[0]
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device="cuda")
+    per_rank = [{"rank": rank, "device": local_rank, "kernel_us_per_step": launch_ms * 1e3 / steps_per_launch,
+                 "timed_region_ms": elapsed_local * 1e3,
+                 "placement": {k: placement.get(k) for k in ("kind", "balanced", "candidates", "parked_GiB", "chunks_created", "class_chunks",
+                                                             "seconds", "peak_GiB", "jumped_GiB", "chosen_us_per_step", "error") if k in placement}}]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if args.backend == "gloo":
+            tc = t.cpu()
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            t = tc
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     elapsed = float(t.item())
 
+    # what the timed region computed, in a form the oracle can reproduce (tests/test_gpu_bench_line.py): the last launch's flags and
+    # actions of the first CHECK_ENVS envs, and how many env-steps of that launch ended an episode
+    work_check = None
+    if rank == 0 and mode == "fused":
+        k_last = args.chunk if timed_steps % args.chunk == 0 else timed_steps % args.chunk
+        with torch.cuda.stream(eng.stream):
+            term, trunc, act = traj["terminated"][:k_last], traj["truncated"][:k_last], traj["actions"][:k_last]
+            ended = int(((term | trunc) != 0).sum().item())
+            c = min(CHECK_ENVS, local_envs)
+            work_check = {"what": "last launch of the timed region; checksum = bench.work_checksum(terminated, truncated, actions) over "
+                                  f"its {k_last} steps x the first {c} envs",
+                          "first_step_index": issued[0] - k_last, "steps": k_last, "envs": c,
+                          "checksum": work_checksum(term[:, :c], trunc[:, :c], act[:, :c]) if eng.NA > 0 else None,
+                          "autoresets_per_env_step": ended / float(k_last * local_envs),
+                          "seed": 0, "action_seed": 1}
+
+    out = None
     if rank == 0:
         value = total_envs * timed_steps / elapsed
         b_env_step = algorithmic_bytes_per_env_step(mode, steps_per_launch)
@@ -353,10 +686,15 @@ def main():
                            + (" (float32 rewards, int32 actions)" if args.compact_outputs else
                               " (float64 rewards, int64 actions: the reference's dtypes)"),
                 "chunk": args.chunk,
-                "placement": placement if placement is not None else "first allocation (no placement tuning)",
-                "spinup": f"{spin_steps} untimed steps ({args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps (clock ramp)",
+                "placement": placement,
+                "spinup": f"{warm_s:.2f} s of the workload until its rate settled ({warm_calls} launches; before reset(seed=0)), then {spin} "
+                          f"untimed steps (nominally {args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps",
                 "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.chunk} steps "
                                                         f"({args.comm} transport)" if world > 1 else ""),
+                "ranks_seen": comm_info.get("ranks_seen", 1),
+                "comm": comm_info,
+                "per_rank": per_rank,
+                "work_check": work_check,
             },
             "roofline": {
                 "bound": "hbm",
@@ -375,9 +713,8 @@ def main():
             },
         }
         if mode == "fused" and not args.compact_outputs and local_envs % 1024 == 0:
-            # what THIS box sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
-            # the very tensors the timed region wrote: boxes of this pool differ by 20 % here, so the kernel's time
-            # is printed next to the box's own ceiling for it
+            # what THIS placement sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
+            # the very tensors the timed region wrote
             from gym_amd import _native
             torch.cuda.synchronize()
             probe_us = _native.write_probe(local_rank, local_envs, args.chunk, 20, traj["obs"], traj["reward"], traj["actions"],
@@ -388,15 +725,33 @@ def main():
                 "us_per_step": probe_us, "real_GBs": real_b / probe_us / 1e3,
                 "kernel_us_per_step": launch_ms * 1e3 / steps_per_launch,
                 "kernel_over_probe": launch_ms * 1e3 / steps_per_launch / probe_us}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_steps)
 
     sr.close()
+    del traj
+    torch.cuda.empty_cache()
     if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_steps)
         if world == 1 and mode == "fused" and not args.compact_outputs and not args.no_variants:
-            # reported beside the headline, never instead of it: the same workload with the engine's contract-minimal output
-            # dtypes (float32 rewards, int32 actions: SURVEY.md §8d's algorithmic bytes, 26 real B/env-step instead of 34)
-            out["variants"] = {"compact_outputs": measure_variant(args, ShardedRollout, torch)}
+            # reported beside the headline, never instead of it
+            v = {}
+            try:
+                v["compact_outputs"] = measure_fused(torch, ENV_ID, ENVS_TOTAL, args.chunk, compact=True)
+                v["configs2_pendulum"] = measure_fused(torch, "Pendulum-v1", 1 << 19, args.chunk)
+                v["configs2_mountaincar_continuous"] = measure_fused(torch, "MountainCarContinuous-v0", 1 << 19, args.chunk)
+                v["mountaincar"] = measure_fused(torch, "MountainCar-v0", 1 << 19, args.chunk)
+                v["configs3_acrobot_shard"] = measure_fused(torch, "Acrobot-v1", 1 << 19, args.chunk, valu_per_env_step=730)
+                v["configs4_mixed_share"] = measure_mixed(torch, 1 << 15, args.chunk)
+                v["step_loop"] = {
+                    "what": "DeviceRollout.step(actions): one launch per vector step with caller-provided actions, 2^20 envs "
+                            "(learner-in-the-loop; 66 algorithmic B per env-step)",
+                    "one_engine": measure_step_loop(torch, ENVS_TOTAL),
+                    "one_engine_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True),
+                    "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
+                    "kernel": measure_step_kernel(torch, ENVS_TOTAL)}
+            except Exception as e:  # noqa: BLE001   a failing secondary measurement must not cost the headline
+                v["error"] = f"{type(e).__name__}: {e}"[:400]
+            out["variants"] = v
         print(json.dumps(out), flush=True)
 
     if world > 1:

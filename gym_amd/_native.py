@@ -38,7 +38,7 @@ EXPORTS = (
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
-    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_host_alloc", "mxv_host_free",
+    "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_write_probe_env", "mxv_host_alloc", "mxv_host_free",
                 "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream", "mxv_staging_view",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_apply",
@@ -48,7 +48,7 @@ EXPORTS = (
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_set_stream",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
-    "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error",
+    "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error", "mxv_hbm_pair_probe",
 )
 
 
@@ -96,7 +96,7 @@ class MxvBjConfig(C.Structure):
 BJ_MAX_DRAWS = 24
 PLACED_CHUNK_BYTES = 256 << 20
 PLACED_MIN_BYTES = 2 << 30
-PLACED_PLAIN, PLACED_WIDE_SEARCH = 1, 2
+PLACED_PLAIN, PLACED_NO_JUMP = 1, 2
 
 
 class MxvPlacedInfo(C.Structure):
@@ -105,15 +105,18 @@ class MxvPlacedInfo(C.Structure):
         ("balanced", C.c_int32),
         ("chunks_created", C.c_int32),
         ("chunks_kept", C.c_int32),
-        ("class_chunks", C.c_int32 * 2),
-        ("group0_class", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("classes_seen", C.c_int32),
+        ("class_chunks", C.c_int32 * 4),
+        ("solo_group", C.c_int32),
+        ("solo_class", C.c_int32),
+        ("stop_reason", C.c_int32),
         ("same_class_us", C.c_double),
         ("different_class_us", C.c_double),
         ("seconds", C.c_double),
         ("requested_bytes", C.c_size_t),
         ("held_bytes", C.c_size_t),
         ("peak_bytes", C.c_size_t),
+        ("jumped_bytes", C.c_size_t),
     ]
 
 
@@ -184,6 +187,7 @@ def _load():
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
         "mxv_write_probe": ([C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
+        "mxv_write_probe_env": ([C.c_int32, C.c_int32, C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
         "mxv_wait_stream": ([vp, vp], C.c_int),
         "mxv_staging_view": ([vp] + [C.POINTER(vp)] * 4, C.c_int),
         "mxv_host_alloc": ([C.c_size_t, C.POINTER(vp)], C.c_int),
@@ -260,6 +264,7 @@ def _load():
         "mxv_bj_set_stream": ([vp, vp], C.c_int),
         "mxv_placed_alloc": ([i32, i32, vp, vp, i32, vp, C.POINTER(vp)], C.c_int),
         "mxv_placed_free": ([vp], C.c_int),
+        "mxv_hbm_pair_probe": ([i32, vp, vp, i32, C.POINTER(C.c_double)], C.c_int),
         "mxv_placed_info_get": ([vp, C.POINTER(MxvPlacedInfo)], C.c_int),
         "mxv_placed_last_error": ([vp], C.c_char_p),
     }
@@ -816,6 +821,16 @@ def write_probe(device, num_envs, K, launches, obs, reward, actions, terminated,
     return us.value
 
 
+def hbm_pair_probe(device: int, wide_ptr: int, narrow_ptr: int, launches: int = 4) -> float:
+    """mxv_hbm_pair_probe: us per step of a 16-B/lane store stream over 256 MiB at wide_ptr running next to an 8-B/lane stream over
+    128 MiB at narrow_ptr — ~10 % faster when the two lie in different HBM classes (include/mxv.h).  Contents are destroyed."""
+    us = C.c_double()
+    rc = lib.mxv_hbm_pair_probe(int(device), C.c_void_p(int(wide_ptr)), C.c_void_p(int(narrow_ptr)), int(launches), C.byref(us))
+    if rc != OK:
+        raise MxvError(rc, (lib.mxv_placed_last_error(None) or b"").decode())
+    return us.value
+
+
 class _PlacedArray:
     """One tensor of a PlacedMemory as a __cuda_array_interface__ object (what torch.as_tensor turns into a zero-copy tensor;
     the tensor keeps this object — and through it the whole PlacedMemory — alive)."""
@@ -849,11 +864,13 @@ class PlacedMemory:
         info = MxvPlacedInfo()
         lib.mxv_placed_info_get(self._h, C.byref(info))
         self.info = {"placed": bool(info.placed), "balanced": bool(info.balanced), "chunks_created": info.chunks_created,
-                     "chunks_kept": info.chunks_kept, "class_chunks": [info.class_chunks[0], info.class_chunks[1]],
-                     "group0_class": info.group0_class, "same_class_us": round(info.same_class_us, 3),
+                     "chunks_kept": info.chunks_kept, "classes_seen": info.classes_seen, "class_chunks": list(info.class_chunks),
+                     "solo_group": info.solo_group, "solo_class": info.solo_class,
+                     "stop_reason": ["balanced", "chunk cap", "jump budget", "spacer allocation failed", "chunk allocation failed"][info.stop_reason],
+                     "note": (lib.mxv_placed_last_error(self._h) or b"").decode(), "same_class_us": round(info.same_class_us, 3),
                      "different_class_us": round(info.different_class_us, 3), "seconds": round(info.seconds, 3),
                      "requested_GiB": round(info.requested_bytes / 2**30, 3), "held_GiB": round(info.held_bytes / 2**30, 3),
-                     "peak_GiB": round(info.peak_bytes / 2**30, 3)}
+                     "peak_GiB": round(info.peak_bytes / 2**30, 3), "jumped_GiB": round(info.jumped_bytes / 2**30, 3)}
 
     def arrays(self) -> dict:
         return {name: _PlacedArray(self, self.pointers[name], shape, dt.str) for name, shape, dt, _ in self.specs}
@@ -874,6 +891,16 @@ class PlacedMemory:
             self.close()
         except Exception:
             pass
+
+
+def write_probe_env(device, env_kind, flags, num_envs, K, launches, obs, reward, actions, terminated, truncated) -> float:
+    """mxv_write_probe_env: the store pattern of env kind `env_kind`'s fused rollout (its observation width, envs per lane, dtypes)."""
+    us = C.c_double()
+    rc = lib.mxv_write_probe_env(int(device), int(env_kind), int(flags), int(num_envs), int(K), int(launches), _ptr(obs), _ptr(reward),
+                                 _ptr(actions), _ptr(terminated), _ptr(truncated), C.byref(us))
+    if rc != OK:
+        raise MxvError(rc, (lib.mxv_last_error(None) or b"").decode())
+    return us.value
 
 
 def comm_unique_id() -> bytes:

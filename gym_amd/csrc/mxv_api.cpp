@@ -1055,6 +1055,34 @@ int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launche
     return MXV_OK;
 }
 
+int mxv_write_probe_env(int32_t device, int32_t env_id, int32_t flags, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev,
+                        void *reward_dev, void *actions_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step) {
+    if (!obs_dev || !reward_dev || !actions_dev || !terminated_dev || !truncated_dev || !us_per_step || K < 1 || launches < 1 || num_envs < 1 ||
+        env_id < 0 || env_id >= MXV_NUM_ENV_KINDS)
+        return fail(nullptr, MXV_ERR_INVALID_ARG, "mxv_write_probe_env: [K][num_envs] buffers of all five outputs and a valid env kind");
+    MXV_HIP(nullptr, hipSetDevice(device));
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    for (int i = 0; i < 2 && err == hipSuccess; ++i)
+        err = launch_write_probe_env(env_id, flags, obs_dev, reward_dev, actions_dev, terminated_dev, truncated_dev, num_envs, K, s);
+    if (err == hipSuccess) err = hipEventRecord(e0, s);
+    for (int i = 0; i < launches && err == hipSuccess; ++i)
+        err = launch_write_probe_env(env_id, flags, obs_dev, reward_dev, actions_dev, terminated_dev, truncated_dev, num_envs, K, s);
+    if (err == hipSuccess) err = hipEventRecord(e1, s);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    if (err != hipSuccess) return fail(nullptr, MXV_ERR_HIP, "mxv_write_probe_env: %s", hipGetErrorString(err));
+    *us_per_step = (double)ms * 1e3 / ((double)launches * K);
+    return MXV_OK;
+}
+
 int mxv_final_packed(mxv_handle *h, int32_t enable, int32_t *supported) {
     MXV_CHECK_HANDLE(h);
     if (int rc = use_device(h)) return rc;

@@ -109,10 +109,13 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
 #pragma unroll
     for (int j = 0; j < E; ++j) er[j] = a.ep_acc ? a.ep_acc[valid[j] ? env_of(j) : 0] : 0.0f;
-    // reset ordinals (index of each env's next draw from the reset stream); only the autoreset path needs them
+    // reset ordinals (index of each env's next draw from the reset stream); only the autoreset path needs them.  A one-step launch
+    // (MULTI = false: mxv_step, the learner-in-the-loop call) reads and advances the ordinal inside the reset branch instead, i.e. only in
+    // the few lanes whose env finishes: the dense 4-byte read per env-step of round 2 shrinks to the lines those lanes touch.
+    constexpr bool LAZY_EP = !MULTI;
     uint32_t ep[E], ep_in[E];
 #pragma unroll
-    for (int j = 0; j < E; ++j) ep[j] = ep_in[j] = autoreset ? a.episodes[valid[j] ? env_of(j) : 0] : 0u;
+    for (int j = 0; j < E; ++j) ep[j] = ep_in[j] = (autoreset && !LAZY_EP) ? a.episodes[valid[j] ? env_of(j) : 0] : 0u;
     __shared__ uint32_t sw[CONSEC ? 4 : TILE];
 
     const int nsteps = MULTI ? a.K : 1;  // MULTI = false: the plain step() launch, no loop-carried bookkeeping
@@ -240,6 +243,10 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                         for (int k = 0; k < O; ++k) cur[k] = obs[j][k];
                     }
                 if (a.final_obs != nullptr && v) store_obs<O>(a.final_obs, so + e, cur);  // info["final_observation"]
+                if constexpr (LAZY_EP) {
+                    k_reset = landed(a.episodes[v ? e : 0]);
+                    if (v) a.episodes[e] = k_reset + 1;
+                }
                 const uint64_t seed = a.seeds ? landed(a.seeds[v ? e : 0]) : a.base_seed + a.env0 + (uint64_t)e;
                 const U4 w = episode_reset_words(seed, k_reset);
                 double ns[S], naux[AUXN];
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
                         for (int k = 0; k < O; ++k) obs[j][k] = nobs[k];
                         el[j] = 0;  // time_limit.py:67
-                        ep[j] += 1;
+                        if constexpr (!LAZY_EP) ep[j] += 1;
                         pend[j] = false;
                     }
             }
@@ -1113,6 +1120,60 @@ __global__ void __launch_bounds__(kWave, 4) write_probe_kernel(float4 *obs, doub
 hipError_t launch_write_probe(float *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t n, int K, hipStream_t stream) {
     hipLaunchKernelGGL(write_probe_kernel, dim3((unsigned)(n / 128)), dim3(kWave), 0, stream, reinterpret_cast<float4 *>(obs), rew, act, term,
                        trunc, n, K);
+    return hipGetLastError();
+}
+
+// The same for any env kind: observation rows of O floats, E envs per lane as the fused rollout of that kind runs them, rewards of 8 or
+// 4 bytes, actions of 8 / 4 bytes (int64 / int32 / float32) — the store pattern of rollout_kernel_v3<ENV, ..., OUT != 0>.
+template <int O, int E>
+__global__ void __launch_bounds__(kWave, 4) write_probe_env_kernel(float *obs, void *rew, void *act, uint8_t *term, uint8_t *trunc, int64_t n, int K,
+                                                                   int rew_f32, int act_bytes) {
+    const unsigned tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    float x = (float)lane;
+    for (int k = 0; k < K; ++k) {
+        const int64_t so = (int64_t)k * n;
+        x = x * 1.0001f + 0.5f;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int64_t e = so + (int64_t)tile * (E * kWave) + j * kWave + lane;
+            if (e - so >= n) continue;
+            if (act_bytes == 8)
+                static_cast<int64_t *>(act)[e] = (k + j) & 1;
+            else
+                static_cast<int32_t *>(act)[e] = (k + j) & 1;
+            if (rew_f32)
+                static_cast<float *>(rew)[e] = 1.0f;
+            else
+                static_cast<double *>(rew)[e] = 1.0;
+            term[e] = x > 1e30f;
+            trunc[e] = 0;
+            float o[O];
+#pragma unroll
+            for (int c = 0; c < O; ++c) o[c] = x + (float)(c + j);
+            store_obs<O>(obs, e, o);
+        }
+    }
+}
+
+hipError_t launch_write_probe_env(int env_id, int flags, float *obs, void *rew, void *act, uint8_t *term, uint8_t *trunc, int64_t n, int K,
+                                  hipStream_t stream) {
+    const int rew_f32 = (flags & MXV_FLAG_REWARD_F32) ? 1 : 0;
+    auto go = [&](auto o_tag, auto e_tag, int act_bytes) {
+        constexpr int O = decltype(o_tag)::value, E = decltype(e_tag)::value;
+        const unsigned grid = (unsigned)((n + E * kWave - 1) / (E * kWave));
+        hipLaunchKernelGGL((write_probe_env_kernel<O, E>), dim3(grid), dim3(kWave), 0, stream, obs, rew, act, term, trunc, n, K, rew_f32, act_bytes);
+    };
+    const int disc = (flags & MXV_FLAG_ACTION_I32) ? 4 : 8;
+    using std::integral_constant;
+    switch (env_id) {
+        case MXV_CARTPOLE: go(integral_constant<int, 4>{}, integral_constant<int, rollout_envs_per_lane(MXV_CARTPOLE)>{}, disc); break;
+        case MXV_PENDULUM: go(integral_constant<int, 3>{}, integral_constant<int, rollout_envs_per_lane(MXV_PENDULUM)>{}, 4); break;
+        case MXV_ACROBOT: go(integral_constant<int, 6>{}, integral_constant<int, rollout_envs_per_lane(MXV_ACROBOT)>{}, disc); break;
+        case MXV_MOUNTAINCAR: go(integral_constant<int, 2>{}, integral_constant<int, rollout_envs_per_lane(MXV_MOUNTAINCAR)>{}, disc); break;
+        case MXV_MOUNTAINCAR_CONT: go(integral_constant<int, 2>{}, integral_constant<int, rollout_envs_per_lane(MXV_MOUNTAINCAR_CONT)>{}, 4); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -183,6 +183,8 @@ hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream);
 int64_t compact_chunks(int64_t n);
 hipError_t launch_compact_final(int obs_dim, const CompactArgs &a, hipStream_t stream);
 hipError_t launch_write_probe(float *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t n, int K, hipStream_t stream);
+hipError_t launch_write_probe_env(int env_id, int flags, float *obs, void *rew, void *act, uint8_t *term, uint8_t *trunc, int64_t n, int K,
+                                  hipStream_t stream);
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);
 
 }  // namespace mxv

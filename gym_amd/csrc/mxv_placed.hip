@@ -1,20 +1,24 @@
-// mxv_placed.hip — device memory for trajectory tensors, placed by physical memory class (include/mxv.h: mxv_placed_*).
+// mxv_placed.hip — device memory for trajectory tensors, placed by HBM class (include/mxv.h: mxv_placed_*).
 //
 // Why.  The fused rollout writes every step's outputs as a few long, parallel store streams (CartPole: observations 16 B per env and
 // step, rewards 8 B, actions 8 B, two flag bytes).  On the MI355X a 16-B/lane stream and an 8-B/lane stream written concurrently run
-// 10-12 % slower when the PHYSICAL memory behind them belongs to the same one of two classes of HBM regions — GiB-scale runs of
-// irregular length in physical allocation order — and the whole trajectory launch runs 5.4 / 5.7 / 6.4 us per 2^20-env step when
-// none / one / both of {rewards, actions} share the observations' class (tools/vmm_probe5.hip, vmm_probe7.hip; profiles/r3a_*).
-// That is the "placement lottery" of DESIGN.md §6: hipMalloc'ed tensors land wherever the allocator is, all in one run more often
-// than not.  Nothing in software sees the class of a page — but HIP's virtual-memory API decides which physical memory backs which
-// virtual range, and the class of a chunk can be MEASURED: two concurrent streams, one into the chunk, one into a reference chunk.
+// 10-12 % slower when the PHYSICAL memory behind them belongs to the same CLASS of HBM regions, and the whole trajectory launch runs
+// 5.4 / 5.7 / 6.4 us per 2^20-env step when none / one / both of {rewards, actions} share the observations' class
+// (tools/vmm_probe5.hip, vmm_probe7.hip; profiles/r3a_*).  The classes are three contiguous thirds of the physical address space —
+// 3 x 96 GB, what the three ranks of a 12-high HBM3E stack would give — (tools/vmm_classmap.hip, profiles/r3c_hbm_class_map_whole_device.jsonl):
+// a fresh process is handed the first third for its first ~90 GiB, so ordinary allocations all share a class ("slow box") unless
+// earlier activity has scrambled the driver's free lists ("fast placement").  That is the placement lottery of DESIGN.md §6.  Nothing in
+// software sees the class of a page — but HIP's virtual-memory API decides which physical memory backs which virtual range, and the class
+// of a chunk can be MEASURED: two concurrent streams, one into the chunk, one into a reference chunk of a known class.
 //
 // How.  Physical memory is created in 256-MiB chunks (hipMemCreate); every chunk is mapped at a scratch address of its own and
-// classified against a reference chunk of each class; chunks are created until both classes can serve their groups of tensors
-// (surplus chunks are released: transient memory stays below 2x the request); then every tensor gets a fresh virtual range with
-// chunks of its group's class mapped into it.  Group 0 and group 1 tensors never share a class; group -1 tensors take what is left.
+// classified against one reference chunk per class seen so far; chunks are created until one class can serve the group-0 tensors
+// and the other classes the group-1 tensors.  While only one class has been seen and the caller allows it, the search JUMPS: it
+// parks unmapped spacer allocations (4 GiB each) so that the next chunk comes from further along in physical memory, until a chunk of
+// another class appears.  Spacers and surplus chunks are released before the call returns; every tensor then gets a fresh virtual
+// range with chunks of its group's class(es) mapped into it.
 //
-// Runtime facts this code is written around (ROCm 7.0 / this driver; tools/_bin/vmmdbg2.hip is the test):
+// Runtime facts this code is written around (ROCm 7.0 / this driver; tools/vmm_remap_check.hip is the test):
 //   * a virtual address that has been mapped once keeps translating to the FIRST physical memory it saw, even after hipMemUnmap and
 //     hipMemMap of another handle -> every mapping here uses a fresh address, and no reservation is ever given back
 //     (hipMemAddressFree) so the runtime cannot hand a used address out again; freeing leaks virtual address space only;
@@ -27,6 +31,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <string>
 #include <vector>
@@ -191,6 +196,22 @@ int mxv_placed_free(mxv_placed *p) {
     return MXV_OK;
 }
 
+int mxv_hbm_pair_probe(int32_t device, void *wide_dev, void *narrow_dev, int32_t launches, double *us_per_step) {
+    if (!wide_dev || !narrow_dev || !us_per_step || launches < 1) return pfail(nullptr, MXV_ERR_INVALID_ARG, "mxv_hbm_pair_probe: NULL argument");
+    if (hipSetDevice(device) != hipSuccess) return pfail(nullptr, MXV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    Prober pr;
+    if (hipError_t e = pr.init(device); e != hipSuccess) return pfail(nullptr, MXV_ERR_HIP, "stream / events: %s", hipGetErrorString(e));
+    Chunk w, n;
+    w.scratch = static_cast<char *>(wide_dev);
+    n.scratch = static_cast<char *>(narrow_dev);
+    float us = 0.f;
+    hipError_t e = pr.time_pair(w, n, 2, 1, &us);   // first touch
+    if (e == hipSuccess) e = pr.time_pair(w, n, launches, 3, &us);
+    if (e != hipSuccess) return pfail(nullptr, MXV_ERR_HIP, "mxv_hbm_pair_probe: %s", hipGetErrorString(e));
+    *us_per_step = us;
+    return MXV_OK;
+}
+
 int mxv_placed_info_get(const mxv_placed *p, mxv_placed_info *out) {
     if (!p || !out) return pfail(nullptr, MXV_ERR_INVALID_ARG, "mxv_placed_info_get: NULL argument");
     *out = p->info;
@@ -239,26 +260,27 @@ int mxv_placed_alloc(int32_t device, int32_t count, const size_t *bytes, const i
     Prober pr;
     if (hipError_t e = pr.init(device); e != hipSuccess) return bail(pfail(p, MXV_ERR_HIP, "stream / events: %s", hipGetErrorString(e)));
     const int needed = need[0] + need[1] + need[2];
-    // Transient physical memory: 2x the request — more only while that is still a small part of what the device has free (a run of one
-    // class can be 15 GiB long and cannot be crossed without holding it: the driver hands released blocks straight out again), never
-    // beyond 6x; MXV_PLACED_WIDE_SEARCH allows 6x outright.
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    int cap = 2 * needed;
-    const int roomy = (int)std::min<size_t>((size_t)6 * needed, free_b / 10 / kChunk);
-    cap = std::max(cap, (flags & MXV_PLACED_WIDE_SEARCH) ? 6 * needed : roomy);
+    // Physical memory the search may hold at any moment.  Chunks: twice the request.  Spacers (the jump, MXV_PLACED_NO_JUMP forbids it):
+    // a class is a third of the device (96 GB), so crossing into the next one can take that much — allowed up to half of what is
+    // free right now, never into the last 16 GiB.
+    const int cap = 2 * needed;
+    const size_t kSpacer = (size_t)4 << 30;
+    size_t jump_budget = (flags & MXV_PLACED_NO_JUMP) ? 0 : std::min<size_t>(free_b / 2, (size_t)112 << 30);
+    if (free_b < ((size_t)16 << 30) + (size_t)cap * kChunk) jump_budget = 0;
 #define PL_TIME(w, n, launches, reps, out)                                                                                      \
     do {                                                                                                                        \
         if (hipError_t e_ = pr.time_pair(p->chunks[w], p->chunks[n], launches, reps, out); e_ != hipSuccess)                     \
             return bail(pfail(p, MXV_ERR_HIP, "classification probe: %s", hipGetErrorString(e_)));                               \
     } while (0)
-    // Bootstrap on the first three chunks, timed pairwise.  With two classes at least two of any three chunks share one, so the slowest
-    // pair is a same-class pair; if the fastest pair is clearly faster, its odd member belongs to the other class.  The device is
-    // spun up first and the three timings are repeated until two rounds agree (a cold clock would stretch the early ones).
+    // Bootstrap on the first three chunks, timed pairwise.  Created back to back they come from one neighbourhood: if all three
+    // pairings agree they share a class and (0, 1) is the calibration pair; if one pairing is clearly slower than the fastest, that
+    // pair shares a class and the third chunk opens a second one.  The device is spun up first and the timings are repeated until two
+    // rounds agree (a cold clock stretches the early ones).
     for (int i = 0; i < 3; ++i)
         if (int rc = new_chunk(p, pr)) return bail(rc);
     const float kDiffRatio = 0.955f;   // measured: a different-class pair runs at 0.89-0.91 of the same-class time
-    const float kMargin = 1.03f;
     float t01 = 0, t02 = 0, t12 = 0;
     {
         const auto t0 = std::chrono::steady_clock::now();
@@ -273,96 +295,161 @@ int mxv_placed_alloc(int32_t device, int32_t count, const size_t *bytes, const i
             prev = sum;
         }
     }
-    int ref0 = 0, twin0 = 1, ref1 = -1;   // ref0, twin0: two chunks of class 0 (by definition); ref1: a chunk of class 1 once one is known
+    constexpr int kMaxClasses = 4;
+    std::vector<int> refs;       // one reference chunk per class, class k = refs[k]
+    int cal_a = 0, cal_b = 1;    // two chunks known to share a class: their pairing, timed next to a candidate's, is "what same-class costs now"
     {
         const float hi = std::max(t01, std::max(t02, t12)), lo = std::min(t01, std::min(t02, t12));
         if (lo > kDiffRatio * hi) {   // all three alike
+            refs = {0};
             p->chunks[0].klass = p->chunks[1].klass = p->chunks[2].klass = 0;
-        } else {                      // the slowest pair shares a class, the third chunk has the other
+        } else {                      // the slowest pair shares a class, the third chunk has another
             const int odd = hi == t01 ? 2 : hi == t02 ? 1 : 0;
-            ref0 = odd == 0 ? 1 : 0;
-            twin0 = odd == 2 ? 1 : 2;
-            ref1 = odd;
+            cal_a = odd == 0 ? 1 : 0;
+            cal_b = odd == 2 ? 1 : 2;
+            refs = {cal_a, odd};
             for (int c = 0; c < 3; ++c) p->chunks[c].klass = c == odd ? 1 : 0;
         }
     }
-    float t_same = std::max(t01, std::max(t02, t12)), t_diff = ref1 >= 0 ? std::min(t01, std::min(t02, t12)) : 0.f;
-    auto classify = [&](int c) -> int {   // sets chunks[c].klass (0, 1, or -1 = could not tell); MXV_OK or an error
+    float t_same = std::max(t01, std::max(t02, t12)), t_diff = refs.size() > 1 ? std::min(t01, std::min(t02, t12)) : 0.f;
+    auto classify = [&](int c) -> int {   // sets chunks[c].klass (>= 0, or -1 = could not tell); MXV_OK or an error
         Chunk &ch = p->chunks[c];
         for (int attempt = 0; attempt < 3; ++attempt) {
-            float a = 0.f, b = 0.f;
-            if (ref1 >= 0) {   // a reference of each class, timed back to back: the slower pairing names the class — no absolute threshold
-                PL_TIME(c, ref0, 4, 2, &a);
-                PL_TIME(c, ref1, 4, 2, &b);
-                if (a > kMargin * b) { ch.klass = 0; t_same = 0.9f * t_same + 0.1f * a; t_diff = 0.9f * t_diff + 0.1f * b; return MXV_OK; }
-                if (b > kMargin * a) { ch.klass = 1; t_same = 0.9f * t_same + 0.1f * b; t_diff = 0.9f * t_diff + 0.1f * a; return MXV_OK; }
-            } else {           // only one class seen so far: against a known same-class pair timed right next to it
-                PL_TIME(c, ref0, 4, 2, &a);
-                PL_TIME(twin0, ref0, 4, 2, &b);
-                if (a > kDiffRatio * b) { ch.klass = 0; t_same = b; return MXV_OK; }
-                float a2 = 0.f, b2 = 0.f;   // looks like the other class: confirm before it becomes the reference
-                PL_TIME(c, ref0, 4, 3, &a2);
-                PL_TIME(twin0, ref0, 4, 3, &b2);
-                if (a2 < kDiffRatio * b2) { ch.klass = 1; ref1 = c; t_same = b2; t_diff = a2; return MXV_OK; }
+            float same = 0.f, worst = 0.f, second = 0.f;
+            int worst_k = -1;
+            PL_TIME(cal_a, cal_b, 4, 2, &same);
+            for (int k = 0; k < (int)refs.size(); ++k) {
+                float a = 0.f;
+                PL_TIME(c, refs[k], 4, 2, &a);
+                if (a > worst) { second = worst; worst = a; worst_k = k; } else if (a > second) second = a;
+            }
+            const bool slow = worst > kDiffRatio * same;                              // some pairing costs what a same-class pair costs
+            const bool clear = refs.size() < 2 || second < kDiffRatio * worst + 0.02f * same;   // ... and only one does
+            if (slow && clear) { ch.klass = worst_k; t_same = 0.8f * t_same + 0.2f * worst; return MXV_OK; }
+            if (!slow && worst < 0.94f * same && (int)refs.size() < kMaxClasses) {       // fast against every class seen so far: a new class, confirmed once
+                float again = 0.f, same2 = 0.f;
+                PL_TIME(cal_a, cal_b, 4, 3, &same2);
+                PL_TIME(c, refs[worst_k], 4, 3, &again);
+                if (again < kDiffRatio * same2) { ch.klass = (int)refs.size(); refs.push_back(c); t_diff = again; return MXV_OK; }
             }
         }
         ch.klass = -1;   // e.g. a chunk that straddles a class boundary: only fit for tensors that do not care
         return MXV_OK;
     };
-    // create until one class covers group 0 and the other group 1 (either way round) and the rest covers group -1
-    int have[3] = {0, 0, 0};   // class 0, class 1, undecided
-    for (int c = 0; c < 3; ++c) have[p->chunks[c].klass]++;
-    auto enough = [&](int *cls_of_group0) {
-        for (int a = 0; a < 2; ++a)
-            if (have[a] >= need[0] && have[1 - a] >= need[1] && have[0] + have[1] + have[2] >= needed) { *cls_of_group0 = a; return true; }
+    int have[kMaxClasses + 1] = {0, 0, 0, 0, 0};   // per class; [kMaxClasses] = undecided
+    auto tally = [&](int c) { have[p->chunks[c].klass < 0 ? kMaxClasses : p->chunks[c].klass]++; };
+    for (int c = 0; c < 3; ++c) tally(c);
+    auto live = [&]() { int n = 0; for (int k = 0; k <= kMaxClasses; ++k) n += have[k]; return n; };
+    // one class serves group 0 alone, everything of the other classes serves group 1 — or the other way round
+    auto enough = [&](int *solo_class, int *solo_group) {
+        int decided = 0;
+        for (int k = 0; k < kMaxClasses; ++k) decided += have[k];
+        for (int g = 0; g < 2; ++g)
+            for (int k = 0; k < kMaxClasses; ++k)
+                if (have[k] >= need[g] && decided - have[k] >= need[1 - g] && live() >= needed) { *solo_class = k; *solo_group = g; return true; }
         return false;
     };
-    int cls0 = 0;
-    int peak_live = 3;
-    while (!enough(&cls0)) {
-        if (have[0] + have[1] + have[2] >= cap) break;   // best effort below; the report says so (balanced = 0)
+    int solo_class = 0, solo_group = 0;
+    int peak_live = 3, stop_reason = 0;   // 0 balanced, 1 chunk cap, 2 jump budget, 3 spacer allocation failed, 4 chunk allocation failed
+    size_t spacer_bytes = 0, peak_bytes = 3 * kChunk;
+    std::vector<hipMemGenericAllocationHandle_t> spacers;
+    auto release_spacers = [&]() {
+        for (auto h : spacers) (void)hipMemRelease(h);
+        spacers.clear();
+        spacer_bytes = 0;
+    };
+    while (!enough(&solo_class, &solo_group)) {
+        if (live() >= cap) {
+            // Twice the request and still short of a second class (or of enough of it).  Drop what is surplus of the largest class —
+            // the jump below needs the room, and a class can never need more than the larger group — then jump or give up.
+            int major = 0;
+            for (int k = 1; k < kMaxClasses; ++k) if (have[k] > have[major]) major = k;
+            const int keep = std::max(need[0], need[1]) + need[2];
+            for (int c = (int)p->chunks.size() - 1; c >= 0 && have[major] > keep; --c)
+                if (p->chunks[c].klass == major && c != cal_a && c != cal_b && c != refs[major]) { drop_chunk(p->chunks[c]); have[major]--; }
+            if (live() >= cap) { stop_reason = 1; break; }   // nothing to drop: best effort
+        }
+        const bool one_class_only = live() - have[kMaxClasses] == have[p->chunks[cal_a].klass];
+        if (one_class_only && live() >= std::max(need[0], need[1]) + need[2] + 2) {
+            // Enough of this class for whichever group ends up on it; more of the same is useless.  Jump: park a spacer so that the next
+            // chunk comes from further along in physical memory.
+            if (spacer_bytes + kSpacer > jump_budget) { stop_reason = 2; break; }
+            // (a spacer is 16 allocations of the chunk size, not one of 4 GiB: the driver serves large requests from elsewhere — 112 GiB of
+            //  4-GiB spacers did not move the chunks out of their class, 256-MiB allocations walk through memory in order)
+            bool failed = false;
+            for (size_t b = 0; b < kSpacer && !failed; b += kChunk) {
+                hipMemGenericAllocationHandle_t h;
+                if (hipError_t e = hipMemCreate(&h, kChunk, &pr.prop, 0); e != hipSuccess) {
+                    pfail(p, MXV_ERR_HIP, "spacer hipMemCreate(%zu): %s", kChunk, hipGetErrorString(e));
+                    failed = true;
+                } else {
+                    spacers.push_back(h);
+                    spacer_bytes += kChunk;
+                }
+            }
+            if (failed) { stop_reason = 3; break; }
+        }
         const size_t before = p->chunks.size();
         if (new_chunk(p, pr) != MXV_OK) {   // out of device memory: best effort with what there is
             if (p->chunks.size() > before) drop_chunk(p->chunks.back());
+            stop_reason = 4;
             break;
         }
         const int c = (int)p->chunks.size() - 1;
         if (int rc = classify(c)) return bail(rc);
-        have[p->chunks[c].klass < 0 ? 2 : p->chunks[c].klass]++;
-        peak_live = std::max(peak_live, have[0] + have[1] + have[2]);
+        tally(c);
+        peak_live = std::max(peak_live, live());
+        peak_bytes = std::max(peak_bytes, (size_t)live() * kChunk + spacer_bytes);
+        if (one_class_only && p->chunks[c].klass == p->chunks[cal_a].klass && !spacers.empty()) {
+            drop_chunk(p->chunks[c]);   // a probe chunk between two spacers that is still the old class: not needed, its room is
+            have[p->chunks[cal_a].klass]--;
+        }
     }
-    const bool balanced = enough(&cls0);
-    if (!balanced) cls0 = have[0] >= have[1] ? (need[0] >= need[1] ? 0 : 1) : (need[0] >= need[1] ? 1 : 0);   // the larger group gets the larger class
-    if (have[0] + have[1] + have[2] < needed) return bail(pfail(p, MXV_ERR_HIP, "mxv_placed_alloc: %d chunks of %zu MiB needed, %d available (out of device memory?)", needed, kChunk >> 20, have[0] + have[1] + have[2]));
+    const size_t jumped = spacer_bytes;
+    release_spacers();
+    const bool balanced = enough(&solo_class, &solo_group);
+    while (live() < needed) {   // best effort still serves the whole request
+        if (int rc = new_chunk(p, pr)) return bail(rc);
+        const int c = (int)p->chunks.size() - 1;
+        if (int rc = classify(c)) return bail(rc);
+        tally(c);
+        peak_bytes = std::max(peak_bytes, (size_t)live() * kChunk);
+    }
+    if (!balanced) {   // best effort: the larger group alone on the largest class
+        solo_group = need[0] >= need[1] ? 0 : 1;
+        solo_class = 0;
+        for (int k = 1; k < kMaxClasses; ++k) if (have[k] > have[solo_class]) solo_class = k;
+    }
+    if (live() < needed) return bail(pfail(p, MXV_ERR_HIP, "mxv_placed_alloc: %d chunks of %zu MiB needed, %d available (out of device memory?)", needed, kChunk >> 20, live()));
 
-    // hand out: group 0 from class cls0, group 1 from the other, group -1 from whatever is left (then shortfalls from anything)
-    std::vector<int> by_class[3];   // class 0, class 1, undecided
-    for (int c = 0; c < (int)p->chunks.size(); ++c)
-        if (p->chunks[c].klass >= -1) by_class[p->chunks[c].klass < 0 ? 2 : p->chunks[c].klass].push_back(c);
-    auto take = [&](int want) {   // want: 0 / 1, or 2 = anything, least useful first
-        const int order[3][3] = {{0, 2, 1}, {1, 2, 0}, {2, by_class[0].size() >= by_class[1].size() ? 0 : 1, by_class[0].size() >= by_class[1].size() ? 1 : 0}};
-        for (int k : order[want])
-            if (!by_class[k].empty()) {
-                const int c = by_class[k].front();
-                by_class[k].erase(by_class[k].begin());
-                return c;
-            }
+    // hand out: the solo group from its class; the other group from the other classes (then from anything); group -1 from what nobody wants
+    std::vector<int> pool_solo, pool_other, pool_any;
+    for (int c = 0; c < (int)p->chunks.size(); ++c) {
+        const int k = p->chunks[c].klass;
+        if (k == -2) continue;
+        (k < 0 ? pool_any : k == solo_class ? pool_solo : pool_other).push_back(c);
+    }
+    auto take = [&](std::initializer_list<std::vector<int> *> order) {
+        for (std::vector<int> *v : order)
+            if (!v->empty()) { const int c = v->front(); v->erase(v->begin()); return c; }
         return -1;
     };
     int mismatched = 0;
-    for (int g : {0, 1, -1})
+    for (int pass = 0; pass < 3; ++pass)
         for (Tensor &t : p->tensors) {
+            const int g = pass == 0 ? solo_group : pass == 1 ? 1 - solo_group : -1;
             if (t.group != g) continue;
             for (size_t j = 0; j < t.reserved / kChunk; ++j) {
-                const int want = g == 0 ? cls0 : g == 1 ? 1 - cls0 : 2;
-                const int c = take(want);
+                int c;
+                if (pass == 0) { c = take({&pool_solo, &pool_any, &pool_other}); if (c >= 0 && p->chunks[c].klass != solo_class) mismatched++; }
+                else if (pass == 1) { c = take({&pool_other, &pool_any, &pool_solo}); if (c >= 0 && (p->chunks[c].klass < 0 || p->chunks[c].klass == solo_class)) mismatched++; }
+                else c = take({&pool_any, pool_solo.size() >= pool_other.size() ? &pool_solo : &pool_other, pool_solo.size() >= pool_other.size() ? &pool_other : &pool_solo});
                 if (c < 0) return bail(pfail(p, MXV_ERR_HIP, "mxv_placed_alloc: ran out of chunks"));
-                if (g >= 0 && p->chunks[c].klass != want) mismatched++;
                 t.chunks.push_back(c);
             }
         }
-    for (int k = 0; k < 3; ++k)
-        for (int c : by_class[k]) drop_chunk(p->chunks[c]);   // surplus
+    for (std::vector<int> *v : {&pool_solo, &pool_other, &pool_any})
+        for (int c : *v) drop_chunk(p->chunks[c]);   // surplus
     // final mappings, every one at a fresh address
     for (int i = 0; i < count; ++i) {
         Tensor &t = p->tensors[i];
@@ -386,13 +473,16 @@ int mxv_placed_alloc(int32_t device, int32_t count, const size_t *bytes, const i
     p->info.placed = 1;
     p->info.balanced = balanced && mismatched == 0;
     p->info.chunks_kept = needed;
-    p->info.class_chunks[0] = have[0];
-    p->info.class_chunks[1] = have[1];
-    p->info.group0_class = cls0;
+    p->info.classes_seen = (int32_t)refs.size();
+    for (int k = 0; k < 4; ++k) p->info.class_chunks[k] = have[k];
+    p->info.stop_reason = stop_reason;
+    p->info.solo_group = solo_group;
+    p->info.solo_class = solo_class;
     p->info.same_class_us = t_same;
     p->info.different_class_us = t_diff;
     p->info.held_bytes = (size_t)needed * kChunk;
-    p->info.peak_bytes = (size_t)peak_live * kChunk;
+    p->info.peak_bytes = peak_bytes;
+    p->info.jumped_bytes = jumped;
     p->info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     *out = p;
     return MXV_OK;

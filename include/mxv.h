@@ -471,39 +471,55 @@ int mxv_comm_stream(mxv_handle *h, void **stream);
 int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev, double *reward_dev, int64_t *actions_dev,
                     uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step);
 
+/* The same for any env kind and output dtypes (flags: MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32): observation rows of that kind's width,
+ * envs per lane as its fused rollout runs them, Box actions float32.  mxv_write_probe_env(MXV_CARTPOLE, 0, ...) is mxv_write_probe. */
+int mxv_write_probe_env(int32_t device, int32_t env_id, int32_t flags, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev,
+                        void *reward_dev, void *actions_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step);
+
 /* -- placed device memory for trajectory tensors ------------------------------------------------------------------------------------
  *    The fused rollout's outputs are a few long, parallel store streams.  On the MI355X a 16-byte-per-lane stream (observations) and
  *    an 8-byte-per-lane stream (rewards, actions) written concurrently run 10-12 % slower when the PHYSICAL memory behind them lies in
- *    the same one of two classes of HBM regions (GiB-scale runs in physical allocation order); a whole CartPole trajectory launch runs
- *    5.4 / 5.7 / 6.4 us per 2^20-env step with none / one / both of {rewards, actions} in the observations' class (DESIGN.md §6,
- *    profiles/r3a_*).  hipMalloc'ed tensors land where the allocator happens to be — the "placement lottery" of rounds 1-2.  This call
- *    builds the tensors from 256-MiB physical chunks (hipMemCreate) whose class it MEASURES (two concurrent streams against a
- *    reference chunk of each class) and maps chunks of one class under the group-0 tensors, chunks of the other class under the group-1
- *    tensors (group -1: whatever is left), each tensor contiguous in a fresh virtual range.  Transient physical memory: at most
- *    2x the request — up to 6x only while that is less than a tenth of the device's free memory (a run of one class can be 15+ GiB long
- *    and cannot be crossed without holding it), or with MXV_PLACED_WIDE_SEARCH; surplus chunks are released before the call returns;
- *    0.2-1 s.  If the search ends without enough chunks of both classes the tensors are served best effort (info.balanced = 0).  Sets below MXV_PLACED_MIN_BYTES (2 GiB: a 2^17-env shard of 1 GiB is latency-bound, not write-bound, and ran 4 % faster on ordinary allocations),
- *    sets with an empty group and MXV_PLACED_PLAIN take ordinary hipMalloc allocations (info.placed = 0).
+ *    the same CLASS of HBM regions — the classes are three contiguous thirds of the physical address space (3 x 96 GB: what the three
+ *    ranks of a 12-high HBM3E stack would give; profiles/r3c_hbm_class_map_whole_device.jsonl) —; a whole CartPole trajectory launch
+ *    runs 5.4 / 5.7 / 6.4 us per 2^20-env step with none / one / both of {rewards, actions} in the observations' class (DESIGN.md §6,
+ *    profiles/r3a_*).  A fresh process is handed the first third for its first ~90 GiB, so hipMalloc'ed tensors all share a class unless
+ *    earlier activity scrambled the driver's free lists — the "placement lottery" of rounds 1-2.  This call builds the tensors from
+ *    256-MiB physical chunks (hipMemCreate) whose class it MEASURES (two concurrent streams against a reference chunk of each class
+ *    seen so far) and maps chunks of one class under the tensors of one group and chunks of the other classes under the other group
+ *    (group -1: whatever is left), each tensor contiguous in a fresh virtual range.
+ *    Transient physical memory: chunks up to 2x the request; in addition, while only ONE class has been seen, unmapped spacer
+ *    allocations (4 GiB each) that make the next chunk come from further along in physical memory — up to half of the device's free
+ *    memory (at most 112 GiB; never into the last 16 GiB), released before the call returns; MXV_PLACED_NO_JUMP forbids the spacers
+ *    (then a process that sits deep inside one class gets best effort: info.balanced = 0).  0.2-1.5 s.
+ *    Sets below MXV_PLACED_MIN_BYTES (2 GiB: a 2^17-env shard of 1 GiB is latency-bound, not write-bound, and ran 4 % faster on ordinary
+ *    allocations), sets with an empty group and MXV_PLACED_PLAIN take ordinary hipMalloc allocations (info.placed = 0).
  *    bytes[i] > 0, group[i] in {-1, 0, 1}; ptrs_out[i] receives tensor i's device address (contents uninitialised).  mxv_placed_free
  *    releases the physical memory; the virtual ranges are NOT returned to the runtime (this runtime keeps stale translations for an
  *    address that is mapped a second time), i.e. every call consumes a little virtual address space for the life of the process. */
 typedef struct mxv_placed mxv_placed;
 #define MXV_PLACED_CHUNK_BYTES ((size_t)256 << 20)
 #define MXV_PLACED_MIN_BYTES ((size_t)2 << 30)
-enum { MXV_PLACED_PLAIN = 1, MXV_PLACED_WIDE_SEARCH = 2 };
+enum { MXV_PLACED_PLAIN = 1, MXV_PLACED_NO_JUMP = 2 };
 typedef struct mxv_placed_info {
     int32_t placed;            /* 1: chunks placed by class; 0: ordinary allocations */
-    int32_t balanced;          /* 1: every group-0 chunk is of one class and every group-1 chunk of the other */
+    int32_t balanced;          /* 1: the two groups share no class */
     int32_t chunks_created;    /* physical chunks created (and classified) in total */
     int32_t chunks_kept;
-    int32_t class_chunks[2];   /* chunks seen of class 0 (= the class of the first chunk) and class 1 */
-    int32_t group0_class;
-    int32_t reserved_;
+    int32_t classes_seen;
+    int32_t class_chunks[4];   /* chunks held of each class when the search ended (class 0 = the class of the first chunk) */
+    int32_t solo_group;        /* the group that sits alone on class solo_class; the other group takes the other classes */
+    int32_t solo_class;
+    int32_t stop_reason;       /* why the search ended: 0 balanced, 1 chunk cap, 2 jump budget, 3 spacer allocation failed, 4 chunk allocation failed */
     double same_class_us;      /* the two-stream probe window, us per 2^20-lane step, both streams in one class ... */
     double different_class_us; /* ... and in different classes (0 if never seen) */
     double seconds;            /* wall time of the call */
-    size_t requested_bytes, held_bytes, peak_bytes;
+    size_t requested_bytes, held_bytes, peak_bytes, jumped_bytes; /* peak: chunks + spacers at the worst moment; jumped: spacers */
 } mxv_placed_info;
+/* The measurement underneath: one 16-step window of two concurrent store streams of the rollout's launch shape (2^20 lanes), a 16-B/lane
+ * stream over the 256 MiB at wide_dev and an 8-B/lane stream over the 128 MiB at narrow_dev (contents destroyed), us per step, best of
+ * three timings of `launches` launches.  The same-class time of a box is ~4.2-4.4 us, a different-class pair runs at 0.89-0.91 of it:
+ * compare against a pair known to share a class (two halves of one allocation), timed next to it. */
+int mxv_hbm_pair_probe(int32_t device, void *wide_dev, void *narrow_dev, int32_t launches, double *us_per_step);
 int mxv_placed_alloc(int32_t device, int32_t count, const size_t *bytes, const int32_t *group, int32_t flags, void **ptrs_out,
                      mxv_placed **out);
 int mxv_placed_free(mxv_placed *p);

@@ -65,3 +65,22 @@ def test_config_bench_dist_two_ranks_complete():
     lines = _torchrun(["tools/config_bench_dist.py", "--chunk", "64", "--steps", "256"], env={"MXV_DIST_BACKEND": "gloo"})
     assert [l["config"].split(":")[0] for l in lines] == ["config4", "config5"]
     assert all(l["n_gpus"] == 2 for l in lines) and lines[0]["total_envs"] == 1 << 20 and lines[1]["total_envs"] == 1 << 18
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` exactly as the driver calls it for N = 1 — no torchrun: bench.py spawns the two ranks itself
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them) and the ONE line says how many ranks the
+    communicator spanned and what every rank measured."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "5"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["comm"]["launcher"] == "bench.py" and cfg["comm"]["backend"] == "gloo"
+    assert [r["rank"] for r in cfg["per_rank"]] == [0, 1]
+    assert all(r["kernel_us_per_step"] > 0 and "placement" in r for r in cfg["per_rank"])
+    assert cfg["num_envs_per_gpu"] == 1 << 19 and cfg["repeats"] >= 100
+    assert "cpu_baseline" not in out and "variants" not in out          # N = 1 only

@@ -19,6 +19,8 @@ ap.add_argument("--separate", type=int, default=4)
 ap.add_argument("--preamble", type=float, default=0.0)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--env-id", default="CartPole-v1")
+ap.add_argument("--layout", default="placed", choices=["placed", "sorted", "both"])
+ap.add_argument("--warm-s", type=float, default=0.2, help="seconds of the workload before anything is measured (a cold box needs > 1 s)")
 args = ap.parse_args()
 
 import torch  # noqa: E402
@@ -60,21 +62,30 @@ def probe(traj):
 # clock ramp on a throw-away set
 warm = r.trajectory_buffers(min(K, 64), layout="separate")
 t0 = time.perf_counter()
-while time.perf_counter() - t0 < 0.2:
+while time.perf_counter() - t0 < args.warm_s:
     r.rollout_per_step(min(K, 64), out=warm)
     r.stream.synchronize()
 del warm
 torch.cuda.empty_cache()
 
-t0 = time.perf_counter()
-placed = r.trajectory_buffers(K, layout="placed")
-t_alloc = time.perf_counter() - t0
-out = {"env_id": args.env_id, "envs": args.envs, "K": K, "preamble_GiB": args.preamble, "placement": r.last_placement,
-       "alloc_s": round(t_alloc, 3), "placed_rollout_us": round(timed(placed), 3)}
-p = probe(placed)
-if p is not None:
-    out["placed_probe_us"] = round(p, 3)
-    out["placed_rollout_over_probe"] = round(out["placed_rollout_us"] / p, 3)
+out = {"layout": args.layout, "env_id": args.env_id, "envs": args.envs, "K": K, "preamble_GiB": args.preamble, "warm_s": args.warm_s}
+for lay in (["placed", "sorted"] if args.layout == "both" else [args.layout]):
+    t0 = time.perf_counter()
+    placed = r.trajectory_buffers(K, layout=lay)
+    t_alloc = time.perf_counter() - t0
+    o = {"placement": r.last_placement, "alloc_s": round(t_alloc, 3), "rollout_us": round(timed(placed), 3)}
+    p = probe(placed)
+    if p is not None:
+        o["probe_us"] = round(p, 3)
+        o["rollout_over_probe"] = round(o["rollout_us"] / p, 3)
+    o["rollout_us_again"] = round(timed(placed), 3)
+    if args.layout == "both":
+        out[lay] = o
+        del placed
+        torch.cuda.empty_cache()
+    else:
+        out.update({"placement": o["placement"], "alloc_s": o["alloc_s"], "placed_rollout_us": o["rollout_us"], "placed_probe_us": o.get("probe_us"),
+                    "placed_rollout_over_probe": o.get("rollout_over_probe")})
 sets, sep = [], []
 for i in range(args.separate):
     s = r.trajectory_buffers(K, layout="separate")
@@ -87,7 +98,7 @@ if args.check:
     b = DeviceRollout(args.env_id, 1 << 16, seed=3, action_seed=4)
     a.reset(seed=3)
     b.reset(seed=3)
-    ta = a.trajectory_buffers(K, layout="placed")      # 2^16 x 256 steps x 34 B = 0.57 GiB: above the placement threshold
+    ta = a.trajectory_buffers(K, layout="placed")
     tb = b.trajectory_buffers(K, layout="separate")
     for _ in range(2):
         a.rollout_per_step(K, out=ta)
