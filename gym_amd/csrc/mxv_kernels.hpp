@@ -122,9 +122,18 @@ constexpr int envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_E_ACROBOT
 #define MXV_ROLLOUT_E_ACROBOT 1
 #endif
+#ifndef MXV_ROLLOUT_E_MOUNTAINCAR
+#define MXV_ROLLOUT_E_MOUNTAINCAR MXV_ROLLOUT_E
+#endif
+#ifndef MXV_ROLLOUT_E_MOUNTAINCAR_CONT
+#define MXV_ROLLOUT_E_MOUNTAINCAR_CONT MXV_ROLLOUT_E
+#endif
 constexpr int rollout_envs_per_lane(int env_id) {
     return env_id == MXV_ACROBOT ? MXV_ROLLOUT_E_ACROBOT
-                                 : (env_id == MXV_PENDULUM ? MXV_ROLLOUT_E_PENDULUM : MXV_ROLLOUT_E);
+           : env_id == MXV_PENDULUM ? MXV_ROLLOUT_E_PENDULUM
+           : env_id == MXV_MOUNTAINCAR ? MXV_ROLLOUT_E_MOUNTAINCAR
+           : env_id == MXV_MOUNTAINCAR_CONT ? MXV_ROLLOUT_E_MOUNTAINCAR_CONT
+                                            : MXV_ROLLOUT_E;
 }
 // 1: a lane owns E consecutive envs (lane-private Philox action group); 0: wave-dense striding + LDS exchange.
 #ifndef MXV_CONSEC

@@ -1,0 +1,123 @@
+"""Resource budget of the hot kernels, guarded on the CPU (hipcc cross-compiles gfx950 without a GPU; ~1 minute).
+
+The headline kernel rollout_kernel_v3<CartPole, DEF, E=2, SAFE=false, OUT=1> lives at its 128-VGPR cap (4 waves per SIMD): the few
+values the allocator parks in scratch are stored before and reloaded after the K-step loop.  One more live value would put scratch
+traffic — or an unconditional `s_waitcnt vmcnt(0)`, which on gfx9 also waits for every store in flight — INTO the loop, and the only
+symptom would be a slower bench line.  This test compiles gym_amd/csrc/mxv_kernels.hip with -Rpass-analysis=kernel-resource-usage
+and -save-temps and asserts, for the five trajectory-recording instantiations (one per env kind): the occupancy the launch code
+assumes, VGPR spills no larger than today's, and, from the ISA, no scratch access and no unconditional vmcnt wait inside the
+innermost (Depth=1) loops that contain the per-step stores."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+SRC = os.path.join(ROOT, "gym_amd", "csrc", "mxv_kernels.hip")
+# env kind -> (envs per lane of the full-size launch, occupancy the launch code pins, VGPR-spill bound = today's figure)
+HOT = {0: (2, 4, 24), 1: (1, 4, 0), 2: (1, 4, 0), 3: (2, 4, 8), 4: (2, 4, 18)}
+
+
+@pytest.fixture(scope="module")
+def build():
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    d = tempfile.mkdtemp(prefix="mxv_kres_")
+    try:
+        p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c", SRC,
+                            "-o", os.path.join(d, "k.o"), "-Rpass-analysis=kernel-resource-usage", "-save-temps"], cwd=d, capture_output=True,
+                           text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        asm = [f for f in os.listdir(d) if f.endswith("gfx950.s")]
+        assert asm
+        yield p.stderr, open(os.path.join(d, asm[0])).read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _resources(remarks):
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: [^ ]+ +(Function Name|VGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill|SGPRs Spill|"
+                      r"LDS Size \[bytes/block\]): (\S+)", line)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None:
+            cur[k.split(" [")[0]] = int(v)
+    return out
+
+
+def _symbol(env, e):
+    return f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi1ELb0EEEvNS_8StepArgsE"
+
+
+def _function_body(asm, sym):
+    start = asm.index(f"\n{sym}:")
+    end = asm.index(".end_amdhsa_kernel", start)
+    body = asm[start:end]
+    return body[: body.rindex("s_endpgm")]
+
+
+def _inner_loops(body):
+    """[(header label, text)] of the Depth=1 loops of a function.  The assembly printer annotates every basic block (a `.LBBn_m:` label or a
+    `; %bb.m:` comment, the annotation on that line or the next one) with `in Loop: Header=BBn_m Depth=1` / `Parent Loop BBn_m Depth=1`;
+    a loop's text = its header block plus every block carrying its tag."""
+    blocks, cur = [], []
+    for line in body.splitlines():
+        if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+:)", line) and cur:
+            blocks.append(cur)
+            cur = []
+        cur.append(line)
+    blocks.append(cur)
+    loops = []
+    for i, blk in enumerate(blocks):
+        head = "\n".join(blk[:3])
+        m = re.match(r"\.L(BB\d+_\d+):", blk[0])
+        if not m or not re.search(r"=>This (?:Inner )?Loop Header: Depth=1", head):
+            continue
+        hdr = m.group(1)
+        member = [blk] + [b for b in blocks[i + 1:] if re.search(rf"(Header={hdr} Depth=1|Parent Loop {hdr} Depth=1)", "\n".join(b[:3]))]
+        loops.append((hdr, "\n".join("\n".join(b) for b in member)))
+    return loops
+
+
+def test_hot_rollout_kernels_keep_their_resource_budget(build):
+    remarks, asm = build
+    res = _resources(remarks)
+    assert len(res) >= 100
+    for env, (e, occ, spill_bound) in HOT.items():
+        r = res[_symbol(env, e)]
+        assert r["Occupancy"] == occ, (env, r)
+        assert r["VGPRs"] <= 128, (env, r)
+        assert r["VGPRs Spill"] <= spill_bound, (env, r)          # today's figures; a larger spill is one step from scratch traffic in the loop
+
+
+# Known blemish, kept as an upper bound so that it cannot grow: MountainCarContinuous' loop reloads one spilled 64-bit store address per
+# step (scratch_load + s_waitcnt vmcnt(0) in front of one reward store).  One env per lane removes it and measures within 4 % either way
+# (profiles/r3f_mountaincar_envs_per_lane_ab.txt), so E = 2 stays.
+SCRATCH_IN_LOOP = {0: 0, 1: 0, 2: 0, 3: 0, 4: 1}
+STORE_BLOCKS_WAITING = {0: 0, 1: 0, 2: 0, 3: 0, 4: 1}
+
+
+def test_no_scratch_and_no_unconditional_vmcnt_wait_inside_the_step_loops(build):
+    _, asm = build
+    for env, (e, _, _) in HOT.items():
+        body = _function_body(asm, _symbol(env, e))
+        loops = [(h, t) for h, t in _inner_loops(body) if "global_store" in t]
+        assert loops, f"env {env}: no store loop found"
+        hdr, text = max(loops, key=lambda ht: ht[1].count("global_store"))      # the K-step loop: the one that stores every output
+        assert text.count("global_store") >= 4 * e, (env, hdr)
+        assert text.count("scratch_") <= SCRATCH_IN_LOOP[env], f"env {env}: scratch access inside the K-step loop ({hdr})"
+        # a vmcnt(0) wait may sit in a conditional block that issued a load itself (per-env seeds of explicit seed lists); the blocks
+        # every step runs through — the ones with the stores — must not wait for the stores in flight
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:|; %bb\.\d+:)", text)
+        waiting = [b.splitlines()[0] for b in blocks if "global_store" in b and "global_load" not in b and re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", b)]
+        assert len(waiting) <= STORE_BLOCKS_WAITING[env], f"env {env}: store blocks of the K-step loop wait for vmcnt(0): {waiting}"
