@@ -94,6 +94,7 @@ class MxvBjConfig(C.Structure):
 
 
 BJ_MAX_DRAWS = 24
+SNAPSHOT_FORMAT = 2   # Handle.snapshot(): 2 = per-env reset ordinals (`episodes`) are part of the RNG position
 PLACED_CHUNK_BYTES = 256 << 20
 PLACED_MIN_BYTES = 2 << 30
 PLACED_PLAIN, PLACED_NO_JUMP = 1, 2
@@ -313,6 +314,19 @@ def _ptr(x):
     return x.data_ptr()  # torch tensor
 
 
+def _idle_refcount() -> int:
+    """What sys.getrefcount reports for an object that only a list and a `for` loop variable reference — measured, not assumed: the
+    figure is an implementation detail of the interpreter (3 on CPython 3.10-3.13: list, loop variable, getrefcount's argument; borrowed
+    references change it on newer versions).  The pools below compare against THIS value, taken with the same code shape."""
+    lst = [np.empty(1)]
+    for a in lst:
+        return sys.getrefcount(a)
+    return 3
+
+
+_IDLE_REFS = _idle_refcount()
+
+
 class _ArrayPool:
     """Recycles the host arrays the NumPy adapter returns.  SyncVectorEnv(copy=True) hands the caller a fresh array per call
     (`deepcopy(self.observations)`, gym/vector/sync_vector_env.py:163); allocating one with np.empty means a fresh anonymous
@@ -331,7 +345,7 @@ class _ArrayPool:
         key = (tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape, np.dtype(dtype).str)
         lst = self._free.setdefault(key, [])
         for a in lst:
-            if sys.getrefcount(a) == 3:   # the list, the loop variable, getrefcount's argument: nobody else
+            if sys.getrefcount(a) == _IDLE_REFS:   # the list, the loop variable, getrefcount's argument: nobody else
                 return a
         a = np.empty(shape, dtype=dtype)
         if len(lst) < self._limit:
@@ -368,7 +382,7 @@ class _BlockPool:
 
     def take(self):
         for raw in self._raw:
-            if sys.getrefcount(raw) == 3:   # the list, the loop variable, getrefcount's argument
+            if sys.getrefcount(raw) == _IDLE_REFS:   # the list, the loop variable, getrefcount's argument
                 return raw
         if len(self._raw) >= self._limit:
             return None
@@ -698,7 +712,7 @@ class Handle:
         TimeLimit counters, RNG seeds and counters, physics parameters, running episode returns."""
         state, elapsed = self.get_state()
         t, r = self.get_counters()
-        snap = dict(env_id=self.env_id, num_envs=self.num_envs, max_episode_steps=self.max_episode_steps,
+        snap = dict(format=SNAPSHOT_FORMAT, env_id=self.env_id, num_envs=self.num_envs, max_episode_steps=self.max_episode_steps,
                     env_offset=self.env_offset, flags=self.flags, base_seed=self._base_seed,
                     per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
                     action_seed=self._action_seed, state=state, elapsed=elapsed, t=t, r=r, episodes=self.get_episodes(),
@@ -709,6 +723,13 @@ class Handle:
         return snap
 
     def restore(self, snap: dict):
+        # format 2 (round 2): reset draws are indexed by per-env reset ordinals (`episodes`).  Older snapshots carry no ordinals and
+        # were written under the step-indexed reset stream: they cannot continue bit-identically, and restoring them silently would
+        # replay reset states — refuse with a message instead of a KeyError
+        if snap.get("format", 1) != SNAPSHOT_FORMAT or "episodes" not in snap:
+            raise ValueError(f"snapshot format {snap.get('format', 1)} (this build reads {SNAPSHOT_FORMAT}): written before the reset "
+                             "stream was indexed by per-env reset ordinals; it cannot be continued bit-identically — re-create the env "
+                             "and set_state() from snap['state'] / snap['elapsed'] if an approximate resume is enough")
         for k in ("env_id", "num_envs", "env_offset", "flags", "max_episode_steps"):
             if snap[k] != getattr(self, k):
                 raise ValueError(f"snapshot {k}={snap[k]!r} does not fit this handle ({getattr(self, k)!r})")

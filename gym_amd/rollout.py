@@ -365,7 +365,10 @@ class DeviceRollout:
         for _ in range(2 * len(sets) if mixes is None else mixes):
             if len(sets) < 2:
                 break
-            mix = {k: sets[rng.randrange(len(sets))][k] for k in sets[0]}
+            donors = [t for t, kind in zip(sets, kinds) if kind == "separate"]   # a tensor of a "spread" set pins that set's whole block
+            if len(donors) < 2:
+                break
+            mix = {k: donors[rng.randrange(len(donors))][k] for k in sets[0]}
             us = timed(mix, 1)
             mix_times.append(us)
             if us < best_us:

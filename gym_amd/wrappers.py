@@ -267,20 +267,29 @@ class NormalizeObservation(_StagedIO, _VectorWrapper):
 
     def step(self, action):
         obs, rews, terminateds, truncateds, infos = self.env.step(action)
-        return self.normalize(obs), rews, terminateds, truncateds, infos
+        return self._normalize_last_step(obs), rews, terminateds, truncateds, infos
 
     def reset(self, **kwargs):
         obs, info = self.env.reset(**kwargs)
-        return self.normalize(obs), info
+        return self._normalize_last_step(obs), info
+
+    def _normalize_last_step(self, obs):
+        """step()/reset() only: `obs` is what the base env's host call JUST returned, so the same values still sit where the GPU can
+        read them (mxv_staging_view) and are normalised there instead of being uploaded again.  Anything else goes through
+        normalize(), which works on the array it is given."""
+        if not self._staged:
+            return self.normalize(obs)
+        t = self._torch
+        out = self.__dict__.get("_out_dev")
+        if out is None:
+            out = self._out_dev = t.empty(obs.shape, dtype=t.float64, device=self._dev)
+        self._rn.normalize_obs_at(self._base.handle.staging_view()[0], out)
+        return self._to_host(out, obs.shape, np.float64)
 
     def normalize(self, obs):
+        """The reference's public method (normalize.py:90-93): folds `obs` — the array passed in, whatever it is — into obs_rms and
+        returns it normalised."""
         t = self._torch
-        if self._staged:
-            out = self.__dict__.get("_out_dev")
-            if out is None:
-                out = self._out_dev = t.empty(obs.shape, dtype=t.float64, device=self._dev)
-            self._rn.normalize_obs_at(self._base.handle.staging_view()[0], out)
-            return self._to_host(out, obs.shape, np.float64)
         x = t.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)).to(self._dev)
         return self._rn.normalize_obs(x).cpu().numpy()
 
@@ -320,7 +329,7 @@ class NormalizeReward(_StagedIO, _VectorWrapper):
     def step(self, action):
         obs, rews, terminateds, truncateds, infos = self.env.step(action)
         t = self._torch
-        if self._staged:
+        if self._staged and rews.dtype == np.float64:     # the staged rewards are the handle's reward dtype: float64 only (normalize_rewards_at)
             out = self.__dict__.get("_out_dev")
             if out is None:
                 out = self._out_dev = t.empty(rews.shape, dtype=t.float64, device=self._dev)

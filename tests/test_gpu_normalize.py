@@ -352,3 +352,30 @@ def test_normalize_wrappers_fall_back_when_an_inner_wrapper_altered_the_arrays()
         ow = outer.step(a)[0]
         np.testing.assert_allclose(ow, o2.normalize_obs(o1.normalize_obs(ob).astype(np.float32)), rtol=1e-6, atol=1e-9)
     outer.close(), bare.close()
+
+
+def test_public_normalize_works_on_the_array_it_is_given():
+    """NormalizeObservation.normalize(obs) is a public method of the reference (normalize.py:90-93): called directly — with an array
+    that is NOT the last host step's output — it must fold and return THAT array; only step()/reset() read the staged copy."""
+    import gym_amd
+    from gym_amd.wrappers import NormalizeObservation
+    from oracle.oracle import RunningNorm
+
+    n = 96
+    env = NormalizeObservation(gym_amd.make("CartPole-v1", n))
+    bare = gym_amd.make("CartPole-v1", n)
+    assert env._staged
+    o0, _ = env.reset(seed=5)
+    b0, _ = bare.reset(seed=5)
+    rn = RunningNorm(n, 4, mode=1)
+    np.testing.assert_allclose(o0, rn.normalize_obs(b0), rtol=1e-12, atol=1e-12)
+    other = (np.random.default_rng(0).standard_normal((n, 4)) * 3 + 1).astype(np.float32)     # nothing the env ever produced
+    got = env.normalize(other)
+    np.testing.assert_allclose(got, rn.normalize_obs(other), rtol=1e-12, atol=1e-12)
+    assert got.dtype == np.float64 and abs(got.mean()) < 0.6 and not np.allclose(got, o0)
+    a = np.zeros(n, dtype=np.int64)
+    o1, *_ = env.step(a)
+    b1, *_ = bare.step(a)
+    np.testing.assert_allclose(o1, rn.normalize_obs(b1), rtol=1e-12, atol=1e-12)               # the statistics include `other`
+    env.close()
+    bare.close()

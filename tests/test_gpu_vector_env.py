@@ -597,3 +597,19 @@ def test_large_env_discrete_action_dtypes_and_out_of_range_values(env_id):
             env.step(bad)
         env.step(good)
     env.close()
+
+
+def test_snapshots_carry_a_format_version_and_old_ones_are_refused_with_a_reason():
+    """Handle.snapshot() is versioned: a snapshot written before the reset stream was indexed by per-env reset ordinals (no `episodes`,
+    no `format`) cannot continue bit-identically and is refused with a message, not a KeyError."""
+    from gym_amd import _native
+
+    h = _native.Handle(_native.CARTPOLE, 64, 500, seed=1, action_seed=2)
+    h.reset_host()
+    snap = h.snapshot()
+    assert snap["format"] == _native.SNAPSHOT_FORMAT == 2 and snap["episodes"].shape == (64,)
+    h.restore(snap)
+    old = {k: v for k, v in snap.items() if k not in ("format", "episodes")}
+    with pytest.raises(ValueError, match="snapshot format 1"):
+        h.restore(old)
+    h.close()
