@@ -37,6 +37,19 @@
  *             uniform(low, high) = low + (high-low)*(word+0.5)*2^-32 in fp64, one word per state component.
  * t = index of the vector step since the last mxv_seed().  Streams use GLOBAL env indices: any sharding of one logical vector env
  * over several handles / GPUs draws the same numbers.
+ *
+ * Numerical contract (what "matches the reference" means at this boundary; tests/helpers.py holds the same bars).  On identical
+ * fp64 states and actions, against gym 0.26.2 under NumPy 2.x + glibc:
+ *   * terminated, truncated, elapsed steps, sampled discrete actions and Philox reset states are BIT-EXACT — with one stated
+ *     exception: Acrobot's termination test `-cos(th1) - cos(th2 + th1) > 1.0` (acrobot.py:232-235) within 8 ulps(fp64) (2e-15) of
+ *     the threshold may come out either way (the device's sincos differs from glibc's in the last bit and cos(th2 + th1) is
+ *     rebuilt from the stage values); the reference itself flips there between libm builds.  Probability ~1e-15 per step on a
+ *     trajectory; tests/golden/Acrobot_p1_threshold.npz pins every mask further than 8 ulps from the threshold;
+ *   * observations agree within 2 float32 ulps (inside north_star's fp32 rtol = 1e-5), not bit for bit: the fp64 state agrees to
+ *     rtol 1e-12 and the last fp64 bit of sin/cos can move a float32 rounding;
+ *   * rewards agree to rtol 1e-13 (Pendulum + 1e-9 absolute: the reference's u**2 is libm powf, not correctly rounded);
+ *   * seeded streams do NOT match the reference's: it draws from PCG64, this engine from Philox4x32-10 (north_star); distributions do
+ *     (tests/test_gpu_distributions.py).
  */
 #ifndef MXV_H
 #define MXV_H
