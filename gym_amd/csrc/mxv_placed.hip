@@ -84,6 +84,7 @@ int pfail(mxv_placed *p, int code, const char *fmt, ...);
 
 struct mxv_placed {
     int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> spacers;   // unmapped allocations parked during the search (released before alloc returns)
     std::vector<Chunk> chunks;
     std::vector<Tensor> tensors;
     mxv_placed_info info{};
@@ -189,9 +190,11 @@ int mxv_placed_free(mxv_placed *p) {
     (void)hipDeviceSynchronize();
     for (Tensor &t : p->tensors) {
         if (t.plain) (void)hipFree(t.plain);
+        if (!t.va) continue;   // never mapped (an allocation that failed half-way)
         for (size_t j = 0; j < t.chunks.size(); ++j) (void)hipMemUnmap(t.va + j * kChunk, kChunk);   // exactly as mapped; the range itself is kept (see top)
     }
     for (Chunk &c : p->chunks) drop_chunk(c);
+    for (auto h : p->spacers) (void)hipMemRelease(h);   // only non-empty when an allocation failed half-way
     delete p;
     return MXV_OK;
 }
@@ -352,13 +355,14 @@ int mxv_placed_alloc(int32_t device, int32_t count, const size_t *bytes, const i
     int solo_class = 0, solo_group = 0;
     int peak_live = 3, stop_reason = 0;   // 0 balanced, 1 chunk cap, 2 jump budget, 3 spacer allocation failed, 4 chunk allocation failed
     size_t spacer_bytes = 0, peak_bytes = 3 * kChunk;
-    std::vector<hipMemGenericAllocationHandle_t> spacers;
+    std::vector<hipMemGenericAllocationHandle_t> &spacers = p->spacers;
     auto release_spacers = [&]() {
         for (auto h : spacers) (void)hipMemRelease(h);
         spacers.clear();
         spacer_bytes = 0;
     };
     while (!enough(&solo_class, &solo_group)) {
+        if (p->info.chunks_created >= 8 * needed + 64) { stop_reason = 1; break; }   // released blocks come straight back: never loop on them
         if (live() >= cap) {
             // Twice the request and still short of a second class (or of enough of it).  Drop what is surplus of the largest class —
             // the jump below needs the room, and a class can never need more than the larger group — then jump or give up.
