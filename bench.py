@@ -547,7 +547,7 @@ def main():
         except (RuntimeError, MemoryError) as e:   # e.g. out of device memory: measure on the first allocation instead
             torch.cuda.empty_cache()
             traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"error": f"placement tuning failed: {e}"[:300]}
-    elif args.placement == "first":
+    elif args.placement in ("first", "tuned") or mode != "fused":   # (tuned with < 2 candidates, or a one-launch-per-step mode: nothing to place)
         traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"kind": "first ordinary allocation"}
     else:
         big = local_envs * args.chunk * 34 >= (2 << 30)      # below 2 GiB (a 2^17-env shard is latency-bound): ordinary allocations
