@@ -34,13 +34,42 @@ def _nbytes(shape, dtype) -> int:
     return math.prod(shape) * torch.empty((), dtype=dtype).element_size()
 
 
+class _Device:
+    """What sorted_tensors needs from the device: allocation, the pair probe, free memory.  tests/test_placement_logic.py substitutes a
+    simulated address space with class regions to drive every branch of the search on the CPU."""
+
+    def __init__(self, device, stream):
+        self.dev = torch.device(device)
+        self.stream = stream
+
+    def alloc(self, shape, dtype, zero):
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else torch.cuda.device(self.dev)
+        with ctx:
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+
+    def ptr(self, t) -> int:
+        return t.data_ptr()
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
+    def free_bytes(self) -> int:
+        return torch.cuda.mem_get_info(self.dev)[0]
+
+    def probe(self, wide_ptr: int, narrow_ptr: int) -> float:
+        return _native.hbm_pair_probe(self.dev.index, wide_ptr, narrow_ptr, 4)
+
+    def release(self):
+        torch.cuda.empty_cache()
+
+
 def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups: Dict[str, int], device: torch.device,
-                   stream: Optional[torch.cuda.Stream] = None, budget_bytes: Optional[int] = None):
+                   stream: Optional[torch.cuda.Stream] = None, budget_bytes: Optional[int] = None, _backend=None):
     """specs: [(name, shape, dtype, zero_fill)]; groups: {name: 0 | 1} for the tensors that carry long store streams (the others are
     allocated last, wherever).  Returns ({name: tensor}, report).  report["balanced"]: every group-0 tensor shares the anchor's class
     from end to end and every group-1 tensor lies outside it."""
     t_begin = time.perf_counter()
-    dev = torch.device(device)
+    be = _backend if _backend is not None else _Device(device, stream)
     names = [n for n, *_ in specs]
     spec = {n: (shape, dt, zero) for n, shape, dt, zero in specs}
     nbytes = {n: _nbytes(spec[n][0], spec[n][1]) for n in names}
@@ -49,10 +78,7 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
     report = {"kind": "sorted", "balanced": False, "parked_GiB": 0.0, "candidates": 0, "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
 
     def alloc(name):
-        shape, dt, zero = spec[name]
-        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.device(dev)
-        with ctx:
-            return (torch.zeros if zero else torch.empty)(shape, dtype=dt, device=dev)
+        return be.alloc(*spec[name])
 
     def plain(note):
         report["note"] = note
@@ -63,38 +89,37 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
     anchor_name = max(g0, key=lambda n: nbytes[n])
     if nbytes[anchor_name] < WIDE + NARROW or any(nbytes[n] < NARROW for n in g0 + g1):
         return plain("tensors too small to classify: ordinary allocations")
-    free, _total = torch.cuda.mem_get_info(dev)
-    budget = min(free // 2, 112 << 30) if budget_bytes is None else int(budget_bytes)
+    budget = min(be.free_bytes() // 2, 112 << 30) if budget_bytes is None else int(budget_bytes)
     parked, parked_bytes = [], 0
+    probe = be.probe
 
-    def probe(wide_ptr, narrow_ptr):
-        return _native.hbm_pair_probe(dev.index, wide_ptr, narrow_ptr, 4)
-
-    def park(*tensors):
+    def park(*named):
         nonlocal parked_bytes
-        for t in tensors:
+        for n, t in named:
             parked.append(t)
-            parked_bytes += t.numel() * t.element_size()
+            parked_bytes += nbytes[n]
 
     out, ok = {}, True
     for attempt in range(4):
         # the anchor: one class from end to end (an allocation that straddles a class boundary is parked and replaced)
         anchor = alloc(anchor_name)
         report["candidates"] += 1
-        torch.cuda.synchronize(dev)
-        a0, a1 = anchor.data_ptr(), anchor.data_ptr() + nbytes[anchor_name]
+        be.sync()
+        a0 = be.ptr(anchor)
+        a1 = a0 + nbytes[anchor_name]
         if attempt == 0:
             for _ in range(40):
                 probe(a0, a0 + WIDE)                       # clock ramp + first touch
         same = probe(a0, a0 + WIDE)                        # both streams inside the first 384 MiB of one allocation: a same-class pair
         if probe(a0, a1 - NARROW) <= SAME_RATIO * same and parked_bytes + nbytes[anchor_name] <= budget:
-            park(anchor)
+            park((anchor_name, anchor))
             continue
         report["same_class_us"] = round(same, 3)
 
         def relation(t, n):
             """+1: same class as the anchor at both ends, -1: another class at both ends, 0: mixed."""
-            c0, c1 = t.data_ptr(), t.data_ptr() + nbytes[n]
+            c0 = be.ptr(t)
+            c1 = c0 + nbytes[n]
             cal = probe(a0, a0 + WIDE)
             p0, p1 = probe(a0, c0), probe(a1 - WIDE, c1 - NARROW)
             s0, s1 = p0 > SAME_RATIO * cal, p1 > SAME_RATIO * cal
@@ -109,11 +134,11 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
                 continue
             t = alloc(n)
             report["candidates"] += 1
-            torch.cuda.synchronize(dev)
+            be.sync()
             if relation(t, n) == 1:
                 out[n] = t
             elif parked_bytes + sum(nbytes[m] for m in out) + nbytes[n] <= budget and attempt < 3:
-                park(t, *out.values())                     # a class boundary inside the group: start it again from here
+                park((n, t), *out.items())                 # a class boundary inside the group: start it again from here
                 restart = True
                 break
             else:
@@ -124,13 +149,13 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             while True:
                 t = alloc(n)
                 report["candidates"] += 1
-                torch.cuda.synchronize(dev)
+                be.sync()
                 r = relation(t, n)
                 if r == -1 or parked_bytes + nbytes[n] > budget:
                     ok = ok and r == -1
                     out[n] = t
                     break
-                park(t)
+                park((n, t))
         break
     else:   # four starts in a row ran into a class boundary: give up sorting
         ok, out = False, {}
@@ -141,5 +166,5 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             out[n] = alloc(n)
     report.update({"balanced": ok, "parked_GiB": round(parked_bytes / 2**30, 2), "seconds": round(time.perf_counter() - t_begin, 3)})
     del parked
-    torch.cuda.empty_cache()
+    be.release()
     return {n: out[n] for n in names}, report

@@ -1,0 +1,150 @@
+"""gym_amd.placement.sorted_tensors — the search logic on a SIMULATED device (no GPU): allocations walk through an address space made of
+class regions, the pair probe answers "slow" for two addresses of one class and "fast" otherwise, exactly what mxv_hbm_pair_probe
+measures on the MI355X (profiles/r3a_vmm_probe7_chunk_matrix_and_prediction.jsonl).  Every branch is driven: nothing to do, a fresh
+device (everything in one class for 90 GiB), a boundary inside the anchor, a boundary inside group 0 (restart), the budget running out
+(best effort, balanced = False), scrambled free lists."""
+import bisect
+
+import pytest
+import torch
+
+from gym_amd.placement import NARROW, WIDE, sorted_tensors
+
+GiB = 1 << 30
+
+
+class SimDevice:
+    """Addresses are handed out in increasing order; `regions` = [(end_address, class)] in increasing order of end_address."""
+
+    def __init__(self, regions, free=288 * GiB, noise=0.0):
+        self.ends = [e for e, _ in regions]
+        self.classes = [c for _, c in regions]
+        self.cursor, self.free, self.live, self.peak, self.noise = 0, free, 0, 0, noise
+        self.probes = 0
+
+    def klass(self, addr):
+        return self.classes[min(bisect.bisect_right(self.ends, addr), len(self.classes) - 1)]
+
+    class T:
+        def __init__(self, dev, addr, n):
+            self.dev, self.addr, self.n = dev, addr, n
+            dev.live += n
+            dev.peak = max(dev.peak, dev.live)
+
+        def __del__(self):
+            self.dev.live -= self.n
+
+    def alloc(self, shape, dtype, zero):
+        n = 1
+        for s in shape:
+            n *= s
+        n *= torch.empty((), dtype=dtype).element_size()
+        if self.live + n > self.free:
+            raise MemoryError("simulated device out of memory")
+        t = SimDevice.T(self, self.cursor, n)
+        self.cursor += n
+        return t
+
+    def ptr(self, t):
+        return t.addr
+
+    def sync(self):
+        pass
+
+    def free_bytes(self):
+        return self.free - self.live
+
+    def probe(self, wide, narrow):
+        self.probes += 1
+        # a window that straddles a boundary behaves like the class of its majority
+        cw, cn = self.klass(wide + WIDE // 2), self.klass(narrow + NARROW // 2)
+        return (4.25 if cw == cn else 3.88) * (1.0 + self.noise * ((self.probes * 2654435761) % 1000 / 1000.0 - 0.5))
+
+    def release(self):
+        pass
+
+
+K, N = 256, 1 << 20
+CARTPOLE = [("obs", (K, N, 4), torch.float32, False), ("reward", (K, N), torch.float64, False), ("terminated", (K, N), torch.uint8, False),
+            ("truncated", (K, N), torch.uint8, False), ("actions", (K, N), torch.int64, False)]
+CP_GROUPS = {"obs": 0, "reward": 1, "actions": 1}
+TAB = [(n, (128, N), torch.int64, False) for n in ("obs", "reward", "actions", "prob")] + [("terminated", (128, N), torch.uint8, True)]
+TAB_GROUPS = {"obs": 0, "reward": 0, "actions": 1, "prob": 1}
+
+
+def _classes(dev, out, specs):
+    res = {}
+    for name, shape, dt, _ in specs:
+        n = out[name].n
+        res[name] = {dev.klass(out[name].addr + 1), dev.klass(out[name].addr + n - 1)}
+    return res
+
+
+def test_fresh_device_walks_to_the_next_class_and_releases_what_it_parked():
+    dev = SimDevice([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")])
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    c = _classes(dev, out, CARTPOLE)
+    assert rep["balanced"] is True and c["obs"] == {"A"} and c["reward"] == {"B"} and c["actions"] == {"B"}
+    assert 80 <= rep["parked_GiB"] <= 92 and rep["candidates"] >= 40
+    assert dev.live == sum(t.n for t in out.values())            # parked tensors are gone
+    assert dev.peak <= 112 * GiB + 9 * GiB
+    assert list(out) == [n for n, *_ in CARTPOLE]
+
+
+def test_scrambled_free_lists_need_little():
+    regions, addr = [], 0
+    for i in range(200):                                         # runs of 6 GiB, alternating classes
+        addr += 6 * GiB
+        regions.append((addr, "AB"[i % 2]))
+    dev = SimDevice(regions)
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    c = _classes(dev, out, CARTPOLE)
+    assert rep["balanced"] is True and len(c["obs"]) == 1 and c["reward"].isdisjoint(c["obs"]) and c["actions"].isdisjoint(c["obs"])
+    assert rep["parked_GiB"] <= 12
+
+
+def test_an_anchor_that_straddles_a_boundary_is_replaced():
+    dev = SimDevice([(2 * GiB, "A"), (60 * GiB, "B"), (288 * GiB, "A")])     # the first 4-GiB observation tensor is half A, half B
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    c = _classes(dev, out, CARTPOLE)
+    assert rep["balanced"] is True and c["obs"] == {"B"} and c["reward"] == {"A"} and c["actions"] == {"A"}
+    assert out["obs"].addr == 4 * GiB
+
+
+def test_a_boundary_inside_group_zero_restarts_the_group():
+    # tabular set: obs + reward (1 GiB each) must share a class; here the boundary falls between them
+    dev = SimDevice([(1 * GiB, "A"), (40 * GiB, "B"), (288 * GiB, "A")])
+    out, rep = sorted_tensors(TAB, TAB_GROUPS, None, _backend=dev)
+    c = _classes(dev, out, TAB)
+    assert rep["balanced"] is True and c["obs"] == c["reward"] == {"B"} and c["actions"] == c["prob"] == {"A"}
+    assert rep["parked_GiB"] >= 1.0
+
+
+def test_the_budget_bounds_what_is_parked_and_the_report_says_so():
+    dev = SimDevice([(288 * GiB, "A")])                          # one class only, as far as the budget reaches
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, budget_bytes=20 * GiB, _backend=dev)
+    assert rep["balanced"] is False and rep["parked_GiB"] <= 20.0
+    assert dev.peak <= 20 * GiB + 11 * GiB and set(out) == {n for n, *_ in CARTPOLE}
+    assert dev.live == sum(t.n for t in out.values())
+
+
+def test_little_free_memory_means_a_small_budget():
+    dev = SimDevice([(288 * GiB, "A")], free=30 * GiB)
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert rep["balanced"] is False and dev.peak <= 30 * GiB and rep["parked_GiB"] <= 15.0
+
+
+def test_nothing_to_sort():
+    dev = SimDevice([(288 * GiB, "A")])
+    out, rep = sorted_tensors([("obs", (8, 64, 4), torch.float32, False), ("reward", (8, 64), torch.float64, False)], {"obs": 0, "reward": 1}, None,
+                              _backend=dev)
+    assert "too small" in rep["note"] and dev.probes == 0
+    out, rep = sorted_tensors(CARTPOLE, {"obs": 0}, None, _backend=dev)
+    assert "nothing to keep apart" in rep["note"] and dev.probes == 0
+
+
+def test_measurement_noise_of_two_percent_does_not_flip_a_classification():
+    dev = SimDevice([(91 * GiB, "A"), (288 * GiB, "B")], noise=0.04)           # +-2 % on every probe: the gap between the modes is 9 %
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    c = _classes(dev, out, CARTPOLE)
+    assert rep["balanced"] is True and c["obs"] == {"A"} and c["reward"] == {"B"} and c["actions"] == {"B"}
