@@ -43,6 +43,38 @@ __device__ __forceinline__ void store_obs(float *base, int64_t e, const float *o
     }
 }
 
+// A 32-bit lane offset that the instruction selector still sees as zext(i32) INSIDE the loop body.  Loop-invariant code motion hoists the
+// 64-bit extension of a lane offset out of the K-step loop; instruction selection works block by block, so in the loop the offset then
+// arrives as an opaque 64-bit pair and every store pays a v_lshl_add_u64 (offset pair + scalar base) and two VGPRs — ten per CartPole
+// wave-step.  An empty asm on the 32-bit value pins the extension behind it: the store takes its scalar base in the instruction's saddr
+// field, `global_store_dwordx4 v_off, v[data], s[base:base+1]`, with one VGPR per offset and no address arithmetic.
+__device__ __forceinline__ uint32_t pin32(uint32_t v) {
+#if MXV_SADDR_STORES
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+// store_obs at a byte offset (a wave-uniform base + a small 32-bit lane offset: see pin32)
+template <int O>
+__device__ __forceinline__ void store_obs_at(char *base, uint32_t byte_off, const float *o) {
+    char *q = base + byte_off;
+    if constexpr (O == 4) {
+        *reinterpret_cast<float4 *>(q) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (O == 2) {
+        *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
+    } else if constexpr (O == 6) {
+        float2 *p = reinterpret_cast<float2 *>(q);
+        p[0] = make_float2(o[0], o[1]);
+        p[1] = make_float2(o[2], o[3]);
+        p[2] = make_float2(o[4], o[5]);
+    } else {
+        float *p = reinterpret_cast<float *>(q);
+#pragma unroll
+        for (int k = 0; k < O; ++k) p[k] = o[k];
+    }
+}
+
 // XCD-aware workgroup -> tile map.  The hardware deals workgroup ids round-robin over the 8 XCDs (id % 8), each with
 // its own L2.  Handing out tiles in id order makes every XCD write 4-8 KiB crumbs interleaved with the other seven
 // all over each output row; giving XCD x the x-th contiguous eighth of the tiles instead lets each L2 stream long
@@ -504,6 +536,20 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         if (p_term) p_term += base;
         if (p_trunc) p_trunc += base;
     }
+#elif MXV_SADDR_STORES
+    // every output base is moved to this wave's tile (wave-uniform: scalar arithmetic), lanes keep an offset below E * 64 elements: the
+    // byte offsets fit 32 bits whatever the shard size, which is what lets the stores use scalar-base addressing (pin32)
+    const int64_t slice = a.slice;
+#pragma unroll
+    for (int j = 0; j < E; ++j) lo[j] = (uint32_t)(j * kWave + lane);
+    p_obs += tile0 * (int64_t)(O * sizeof(float));
+    if (p_rew) p_rew += tile0 * (int64_t)rew_b;
+    if (p_act) p_act += tile0 * (int64_t)act_b;
+    if (p_term) p_term += tile0;
+    if (p_trunc) p_trunc += tile0;
+    if (p_fin) p_fin += tile0 * (int64_t)(O * sizeof(float));
+    if (p_epr) p_epr += tile0;
+    if (p_epl) p_epl += tile0;
 #else
     const int64_t slice = a.slice;
 #pragma unroll
@@ -562,7 +608,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if (!ALLV && !valid[j]) continue;
-                char *q = p_act + lo[j] * act_b;
+                char *q = p_act + pin32(lo[j] * act_b);
                 if constexpr (NA > 0) {
                     if (act_i32)
                         *reinterpret_cast<int32_t *>(q) = ai[j];
@@ -590,8 +636,8 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             for (int j = 0; j < E; ++j) {
                 er[j] = (float)((double)er[j] + rew[j]);  // float32 array += float64 rewards
                 if (pend[j]) {
-                    if (p_epr) p_epr[lo[j]] = er[j];
-                    if (p_epl) p_epl[lo[j]] = el[j];
+                    if (p_epr) *reinterpret_cast<float *>(reinterpret_cast<char *>(p_epr) + pin32(lo[j] * 4u)) = er[j];
+                    if (p_epl) *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(p_epl) + pin32(lo[j] * 4u)) = el[j];
                     er[j] = 0.0f;
                 }
             }
@@ -601,15 +647,15 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         for (int j = 0; j < E; ++j) {
             if (!ALLV && !valid[j]) continue;
             if (FULL || p_rew != nullptr) {
-                char *q = p_rew + lo[j] * rew_b;
+                char *q = p_rew + pin32(lo[j] * rew_b);
                 if (rew_f32)
                     *reinterpret_cast<float *>(q) = (float)rew[j];
                 else
                     *reinterpret_cast<double *>(q) = rew[j];
             }
-            if (FULL || p_term != nullptr) reinterpret_cast<uint8_t *>(p_term)[lo[j]] = term[j] ? 1 : 0;
-            if (FULL || p_trunc != nullptr) reinterpret_cast<uint8_t *>(p_trunc)[lo[j]] = trunc[j] ? 1 : 0;
-            if (!FULL && pend[j] && p_fin != nullptr) store_obs<O>(reinterpret_cast<float *>(p_fin), lo[j], obs[j]);
+            if (FULL || p_term != nullptr) *reinterpret_cast<uint8_t *>(p_term + pin32(lo[j])) = term[j] ? 1 : 0;
+            if (FULL || p_trunc != nullptr) *reinterpret_cast<uint8_t *>(p_trunc + pin32(lo[j])) = trunc[j] ? 1 : 0;
+            if (!FULL && pend[j] && p_fin != nullptr) store_obs_at<O>(p_fin, pin32(lo[j] * (uint32_t)(O * sizeof(float))), obs[j]);
         }
 
         // ---- autoreset (sync_vector_env.py:152-156): finished envs take their ready-made entry ----
@@ -646,7 +692,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         }
 #pragma unroll
         for (int j = 0; j < E; ++j)
-            if (ALLV || valid[j]) store_obs<O>(reinterpret_cast<float *>(p_obs), lo[j], obs[j]);
+            if (ALLV || valid[j]) store_obs_at<O>(p_obs, pin32(lo[j] * (uint32_t)(O * sizeof(float))), obs[j]);
         // ---- the chunk's FINAL tensors once more, into the caller's snapshot (what a sharded vector env all-gathers while the
         //      next chunk runs: written here, no copy kernels between rollout and gather) ----
         if (step + 1 == a.K && a.snap_obs != nullptr) {

@@ -172,6 +172,11 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_MIN_WAVES
 #define MXV_ROLLOUT_MIN_WAVES 1
 #endif
+// 1: the fused rollout's stores take a wave-uniform scalar base + a pinned 32-bit lane offset (pin32 in mxv_kernels.hip); 0: round 2's
+// 64-bit vector addresses (A/B hook)
+#ifndef MXV_SADDR_STORES
+#define MXV_SADDR_STORES 1
+#endif
 // 1: XCD-aware workgroup -> tile map (see xcd_contiguous_tile in mxv_kernels.hip); 0: tiles in workgroup-id order.
 #ifndef MXV_XCD_MAP
 #define MXV_XCD_MAP 1
