@@ -29,6 +29,12 @@ using namespace mxv;
 
 namespace {
 
+#ifndef MXV_BJ_QUAD_ACTIONS
+#define MXV_BJ_QUAD_ACTIONS 1   // 1: the lanes of a quad share one action-word Philox call per four steps; 0: one call per lane per step (A/B hook)
+#endif
+#ifndef MXV_BJ_PACKED_DRAWS
+#define MXV_BJ_PACKED_DRAWS 1   // 1: the step's first eight cards evaluated up front (CardSource); 0: a Philox call at every draw (A/B hook)
+#endif
 constexpr int kBjBlock = 256;
 constexpr uint32_t kStreamDraw = 5u;
 
@@ -63,21 +69,37 @@ struct BjArgs {
     int64_t slice, act_slice;
 };
 
+// The step's cards.  Philox draws: a step consumes 1 card (a hit that does not bust) to 4 + the dealer's draws + 4 (a stick, then the next
+// episode's hands), lane by lane, and a lane-by-lane "refill when the cursor crosses a call boundary" makes the WAVE run a Philox call
+// at nearly every draw (some lane always crosses).  Instead the first two calls of the step's draw stream are evaluated once, up front,
+// and their eight cards packed four bits each into one register: a draw is a shift and a mask.  Draws past the eighth (a dealer hand
+// of five and more cards) evaluate their call on the spot.
 struct CardSource {
     const int8_t *inj;
     uint64_t seed, t;
     int cursor;
-    U4 w;
+    uint32_t pk;   // cards 0..7 of the step's draw stream, 4 bits each
+    __device__ __forceinline__ U4 call(uint32_t i) const {
+        U4 ctr;
+        ctr.x = (uint32_t)t; ctr.y = (uint32_t)(t >> 32); ctr.z = i; ctr.w = (kStreamDraw << 28);
+        return philox4x32_10_vkey(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    }
+    __device__ __forceinline__ void begin() {
+        if (inj) return;
+#if MXV_BJ_PACKED_DRAWS
+        const U4 w0 = call(0), w1 = call(1);
+        pk = (uint32_t)card_of(w0.x) | ((uint32_t)card_of(w0.y) << 4) | ((uint32_t)card_of(w0.z) << 8) | ((uint32_t)card_of(w0.w) << 12) |
+             ((uint32_t)card_of(w1.x) << 16) | ((uint32_t)card_of(w1.y) << 20) | ((uint32_t)card_of(w1.z) << 24) | ((uint32_t)card_of(w1.w) << 28);
+#endif
+    }
     __device__ __forceinline__ int next() {
         int c;
         if (inj) {
             c = inj[cursor < MXV_BJ_MAX_DRAWS ? cursor : MXV_BJ_MAX_DRAWS - 1];
+        } else if (MXV_BJ_PACKED_DRAWS && cursor < 8) {
+            c = (int)((pk >> (4 * cursor)) & 15u);
         } else {
-            if ((cursor & 3) == 0) {
-                U4 ctr;
-                ctr.x = (uint32_t)t; ctr.y = (uint32_t)(t >> 32); ctr.z = (uint32_t)(cursor >> 2); ctr.w = (kStreamDraw << 28);
-                w = philox4x32_10_vkey(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-            }
+            const U4 w = call((uint32_t)(cursor >> 2));
             const int q = cursor & 3;
             c = card_of(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
         }
@@ -100,13 +122,20 @@ __device__ __forceinline__ void deal(int c1, int c2, Hand &h) {
 
 __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
     const int64_t e = (int64_t)blockIdx.x * kBjBlock + threadIdx.x;
-    if (e >= a.n) return;
+    const bool valid = e < a.n;  // sampled actions: lanes past the end stay in the loop, their quad partners need their action words
+    if (!valid && a.actions) return;
     const uint64_t ge = a.env0 + (uint64_t)e;
-    const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + ge;
+    const uint64_t seed = (a.seeds && valid) ? a.seeds[e] : a.base_seed + ge;
     Hand p, d;
     int dfirst;
-    unpack(a.state[e], p, d, dfirst);
-    int32_t el = a.elapsed[e];
+    unpack(valid ? a.state[e] : 0, p, d, dfirst);
+    int32_t el = valid ? a.elapsed[e] : 0;
+    // Action words: one Philox call yields the words of the 4 envs of group g = env >> 2 at ONE step.  The four lanes of a quad (= one
+    // group) each evaluate a different step of the aligned block 4 * (t >> 2) .. + 3 and trade words through quad shuffles: one call per
+    // lane per four steps instead of one per step (the same stream, the same words: mxv_tab.hip's scheme).
+    const uint32_t q = (uint32_t)(ge & 3);
+    uint64_t act_block = ~0ull;
+    uint32_t act_word[4] = {0, 0, 0, 0};
     mxv::settle_entry_loads();
     for (int k = 0; k < a.K; ++k) {
         const uint64_t t = a.t + (uint64_t)k;
@@ -121,12 +150,37 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
                 continue;
             }
         } else {
-            const U4 w = action_words(a.action_seed, t, ge >> 2);
-            const uint32_t q = (uint32_t)(ge & 3);
-            act = (int64_t)(((uint64_t)(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w))) * 2u) >> 32);
+#if !MXV_BJ_QUAD_ACTIONS
+            {   // A/B hook: round 2's one call per lane per step
+                const U4 w1 = action_words(a.action_seed, t, ge >> 2);
+                act_word[t & 3] = q == 0 ? w1.x : (q == 1 ? w1.y : (q == 2 ? w1.z : w1.w));
+            }
+#endif
+            if (MXV_BJ_QUAD_ACTIONS && (t >> 2) != act_block) {  // uniform across the launch: every lane refills its cache at the same step
+                act_block = t >> 2;
+                const U4 w = action_words(a.action_seed, (act_block << 2) + q, ge >> 2);
+                const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r) {
+                    // lane q sends the word of env (q ^ r) and receives, from lane q ^ r (which evaluated step q ^ r of the block), the
+                    // word of env (q ^ r) ^ r = q: its own word for step q ^ r
+                    const uint32_t i = q ^ r;
+                    const uint32_t send = i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
+                    const uint32_t recv = r == 0 ? send : (uint32_t)__shfl_xor((int)send, (int)r, 64);
+                    act_word[0] = i == 0 ? recv : act_word[0];
+                    act_word[1] = i == 1 ? recv : act_word[1];
+                    act_word[2] = i == 2 ? recv : act_word[2];
+                    act_word[3] = i == 3 ? recv : act_word[3];
+                }
+            }
+            const uint32_t j = (uint32_t)(t & 3);
+            const uint32_t word = j == 0 ? act_word[0] : (j == 1 ? act_word[1] : (j == 2 ? act_word[2] : act_word[3]));
+            act = (int64_t)(((uint64_t)word * 2u) >> 32);
+            if (!valid) continue;
             if (a.actions_out) a.actions_out[o1] = act;
         }
-        CardSource src{a.cards ? a.cards + e * MXV_BJ_MAX_DRAWS : nullptr, seed, t, 0, U4{0, 0, 0, 0}};
+        CardSource src{a.cards ? a.cards + e * MXV_BJ_MAX_DRAWS : nullptr, seed, t, 0, 0u};
+        src.begin();
         bool term;
         double rew;
         if (act) {                                             // hit (:123-130)
@@ -167,6 +221,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
         if (a.terminated) a.terminated[o1] = term ? 1 : 0;
         if (a.truncated) a.truncated[o1] = trunc ? 1 : 0;
     }
+    if (!valid) return;
     a.state[e] = pack(p, d, dfirst);
     a.elapsed[e] = el;
 }
