@@ -230,7 +230,7 @@ def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin
     r = DeviceRollout(env_id, envs, seed=0, action_seed=1, reward_f32=compact, action_i32=compact)
     r.reset(seed=0)
     traj = r.trajectory_buffers(chunk)
-    placement = getattr(r, "last_placement", None) if sum(t.numel() * t.element_size() for t in traj.values()) >= _native.PLACED_MIN_BYTES else None
+    placement = getattr(r, "last_placement", None) if sum(t.numel() * t.element_size() for t in traj.values()) >= _native.SORTED_MIN_BYTES else None
     fn = lambda: r.rollout_per_step(chunk, out=traj)   # noqa: E731
     _spin(fn, r.stream.synchronize, spin_ms)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -550,9 +550,10 @@ def main():
     elif args.placement in ("first", "tuned") or mode != "fused":   # (tuned with < 2 candidates, or a one-launch-per-step mode: nothing to place)
         traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"kind": "first ordinary allocation"}
     else:
-        big = local_envs * args.chunk * 34 >= (2 << 30)      # below 2 GiB (a 2^17-env shard is latency-bound): ordinary allocations
+        from gym_amd import _native
+        big = local_envs * args.chunk * 34 >= _native.SORTED_MIN_BYTES      # 2^17-env shards (8 GPUs) and larger are sorted by HBM class
         traj = eng.trajectory_buffers(args.chunk, layout=args.placement if big else "separate")
-        placement = dict(getattr(eng, "last_placement", None) or {}) if big else {"kind": "ordinary allocations (set below 2 GiB)"}
+        placement = dict(getattr(eng, "last_placement", None) or {}) if big else {"kind": "ordinary allocations (set below 1 GiB)"}
         if big:
             placement["kind"] = {"sorted": "sorted (ordinary allocations classified with mxv_hbm_pair_probe)",
                                  "placed": "placed (mxv_placed_alloc)"}[args.placement]

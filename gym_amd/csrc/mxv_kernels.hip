@@ -1027,10 +1027,11 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
         };
         // Two envs per lane (the tuned choice of the light envs: two independent chains of ILP) only pay when the shard fills
         // the chip: below one E = 2 wave per SIMD (1024 SIMDs x 128 envs) the work is latency-bound and one env per lane
-        // puts twice as many waves on it (profiles/r02a_shard_sweep.jsonl: 0.76 vs 1.05 us per step at 2^16 CartPole envs,
-        // equal at 2^17) — the shard sizes of an 8-GPU strong-scaling or mixed-batch job.
+        // puts twice as many waves on it (profiles/r02a_shard_sweep.jsonl: 0.76 vs 1.05 us per step at 2^16 CartPole envs;
+        // at 2^17 itself, one E = 2 wave per SIMD: 0.92 vs 1.01, profiles/r3k_small_shard_e1_ab.jsonl) — the shard sizes of an 8-GPU
+        // strong-scaling or mixed-batch job.
         constexpr int ER = rollout_envs_per_lane(ENV);
-        if (ER > 1 && a.n < (int64_t)kSimds * ER * kWave && MXV_ROLLOUT_SMALL_E1)
+        if (ER > 1 && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
             go(std::integral_constant<int, 1>{});
         else
             go(std::integral_constant<int, ER>{});

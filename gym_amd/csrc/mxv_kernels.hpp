@@ -148,6 +148,15 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_SMALL_E1
 #define MXV_ROLLOUT_SMALL_E1 1
 #endif
+// the shard size below which a two-envs-per-lane kind runs one env per lane: FACTOR x (one E = 2 wave per SIMD); INCLUSIVE = 1 includes
+// the boundary itself, i.e. the 2^17-env shard of an 8-GPU strong-scaling job (round 3: 1.01 -> 0.92 us per CartPole step, MountainCar
+// 0.85 -> 0.75, MountainCarContinuous 0.99 -> 0.79; 2^18: equal.  profiles/r3k_small_shard_e1_ab.jsonl)
+#ifndef MXV_ROLLOUT_E1_FACTOR
+#define MXV_ROLLOUT_E1_FACTOR 1
+#endif
+#ifndef MXV_ROLLOUT_E1_INCLUSIVE
+#define MXV_ROLLOUT_E1_INCLUSIVE 1
+#endif
 // measurement hook: 1 = the fused rollout writes its trajectories tile-major ([N/TILE][K][TILE]) instead of step-major ([K][N])
 #ifndef MXV_EXP_TILE_MAJOR
 #define MXV_EXP_TILE_MAJOR 0

@@ -27,7 +27,7 @@ from . import _native
 MiB = 1 << 20
 WIDE, NARROW = 256 * MiB, 128 * MiB     # what one probe window writes: 16 steps x 2^20 lanes x 16 B / 8 B
 SAME_RATIO = 0.955                      # a different-class pair runs at 0.89-0.91 of the same-class time
-MIN_SET_BYTES = _native.PLACED_MIN_BYTES
+MIN_SET_BYTES = _native.SORTED_MIN_BYTES
 
 
 def _nbytes(shape, dtype) -> int:

@@ -147,7 +147,7 @@ class DeviceRollout:
         `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
         of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content.
 
-        layout="sorted" (what "auto" picks for sets of 2 GiB and more): ordinary allocations, but the reward / action tensors are
+        layout="sorted" (what "auto" picks for sets of 1 GiB and more): ordinary allocations, but the reward / action tensors are
         made to lie in another third of the HBM address space than the observations (_sorted_buffers): the write-bound rollout then
         runs in its fast mode by construction instead of one time in three; the report is left in
         `self.last_placement`.  layout="placed": the same goal through HIP's virtual-memory API (mxv_placed_alloc, include/mxv.h:
@@ -168,7 +168,7 @@ class DeviceRollout:
                   ("actions", (K, n), self.action_dtype, False)]
         if layout == "auto":
             total = sum(math.prod(shape) * torch.empty((), dtype=dt).element_size() for _, shape, dt, _ in specs)
-            layout = "sorted" if total >= _native.PLACED_MIN_BYTES else "separate"
+            layout = "sorted" if total >= _native.SORTED_MIN_BYTES else "separate"
         if layout == "sorted":
             return self._sorted_buffers(specs)
         if layout == "placed":

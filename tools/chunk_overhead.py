@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--chunks", type=int, default=400)
     ap.add_argument("--comm", default="torch")
+    ap.add_argument("--skip-wait", action="store_true",
+                    help="MEASUREMENT ONLY (unsafe): do not order the engine's stream after the gather that last read a snapshot set — "
+                         "what does that stream-wait packet cost per chunk?")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -38,6 +41,8 @@ def main():
     traj = sr.engine.trajectory_buffers(args.chunk)
     sr._force_collective = True      # the real collective call at world size 1 (ShardedRollout otherwise short-cuts it to a local copy)
     gather = sr.gather_async
+    if args.skip_wait:
+        sr._wait_set = lambda idx: None
 
     def run(chunks, with_gather):
         for _ in range(chunks):
@@ -45,7 +50,7 @@ def main():
             if with_gather:
                 gather()
 
-    out = {"n": args.n, "chunk": args.chunk, "comm": args.comm}
+    out = {"n": args.n, "chunk": args.chunk, "comm": args.comm, "skip_wait": bool(args.skip_wait)}
     for with_gather in (False, True):
         run(50, with_gather)
         sr.synchronize(); torch.cuda.synchronize()

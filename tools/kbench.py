@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--modes", default="fused,graph,given,fused-final,fusedf32")
     ap.add_argument("--tag", default="")
     ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--layout", default="auto", help="trajectory_buffers(layout=...): auto / sorted / separate / placed")
     args = ap.parse_args()
     if args.lib:
         os.environ["MXV_LIB_PATH"] = os.path.abspath(args.lib)
@@ -59,7 +60,7 @@ def main():
                     for _ in range(k // K):
                         r.rollout(K, mode=m)
             else:                    # trajectory mode: every step writes its own [k][N] slice
-                traj = r.trajectory_buffers(K)
+                traj = r.trajectory_buffers(K, layout=args.layout)
 
                 def go(k, m=base):
                     for _ in range(k // K):
@@ -76,7 +77,7 @@ def main():
                 ev1.record(r.stream)
                 r.synchronize()
                 best = min(best, ev0.elapsed_time(ev1) / steps * 1e3)
-            print(json.dumps({"tag": args.tag, "env": env, "n": args.n, "mode": mode, "chunk": K,
+            print(json.dumps({"tag": args.tag, "layout": args.layout, "placement": getattr(r, "last_placement", None), "env": env, "n": args.n, "mode": mode, "chunk": K,
                               "us_per_step": round(best, 3), "env_steps_per_s": float(f"{args.n / (best * 1e-6):.4g}"),
                               "GBs_at_66B": round(ALGO_B[env] * args.n / (best * 1e-6) / 1e9, 1)}), flush=True)
             r.close()
