@@ -23,10 +23,12 @@ def main():
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--chunks", type=int, default=400)
     ap.add_argument("--comm", default="torch")
+    ap.add_argument("--normal-priority", action="store_true", help="RCCL's kernels on a normal-priority stream (TORCH_NCCL_HIGH_PRIORITY=0)")
     ap.add_argument("--skip-wait", action="store_true",
                     help="MEASUREMENT ONLY (unsafe): do not order the engine's stream after the gather that last read a snapshot set — "
                          "what does that stream-wait packet cost per chunk?")
     args = ap.parse_args()
+    os.environ["TORCH_NCCL_HIGH_PRIORITY"] = "0" if args.normal_priority else "1"
     import torch
     import torch.distributed as dist
 
@@ -50,7 +52,7 @@ def main():
             if with_gather:
                 gather()
 
-    out = {"n": args.n, "chunk": args.chunk, "comm": args.comm, "skip_wait": bool(args.skip_wait)}
+    out = {"n": args.n, "chunk": args.chunk, "comm": args.comm, "skip_wait": bool(args.skip_wait), "rccl_high_priority": not args.normal_priority}
     for with_gather in (False, True):
         run(50, with_gather)
         sr.synchronize(); torch.cuda.synchronize()
