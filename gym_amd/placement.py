@@ -13,6 +13,12 @@ stream into the candidate, at both ends of both tensors; a pair known to share a
 next to it, so no absolute threshold is involved) and, if it lies on the wrong side, parked and replaced by the next allocation,
 which lies further along in physical memory.  Parked tensors are released at the end.  Typical: a few GiB parked for 0.1 s; a fresh
 device: up to ~90 GiB for ~3 s.  Nothing here touches the results: only WHERE the tensors live.
+
+What was measured is remembered per device (`_ClassMemo`): torch's caching allocator hands a learner's loop the same blocks again and
+again (`out = r.rollout_per_step(K)` alternates between two sets), and a block keeps its physical memory for as long as its segment is
+not returned to the driver.  The memo is keyed by block address and size and is dropped whenever the allocator's count of segments
+returned to the driver has moved since it was written (`torch.cuda.empty_cache()` by anyone, an out-of-memory retry) — a set built from
+remembered blocks costs no probe launch at all.
 """
 from __future__ import annotations
 
@@ -62,6 +68,35 @@ class _Device:
     def release(self):
         torch.cuda.empty_cache()
 
+    def segment_frees(self):
+        """How many device segments the caching allocator has returned to the driver so far (None: unknown — nothing is remembered)."""
+        return torch.cuda.memory_stats(self.dev).get("num_device_free")
+
+    def key(self):
+        return self.dev.index
+
+
+class _ClassMemo:
+    """Per device: what the probes found out about blocks of the caching allocator.  `single[(ptr, nbytes)]`: the block lies in one HBM
+    class from end to end (anchor-grade); `rel[(anchor ptr, ptr, nbytes)]`: the block's relation to that anchor (+1 / -1 / 0)."""
+
+    def __init__(self):
+        self.stamp, self.single, self.rel = None, set(), {}
+
+    def validate(self, frees):
+        if frees is None or frees != self.stamp:
+            self.single.clear()
+            self.rel.clear()
+
+    def seal(self, frees):
+        self.stamp = frees
+        if frees is None:
+            self.single.clear()
+            self.rel.clear()
+
+
+_MEMO: Dict[object, _ClassMemo] = {}
+
 
 def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups: Dict[str, int], device: torch.device,
                    stream: Optional[torch.cuda.Stream] = None, budget_bytes: Optional[int] = None, _backend=None):
@@ -70,12 +105,16 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
     from end to end and every group-1 tensor lies outside it."""
     t_begin = time.perf_counter()
     be = _backend if _backend is not None else _Device(device, stream)
+    memo = _MEMO.setdefault(be.key() if hasattr(be, "key") else id(be), _ClassMemo())
+    frees_of = getattr(be, "segment_frees", lambda: None)
+    memo.validate(frees_of())
     names = [n for n, *_ in specs]
     spec = {n: (shape, dt, zero) for n, shape, dt, zero in specs}
     nbytes = {n: _nbytes(spec[n][0], spec[n][1]) for n in names}
     g0 = [n for n in names if groups.get(n) == 0]
     g1 = [n for n in names if groups.get(n) == 1]
-    report = {"kind": "sorted", "balanced": False, "parked_GiB": 0.0, "candidates": 0, "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
+    report = {"kind": "sorted", "balanced": False, "parked_GiB": 0.0, "candidates": 0, "remembered": 0,
+              "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
 
     def alloc(name):
         return be.alloc(*spec[name])
@@ -91,7 +130,15 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
         return plain("tensors too small to classify: ordinary allocations")
     budget = min(be.free_bytes() // 2, 112 << 30) if budget_bytes is None else int(budget_bytes)
     parked, parked_bytes = [], 0
-    probe = be.probe
+    warmed = [False]
+
+    def probe(wide_ptr, narrow_ptr, _warm_at=None):
+        if not warmed[0]:                                  # clock ramp + first touch, once per call and only if anything is measured at all
+            warmed[0] = True
+            w = wide_ptr if _warm_at is None else _warm_at
+            for _ in range(40):
+                be.probe(w, w + WIDE)
+        return be.probe(wide_ptr, narrow_ptr)
 
     def park(*named):
         nonlocal parked_bytes
@@ -107,25 +154,32 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
         be.sync()
         a0 = be.ptr(anchor)
         a1 = a0 + nbytes[anchor_name]
-        if attempt == 0:
-            for _ in range(40):
-                probe(a0, a0 + WIDE)                       # clock ramp + first touch
-        same = probe(a0, a0 + WIDE)                        # both streams inside the first 384 MiB of one allocation: a same-class pair
-        if probe(a0, a1 - NARROW) <= SAME_RATIO * same and parked_bytes + nbytes[anchor_name] <= budget:
-            park((anchor_name, anchor))
-            continue
-        report["same_class_us"] = round(same, 3)
+        if (a0, nbytes[anchor_name]) in memo.single:
+            report["remembered"] += 1
+        else:
+            same = probe(a0, a0 + WIDE, a0)                # both streams inside the first 384 MiB of one allocation: a same-class pair
+            if probe(a0, a1 - NARROW) <= SAME_RATIO * same and parked_bytes + nbytes[anchor_name] <= budget:
+                park((anchor_name, anchor))
+                continue
+            memo.single.add((a0, nbytes[anchor_name]))
+            report["same_class_us"] = round(same, 3)
 
         def relation(t, n):
             """+1: same class as the anchor at both ends, -1: another class at both ends, 0: mixed."""
             c0 = be.ptr(t)
             c1 = c0 + nbytes[n]
-            cal = probe(a0, a0 + WIDE)
+            known = memo.rel.get((a0, c0, nbytes[n]))
+            if known is not None:
+                report["remembered"] += 1
+                return known
+            cal = probe(a0, a0 + WIDE, a0)
             p0, p1 = probe(a0, c0), probe(a1 - WIDE, c1 - NARROW)
             s0, s1 = p0 > SAME_RATIO * cal, p1 > SAME_RATIO * cal
             if not s0 and not s1:
                 report.setdefault("different_class_us", round(min(p0, p1), 3))
-            return 1 if (s0 and s1) else -1 if (not s0 and not s1) else 0
+            r = 1 if (s0 and s1) else -1 if (not s0 and not s1) else 0
+            memo.rel[(a0, c0, nbytes[n])] = r
+            return r
 
         out = {anchor_name: anchor}
         restart = False
@@ -164,7 +218,15 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
     for n in names:
         if n not in out:
             out[n] = alloc(n)
-    report.update({"balanced": ok, "parked_GiB": round(parked_bytes / 2**30, 2), "seconds": round(time.perf_counter() - t_begin, 3)})
+    had_parked = bool(parked)
     del parked
-    be.release()
+    if had_parked:
+        # the parked tensors go back to the driver, not into the allocator's cache — and so does every other unused block the allocator
+        # held: only what this call returns is known to keep its memory
+        be.release()
+        keep = {be.ptr(t) for t in out.values()}
+        memo.single = {k for k in memo.single if k[0] in keep}
+        memo.rel = {k: v for k, v in memo.rel.items() if k[0] in keep and k[1] in keep}
+    memo.seal(frees_of())  # the release moved the allocator's count: what survives stays valid from the new count on
+    report.update({"balanced": ok, "parked_GiB": round(parked_bytes / 2**30, 2), "seconds": round(time.perf_counter() - t_begin, 3)})
     return {n: out[n] for n in names}, report

@@ -148,3 +148,73 @@ def test_measurement_noise_of_two_percent_does_not_flip_a_classification():
     out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
     c = _classes(dev, out, CARTPOLE)
     assert rep["balanced"] is True and c["obs"] == {"A"} and c["reward"] == {"B"} and c["actions"] == {"B"}
+
+
+class CachingSim(SimDevice):
+    """SimDevice + the behaviour of torch's caching allocator that the memo relies on: a freed block is handed out again for a request
+    of exactly its size; release() (= empty_cache) returns every unused block to the driver and moves the segment-free count."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.cache, self.frees = [], 0
+
+    class T(SimDevice.T):
+        def __del__(self):
+            self.dev.live -= self.n
+            self.dev.cache.append((self.addr, self.n))
+
+    def alloc(self, shape, dtype, zero):
+        n = 1
+        for s in shape:
+            n *= s
+        n *= torch.empty((), dtype=dtype).element_size()
+        for i, (addr, m) in enumerate(self.cache):
+            if m == n:
+                del self.cache[i]
+                return CachingSim.T(self, addr, n)
+        t = CachingSim.T(self, self.cursor, n)
+        self.cursor += n
+        return t
+
+    def release(self):
+        self.frees += len(self.cache)
+        self.cache.clear()
+
+    def segment_frees(self):
+        return self.frees
+
+    def key(self):
+        return id(self)
+
+
+def test_blocks_the_allocator_hands_out_again_are_not_measured_again():
+    """`out = r.rollout_per_step(K)` in a loop: the learner alternates between two sets of blocks; from the third call on nothing is probed."""
+    dev = CachingSim([(6 * GiB, "A"), (40 * GiB, "B"), (80 * GiB, "A"), (288 * GiB, "B")])
+    first, rep1 = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert rep1["balanced"] and rep1["remembered"] == 0 and dev.probes > 0
+    second, rep2 = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)      # the first set is still alive: new blocks, new measurements
+    assert rep2["balanced"] and {t.addr for t in first.values()}.isdisjoint({t.addr for t in second.values()})
+    calls = []
+    for _ in range(4):                                                          # the loop proper: the older set is dropped, then a new one asked for
+        first = None
+        before = dev.probes
+        first, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+        first, second = second, first
+        calls.append((dev.probes - before, rep["remembered"], rep["balanced"], rep["parked_GiB"]))
+    assert all(b for _, _, b, _ in calls)
+    assert calls[-1][0] == 0 and calls[-2][0] == 0 and calls[-1][1] == 3, calls   # anchor + reward + actions remembered, no probe launch
+    c = _classes(dev, second, CARTPOLE)
+    assert len(c["obs"]) == 1 and c["reward"].isdisjoint(c["obs"]) and c["actions"].isdisjoint(c["obs"])
+
+
+def test_a_cache_flush_by_anyone_drops_what_was_remembered():
+    dev = CachingSim([(6 * GiB, "A"), (40 * GiB, "B"), (80 * GiB, "A"), (288 * GiB, "B")])
+    a, _ = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    b, _ = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    a = None
+    a, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    b = None
+    dev.release()                      # torch.cuda.empty_cache() by the user: the blocks of `b` go back to the driver
+    before = dev.probes
+    b, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert dev.probes > before and rep["balanced"]
