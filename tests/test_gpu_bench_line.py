@@ -55,11 +55,13 @@ def test_line_carries_what_the_review_asked_for(line):
     ref = line["cpu_baseline"]["reference_python"]
     assert ref["source"].startswith("profiles/reference_cpu_baseline.json") and ref["value"] > 1e4
     v = line["variants"]
-    assert "error" not in v, v.get("error")
+    assert not [k for k, x in v.items() if isinstance(x, dict) and "error" in x], v
     for key in ("compact_outputs", "configs2_pendulum", "configs2_mountaincar_continuous", "mountaincar", "configs3_acrobot_shard"):
         assert v[key]["roofline"]["frac"] > 0.1 and v[key]["write_probe"]["kernel_over_probe"] > 0.9, key
     assert v["configs3_acrobot_shard"]["roofline_valu"]["frac"] > 0.5
     assert v["configs4_mixed_share"]["value"] > 1e10
+    share = v["strong_scaling_share_of_8"]                    # 2^17 envs: what each GPU of an 8-GPU strong-scaling job steps
+    assert share["placement"]["balanced"] is True and share["us_per_step"] * 8 < 1.35 * line["ms_per_step"] * 1e3
     sl = v["step_loop"]
     assert sl["one_engine"]["roofline"]["algorithmic_bytes_per_env_step"] == 66
     assert sl["one_engine"]["roofline"]["frac"] > 0.38        # round 2's loop: 0.34 (a cross-stream wait per step), kernel 0.44
