@@ -527,6 +527,17 @@ def main():
         if ranks_seen != world:
             raise SystemExit(f"bench.py: the communicator spans {ranks_seen} ranks, expected {world}")
 
+    t_start = time.perf_counter()
+
+    def trace(what):
+        """Phase markers on stderr at N > 1 (never stdout: that carries the one JSON line): if a multi-GPU run stalls or a rank is slow,
+        the log says where.  MXV_BENCH_TRACE=0 silences them, =1 forces them at N = 1."""
+        flag = os.environ.get("MXV_BENCH_TRACE")
+        if flag == "0" or (world == 1 and flag != "1"):
+            return
+        print(f"[bench rank {rank}/{world} +{time.perf_counter() - t_start:7.2f}s] {what}", file=sys.stderr, flush=True)
+
+    trace(f"process group up ({comm_info.get('backend')}, ranks_seen={comm_info.get('ranks_seen', 1)}), device {local_rank}")
     from gym_amd.distributed import ShardedRollout
 
     total_envs = ENVS_TOTAL * (world if args.scaling == "weak" else 1)
@@ -557,6 +568,8 @@ def main():
         if big:
             placement["kind"] = {"sorted": "sorted (ordinary allocations classified with mxv_hbm_pair_probe)",
                                  "placed": "placed (mxv_placed_alloc)"}[args.placement]
+    trace(f"engine + trajectory tensors ready: {local_envs} envs, placement {placement.get('kind') if placement else None}"
+          f" balanced={placement.get('balanced') if placement else None} parked_GiB={placement.get('parked_GiB') if placement else None}")
     launches = [0]
     since_gather = [0]
     issued = [0]
@@ -589,17 +602,20 @@ def main():
     if args.warm_max_s > 0:
         warm_s, warm_calls = warm_until_stable(lambda: sr.rollout_per_step(args.chunk, mode=mode, out=traj, record_actions=True),
                                                sr.synchronize, max_s=args.warm_max_s)
+    trace(f"rate settled after {warm_s:.2f} s ({warm_calls} launches)")
     sr.reset(seed=0)
     # device spin-up: a fixed number of untimed steps; then W warmup steps, which also instantiate the hipGraph(s) and RCCL communicators
     # used in the timed region
     spin = spinup_steps(args.spinup_ms, args.chunk, local_envs)
     run(spin, gather=False)
     fence()   # ranks leave placement and spin-up at different times
+    trace(f"spin-up done ({spin} steps), all ranks at the fence")
     since_gather[0] = 0
     run(max(args.warmup, 1))
     if world > 1:
         sr.gather()
     fence()
+    trace("warm-up done (first gather through the transport included)")
 
     repeats = args.repeats if args.repeats > 0 else timed_repeats(args.steps, args.chunk, local_envs, args.min_timed_ms, mode)
     timed_steps = args.steps * repeats
@@ -617,6 +633,7 @@ def main():
         sr.wait_gather()
     fence()
     elapsed_local = time.perf_counter() - t0
+    trace(f"timed region done: {timed_steps} steps in {elapsed_local * 1e3:.1f} ms")
 
     launch_ms = ev0.elapsed_time(ev1) / launches[0]  # avg step-kernel launch duration on the engine's stream
     steps_per_launch = timed_steps / launches[0]
