@@ -479,6 +479,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # stdout carries ONE JSON line and nothing else: RCCL ("Hostname : ... / Librccl path : ...") and gloo ("[Gloo] Rank 0 is connected
+    # ...") print from C++ straight to file descriptor 1 when a communicator comes up.  The descriptor is pointed at stderr for the whole
+    # run (in every rank), and the line goes out through a private duplicate of the original one.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -777,7 +784,7 @@ def main():
                 "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
                 "kernel": measure_step_kernel(torch, ENVS_TOTAL)})
             out["variants"] = v
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     if world > 1:
         dist.barrier()

@@ -75,6 +75,10 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "5"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
+    # stdout is the ONE line and nothing else: what gloo / RCCL print when a communicator comes up ("[Gloo] Rank 0 is connected ...",
+    # "Librccl path : ...") goes to stderr, and so do the ranks' phase markers
+    assert len(p.stdout.strip().splitlines()) == 1, p.stdout[:2000]
+    assert "[bench rank 1/2" in p.stderr and "timed region done" in p.stderr
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = lines[0]
