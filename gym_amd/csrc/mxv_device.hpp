@@ -226,21 +226,45 @@ __device__ __forceinline__ double div_par(double x, double c) {
 // half the instructions of separate multiply/add.  CartPole's pole angle never leaves (-0.42, 0.42) on an
 // autoresetting trajectory, so its sin/cos need no reduction at all; callers fall back to the general sincos()
 // outside the interval.
+// a * b + k for a coefficient k that lives on (a Horner step inside a loop): the compiler forms `v_fmac_f64 acc, a, b` with the accumulator
+// preloaded — fine while k is a literal it has to materialise anyway — and loop-invariant code motion then hoists the materialisation,
+// leaving `v_mov_b64 acc, k_regs ; v_fmac_f64 acc, a, b`: one full-rate copy per polynomial term, 11 per sincos (88 of Acrobot's 730 VALU
+// instructions per env-step).  The three-address form reads the coefficient where it is.  Same operation, same bits.
+// It pays where the coefficients stay in registers across the loop (Pendulum, MountainCarContinuous: -7 % / -9 % instructions in the
+// K-step loop); the kernels at their 128-VGPR budget (CartPole and MountainCar at two envs per lane, Acrobot) re-materialise or spill
+// instead, so the form is chosen per env kind: bit `env id` of MXV_FMA3_ENVS (A/B hook; profiles/r3p_fma3_ab.jsonl).
+#ifndef MXV_FMA3_ENVS
+#define MXV_FMA3_ENVS ((1 << MXV_PENDULUM) | (1 << MXV_MOUNTAINCAR_CONT))
+#endif
+template <int ENV>
+constexpr bool fma3_for() { return ((MXV_FMA3_ENVS >> ENV) & 1) != 0; }
+template <bool F3>
+__device__ __forceinline__ double fma_coef(double a, double b, double k) {
+    if constexpr (F3) {
+        double r;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(k));
+        return r;
+    } else {
+        return __fma_rn(a, b, k);
+    }
+}
+
+template <bool F3 = false>
 __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) {
     const double z = x * x;
     // sin: x + x*z*(S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6)))))
-    double r = __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    r = __fma_rn(z, r, 2.75573137070700676789e-06);
-    r = __fma_rn(z, r, -1.98412698298579493134e-04);
-    r = __fma_rn(z, r, 8.33333333332248946124e-03);
-    r = __fma_rn(z, r, -1.66666666666666324348e-01);
+    double r = fma_coef<F3>(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    r = fma_coef<F3>(z, r, 2.75573137070700676789e-06);
+    r = fma_coef<F3>(z, r, -1.98412698298579493134e-04);
+    r = fma_coef<F3>(z, r, 8.33333333332248946124e-03);
+    r = fma_coef<F3>(z, r, -1.66666666666666324348e-01);
     *sn = __fma_rn(x * z, r, x);
     // cos: 1 - z/2 + z*z*(C1 + z*(C2 + ... z*C6)), summed so that the rounding error of 1 - z/2 is recovered
-    double c = __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    c = __fma_rn(z, c, -2.75573143513906633035e-07);
-    c = __fma_rn(z, c, 2.48015872894767294178e-05);
-    c = __fma_rn(z, c, -1.38888888888741095749e-03);
-    c = __fma_rn(z, c, 4.16666666666666019037e-02);
+    double c = fma_coef<F3>(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    c = fma_coef<F3>(z, c, -2.75573143513906633035e-07);
+    c = fma_coef<F3>(z, c, 2.48015872894767294178e-05);
+    c = fma_coef<F3>(z, c, -1.38888888888741095749e-03);
+    c = fma_coef<F3>(z, c, 4.16666666666666019037e-02);
     const double hz = 0.5 * z;
     const double t = 1.0 - hz;
     *cs = t + __fma_rn(z, z * c, (1.0 - t) - hz);
@@ -260,13 +284,14 @@ __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) 
 #ifndef MXV_FAST_TRIG
 #define MXV_FAST_TRIG 1  // A/B hook: 0 = ocml's sincos / cos everywhere
 #endif
+template <bool F3 = false>
 __device__ __forceinline__ void sincos_medium(double x, double *sn, double *cs) {
     const double k = rint(x * 6.36619772367581382433e-01);        // 2/pi
     double r = __fma_rn(-k, 1.5707963267341256, x);               // pi/2, first 33 bits: exact product for |k| < 2^20
     r = __fma_rn(-k, 6.077100506303966e-11, r);                   // next 33 bits
     r = __fma_rn(-k, 2.0222662487959506e-21, r);                  // the following 53
     double s, c;
-    sincos_kernel(r, &s, &c);
+    sincos_kernel<F3>(r, &s, &c);
     const uint32_t q = (uint32_t)(int)k;
     const bool swap = (q & 1u) != 0u;
     const double ss = swap ? c : s, cc = swap ? s : c;
@@ -278,29 +303,29 @@ __device__ __forceinline__ void sincos_medium(double x, double *sn, double *cs) 
 // angles to [-pi, pi] and bounds the velocities, MountainCar's argument is 3 * position, a time-limited Pendulum turns at most
 // 0.4 rad per step) — no range check and none of ocml's code or registers in the kernel.  mxv_set_state and unusual reset
 // bounds break that knowledge for one launch, which then takes the guarded instantiation (see launch_step_env, SAFE).
-template <bool GUARD = true>
+template <bool GUARD = true, bool F3 = false>
 __device__ __forceinline__ void mx_sincos(double x, double *sn, double *cs) {
 #if MXV_FAST_TRIG
     if (!GUARD || fabs(x) < 524288.0)
-        sincos_medium(x, sn, cs);
+        sincos_medium<F3>(x, sn, cs);
     else
 #endif
         sincos(x, sn, cs);
 }
-template <bool GUARD = true>
+template <bool GUARD = true, bool F3 = false>
 __device__ __forceinline__ double mx_cos(double x) {
 #if MXV_FAST_TRIG
     double s, c;
-    mx_sincos<GUARD>(x, &s, &c);
+    mx_sincos<GUARD, F3>(x, &s, &c);
     return c;
 #else
     return cos(x);
 #endif
 }
-template <bool GUARD = true>
+template <bool GUARD = true, bool F3 = false>
 __device__ __forceinline__ double mx_sin(double x) {
     double s, c;
-    mx_sincos<GUARD>(x, &s, &c);  // the sine of sincos, so that a cached sine (Pendulum aux) and a fresh one are the same bits
+    mx_sincos<GUARD, F3>(x, &s, &c);  // the sine of sincos, so that a cached sine (Pendulum aux) and a fresh one are the same bits
     return s;
 }
 
@@ -355,7 +380,7 @@ struct Env<MXV_CARTPOLE> {
         const double force = (ai == 1) ? force_mag : -force_mag;  // :135
         double sintheta, costheta;
         if constexpr (DEF == PM_DEFAULT && !SAFE)
-            sincos_kernel(theta, &sintheta, &costheta);
+            sincos_kernel<fma3_for<MXV_CARTPOLE>()>(theta, &sintheta, &costheta);
         else
             sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
         const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
@@ -414,12 +439,12 @@ struct Env<MXV_PENDULUM> {
     static constexpr int S = 2, O = 3, NA = 0;
     static constexpr int AUX = 1;  // fp64 values derived from the state that a fused rollout carries across steps
     template <bool GUARD = true>
-    __device__ __forceinline__ static void prime(const double *s, double *aux) { aux[0] = mx_sin<GUARD>(s[0]); }
+    __device__ __forceinline__ static void prime(const double *s, double *aux) { aux[0] = mx_sin<GUARD, fma3_for<MXV_PENDULUM>()>(s[0]); }
     // aux[0] = sin(theta): `sin(th)` of step t+1 (:131) is the sine _get_obs took at the end of step t (:162)
     template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux) {  // :161-163
         double sn, cs;
-        mx_sincos<GUARD>(s[0], &sn, &cs);
+        mx_sincos<GUARD, fma3_for<MXV_PENDULUM>()>(s[0], &sn, &cs);
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
         aux[0] = sn;
     }
@@ -482,8 +507,8 @@ struct Env<MXV_ACROBOT> {
     static constexpr int AUX = 4;  // sin(theta1), cos(theta1), sin(theta2), cos(theta2) of the current state
     template <bool GUARD = true>
     __device__ __forceinline__ static void prime(const double *s, double *aux) {
-        mx_sincos<GUARD>(s[0], &aux[0], &aux[1]);
-        mx_sincos<GUARD>(s[1], &aux[2], &aux[3]);
+        mx_sincos<GUARD, fma3_for<MXV_ACROBOT>()>(s[0], &aux[0], &aux[1]);
+        mx_sincos<GUARD, fma3_for<MXV_ACROBOT>()>(s[1], &aux[2], &aux[3]);
     }
     // sc = sin/cos of sa[0], sa[1]
     template <int DEF>
@@ -541,8 +566,8 @@ struct Env<MXV_ACROBOT> {
     template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux = nullptr) {  // :225-230
         double s0, c0, s1, c1;
-        mx_sincos<GUARD>(s[0], &s0, &c0);
-        mx_sincos<GUARD>(s[1], &s1, &c1);
+        mx_sincos<GUARD, fma3_for<MXV_ACROBOT>()>(s[0], &s0, &c0);
+        mx_sincos<GUARD, fma3_for<MXV_ACROBOT>()>(s[1], &s1, &c1);
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
         if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
@@ -564,18 +589,18 @@ struct Env<MXV_ACROBOT> {
         dsdt(P, y0, aux, torque, k1);  // :453  (the augmented torque component has derivative 0.0: it stays `torque`)
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k1[k];
-        mx_sincos<SAFE>(y[0], &sc[0], &sc[1]);
-        mx_sincos<SAFE>(y[1], &sc[2], &sc[3]);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(y[0], &sc[0], &sc[1]);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(y[1], &sc[2], &sc[3]);
         dsdt(P, y, sc, torque, k2);   // :454
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt2 * k2[k];
-        mx_sincos<SAFE>(y[0], &sc[0], &sc[1]);
-        mx_sincos<SAFE>(y[1], &sc[2], &sc[3]);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(y[0], &sc[0], &sc[1]);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(y[1], &sc[2], &sc[3]);
         dsdt(P, y, sc, torque, k3);   // :455
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y0[k] + dt * k3[k];
-        mx_sincos<SAFE>(y[0], &sc[0], &sc[1]);
-        mx_sincos<SAFE>(y[1], &sc[2], &sc[3]);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(y[0], &sc[0], &sc[1]);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(y[1], &sc[2], &sc[3]);
         dsdt(P, y, sc, torque, k4);   // :456
         const double dt6 = dt / 6.0;
         double ns[4];
@@ -586,8 +611,8 @@ struct Env<MXV_ACROBOT> {
         s[2] = bound(ns[2], -P.get(8, 4 * kPi), P.get(8, 4 * kPi));  // :215
         s[3] = bound(ns[3], -P.get(9, 9 * kPi), P.get(9, 9 * kPi));  // :216
         double s0, c0, s1, c1;
-        mx_sincos<SAFE>(s[0], &s0, &c0);
-        mx_sincos<SAFE>(s[1], &s1, &c1);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(s[0], &s0, &c0);
+        mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(s[1], &s1, &c1);
         // cos(s[1] + s[0]) :235 from the same four values
         const double t21 = s[1] + s[0];
         const double cos21 = __fma_rn(two_sum_residual(s[1], s[0], t21), __fma_rn(s0, c1, c0 * s1), __fma_rn(c0, c1, -(s0 * s1)));
@@ -625,7 +650,7 @@ struct Env<MXV_MOUNTAINCAR> {
         const double goal_position = P.get(3, 0.5), goal_velocity = P.get(4, 0.0);
         const double force = P.get(5, 0.001), gravity = P.get(6, 0.0025);
         double position = s[0], velocity = s[1];
-        velocity = velocity + ((double)(ai - 1) * force + mx_cos<SAFE>(3 * position) * (-gravity));  // :133
+        velocity = velocity + ((double)(ai - 1) * force + mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR>()>(3 * position) * (-gravity));  // :133
         if (velocity < -max_speed) velocity = -max_speed;                                  // np.clip :134
         if (velocity > max_speed) velocity = max_speed;
         position = position + velocity;                                                    // :135
@@ -673,7 +698,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
         bool term;
         if (fresh) {
             double position = s[0], velocity = s[1];
-            const double g = 0.0025 * mx_cos<SAFE>(3 * position);  // :148
+            const double g = 0.0025 * mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR_CONT>()>(3 * position);  // :148
             const double inc = clipped ? (force_py * power - g) : (double)(fp - (float)g);
             velocity = velocity + inc;
             if (velocity > max_speed) velocity = max_speed;    // :149-152
@@ -688,7 +713,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
         } else {
             float position = (float)s[0], velocity = (float)s[1];
             const float three_p = 3.0f * position;            // int * np.float32 -> float32
-            const double g = 0.0025 * mx_cos<SAFE>((double)three_p);
+            const double g = 0.0025 * mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR_CONT>()>((double)three_p);
             const float inc = clipped ? (float)(force_py * power - g) : (fp - (float)g);
             velocity = velocity + inc;
             if (velocity > (float)max_speed) velocity = (float)max_speed;
