@@ -236,11 +236,13 @@ __device__ __forceinline__ double div_par(double x, double c) {
 #ifndef MXV_FMA3_ENVS
 #define MXV_FMA3_ENVS ((1 << MXV_PENDULUM) | (1 << MXV_MOUNTAINCAR_CONT))
 #endif
+// (The same with the coefficients in SGPR pairs — 20 VGPRs freed for 20 SGPRs — was tried for the register-bound kernels: Acrobot -1 % of its
+// loop's VALU instructions, every other kind more: dropped.)
 template <int ENV>
-constexpr bool fma3_for() { return ((MXV_FMA3_ENVS >> ENV) & 1) != 0; }
-template <bool F3>
+constexpr int fma3_for() { return ((MXV_FMA3_ENVS >> ENV) & 1) ? 1 : 0; }
+template <int F3>
 __device__ __forceinline__ double fma_coef(double a, double b, double k) {
-    if constexpr (F3) {
+    if constexpr (F3 == 1) {
         double r;
         asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(k));
         return r;
@@ -249,7 +251,7 @@ __device__ __forceinline__ double fma_coef(double a, double b, double k) {
     }
 }
 
-template <bool F3 = false>
+template <int F3 = 0>
 __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) {
     const double z = x * x;
     // sin: x + x*z*(S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6)))))
@@ -284,7 +286,7 @@ __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) 
 #ifndef MXV_FAST_TRIG
 #define MXV_FAST_TRIG 1  // A/B hook: 0 = ocml's sincos / cos everywhere
 #endif
-template <bool F3 = false>
+template <int F3 = 0>
 __device__ __forceinline__ void sincos_medium(double x, double *sn, double *cs) {
     const double k = rint(x * 6.36619772367581382433e-01);        // 2/pi
     double r = __fma_rn(-k, 1.5707963267341256, x);               // pi/2, first 33 bits: exact product for |k| < 2^20
@@ -303,7 +305,7 @@ __device__ __forceinline__ void sincos_medium(double x, double *sn, double *cs) 
 // angles to [-pi, pi] and bounds the velocities, MountainCar's argument is 3 * position, a time-limited Pendulum turns at most
 // 0.4 rad per step) — no range check and none of ocml's code or registers in the kernel.  mxv_set_state and unusual reset
 // bounds break that knowledge for one launch, which then takes the guarded instantiation (see launch_step_env, SAFE).
-template <bool GUARD = true, bool F3 = false>
+template <bool GUARD = true, int F3 = 0>
 __device__ __forceinline__ void mx_sincos(double x, double *sn, double *cs) {
 #if MXV_FAST_TRIG
     if (!GUARD || fabs(x) < 524288.0)
@@ -312,7 +314,7 @@ __device__ __forceinline__ void mx_sincos(double x, double *sn, double *cs) {
 #endif
         sincos(x, sn, cs);
 }
-template <bool GUARD = true, bool F3 = false>
+template <bool GUARD = true, int F3 = 0>
 __device__ __forceinline__ double mx_cos(double x) {
 #if MXV_FAST_TRIG
     double s, c;
@@ -322,7 +324,7 @@ __device__ __forceinline__ double mx_cos(double x) {
     return cos(x);
 #endif
 }
-template <bool GUARD = true, bool F3 = false>
+template <bool GUARD = true, int F3 = 0>
 __device__ __forceinline__ double mx_sin(double x) {
     double s, c;
     mx_sincos<GUARD, F3>(x, &s, &c);  // the sine of sincos, so that a cached sine (Pendulum aux) and a fresh one are the same bits
