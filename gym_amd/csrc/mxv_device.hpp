@@ -238,6 +238,11 @@ __device__ __forceinline__ double div_par(double x, double c) {
 #endif
 // (The same with the coefficients in SGPR pairs — 20 VGPRs freed for 20 SGPRs — was tried for the register-bound kernels: Acrobot -1 % of its
 // loop's VALU instructions, every other kind more: dropped.)
+// CartPole with ONE env per lane (shards of up to 2^17 envs: the per-GPU share of an 8-GPU strong-scaling job, latency-bound, 87 VGPRs)
+// gains 5 % (0.818 -> 0.778 us per step); at two envs per lane (113 VGPRs) it is the compiler's form that wins.
+#ifndef MXV_FMA3_CARTPOLE_E1
+#define MXV_FMA3_CARTPOLE_E1 1
+#endif
 template <int ENV>
 constexpr int fma3_for() { return ((MXV_FMA3_ENVS >> ENV) & 1) ? 1 : 0; }
 template <int F3>
@@ -371,7 +376,7 @@ struct Env<MXV_CARTPOLE> {
     // SAFE = false (rollout fast path, default parameters only): the caller guarantees |theta| <= pi/4 on entry, which
     // holds inductively after reset() under autoreset (an env leaves (-0.2095, 0.2095) only in the step that ends it);
     // mxv_set_state() breaks the induction, so the launch after it uses the SAFE instantiation (see mxv_api.cpp).
-    template <int DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true, int EPL = 0>   // EPL: envs per lane of the calling kernel (0 = not said)
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double gravity = P.get(0, 9.8), masspole = P.get(2, 0.1), total_mass = P.get(3, 0.1 + 1.0);
@@ -382,7 +387,7 @@ struct Env<MXV_CARTPOLE> {
         const double force = (ai == 1) ? force_mag : -force_mag;  // :135
         double sintheta, costheta;
         if constexpr (DEF == PM_DEFAULT && !SAFE)
-            sincos_kernel<fma3_for<MXV_CARTPOLE>()>(theta, &sintheta, &costheta);
+            sincos_kernel<(fma3_for<MXV_CARTPOLE>() || (EPL == 1 && MXV_FMA3_CARTPOLE_E1)) ? 1 : 0>(theta, &sintheta, &costheta);
         else
             sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
         const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
@@ -450,7 +455,7 @@ struct Env<MXV_PENDULUM> {
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
         aux[0] = sn;
     }
-    template <int DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true, int EPL = 0>   // EPL: envs per lane of the calling kernel (0 = not said)
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int, float a0,
                                                 double &reward, float *obs) {
         const double max_speed = P.get(0, 8.0), max_torque = P.get(1, 2.0), dt = P.get(2, 0.05);
@@ -574,7 +579,7 @@ struct Env<MXV_ACROBOT> {
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
         if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
     }
-    template <int DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true, int EPL = 0>   // EPL: envs per lane of the calling kernel (0 = not said)
     // `noise_word`: for this env the Box-action slot of the shared step() signature carries the raw Philox word of the
     // step-noise stream (bit pattern in a float), consumed only when torque_noise_max > 0 (never on the default path).
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *aux, bool, int ai, float noise_word,
@@ -645,7 +650,7 @@ struct Env<MXV_MOUNTAINCAR> {
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
-    template <int DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true, int EPL = 0>   // EPL: envs per lane of the calling kernel (0 = not said)
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool, int ai, float, double &reward,
                                                 float *obs) {
         const double min_position = P.get(0, -1.2), max_position = P.get(1, 0.6), max_speed = P.get(2, 0.07);
@@ -684,7 +689,7 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
     __device__ __forceinline__ static void observe(const double *s, float *obs, double * = nullptr) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     }
-    template <int DEF, bool SAFE = true>
+    template <int DEF, bool SAFE = true, int EPL = 0>   // EPL: envs per lane of the calling kernel (0 = not said)
     __device__ __forceinline__ static bool step(const Par<DEF> &P, double *s, double *, bool fresh, int, float a0,
                                                 double &reward, float *obs) {
         const double min_action = P.get(0, -1.0), max_action = P.get(1, 1.0);

@@ -626,7 +626,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         bool term[E], trunc[E], pend[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            term[j] = EV::template step<DEF, SAFE>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            term[j] = EV::template step<DEF, SAFE, E>(P, s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = (ALLV || valid[j]) && (term[j] || trunc[j]);
