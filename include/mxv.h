@@ -504,8 +504,10 @@ int mxv_write_probe_env(int32_t device, int32_t env_id, int32_t flags, int64_t n
  *    allocations (4 GiB each) that make the next chunk come from further along in physical memory — up to half of the device's free
  *    memory (at most 112 GiB; never into the last 16 GiB), released before the call returns; MXV_PLACED_NO_JUMP forbids the spacers
  *    (then a process that sits deep inside one class gets best effort: info.balanced = 0).  0.2-1.5 s.
- *    Sets below MXV_PLACED_MIN_BYTES (2 GiB: a 2^17-env shard of 1 GiB is latency-bound, not write-bound, and ran 4 % faster on ordinary
- *    allocations), sets with an empty group and MXV_PLACED_PLAIN take ordinary hipMalloc allocations (info.placed = 0).
+ *    Sets below MXV_PLACED_MIN_BYTES (2 GiB: the real kernel runs 4-10 % slower on memory mapped through this API than on hipMalloc'ed
+ *    memory, which the 8 % a 2^17-env shard of 1 GiB gains from separated classes does not win back — such sets are better served by
+ *    ordinary allocations SORTED by class with mxv_hbm_pair_probe, what gym_amd/placement.py does from 1 GiB on), sets with an empty
+ *    group and MXV_PLACED_PLAIN take ordinary hipMalloc allocations (info.placed = 0).
  *    bytes[i] > 0, group[i] in {-1, 0, 1}; ptrs_out[i] receives tensor i's device address (contents uninitialised).  mxv_placed_free
  *    releases the physical memory; the virtual ranges are NOT returned to the runtime (this runtime keeps stale translations for an
  *    address that is mapped a second time), i.e. every call consumes a little virtual address space for the life of the process. */
