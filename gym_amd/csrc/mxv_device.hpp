@@ -440,6 +440,27 @@ __device__ __forceinline__ double np_remainder(double a, double b) {  // numpy f
     }
     return mod;
 }
+// The same value for a literal b > 0 when the caller knows |a| < 2^20 * b (the fused rollout on a time-limited Pendulum: |theta| < 90),
+// as straight-line selects: no range guard with ocml's fmod behind it, no exec-mask blocks around single additions.  Every step is exact
+// (see fmod_const), so the bits are those of np_remainder by construction.
+#ifndef MXV_REMAINDER_SELECTS
+#define MXV_REMAINDER_SELECTS 1   // A/B hook
+#endif
+__device__ __forceinline__ double np_remainder_bounded(double a, double b) {
+#if MXV_REMAINDER_SELECTS
+    const double aa = fabs(a);
+    const double q = trunc(aa * (1.0 / b));
+    double r = __fma_rn(-q, b, aa);              // exact: the true remainder or off by one period
+    const double up = r + b, down = r - b;
+    r = (r < 0.0) ? up : ((r >= b) ? down : r);
+    double mod = copysign(r, a);                 // C fmod: the sign of the dividend
+    const double lifted = mod + b;               // Python / NumPy `%`: the sign of the divisor
+    mod = (mod < 0.0) ? lifted : mod;
+    return (mod == 0.0) ? 0.0 : mod;             // copysign(0.0, b) for a zero remainder
+#else
+    return np_remainder(a, b);
+#endif
+}
 
 template <>
 struct Env<MXV_PENDULUM> {
@@ -466,7 +487,7 @@ struct Env<MXV_PENDULUM> {
         if (u < lo) u = lo;
         if (u > hi) u = hi;
         const float uterm = (float)0.001 * (u * u);                       // 0.001 * (u**2) in float32 :129
-        const double an = np_remainder(th + kPi, 2 * kPi) - kPi;           // angle_normalize :270-271
+        const double an = (SAFE ? np_remainder(th + kPi, 2 * kPi) : np_remainder_bounded(th + kPi, 2 * kPi)) - kPi;  // angle_normalize :270-271
         const double costs = an * an + 0.1 * (thdot * thdot) + (double)uterm;
         const double A = 3 * g / (2 * l);                                  // python floats :131
         const float B = (float)(3.0 / (m * (l * l)));
