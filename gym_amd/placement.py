@@ -23,6 +23,7 @@ remembered blocks costs no probe launch at all.
 from __future__ import annotations
 
 import math
+import os
 import time
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -69,7 +70,12 @@ class _Device:
         torch.cuda.empty_cache()
 
     def segment_frees(self):
-        """How many device segments the caching allocator has returned to the driver so far (None: unknown — nothing is remembered)."""
+        """How many device segments the caching allocator has returned to the driver so far (None: unknown — nothing is remembered).
+        With expandable segments the allocator maps and unmaps physical memory under stable addresses, which this count does not
+        describe: nothing is remembered then."""
+        conf = " ".join(os.environ.get(k, "") for k in ("PYTORCH_CUDA_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF", "PYTORCH_ALLOC_CONF"))
+        if "expandable_segments:true" in conf.replace(" ", "").lower():
+            return None
         return torch.cuda.memory_stats(self.dev).get("num_device_free")
 
     def key(self):
