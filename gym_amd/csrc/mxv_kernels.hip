@@ -565,6 +565,14 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 #endif
 
     settle_entry_loads();
+#if MXV_EXP_STAGGER > 0  // measurement only: a one-time phase offset between the waves that share a SIMD (units of 64 clocks x 0..3):
+    {                    // do the store bursts of waves running in lockstep cost the compute-bound kinds their overlap?
+        const unsigned ph = (bid >> 3) & 3u;  // consecutive workgroups of one XCD (ids 8 apart) fill a CU's SIMDs in turn
+        if (ph == 1) __builtin_amdgcn_s_sleep(MXV_EXP_STAGGER);
+        else if (ph == 2) __builtin_amdgcn_s_sleep(2 * MXV_EXP_STAGGER);
+        else if (ph == 3) __builtin_amdgcn_s_sleep(3 * MXV_EXP_STAGGER);
+    }
+#endif
     // The loop exists twice in a tape-driven kernel: ALLV = every env slot of the wave is a real env (all tiles but possibly the
     // last), so no store sits behind an exec-mask branch — the compiler can then prove how many stores follow a tape load on
     // every path and waits for the load with s_waitcnt vmcnt(N > 0) instead of draining the wave's stores.

@@ -173,6 +173,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_EXP_SLEEP
 #define MXV_EXP_SLEEP 0
 #endif
+// measurement hook: one-time phase offset between waves at the top of the fused rollout (see rollout_body_v3)
+#ifndef MXV_EXP_STAGGER
+#define MXV_EXP_STAGGER 0
+#endif
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8
