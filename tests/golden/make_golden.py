@@ -117,7 +117,9 @@ def p1_actions(name, rng, n):
     return a
 
 
-def make_p1(name, n=4096, seed=20260921):
+def make_p1(name, n=4096, seed=20260921, save=True):
+    """save=False: return the vectors instead of writing the fixture (tests/test_oracle_live_reference.py: fresh seeds against the live
+    reference, where it exists)."""
     gid, S, O, nd, _ = ENVS[name]
     rng = np.random.default_rng(seed + sum(map(ord, name)))
     raw = gym.make(gid, disable_env_checker=True).unwrapped
@@ -141,12 +143,14 @@ def make_p1(name, n=4096, seed=20260921):
         rew[i] = r
         term[i] = te
         s1[i] = get_state(raw)
+    if not save:
+        return dict(state0=s0, action=act, fresh=fresh, obs=obs, reward=rew, terminated=term, state1=s1)
     np.savez_compressed(os.path.join(HERE, f"{name}_p1.npz"), state0=s0, action=act, fresh=fresh, obs=obs,
                         reward=rew, terminated=term, state1=s1)
     print(f"{name:24s} P1: {n} steps, {int(term.sum())} terminations")
 
 
-def make_p2(name, tag, T, max_episode_steps=None, num_envs=8, seed=123):
+def make_p2(name, tag, T, max_episode_steps=None, num_envs=8, seed=123, save=True):
     gid, S, O, nd, _ = ENVS[name]
     kwargs = {} if max_episode_steps is None else {"max_episode_steps": max_episode_steps}
     venv = gym.vector.make(gid, num_envs=num_envs, asynchronous=False, **kwargs)
@@ -192,6 +196,9 @@ def make_p2(name, tag, T, max_episode_steps=None, num_envs=8, seed=123):
         for i, e in enumerate(venv.envs):
             rec["state_post"][t, i] = get_state(e.unwrapped)
             rec["elapsed_post"][t, i] = e._elapsed_steps
+    if not save:
+        venv.close()
+        return dict(obs0=obs0, max_episode_steps=np.int32(limit), **rec)
     np.savez_compressed(os.path.join(HERE, f"{name}_p2_{tag}.npz"), obs0=obs0, max_episode_steps=np.int32(limit),
                         **rec)
     print(f"{name:24s} P2[{tag}]: T={T} limit={limit} term={int(rec['terminated'].sum())} "

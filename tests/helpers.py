@@ -120,10 +120,10 @@ def compare_step(tag, got, ref, done_ref, strict):
                                    err_msg=f"{tag}: fp64 state")
 
 
-def run_p1(engine_cls, name, strict, kind="p1"):
+def run_p1(engine_cls, name, strict, kind="p1", golden=None):
     """Single raw-env steps from hand-set states (golden <env>_p1.npz; kind="p1_threshold": Acrobot states whose post-step
-    height sits within ulps of the termination threshold, make_golden_goal.py)."""
-    g = load_golden(name, kind)
+    height sits within ulps of the termination threshold, make_golden_goal.py; golden=: vectors made on the spot)."""
+    g = load_golden(name, kind) if golden is None else golden
     n = len(g["action"])
     eng = engine_cls(name, n, 0, autoreset=False)
     elapsed = np.where(g["fresh"] == 1, 0, 5).astype(np.int32)
@@ -160,11 +160,11 @@ def run_p1_variants(engine_cls, name, strict):
     return total
 
 
-def run_p2(engine_cls, name, tag, strict):
+def run_p2(engine_cls, name, tag, strict, golden=None):
     """Teacher-forced replay of a SyncVectorEnv trajectory (golden <env>_p2_<tag>.npz): before every step the
     engine is given the reference's pre-step fp64 state and elapsed counters (so PCG64-vs-Philox resets cannot
     desynchronise the two), then one vector step is compared output by output."""
-    g = load_golden(name, f"p2_{tag}")
+    g = load_golden(name, f"p2_{tag}") if golden is None else golden
     T, N = g["action"].shape
     eng = engine_cls(name, N, int(g["max_episode_steps"]), autoreset=True)
     ndone = 0

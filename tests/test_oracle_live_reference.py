@@ -1,0 +1,57 @@
+"""The oracle against the LIVE reference, on vectors nobody has seen before (CPU; skipped where /root/reference does not exist, i.e. on
+the GPU box).  tests/test_oracle_golden.py pins the oracle to committed fixtures; this file runs the generator of those fixtures
+(tests/golden/make_golden.py: the reference itself, imported read-only, under the NumPy-2 alias shim) with seeds derived from the clock
+and holds the oracle to the same bar — BIT-EXACT observations, rewards, masks, fp64 post-step states, final observations — on
+
+  * 12 000 single raw-env steps per env kind from states sampled broadly and next to every threshold, in- and out-of-range actions;
+  * a 32-env SyncVectorEnv trajectory per env kind (TimeLimit + autoreset + final_observation, RecordEpisodeStatistics riding along),
+    once with the registered TimeLimit and once with a short one.
+
+A failure prints the seed, which reproduces it."""
+import importlib.util
+import os
+import time
+
+import numpy as np
+import pytest
+
+from helpers import ENV_NAMES, OracleEngine, run_p1, run_p2
+
+REFERENCE = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "gym")), reason="the reference tree is not here (GPU box)")
+
+
+@pytest.fixture(scope="module")
+def gen():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    spec = importlib.util.spec_from_file_location("make_golden_live", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)      # imports gym from /root/reference (read-only)
+    return mod
+
+
+SEED = int(os.environ.get("MXV_LIVE_SEED", "0")) or int(time.time()) % 1_000_000_007
+
+
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_fresh_single_steps_bit_exact(gen, name):
+    g = gen.make_p1(name, n=12000, seed=SEED, save=False)
+    try:
+        run_p1(OracleEngine, name, strict=True, golden=g)
+    except AssertionError as e:
+        raise AssertionError(f"MXV_LIVE_SEED={SEED} reproduces this: {e}") from e
+    if name in ("CartPole", "Acrobot", "MountainCar", "MountainCarContinuous"):
+        assert int(g["terminated"].sum()) > 0          # the sampler reaches the thresholds
+
+
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_fresh_vector_trajectories_bit_exact(gen, name):
+    short = gen.ENVS[name][4]
+    for tag, kw in (("default", {}), ("short", {"max_episode_steps": short})):
+        g = gen.make_p2(name, tag, T=240, num_envs=32, seed=SEED + 17, save=False, **kw)
+        try:
+            ndone = run_p2(OracleEngine, name, tag, strict=True, golden=g)
+        except AssertionError as e:
+            raise AssertionError(f"MXV_LIVE_SEED={SEED} reproduces this: {e}") from e
+        if tag == "short":
+            assert ndone > 32                           # truncations + autoresets were exercised
