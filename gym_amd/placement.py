@@ -164,10 +164,12 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             report["remembered"] += 1
         else:
             same = probe(a0, a0 + WIDE, a0)                # both streams inside the first 384 MiB of one allocation: a same-class pair
-            if probe(a0, a1 - NARROW) <= SAME_RATIO * same and parked_bytes + nbytes[anchor_name] <= budget:
+            straddles = probe(a0, a1 - NARROW) <= SAME_RATIO * same
+            if straddles and parked_bytes + nbytes[anchor_name] <= budget:
                 park((anchor_name, anchor))
                 continue
-            memo.single.add((a0, nbytes[anchor_name]))
+            if not straddles:
+                memo.single.add((a0, nbytes[anchor_name]))
             report["same_class_us"] = round(same, 3)
 
         def relation(t, n):
