@@ -570,11 +570,16 @@ def main():
     else:
         from gym_amd import _native
         big = local_envs * args.chunk * 34 >= _native.SORTED_MIN_BYTES      # 2^17-env shards (8 GPUs) and larger are sorted by HBM class
-        traj = eng.trajectory_buffers(args.chunk, layout=args.placement if big else "separate")
-        placement = dict(getattr(eng, "last_placement", None) or {}) if big else {"kind": "ordinary allocations (set below 1 GiB)"}
-        if big:
-            placement["kind"] = {"sorted": "sorted (ordinary allocations classified with mxv_hbm_pair_probe)",
-                                 "placed": "placed (mxv_placed_alloc)"}[args.placement]
+        try:
+            traj = eng.trajectory_buffers(args.chunk, layout=args.placement if big else "separate")
+            placement = dict(getattr(eng, "last_placement", None) or {}) if big else {"kind": "ordinary allocations (set below 1 GiB)"}
+            if big:
+                placement["kind"] = {"sorted": "sorted (ordinary allocations classified with mxv_hbm_pair_probe)",
+                                     "placed": "placed (mxv_placed_alloc)"}[args.placement]
+        except (RuntimeError, MemoryError) as e:   # e.g. a device someone else is using: measure on ordinary allocations instead of dying
+            torch.cuda.empty_cache()
+            traj = eng.trajectory_buffers(args.chunk, layout="separate")
+            placement = {"kind": "ordinary allocations", "error": f"{args.placement} placement failed: {e}"[:300]}
     trace(f"engine + trajectory tensors ready: {local_envs} envs, placement {placement.get('kind') if placement else None}"
           f" balanced={placement.get('balanced') if placement else None} parked_GiB={placement.get('parked_GiB') if placement else None}")
     launches = [0]
