@@ -35,3 +35,7 @@ class NoAsyncCallError(Error):
 
 class ClosedEnvironmentError(Error):
     """Operation on a closed vector env (gym/error.py:189)."""
+
+
+class CustomSpaceError(Error):
+    """A space that is none of the built-in kinds reached a batching helper (gym/error.py:190-197, gym/vector/utils/spaces.py:205-212)."""

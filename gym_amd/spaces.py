@@ -233,13 +233,16 @@ class Tuple(Space):
 
 
 def batch_space(space: Space, n: int = 1) -> Space:
-    """gym/vector/utils/spaces.py:17-68 for Box and Discrete (and Tuple: :102-108)."""
+    """gym/vector/utils/spaces.py:17-125 for Box, Discrete, MultiDiscrete and Tuple."""
     if isinstance(space, Tuple):
         return Tuple(tuple(batch_space(sp, n) for sp in space.spaces), seed=deepcopy(space.np_random))
     if isinstance(space, Box):
         repeats = tuple([n] + [1] * space.low.ndim)
         low, high = np.tile(space.low, repeats), np.tile(space.high, repeats)
         return Box(low=low, high=high, dtype=space.dtype, seed=deepcopy(space.np_random))
+    if isinstance(space, MultiDiscrete):                # :71-81: a Box of integer vectors, one row per sub-env
+        high = np.tile(space.nvec, tuple([n] + [1] * space.nvec.ndim)) - 1
+        return Box(low=np.zeros_like(high), high=high, dtype=space.dtype, seed=deepcopy(space.np_random))
     if isinstance(space, Discrete):
         if space.start == 0:
             return MultiDiscrete(np.full((n,), space.n, dtype=space.dtype), dtype=space.dtype,

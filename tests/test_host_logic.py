@@ -460,3 +460,96 @@ def test_adapter_error_and_time_limit_contract_on_the_stand_in(packed, monkeypat
     assert term.all() and trunc.all() and infos["_final_observation"].all()
     assert all(abs(o[0]) > 2.4 for o in infos["final_observation"])      # the terminal observation, not the reset one
     env.close()
+
+
+def _space_pairs(rs):
+    from gym_amd.spaces import Tuple
+
+    box_m, box_r = Box(-1.0, 1.0, (3,), np.float32), rs.Box(-1.0, 1.0, (3,), np.float32)
+    md_m, md_r = MultiDiscrete([3, 4]), rs.MultiDiscrete([3, 4])
+    return [("box", box_m, box_r), ("discrete", Discrete(5), rs.Discrete(5)), ("multidiscrete", md_m, md_r),
+            ("tuple", Tuple((box_m, md_m)), rs.Tuple((box_r, md_r)))]
+
+
+def test_vector_utils_against_the_reference():
+    """gym_amd.vector.utils.{batch_space, create_empty_array, concatenate, iterate} do what gym.vector.utils does for the spaces this engine
+    has (gym/vector/utils/numpy_utils.py:14-150, spaces.py:17-212; the reference's own tests: tests/vector/test_numpy_utils.py,
+    tests/vector/test_spaces.py)."""
+    gym = _ref_gym()
+    from gym import spaces as rs
+    from gym.vector import utils as ru
+
+    from gym_amd.vector import utils as mu
+
+    def same(a, b):
+        if isinstance(a, tuple):
+            assert isinstance(b, tuple) and len(a) == len(b)
+            for x, y in zip(a, b):
+                same(x, y)
+        else:
+            a, b = np.asarray(a), np.asarray(b)
+            assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
+
+    n = 4
+    for name, mine, ref in _space_pairs(rs):
+        mine.seed(11), ref.seed(11)
+        # batch_space: class, shape, dtype, bounds, and the same sample stream
+        bm, br = mu.batch_space(mine, n), ru.batch_space(ref, n)
+        assert type(bm).__name__ == type(br).__name__, name
+        if name != "tuple":
+            assert bm.shape == br.shape and bm.dtype == br.dtype, name
+            if isinstance(bm, Box):
+                assert np.array_equal(bm.low, br.low) and np.array_equal(bm.high, br.high)
+        same(bm.sample(), br.sample())
+        # create_empty_array: n elements, one element (n=None), another constructor
+        same(mu.create_empty_array(mine, n), ru.create_empty_array(ref, n))
+        same(mu.create_empty_array(mine, None), ru.create_empty_array(ref, None))
+        same(mu.create_empty_array(mine, 2, fn=np.ones), ru.create_empty_array(ref, 2, fn=np.ones))
+        # concatenate: stack n samples into the preallocated batch; the result IS `out` for array spaces
+        items_m = [mine.sample() for _ in range(n)]
+        items_r = [ref.sample() for _ in range(n)]
+        out_m, out_r = mu.create_empty_array(mine, n), ru.create_empty_array(ref, n)
+        cm, cr = mu.concatenate(mine, items_m, out_m), ru.concatenate(ref, items_r, out_r)
+        same(cm, cr)
+        if name != "tuple":
+            assert cm is out_m
+        # iterate: the batch taken apart again (Discrete: TypeError, in both)
+        if name == "discrete":
+            with pytest.raises(TypeError):
+                mu.iterate(mine, cm)
+            with pytest.raises(TypeError):
+                ru.iterate(ref, cr)
+        else:
+            back_m, back_r = list(mu.iterate(mine, cm)), list(ru.iterate(ref, cr))
+            assert len(back_m) == len(back_r) == n
+            for x, y, item in zip(back_m, back_r, items_m):
+                same(x, y)
+                same(x, item)
+    with pytest.raises(TypeError):
+        mu.iterate(Box(-1.0, 1.0, (3,), np.float32), 5)           # not iterable (spaces.py:171-175)
+
+
+def test_vector_utils_without_the_reference():
+    from gym_amd.error import CustomSpaceError
+    from gym_amd.spaces import Space, Tuple
+    from gym_amd.vector import utils as mu
+
+    class Odd(Space):
+        pass
+
+    odd = Odd((), np.float32)
+    assert mu.create_empty_array(odd, 3) is None and mu.concatenate(odd, [1, 2], None) == (1, 2)
+    with pytest.raises(CustomSpaceError):
+        mu.iterate(odd, [1, 2])
+    for f in (lambda: mu.create_empty_array("no space"), lambda: mu.concatenate(3, [], None), lambda: mu.iterate(None, [])):
+        with pytest.raises(ValueError):
+            f()
+    t = Tuple((Box(0.0, 1.0, (2,), np.float32), MultiDiscrete([2, 2])))
+    out = mu.create_empty_array(t, 3)
+    assert isinstance(out, tuple) and out[0].shape == (3, 2) and out[0].dtype == np.float32 and out[1].shape == (3, 2) and out[1].dtype == np.int64
+    rows = list(mu.iterate(t, out))
+    assert len(rows) == 3 and rows[0][0].shape == (2,) and rows[0][1].shape == (2,)
+    b = mu.batch_space(MultiDiscrete([3, 4]), 5)
+    assert isinstance(b, Box) and b.shape == (5, 2) and b.dtype == np.int64 and np.array_equal(b.high[0], [2, 3]) and np.all(b.low == 0)
+    import gym_amd
+    assert gym_amd.vector.utils is mu and gym_amd.vector.make is gym_amd.make
