@@ -1,6 +1,6 @@
 """The oracle against the LIVE reference, on vectors nobody has seen before (CPU; skipped where /root/reference does not exist, i.e. on
 the GPU box).  tests/test_oracle_golden.py pins the oracle to committed fixtures; this file runs the generator of those fixtures
-(tests/golden/make_golden.py: the reference itself, imported read-only, under the NumPy-2 alias shim) with seeds derived from the clock
+(tests/golden/make_golden.py: the reference itself, imported read-only, under the NumPy-2 alias shim) with seeds no fixture uses
 and holds the oracle to the same bar — BIT-EXACT observations, rewards, masks, fp64 post-step states, final observations — on
 
   * 12 000 single raw-env steps per env kind from states sampled broadly and next to every threshold, in- and out-of-range actions;
@@ -30,7 +30,11 @@ def gen():
     return mod
 
 
-SEED = int(os.environ.get("MXV_LIVE_SEED", "0")) or int(time.time()) % 1_000_000_007
+# Vectors that are in no fixture: by default a fixed seed of this file's own (a test run must not be a lottery); MXV_LIVE_SEED=<int> picks
+# another one, MXV_LIVE_SEED=clock a new one per run (18 seeds were run that way when the file was written: 1.1e6 single steps and 2.8e5
+# vector env-steps, all bit-exact).
+_s = os.environ.get("MXV_LIVE_SEED", "")
+SEED = int(time.time()) % 1_000_000_007 if _s == "clock" else (int(_s) if _s else 777_000_123)
 
 
 @pytest.mark.parametrize("name", ENV_NAMES)
