@@ -159,6 +159,24 @@ def test_example_policy_search_learns_on_device():
     assert w[2] > 0 and w[3] > 0    # push the cart towards the side the pole falls to
 
 
+def test_example_dropin_loop_runs_on_the_engine():
+    """examples/dropin_sync_vector_env.py: one loop written against the gym.vector interface (BASELINE.json configs[0]); here driven by
+    gym_amd.vector.make.  A random CartPole policy lasts ~22 steps per episode."""
+    import importlib.util
+    import os
+
+    import gym_amd
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "dropin_sync_vector_env.py")
+    spec = importlib.util.spec_from_file_location("dropin_sync_vector_env", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(gym_amd.vector.make, "CartPole-v1", 8, 1000)
+    assert r["episodes"] > 200 and 15 < r["mean_episode_length"] < 30, r
+    r = mod.run(gym_amd.vector.make, "MountainCar-v0", 64, 450)
+    assert r["episodes"] == 128 and r["mean_episode_length"] == 200, r       # a random policy never reaches the flag: two truncations per env
+
+
 def test_device_rollout_state_dict_resumes_bit_identically():
     """Checkpoint / resume of the device-resident API incl. the fused episode statistics' running returns."""
     import pickle
