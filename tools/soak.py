@@ -19,7 +19,8 @@ def main():
 
     t0 = time.time()
     total = 0
-    for seed in (11, 222, 3333, 44444):
+    extra = int(os.environ.get("SOAK_EXTRA_SEEDS", "0"))      # more device-vs-oracle-twin seeds (each: 5 env kinds x 2 shapes)
+    for seed in (11, 222, 3333, 44444) + tuple(100003 + 7919 * i for i in range(extra)):
         for name in ENV_NAMES:
             for n, steps, limit in ((4097, 300, None), (1000, 120, 17)):
                 nd = tp._rollout_compare(name, n=n, steps=steps, seed=seed, limit=limit, env_offset=(seed % 7) * 4096)
@@ -88,7 +89,7 @@ def main():
     # randomized shapes: sampled rollout (fused) == one launch per step (eager) == tape-driven rollout fed the recorded actions,
     # every output of every step and the final state, over random env kinds, sizes, chunk lengths, time limits, shard offsets
     # and dtype sets
-    rng = np.random.default_rng(20260923)
+    rng = np.random.default_rng(int(os.environ.get("SOAK_RANDOM_SEED", "20260923")))
     for case in range(int(os.environ.get("SOAK_RANDOM_CASES", "80"))):
         name = ENV_NAMES[int(rng.integers(len(ENV_NAMES)))]
         n = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 1000, 4097])) if rng.random() < 0.5 else int(rng.integers(1, 6000))
