@@ -35,6 +35,9 @@ namespace {
 #ifndef MXV_BJ_PACKED_DRAWS
 #define MXV_BJ_PACKED_DRAWS 1   // 1: the step's first eight cards evaluated up front (CardSource); 0: a Philox call at every draw (A/B hook)
 #endif
+#ifndef MXV_BJ_NEXT4
+#define MXV_BJ_NEXT4 1          // 1: a reset's four cards in one go, the third call decided once per wave (A/B hook)
+#endif
 constexpr int kBjBlock = 256;
 constexpr uint32_t kStreamDraw = 5u;
 
@@ -73,12 +76,15 @@ struct BjArgs {
 // episode's hands), lane by lane, and a lane-by-lane "refill when the cursor crosses a call boundary" makes the WAVE run a Philox call
 // at nearly every draw (some lane always crosses).  Instead the first two calls of the step's draw stream are evaluated once, up front,
 // and their eight cards packed four bits each into one register: a draw is a shift and a mask.  Draws past the eighth (a dealer hand
-// of five and more cards) evaluate their call on the spot.
+// of five and more cards) evaluate their call on the spot — except the four cards of the next episode's hands, which are taken in one go
+// (next4): whether ANY lane of the wave reaches into cards 8..11 is decided once (in a wave of 64 tables some dealer has drawn five
+// cards in about every second step) and the third call is then evaluated once, not at each of the four draws.
 struct CardSource {
     const int8_t *inj;
     uint64_t seed, t;
     int cursor;
     uint32_t pk;   // cards 0..7 of the step's draw stream, 4 bits each
+    uint32_t pk2;  // cards 8..11 (valid inside next4 only)
     __device__ __forceinline__ U4 call(uint32_t i) const {
         U4 ctr;
         ctr.x = (uint32_t)t; ctr.y = (uint32_t)(t >> 32); ctr.z = i; ctr.w = (kStreamDraw << 28);
@@ -91,6 +97,27 @@ struct CardSource {
         pk = (uint32_t)card_of(w0.x) | ((uint32_t)card_of(w0.y) << 4) | ((uint32_t)card_of(w0.z) << 8) | ((uint32_t)card_of(w0.w) << 12) |
              ((uint32_t)card_of(w1.x) << 16) | ((uint32_t)card_of(w1.y) << 20) | ((uint32_t)card_of(w1.z) << 24) | ((uint32_t)card_of(w1.w) << 28);
 #endif
+    }
+    static __device__ __forceinline__ uint32_t pack4(const U4 &w) {
+        return (uint32_t)card_of(w.x) | ((uint32_t)card_of(w.y) << 4) | ((uint32_t)card_of(w.z) << 8) | ((uint32_t)card_of(w.w) << 12);
+    }
+    // the next four cards (a reset: dealer's two, player's two)
+    __device__ __forceinline__ void next4(int c[4]) {
+#if MXV_BJ_PACKED_DRAWS && MXV_BJ_NEXT4
+        if (!inj) {
+            const bool fast = cursor <= 8;                 // all four inside cards 0..11
+            if (__any(fast && cursor > 4)) pk2 = pack4(call(2));   // somebody's four reach past card 7: one call for the wave
+            if (fast) {
+                const uint64_t both = (uint64_t)pk | ((uint64_t)pk2 << 32);
+                const uint32_t four = (uint32_t)(both >> (4 * cursor)) & 0xffffu;
+                c[0] = (int)(four & 15u); c[1] = (int)((four >> 4) & 15u); c[2] = (int)((four >> 8) & 15u); c[3] = (int)(four >> 12);
+                cursor += 4;
+                return;
+            }
+        }
+#endif
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) c[i] = next();
     }
     __device__ __forceinline__ int next() {
         int c;
@@ -179,7 +206,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
             if (!valid) continue;
             if (a.actions_out) a.actions_out[o1] = act;
         }
-        CardSource src{a.cards ? a.cards + e * MXV_BJ_MAX_DRAWS : nullptr, seed, t, 0, 0u};
+        CardSource src{a.cards ? a.cards + e * MXV_BJ_MAX_DRAWS : nullptr, seed, t, 0, 0u, 0u};
         src.begin();
         bool term;
         double rew;
@@ -207,11 +234,11 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
                 a.final_obs[o + col] = dfirst;
                 a.final_obs[o + 2 * col] = p.usable() ? 1 : 0;
             }
-            const int c1 = src.next(), c2 = src.next();        // reset (:157-158): the dealer's hand first
-            deal(c1, c2, d);
-            dfirst = c1;
-            const int c3 = src.next(), c4 = src.next();
-            deal(c3, c4, p);
+            int c4[4];
+            src.next4(c4);                                     // reset (:157-158): the dealer's hand first
+            deal(c4[0], c4[1], d);
+            dfirst = c4[0];
+            deal(c4[2], c4[3], p);
             el = 0;
         }
         a.obs[o] = p.total();
