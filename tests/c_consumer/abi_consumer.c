@@ -15,6 +15,7 @@
  */
 #include <dlfcn.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -99,6 +100,26 @@ int main(int argc, char **argv) {
         }
     }
     if (symbols_only) {
+        /* every struct of the header as C lays it out: "layout <struct> <size> <field>=<offset> ..." (tests/test_c_consumer.py holds
+         * gym_amd/_native.py's ctypes mirrors against these lines) */
+#define OFF(T, f) printf(" " #f "=%zu", offsetof(T, f))
+        printf("layout mxv_config %zu", sizeof(mxv_config));
+        OFF(mxv_config, env_id); OFF(mxv_config, device); OFF(mxv_config, num_envs); OFF(mxv_config, env_offset);
+        OFF(mxv_config, max_episode_steps); OFF(mxv_config, flags); OFF(mxv_config, seed); OFF(mxv_config, action_seed);
+        printf("\nlayout mxv_tab_config %zu", sizeof(mxv_tab_config));
+        OFF(mxv_tab_config, device); OFF(mxv_tab_config, num_states); OFF(mxv_tab_config, num_actions); OFF(mxv_tab_config, max_transitions);
+        OFF(mxv_tab_config, num_envs); OFF(mxv_tab_config, env_offset); OFF(mxv_tab_config, max_episode_steps); OFF(mxv_tab_config, flags);
+        OFF(mxv_tab_config, seed); OFF(mxv_tab_config, action_seed);
+        printf("\nlayout mxv_bj_config %zu", sizeof(mxv_bj_config));
+        OFF(mxv_bj_config, device); OFF(mxv_bj_config, natural); OFF(mxv_bj_config, sab); OFF(mxv_bj_config, max_episode_steps);
+        OFF(mxv_bj_config, num_envs); OFF(mxv_bj_config, env_offset); OFF(mxv_bj_config, seed); OFF(mxv_bj_config, action_seed);
+        printf("\nlayout mxv_placed_info %zu", sizeof(mxv_placed_info));
+        OFF(mxv_placed_info, placed); OFF(mxv_placed_info, balanced); OFF(mxv_placed_info, chunks_created); OFF(mxv_placed_info, chunks_kept);
+        OFF(mxv_placed_info, classes_seen); OFF(mxv_placed_info, class_chunks); OFF(mxv_placed_info, solo_group);
+        OFF(mxv_placed_info, solo_class); OFF(mxv_placed_info, stop_reason); OFF(mxv_placed_info, same_class_us);
+        OFF(mxv_placed_info, different_class_us); OFF(mxv_placed_info, seconds); OFF(mxv_placed_info, requested_bytes);
+        OFF(mxv_placed_info, held_bytes); OFF(mxv_placed_info, peak_bytes); OFF(mxv_placed_info, jumped_bytes);
+        printf("\nlayout mxv_step_outputs %zu\n", sizeof(mxv_step_outputs));
         printf("symbols ok\n");
         return 0;
     }

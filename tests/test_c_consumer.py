@@ -49,6 +49,24 @@ def test_c_consumer_links_the_symbols_it_uses_and_agrees_on_the_config_layout(co
 
     size_in_c = int(p.stdout.split("sizeof(mxv_config) = ")[1].split()[0])
     assert size_in_c == ctypes.sizeof(_native.MxvConfig)
+    # every struct that crosses the boundary: size and the offset of every field, as the C compiler lays the header's struct out, against
+    # the ctypes mirror the Python host uses
+    mirrors = {"mxv_config": _native.MxvConfig, "mxv_tab_config": _native.MxvTabConfig, "mxv_bj_config": _native.MxvBjConfig,
+               "mxv_placed_info": _native.MxvPlacedInfo, "mxv_step_outputs": _native.StepOutputs}
+    seen = set()
+    for line in p.stdout.splitlines():
+        if not line.startswith("layout "):
+            continue
+        _, name, size, *fields = line.split()
+        mirror = mirrors[name]
+        seen.add(name)
+        assert int(size) == ctypes.sizeof(mirror), name
+        c_fields = dict(f.split("=") for f in fields)
+        if c_fields:
+            assert list(c_fields) == [f[0] for f in mirror._fields_], name          # same fields, same order
+        for fname, off in c_fields.items():
+            assert getattr(mirror, fname).offset == int(off), (name, fname)
+    assert seen == set(mirrors)
 
 
 @pytest.mark.gpu
