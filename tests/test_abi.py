@@ -90,3 +90,70 @@ def test_product_code_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower().replace("# oracle-free", ""), f"{f} mentions the oracle"
                 assert "liborc" not in src
+
+
+def _header_prototypes():
+    """{symbol: (return type, [argument type strings])} parsed from include/mxv.h."""
+    src = open(os.path.join(ROOT, "include", "mxv.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(?:^|\n)\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(mxv_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        out[name] = (ret, [] if args in ("", "void") else [a.strip() for a in args.split(",")])
+    return out
+
+
+def _kind(c_type: str) -> str:
+    """Coarse class of a C parameter type: what must agree between the header and a ctypes argtypes entry."""
+    t = c_type.replace("const", " ").strip()
+    if "*" in t:
+        return "pointer"
+    base = t.split()[0] if len(t.split()) == 1 else " ".join(t.split()[:-1])      # drop the parameter name
+    return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "size_t": "size", "double": "f64",
+            "float": "f32"}[base]
+
+
+def _ctypes_kind(t) -> str:
+    if t in (ctypes.c_int, ctypes.c_int32):
+        return "i32"
+    if t is ctypes.c_int64:
+        return "i64"
+    if t is ctypes.c_uint64:
+        return "u64"
+    if t is ctypes.c_uint32:
+        return "u32"
+    if t is ctypes.c_size_t:
+        return "size" if ctypes.sizeof(ctypes.c_size_t) != 8 or True else "u64"
+    if t is ctypes.c_double:
+        return "f64"
+    if t is ctypes.c_float:
+        return "f32"
+    return "pointer"      # c_void_p, c_char_p, POINTER(...)
+
+
+def test_ctypes_signatures_agree_with_the_header_prototypes():
+    """Every prototype of include/mxv.h against the argtypes / restype gym_amd/_native.py declares for it: the same number of parameters,
+    each of the same class (pointer, 32/64-bit signed/unsigned integer, size_t, float, double), the same kind of return value.  A drift
+    between the hand-written ctypes mirror and the header would otherwise surface as a crash on the GPU box."""
+    from gym_amd import _native
+
+    protos = _header_prototypes()
+    assert set(protos) == set(_declared_symbols()), set(protos) ^ set(_declared_symbols())
+    undeclared = []
+    for name, (ret, args) in sorted(protos.items()):
+        f = getattr(_native.lib, name)
+        if f.argtypes is None:
+            undeclared.append(name)
+            continue
+        assert len(f.argtypes) == len(args), (name, args, f.argtypes)
+        for i, (a, t) in enumerate(zip(args, f.argtypes)):
+            got, want = _ctypes_kind(t), _kind(a)
+            if want == "size":
+                assert t in (ctypes.c_size_t, ctypes.c_uint64), (name, i, a)
+            else:
+                assert got == want, (name, i, a, t)
+        if "char" in ret:
+            assert f.restype is ctypes.c_char_p, name
+        else:
+            assert f.restype in (ctypes.c_int, ctypes.c_int32), (name, ret)
+    assert not undeclared, f"exported by the header, but gym_amd/_native.py declares no signature: {undeclared}"
