@@ -35,6 +35,12 @@ FN(mxv_step_host);
 FN(mxv_get_state);
 FN(mxv_get_counters);
 FN(mxv_get_episodes);
+FN(mxv_bj_create);
+FN(mxv_bj_destroy);
+FN(mxv_bj_last_error);
+FN(mxv_bj_reset_host);
+FN(mxv_bj_step_host);
+FN(mxv_bj_get_counters);
 
 /* the oracle's entry points (oracle/classic_control.c) */
 typedef void (*orc_vec_reset_t)(int, int64_t, uint64_t, const uint64_t *, uint64_t, uint32_t *, const double *, const uint8_t *, double *,
@@ -43,6 +49,11 @@ typedef int64_t (*orc_vec_step_t)(int, int64_t, uint64_t, const double *, int, i
                                   const double *, const int64_t *, const float *, double *, int32_t *, float *, double *, uint8_t *,
                                   uint8_t *, float *, uint8_t *);
 typedef void (*orc_sample_actions_t)(int, int64_t, uint64_t, uint64_t, uint64_t, const double *, int64_t *, float *);
+typedef void (*orc_bj_reset_t)(int64_t, uint64_t, const uint64_t *, uint64_t, uint64_t, uint32_t, const int8_t *, int32_t *, int32_t *,
+                               int32_t *, int64_t *);
+typedef int64_t (*orc_bj_step_t)(int64_t, uint64_t, const uint64_t *, uint64_t, uint64_t, uint64_t, int, int, int, const int64_t *,
+                                 const int8_t *, int, int32_t *, int32_t *, int32_t *, int64_t *, int64_t *, double *, uint8_t *, uint8_t *,
+                                 int64_t *, uint8_t *);
 typedef void (*orc_default_params_t)(int, double *);
 typedef void (*orc_default_reset_bounds_t)(int, double *);
 
@@ -90,6 +101,12 @@ int main(int argc, char **argv) {
     LOAD(mxv, mxv_get_state);
     LOAD(mxv, mxv_get_counters);
     LOAD(mxv, mxv_get_episodes);
+    LOAD(mxv, mxv_bj_create);
+    LOAD(mxv, mxv_bj_destroy);
+    LOAD(mxv, mxv_bj_last_error);
+    LOAD(mxv, mxv_bj_reset_host);
+    LOAD(mxv, mxv_bj_step_host);
+    LOAD(mxv, mxv_bj_get_counters);
     printf("%s: sizeof(mxv_config) = %zu\n", p_mxv_version(), sizeof(mxv_config));
     /* static information needs no device */
     for (int env = 0; env < 5; ++env) {
@@ -224,6 +241,53 @@ int main(int argc, char **argv) {
         free(st); free(dst); free(rew); free(drew); free(el); free(del); free(ep); free(dep); free(obs); free(dobs); free(fin); free(dfin);
         free(af); free(ai); free(te); free(tr); free(dte); free(dtr); free(fm);
     }
-    printf(failures ? "abi_consumer: %d env kind(s) FAILED\n" : "abi_consumer: all five env kinds agree with the oracle\n", failures);
+    /* Blackjack-v1 (mxv_bj_*): integer work — observations, rewards, masks, final observations bit for bit.  Actions: the oracle samples
+     * them from the engine's action stream (actions = NULL) and the device gets what the oracle took. */
+    {
+        orc_bj_reset_t orc_bj_reset = (orc_bj_reset_t)must(orc, "orc_bj_reset");
+        orc_bj_step_t orc_bj_step = (orc_bj_step_t)must(orc, "orc_bj_step");
+        const int64_t nb = n;
+        mxv_bj_config bc;
+        memset(&bc, 0, sizeof bc);
+        bc.device = 0; bc.natural = 1; bc.sab = 0; bc.max_episode_steps = 0; bc.num_envs = nb; bc.env_offset = (int64_t)env0;
+        bc.seed = seed; bc.action_seed = action_seed;
+        mxv_bj *hb = NULL;
+        if (p_mxv_bj_create(&bc, &hb) != MXV_OK) {
+            fprintf(stderr, "Blackjack-v1: mxv_bj_create: %s\n", p_mxv_bj_last_error(NULL));
+            return 1;
+        }
+        int32_t *dealer = calloc(nb * 33, 4), *player = calloc(nb * 33, 4), *bel = calloc(nb, 4);
+        int64_t *obs = malloc(8 * 3 * nb), *dobs = malloc(8 * 3 * nb), *fin = calloc(3 * nb, 8), *dfin = calloc(3 * nb, 8), *act = malloc(8 * nb);
+        double *rew = malloc(8 * nb), *drew = malloc(8 * nb);
+        uint8_t *te = malloc(nb), *tr = malloc(nb), *dte = malloc(nb), *dtr = malloc(nb), *fm = malloc(nb);
+        orc_bj_reset(nb, env0, NULL, seed, 0, 1, NULL, dealer, player, bel, obs); /* the first reset call since seeding: ordinal 1 */
+        int bad = p_mxv_bj_reset_host(hb, NULL, dobs) != MXV_OK || memcmp(obs, dobs, 8 * 3 * nb) != 0;
+        long dones = 0;
+        for (int t = 0; t < steps && !bad; ++t) {
+            orc_bj_step(nb, env0, NULL, seed, action_seed, (uint64_t)t, 1, 0, 0, NULL, NULL, MXV_BJ_MAX_DRAWS, dealer, player, bel, act, obs, rew, te,
+                        tr, fin, fm);
+            if (p_mxv_bj_step_host(hb, act, NULL, dobs, drew, dte, dtr, dfin) != MXV_OK) {
+                fprintf(stderr, "Blackjack-v1: mxv_bj_step_host: %s\n", p_mxv_bj_last_error(hb));
+                return 1;
+            }
+            bad = memcmp(obs, dobs, 8 * 3 * nb) || memcmp(rew, drew, 8 * nb) || memcmp(te, dte, nb) || memcmp(tr, dtr, nb);
+            for (int64_t i = 0; i < nb && !bad; ++i) {
+                dones += fm[i];
+                if (fm[i] && (fin[i] != dfin[i] || fin[nb + i] != dfin[nb + i] || fin[2 * nb + i] != dfin[2 * nb + i])) bad = 1;
+            }
+            if (bad) fprintf(stderr, "Blackjack-v1: mismatch at step %d\n", t);
+        }
+        uint64_t tt = 0;
+        uint32_t rr = 0;
+        p_mxv_bj_get_counters(hb, &tt, &rr);
+        if (!bad && tt != (uint64_t)steps) bad = 1;
+        printf("%-26s %s  envs=%lld steps=%d episodes_ended=%ld (every output bit for bit)\n", "Blackjack-v1", bad ? "FAILED" : "ok", (long long)nb,
+               steps, dones);
+        failures += bad;
+        p_mxv_bj_destroy(hb);
+        free(dealer); free(player); free(bel); free(obs); free(dobs); free(fin); free(dfin); free(act); free(rew); free(drew);
+        free(te); free(tr); free(dte); free(dtr); free(fm);
+    }
+    printf(failures ? "abi_consumer: %d env kind(s) FAILED\n" : "abi_consumer: all five env kinds and Blackjack agree with the oracle\n", failures);
     return failures ? 1 : 0;
 }

@@ -74,6 +74,6 @@ def test_c_consumer_steps_all_five_env_kinds_against_the_oracle(consumer):
     p = subprocess.run([consumer, LIB, ORC, "1000", "260"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     lines = [l for l in p.stdout.splitlines() if " ok " in l]
-    assert len(lines) == 5 and "all five env kinds agree" in p.stdout, p.stdout
+    assert len(lines) == 6 and "all five env kinds and Blackjack agree" in p.stdout, p.stdout
     for l in lines:                                   # TimeLimit 37: every env ends ~7 episodes in 260 steps
         assert int(l.split("episodes_ended=")[1].split()[0]) >= 5000, l
