@@ -25,9 +25,6 @@ from __future__ import annotations
 
 import copy
 import sys
-from typing import Optional
-
-import numpy as np
 
 from . import error, spaces
 

@@ -12,7 +12,6 @@ import importlib.util
 import os
 import time
 
-import numpy as np
 import pytest
 
 from helpers import ENV_NAMES, OracleEngine, run_p1, run_p2
