@@ -29,7 +29,7 @@ import sys
 from . import error, spaces
 
 _ERROR_NAMES = ("Error", "UnregisteredEnv", "ResetNeeded", "InvalidAction", "AlreadyPendingCallError", "NoAsyncCallError",
-                "ClosedEnvironmentError")
+                "ClosedEnvironmentError", "CustomSpaceError")
 _class_cache: dict = {}
 _errors_bound_to = None
 

@@ -15,7 +15,7 @@ from typing import Callable, Iterable, Iterator
 
 import numpy as np
 
-from ..error import CustomSpaceError
+from .. import error
 from ..spaces import Box, Discrete, MultiDiscrete, Space, Tuple, batch_space
 
 __all__ = ["batch_space", "iterate", "create_empty_array", "concatenate"]
@@ -41,7 +41,7 @@ def iterate(space: Space, items) -> Iterator:
         # a tuple of batches -> a sequence of tuples (:178-190)
         return zip(*(iterate(sub, items[i]) for i, sub in enumerate(space.spaces)))
     if isinstance(space, Space):
-        raise CustomSpaceError(f"Unable to iterate over {items}, since {space} is a custom `gym.Space` instance "
+        raise error.CustomSpaceError(f"Unable to iterate over {items}, since {space} is a custom `gym.Space` instance "
                                "(i.e. not one of `Box`, `Dict`, etc...).")
     raise ValueError(f"Space of type `{type(space)}` is not a valid `gym.Space` instance.")
 
