@@ -344,6 +344,41 @@ __device__ __forceinline__ void sincos_small_or_general(double x, double *sn, do
     }
 }
 
+// The reference's clamps — np.clip(x, lo, hi), `if x > hi: x = hi`, min(max(x, lo), hi) — as v_max / v_min: for every x that is not a NaN
+// (the dynamics produce none) `x < lo ? lo : x` IS max(x, lo), bit for bit, but the compiler may not assume that and emits a compare, a
+// wait state for vcc and one select per dword.  (lo and hi are never zeros of opposite sign, the one other case where the forms differ.)
+#ifndef MXV_MINMAX_CLAMPS
+#define MXV_MINMAX_CLAMPS 1   // A/B hook: 0 = compare + select
+#endif
+__device__ __forceinline__ double clamp_lo(double x, double lo) {
+#if MXV_MINMAX_CLAMPS
+    return __builtin_fmax(x, lo);
+#else
+    return (x < lo) ? lo : x;
+#endif
+}
+__device__ __forceinline__ double clamp_hi(double x, double hi) {
+#if MXV_MINMAX_CLAMPS
+    return __builtin_fmin(x, hi);
+#else
+    return (x > hi) ? hi : x;
+#endif
+}
+__device__ __forceinline__ float clamp_lo(float x, float lo) {
+#if MXV_MINMAX_CLAMPS
+    return __builtin_fmaxf(x, lo);
+#else
+    return (x < lo) ? lo : x;
+#endif
+}
+__device__ __forceinline__ float clamp_hi(float x, float hi) {
+#if MXV_MINMAX_CLAMPS
+    return __builtin_fminf(x, hi);
+#else
+    return (x > hi) ? hi : x;
+#endif
+}
+
 // C fmod(a, b) for a compile-time b > 0 and |a| < 2^20 * b in ~8 instructions.  fmod is exact by definition, so any
 // exact algorithm returns identical bits: q = trunc(|a| * (1/b)) is the true quotient or off by one, |a| - q*b is
 // then exactly representable (a multiple of ulp(b) below 2b), so the FMA computes it without rounding and one
@@ -484,8 +519,7 @@ struct Env<MXV_PENDULUM> {
         const double th = s[0], thdot = s[1];
         const float lo = (float)(-max_torque), hi = (float)max_torque;  // np.clip(u, -max_torque, max_torque)[0] :127
         float u = a0;
-        if (u < lo) u = lo;
-        if (u > hi) u = hi;
+        u = clamp_hi(clamp_lo(u, lo), hi);
         const float uterm = (float)0.001 * (u * u);                       // 0.001 * (u**2) in float32 :129
         const double an = (SAFE ? np_remainder(th + kPi, 2 * kPi) : np_remainder_bounded(th + kPi, 2 * kPi)) - kPi;  // angle_normalize :270-271
         const double costs = an * an + 0.1 * (thdot * thdot) + (double)uterm;
@@ -493,8 +527,7 @@ struct Env<MXV_PENDULUM> {
         const float B = (float)(3.0 / (m * (l * l)));
         const float Bu = B * u;                                            // python float * np.float32 -> f32
         double newthdot = thdot + (A * aux[0] + (double)Bu) * dt;         // aux[0] = sin(th)
-        if (newthdot < -max_speed) newthdot = -max_speed;                  // np.clip :132
-        if (newthdot > max_speed) newthdot = max_speed;
+        newthdot = clamp_hi(clamp_lo(newthdot, -max_speed), max_speed);    // np.clip :132
         const double newth = th + newthdot * dt;                           // :133
         s[0] = newth; s[1] = newthdot;
         reward = -costs;                                                   // :139
@@ -588,8 +621,7 @@ struct Env<MXV_ACROBOT> {
         return x;
     }
     __device__ __forceinline__ static double bound(double x, double m, double M) {  // :399-415 min(max(x, m), M)
-        const double t = (m > x) ? m : x;
-        return (M < t) ? M : t;
+        return clamp_hi(clamp_lo(x, m), M);
     }
     template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux = nullptr) {  // :225-230
@@ -679,11 +711,9 @@ struct Env<MXV_MOUNTAINCAR> {
         const double force = P.get(5, 0.001), gravity = P.get(6, 0.0025);
         double position = s[0], velocity = s[1];
         velocity = velocity + ((double)(ai - 1) * force + mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR>()>(3 * position) * (-gravity));  // :133
-        if (velocity < -max_speed) velocity = -max_speed;                                  // np.clip :134
-        if (velocity > max_speed) velocity = max_speed;
+        velocity = clamp_hi(clamp_lo(velocity, -max_speed), max_speed);                    // np.clip :134
         position = position + velocity;                                                    // :135
-        if (position < min_position) position = min_position;                              // np.clip :136
-        if (position > max_position) position = max_position;
+        position = clamp_hi(clamp_lo(position, min_position), max_position);               // np.clip :136
         if (position == min_position && velocity < 0) velocity = 0;                        // :137-138
         s[0] = position; s[1] = velocity;
         reward = -1.0;                                                                     // :143
@@ -729,11 +759,9 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
             const double g = 0.0025 * mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR_CONT>()>(3 * position);  // :148
             const double inc = clipped ? (force_py * power - g) : (double)(fp - (float)g);
             velocity = velocity + inc;
-            if (velocity > max_speed) velocity = max_speed;    // :149-152
-            if (velocity < -max_speed) velocity = -max_speed;
+            velocity = clamp_lo(clamp_hi(velocity, max_speed), -max_speed);    // :149-152
             position = position + velocity;                    // :153
-            if (position > max_position) position = max_position;  // :154-157
-            if (position < min_position) position = min_position;
+            position = clamp_lo(clamp_hi(position, max_position), min_position);  // :154-157
             if (position == min_position && velocity < 0) velocity = 0;  // :158-159
             term = position >= goal_position && velocity >= goal_velocity;  // :162-164
             s[0] = (double)(float)position;  // :171 dtype=np.float32
@@ -744,11 +772,9 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
             const double g = 0.0025 * mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR_CONT>()>((double)three_p);
             const float inc = clipped ? (float)(force_py * power - g) : (fp - (float)g);
             velocity = velocity + inc;
-            if (velocity > (float)max_speed) velocity = (float)max_speed;
-            if (velocity < (float)(-max_speed)) velocity = (float)(-max_speed);
+            velocity = clamp_lo(clamp_hi(velocity, (float)max_speed), (float)(-max_speed));
             position = position + velocity;
-            if (position > (float)max_position) position = (float)max_position;
-            if (position < (float)min_position) position = (float)min_position;
+            position = clamp_lo(clamp_hi(position, (float)max_position), (float)min_position);
             if (position == (float)min_position && velocity < 0) velocity = 0;
             term = position >= (float)goal_position && velocity >= (float)goal_velocity;
             s[0] = (double)position;
