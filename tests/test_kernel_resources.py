@@ -123,3 +123,31 @@ def test_no_scratch_and_no_unconditional_vmcnt_wait_inside_the_step_loops(build)
         blocks = re.split(r"\n(?=\.LBB\d+_\d+:|; %bb\.\d+:)", text)
         waiting = [b.splitlines()[0] for b in blocks if "global_store" in b and "global_load" not in b and re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", b)]
         assert len(waiting) <= STORE_BLOCKS_WAITING[env], f"env {env}: store blocks of the K-step loop wait for vmcnt(0): {waiting}"
+
+
+def test_the_instruction_forms_this_round_bought_are_still_in_the_loops(build):
+    """Round 3 removed instructions the compiler emits on its own: the `v_mov_b64 + v_fmac_f64` pair per polynomial term
+    that loop-invariant code motion leaves behind (three-address `v_fma_f64` instead: Pendulum, MountainCarContinuous), compare + select
+    clamps (`v_max` / `v_min` instead), the branchy NumPy `%` of Pendulum's bounded path.  A later edit or compiler that loses them would
+    only show as a slower variants line; here it fails.  Static counts of the K-step loop, with generous margins."""
+    _, asm = build
+
+    def loop_text(env):
+        e = HOT[env][0]
+        loops = [(h, t) for h, t in _inner_loops(_function_body(asm, _symbol(env, e))) if "global_store" in t]
+        return max(loops, key=lambda ht: ht[1].count("global_store"))[1]
+
+    def count(text, op):
+        return sum(1 for l in text.splitlines() if l.strip().startswith(op))
+
+    pend, mcc, mc = loop_text(1), loop_text(4), loop_text(3)
+    # three-address polynomial steps: 10 per sincos evaluated in the loop body (hot path + reset path), hardly any 64-bit copies left
+    assert count(pend, "v_fma_f64") >= 20 and count(pend, "v_mov_b64") <= 10, (count(pend, "v_fma_f64"), count(pend, "v_mov_b64"))
+    assert count(mcc, "v_fma_f64") >= 20 and count(mcc, "v_mov_b64") <= 10, (count(mcc, "v_fma_f64"), count(mcc, "v_mov_b64"))
+    # clamps
+    assert count(pend, "v_max_f64") + count(pend, "v_min_f64") >= 2 and (count(pend, "v_med3_f32") + count(pend, "v_max_f32") + count(pend, "v_min_f32")) >= 1
+    assert count(mc, "v_max_f64") + count(mc, "v_min_f64") >= 4 * HOT[3][0] - 2
+    assert count(mcc, "v_max_f32") + count(mcc, "v_min_f32") + count(mcc, "v_med3_f32") >= 2
+    # Pendulum's K-step loop: 614 instructions / 27 branches before, 501 / 20 after
+    n_instr = sum(1 for l in pend.splitlines() if l.startswith("\t") and not l.strip().startswith((".", ";")))
+    assert n_instr <= 540 and sum(1 for l in pend.splitlines() if "s_cbranch" in l) <= 22, n_instr
