@@ -154,9 +154,13 @@ class CachingSim(SimDevice):
     """SimDevice + the behaviour of torch's caching allocator that the memo relies on: a freed block is handed out again for a request
     of exactly its size; release() (= empty_cache) returns every unused block to the driver and moves the segment-free count."""
 
+    _instances = 0
+
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.cache, self.frees = [], 0
+        CachingSim._instances += 1
+        self._key = ("simulated device", CachingSim._instances)      # never reused (id() of a dead simulator may be)
 
     class T(SimDevice.T):
         def __del__(self):
@@ -184,7 +188,7 @@ class CachingSim(SimDevice):
         return self.frees
 
     def key(self):
-        return id(self)
+        return self._key
 
 
 def test_blocks_the_allocator_hands_out_again_are_not_measured_again():
@@ -218,3 +222,79 @@ def test_a_cache_flush_by_anyone_drops_what_was_remembered():
     before = dev.probes
     b, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
     assert dev.probes > before and rep["balanced"]
+
+
+class RemappingSim(CachingSim):
+    """CachingSim + what makes a stale memo dangerous on the real device: once a block has gone back to the driver (release()), a later
+    allocation may get the SAME virtual address over DIFFERENT physical memory.  Classes belong to physical addresses, which only ever
+    grow here; virtual addresses of released blocks are handed out again for requests of the same size."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.pcur, self.va_free, self.blocks = 0, [], {}          # blocks: va -> (bytes, physical start)
+
+    def klass(self, addr):
+        for va, (n, phys) in self.blocks.items():
+            if va <= addr < va + n:
+                return SimDevice.klass(self, phys + (addr - va))
+        raise AssertionError(f"address {addr} is not mapped")
+
+    def alloc(self, shape, dtype, zero):
+        n = 1
+        for s in shape:
+            n *= s
+        n *= torch.empty((), dtype=dtype).element_size()
+        for i, (addr, m) in enumerate(self.cache):                # the allocator's own cache first: same block, same memory
+            if m == n:
+                del self.cache[i]
+                return CachingSim.T(self, addr, n)
+        va = next((v for v, m in self.va_free if m == n), None)   # the driver re-uses a virtual range it got back ...
+        if va is None:
+            va = self.cursor
+            self.cursor += n
+        else:
+            self.va_free.remove((va, n))
+        self.blocks[va] = (n, self.pcur)                          # ... over new physical memory
+        self.pcur += n
+        return CachingSim.T(self, va, n)
+
+    def release(self):
+        self.frees += len(self.cache)
+        for addr, m in self.cache:
+            del self.blocks[addr]
+            self.va_free.append((addr, m))
+        self.cache.clear()
+
+
+def test_memo_never_claims_a_balance_the_memory_does_not_have():
+    """Random learner behaviour on the caching simulated allocator — sets kept, dropped, the cache flushed at random moments, class regions
+    of random sizes — and one invariant: whenever sorted_tensors reports balanced = True, the tensors it returned really lie the way it
+    says (checked against the simulator's ground truth), whether their classification was measured in this call or remembered."""
+    import random
+
+    rnd = random.Random(20260923)
+    for scenario in range(60):
+        regions, addr = [], 0
+        while addr < 288 * GiB:
+            addr += rnd.choice([3, 6, 11, 24, 48, 96]) * GiB
+            regions.append((addr, "ABC"[len(regions) % 3] if rnd.random() < 0.5 else rnd.choice("AB")))
+        dev = RemappingSim(regions)
+        held = []
+        for call in range(12):
+            action = rnd.random()
+            if held and action < 0.45:
+                held.pop(rnd.randrange(len(held)))               # the learner drops a set: its blocks go to the allocator's cache
+            if action > 0.9:
+                dev.release()                                    # somebody calls empty_cache()
+            try:
+                out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, budget_bytes=60 * GiB, _backend=dev)
+            except MemoryError:
+                held.clear()
+                continue
+            c = _classes(dev, out, CARTPOLE)
+            if rep["balanced"]:
+                assert len(c["obs"]) == 1, (scenario, call, c, rep)
+                assert c["reward"].isdisjoint(c["obs"]) and c["actions"].isdisjoint(c["obs"]), (scenario, call, c, rep)
+            held.append(out)
+            if len(held) > 3:
+                held.pop(0)
