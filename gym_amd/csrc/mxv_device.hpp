@@ -12,6 +12,11 @@
 
 #include "../../include/mxv.h"
 
+#define MXV_XFN __device__ inline
+#define MXV_XCONST __device__ const
+#define MXV_XCOLD __device__ __noinline__ inline
+#include "mxv_exact.hpp"
+
 #ifndef MXV_CARTPOLE_RCP
 #define MXV_CARTPOLE_RCP 1  // tuning hook: 0 = the compiler's `/` for CartPole's one runtime division
 #endif
@@ -561,6 +566,12 @@ __device__ __forceinline__ double two_sum_residual(double a, double b, double su
     return (a - (sum - bb)) + (b - bb);
 }
 constexpr double kHalfPiTail = 6.123233995736766036e-17;  // pi/2 - fl(pi/2)
+#ifndef MXV_ACROBOT_EXACT_BAND
+#define MXV_ACROBOT_EXACT_BAND 1   // A/B hook: 0 = the hot path's mask everywhere (rounds 1-3)
+#endif
+#ifndef MXV_ACROBOT_DIRECT_COS
+#define MXV_ACROBOT_DIRECT_COS 0   // measurement only (tools/acrobot_threshold_ab.py): every cosine evaluated directly, no angle addition
+#endif
 
 template <>
 struct Env<MXV_ACROBOT> {
@@ -586,10 +597,14 @@ struct Env<MXV_ACROBOT> {
         const double a12 = t12 - halfpi;
         const double eps12 = kHalfPiTail - two_sum_residual(theta1, theta2, t12) - two_sum_residual(t12, -halfpi, a12);
         const double S12 = __fma_rn(s1, c2, c1 * s2), C12 = __fma_rn(c1, c2, -(s1 * s2));
-        const double cos_t12_shift = __fma_rn(eps12, C12, S12);
         // cos(theta1 - pi / 2) :264
         const double a1 = theta1 - halfpi;
+#if MXV_ACROBOT_DIRECT_COS
+        const double cos_t12_shift = mx_cos(a12), cos_t1_shift = mx_cos(a1);
+#else
+        const double cos_t12_shift = __fma_rn(eps12, C12, S12);
         const double cos_t1_shift = __fma_rn(kHalfPiTail - two_sum_residual(theta1, -halfpi, a1), c1, s1);
+#endif
         const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;  // :252-257
         const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;                                          // :258
         const double phi2 = m2 * lc2 * g * cos_t12_shift;                                                   // :259
@@ -631,6 +646,14 @@ struct Env<MXV_ACROBOT> {
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
         if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
+    }
+    // the cold exact path (mxv_exact.hpp) with this launch's parameter values; never inlined: one copy per parameter mode serves every
+    // kernel instantiation, and its registers are not the K-step loop's
+    template <int DEF>
+    __device__ __forceinline__ static bool acrobot_exact(const Par<DEF> &P, double *s, double torque, double *sc) {
+        const double Pv[12] = {P.get(0, 0.2), P.get(1, 1.0), P.get(2, 1.0), P.get(3, 1.0),  P.get(4, 1.0),  P.get(5, 0.5),
+                               P.get(6, 0.5), P.get(7, 1.0), P.get(8, 4 * kPi), P.get(9, 9 * kPi), P.get(10, 0.0), P.get(11, 0.0)};
+        return exact::acrobot_step_exact(Pv, s, torque, sc);
     }
     template <int DEF, bool SAFE = true, int EPL = 0>   // EPL: envs per lane of the calling kernel (0 = not said)
     // `noise_word`: for this env the Box-action slot of the shared step() signature carries the raw Philox word of the
@@ -675,8 +698,28 @@ struct Env<MXV_ACROBOT> {
         mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(s[1], &s1, &c1);
         // cos(s[1] + s[0]) :235 from the same four values
         const double t21 = s[1] + s[0];
+#if MXV_ACROBOT_DIRECT_COS
+        const double cos21 = mx_cos(t21);
+#else
         const double cos21 = __fma_rn(two_sum_residual(s[1], s[0], t21), __fma_rn(s0, c1, c0 * s1), __fma_rn(c0, c1, -(s0 * s1)));
-        const bool term = (-c0 - cos21) > 1.0;               // :235
+#endif
+        const double height = -c0 - cos21;
+        bool term = height > 1.0;                            // :235
+#if MXV_ACROBOT_EXACT_BAND
+        // Within 2^-40 of the threshold (the hot path's own error is a few 2^-52; ~1 env-step in 10^12 comes here) the mask is not
+        // decided by 1.5-ulp trigonometry: the whole step is taken again as the reference writes it, on correctly rounded sin / cos
+        // (mxv_exact.hpp), and THAT state, observation and mask stand.
+        if (__builtin_expect(fabs(height - 1.0) < 0x1p-40, 0)) {
+            double sx[4] = {y0[0], y0[1], y0[2], y0[3]}, scx[4];
+            term = acrobot_exact(P, sx, torque, scx);
+            // the results come back through scratch memory: they are consumed (`landed`) and every access of this block is waited for
+            // HERE, so that the block every step runs through keeps no vmcnt wait of its own (it would wait for the stores in flight)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = landed(sx[k]);
+            s0 = landed(scx[0]); c0 = landed(scx[1]); s1 = landed(scx[2]); c1 = landed(scx[3]);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+#endif
         reward = (!term) ? -1.0 : 0.0;                     // :219
         obs[0] = (float)c0; obs[1] = (float)s0; obs[2] = (float)c1; obs[3] = (float)s1;
         obs[4] = (float)s[2]; obs[5] = (float)s[3];

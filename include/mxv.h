@@ -40,11 +40,14 @@
  *
  * Numerical contract (what "matches the reference" means at this boundary; tests/helpers.py holds the same bars).  On identical
  * fp64 states and actions, against gym 0.26.2 under NumPy 2.x + glibc:
- *   * terminated, truncated, elapsed steps, sampled discrete actions and Philox reset states are BIT-EXACT — with one stated
- *     exception: Acrobot's termination test `-cos(th1) - cos(th2 + th1) > 1.0` (acrobot.py:232-235) within 8 ulps(fp64) (2e-15) of
- *     the threshold may come out either way (the device's sincos differs from glibc's in the last bit and cos(th2 + th1) is
- *     rebuilt from the stage values); the reference itself flips there between libm builds.  Probability ~1e-15 per step on a
- *     trajectory; tests/golden/Acrobot_p1_threshold.npz pins every mask further than 8 ulps from the threshold;
+ *   * terminated, truncated, elapsed steps, sampled discrete actions and Philox reset states are BIT-EXACT.  Acrobot's termination
+ *     test `-cos(th1) - cos(th2 + th1) > 1.0` (acrobot.py:232-235) is decided by the last bit of sin / cos when the height is within
+ *     an ulp of 1.0; there (whenever the engine's own height is within 2^-40 of 1.0: ~1 env-step in 10^12) the whole step is
+ *     evaluated as the reference writes it on CORRECTLY ROUNDED sin / cos (gym_amd/csrc/mxv_exact.hpp), and the mask is the
+ *     reference's on a correctly rounded libm — for all 4096 states of tests/golden/Acrobot_p1_threshold.npz, which straddle the
+ *     threshold from 0 to 15 000 ulps.  The reference's glibc run differs from THAT in 2 of those states (heights that round to
+ *     exactly 1.0, where glibc's cos is a neighbour of the rounded value, as it is for ~0.1 % of arguments): the one place where the
+ *     reference's mask is a property of its libm build rather than of its arithmetic;
  *   * observations agree within 2 float32 ulps (inside north_star's fp32 rtol = 1e-5), not bit for bit: the fp64 state agrees to
  *     rtol 1e-12 and the last fp64 bit of sin/cos can move a float32 rounding;
  *   * rewards agree to rtol 1e-13 (Pendulum + 1e-9 absolute: the reference's u**2 is libm powf, not correctly rounded);

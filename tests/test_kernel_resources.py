@@ -115,12 +115,19 @@ def test_no_scratch_and_no_unconditional_vmcnt_wait_inside_the_step_loops(build)
         assert loops, f"env {env}: no store loop found"
         hdr, text = max(loops, key=lambda ht: ht[1].count("global_store"))      # the K-step loop: the one that stores every output
         assert text.count("global_store") >= 4 * e, (env, hdr)
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:|; %bb\.\d+:)", text)
+        # Acrobot's loop contains the cold exact path (mxv_exact.hpp, entered when the height is within 2^-40 of the threshold: ~1 env-step
+        # in 10^12): the blocks that call cr_sincos (s_swappc) save and reload registers through scratch.  Every other block is the step.
+        cold = [b for b in blocks if "s_swappc_b64" in b]
+        assert (len(cold) >= 1) == (env == 2), f"env {env}: {len(cold)} blocks with calls in the K-step loop"
+        assert all("global_store" not in b for b in cold)
+        text = "\n".join(b for b in blocks if "s_swappc_b64" not in b)
         assert text.count("scratch_") <= SCRATCH_IN_LOOP[env], f"env {env}: scratch access inside the K-step loop ({hdr})"
         saddr = [l for l in text.splitlines() if "global_store" in l and re.search(r", (s\[\d+:\d+\]|vcc)\s*(offset:\S+)?\s*$", l.split(";")[0].rstrip())]
         assert len(saddr) >= SADDR_STORES_AT_LEAST[env], f"env {env}: only {len(saddr)} stores with a scalar base: the 32-bit lane offsets lost their pin"
         # a vmcnt(0) wait may sit in a conditional block that issued a load itself (per-env seeds of explicit seed lists); the blocks
         # every step runs through — the ones with the stores — must not wait for the stores in flight
-        blocks = re.split(r"\n(?=\.LBB\d+_\d+:|; %bb\.\d+:)", text)
+        blocks = [b for b in blocks if "s_swappc_b64" not in b]
         waiting = [b.splitlines()[0] for b in blocks if "global_store" in b and "global_load" not in b and re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", b)]
         assert len(waiting) <= STORE_BLOCKS_WAITING[env], f"env {env}: store blocks of the K-step loop wait for vmcnt(0): {waiting}"
 
