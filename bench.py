@@ -221,7 +221,7 @@ def warm_until_stable(fn, sync, max_s=4.0, window_s=0.1, tol=0.01, min_s=0.6):
         prev = rate
 
 
-def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin_ms=60.0, probe=True, valu_per_env_step=None):
+def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin_ms=60.0, probe=True, valu=False):
     """One env kind, fused trajectory launches on one GPU: us per step, env-steps/s, roofline on the algorithmic bytes, the
     write probe of its own store pattern into the same tensors."""
     from gym_amd import _native
@@ -247,11 +247,16 @@ def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin
            "value": envs / us * 1e6, "unit": "env-steps/s", "us_per_step": us,
            "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / us / 1e3, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS, "stored_bytes_per_env_step": real_b}}
-    if valu_per_env_step:
-        rate = envs / us * 1e6 * valu_per_env_step / 64.0
-        out["roofline_valu"] = {"bound": "valu", "valu_instructions_per_env_step": valu_per_env_step, "achieved": rate,
-                                "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave64 VALU instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTR_PER_S,
-                                "source": "PMC SQ_INSTS_VALU, profiles/r02g_rooflines.jsonl"}
+    out["launch_info"] = r.handle.last_launch()
+    if valu:
+        per_env_step, source = read_valu(env_id)     # wave64 VALU instructions a wave issues per env-step of each of its lanes
+        if per_env_step:
+            rate = envs / us * 1e6 * per_env_step / 64.0
+            out["roofline_valu"] = {"bound": "valu", "valu_instructions_per_env_step": per_env_step, "achieved": rate,
+                                    "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave64 VALU instructions/s",
+                                    "frac": rate / VALU_PEAK_WAVE_INSTR_PER_S, "source": source}
+        else:
+            out["roofline_valu"] = {"bound": "valu", "frac": None, "source": source}
     if probe:
         torch.cuda.synchronize()
         flags = (_native.FLAG_REWARD_F32 | _native.FLAG_ACTION_I32) if compact else 0
@@ -362,6 +367,23 @@ def measure_step_kernel(torch, envs, launches=400, compact=False):
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / med / 1e3, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": envs * b / med / 1e3 / HBM_PEAK_GBS},
             "note": "event pair around single launches (includes the events' own ~1-2 us); rocprofv3 kernel time in profiles/"}
+
+
+def read_valu(env_id: str):
+    """(wave64 VALU instructions per wave-step of the fused trajectory kernel, source) from the latest committed PMC pass
+    (profiles/valu_*.json, written by tools/gpu_valu.sh from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` of the kernel itself), or
+    (None, reason): a counter cannot be read from inside the process being timed."""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        for name in sorted((f for f in os.listdir(pdir) if f.startswith("valu_") and f.endswith(".json")), reverse=True):
+            with open(os.path.join(pdir, name)) as f:
+                j = json.load(f)
+            if env_id in j.get("kinds", {}):
+                k = j["kinds"][env_id]
+                return float(k["valu_per_wave_step"]) / float(k["envs_per_lane"]), f"profiles/{name} ({k.get('kernel', 'rollout_kernel_v3')}: SQ_INSTS_VALU / (waves x steps))"
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/valu_*.json unreadable: {e}"
+    return None, "no committed SQ_INSTS_VALU pass for this env kind"
 
 
 def read_traffic(mode: str, steps_per_launch: float, envs: int, compact: bool):
@@ -675,8 +697,13 @@ def main():
             term, trunc, act = traj["terminated"][:k_last], traj["truncated"][:k_last], traj["actions"][:k_last]
             ended = int(((term | trunc) != 0).sum().item())
             c = min(CHECK_ENVS, local_envs)
+            o64 = traj["obs"][:k_last, :c].to(torch.float64)
             work_check = {"what": "last launch of the timed region; checksum = bench.work_checksum(terminated, truncated, actions) over "
-                                  f"its {k_last} steps x the first {c} envs",
+                                  f"its {k_last} steps x the first {c} envs; obs_abs_sum / obs_sq_sum / reward_sum over the same block "
+                                  "(float64 sums of the float32 observations: the oracle reproduces them to 1e-6 relative, "
+                                  "tests/test_gpu_bench_line.py; bit-level observation parity of this very instantiation: tests/test_gpu_soak.py)",
+                          "obs_abs_sum": float(o64.abs().sum().item()), "obs_sq_sum": float((o64 * o64).sum().item()),
+                          "reward_sum": float(traj["reward"][:k_last, :c].to(torch.float64).sum().item()),
                           "first_step_index": issued[0] - k_last, "steps": k_last, "envs": c,
                           "checksum": work_checksum(term[:, :c], trunc[:, :c], act[:, :c]) if eng.NA > 0 else None,
                           "autoresets_per_env_step": ended / float(k_last * local_envs),
@@ -725,6 +752,7 @@ def main():
                 "comm": comm_info,
                 "per_rank": per_rank,
                 "work_check": work_check,
+                "launch_info": eng.handle.last_launch(),     # mxv_last_launch: the kernel instantiation the timed region ran
             },
             "roofline": {
                 "bound": "hbm",
@@ -773,11 +801,17 @@ def main():
                     v[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
                     torch.cuda.empty_cache()
 
-            variant("compact_outputs", lambda: measure_fused(torch, ENV_ID, ENVS_TOTAL, args.chunk, compact=True))
-            variant("configs2_pendulum", lambda: measure_fused(torch, "Pendulum-v1", 1 << 19, args.chunk))
-            variant("configs2_mountaincar_continuous", lambda: measure_fused(torch, "MountainCarContinuous-v0", 1 << 19, args.chunk))
-            variant("mountaincar", lambda: measure_fused(torch, "MountainCar-v0", 1 << 19, args.chunk))
-            variant("configs3_acrobot_shard", lambda: measure_fused(torch, "Acrobot-v1", 1 << 19, args.chunk, valu_per_env_step=730))
+            variant("configs2_pendulum", lambda: measure_fused(torch, "Pendulum-v1", 1 << 19, args.chunk, valu=True))
+            variant("configs2_mountaincar_continuous", lambda: measure_fused(torch, "MountainCarContinuous-v0", 1 << 19, args.chunk, valu=True))
+            variant("mountaincar", lambda: measure_fused(torch, "MountainCar-v0", 1 << 19, args.chunk, valu=True))
+            variant("configs3_acrobot_shard", lambda: measure_fused(torch, "Acrobot-v1", 1 << 19, args.chunk, valu=True))
+            # the contract-dtype twins (SURVEY.md §8d prices 4-byte rewards and actions; the NumPy adapter widens at the API,
+            # gym/vector/sync_vector_env.py:66-71): float32 rewards + int32 actions on the device tensors, every env kind
+            variant("compact_cartpole", lambda: measure_fused(torch, ENV_ID, ENVS_TOTAL, args.chunk, compact=True, valu=True))
+            variant("compact_pendulum", lambda: measure_fused(torch, "Pendulum-v1", 1 << 19, args.chunk, compact=True))
+            variant("compact_mountaincar_continuous", lambda: measure_fused(torch, "MountainCarContinuous-v0", 1 << 19, args.chunk, compact=True))
+            variant("compact_mountaincar", lambda: measure_fused(torch, "MountainCar-v0", 1 << 19, args.chunk, compact=True))
+            variant("compact_acrobot", lambda: measure_fused(torch, "Acrobot-v1", 1 << 19, args.chunk, compact=True))
             variant("configs4_mixed_share", lambda: measure_mixed(torch, 1 << 15, args.chunk))
             variant("strong_scaling_share_of_8", lambda: measure_fused(torch, ENV_ID, ENVS_TOTAL // 8, args.chunk))
             variant("step_loop", lambda: {

@@ -35,7 +35,7 @@ COMM_ID_BYTES = 128
 EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
-    "mxv_rollout_tape", "mxv_sample_actions", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
+    "mxv_rollout_tape", "mxv_sample_actions", "mxv_last_launch", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
     "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_write_probe_env", "mxv_host_alloc", "mxv_host_free",
@@ -50,6 +50,12 @@ EXPORTS = (
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
     "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error", "mxv_hbm_pair_probe",
 )
+
+
+class MxvLaunchInfo(C.Structure):
+    """mxv_launch_info (include/mxv.h): the kernel instantiation of a handle's last step / rollout launch."""
+    _fields_ = [(k, C.c_int32) for k in ("kernel", "env_id", "param_mode", "envs_per_lane", "safe", "out_mode", "tape", "steps")] + \
+               [("grid", C.c_uint32), ("block", C.c_uint32)]
 
 
 class MxvConfig(C.Structure):
@@ -181,6 +187,7 @@ def _load():
         "mxv_rollout": ([vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_rollout_tape": ([vp, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_sample_actions": ([vp, vp], C.c_int),
+        "mxv_last_launch": ([vp, C.POINTER(MxvLaunchInfo)], C.c_int),
         "mxv_reset_host": ([vp, vp, vp, vp], C.c_int),
         "mxv_step_host": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_get_state": ([vp, vp, vp], C.c_int),
@@ -655,6 +662,12 @@ class Handle:
         if el is not None:
             assert el.shape == (self.num_envs,)
         self._check(lib.mxv_set_state(self._h, _ptr(st), _ptr(el)))
+
+    def last_launch(self) -> dict:
+        """Which kernel instantiation the last step / rollout launch took (mxv_last_launch)."""
+        info = MxvLaunchInfo()
+        self._check(lib.mxv_last_launch(self._h, C.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in MxvLaunchInfo._fields_}
 
     def get_counters(self):
         t, r = C.c_uint64(), C.c_uint32()

@@ -80,7 +80,9 @@ struct mxv_handle {
     uint64_t t = 0;
     uint32_t r = 0;
     bool was_reset = false;
-    bool state_injected = false;  // set by mxv_set_state, consumed by the next step launch
+    bool state_injected = false;  // set by mxv_set_state / unusual reset bounds, consumed by the next step launch
+    bool state_out_of_range = false;  // Pendulum only: an injected angle beyond the unguarded range stays until a full reset
+    LaunchInfo last_launch{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // mxv_last_launch
     bool step_noise = false;      // Acrobot torque_noise_max > 0 (acrobot.py:202-205): the step draws from the step-noise stream
     EnvParams P{};
     bool default_params = true;
@@ -214,7 +216,7 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.max_steps = h->cfg.max_episode_steps;
     a.flags = h->cfg.flags;
     a.K = 1;
-    a.state_injected = h->state_injected ? 1 : 0;
+    a.state_injected = (h->state_injected || h->state_out_of_range) ? 1 : 0;
     a.step_noise = h->step_noise ? 1 : 0;
     a.slice = 0;
     a.act_slice = 0;
@@ -243,7 +245,7 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
-    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream));
+    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
     h->state_injected = false;
     h->t += 1;
     return MXV_OK;
@@ -282,6 +284,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     a.b1 = b[1];
     MXV_HIP(h, launch_reset(h->cfg.env_id, a, h->stream));
     h->was_reset = true;
+    if (mask_dev == nullptr) h->state_out_of_range = false;  // every env re-drawn
     // CartPole's range-reduction-free sin/cos (rollout fast path, SAFE = false) assumes |theta| <= pi/4 on entry; reset bounds
     // from reset(options={"low","high"}) beyond that break the induction exactly like an injected state does: the next
     // fused launch takes the SAFE instantiation (every such env terminates in its first step and autoresets with the
@@ -289,6 +292,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     const double widest = std::fmax(std::fabs(b[0]), std::fabs(b[1]));
     if ((h->cfg.env_id == MXV_CARTPOLE && widest > 0.78539816339744830962) || widest > 65536.0)
         h->state_injected = true;  // (other kinds: the unguarded medium-range sin/cos of the fused rollout, mx_sincos<false>)
+    if (h->cfg.env_id == MXV_PENDULUM && widest > 65536.0) h->state_out_of_range = true;  // the angle is never wrapped: see mxv_set_state
     return MXV_OK;
 }
 
@@ -643,7 +647,7 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
         a.snap_terminated = h->snap_term;
         a.snap_truncated = h->snap_trunc;
     }
-    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream));
+    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
     h->state_injected = false;
     h->t += (uint64_t)K;
     if (h->snap_obs && !in_kernel) return copy_final_snapshot(h, K, per_step, obs, reward, term, trunc);
@@ -681,7 +685,7 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         a.final_obs = (float *)slice(final_obs_dev, h->O * sizeof(float), k);
         a.ep_return_out = (float *)slice(a.ep_return_out, sizeof(float), k);
         a.ep_length_out = (int32_t *)slice(a.ep_length_out, sizeof(int32_t), k);
-        return launch_step(h->cfg.env_id, h->param_mode(), a, h->stream);
+        return launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch);
     };
     if (mode == MXV_ROLLOUT_EAGER) {
         for (int k = 0; k < K; ++k) MXV_HIP(h, launch_k(k, nullptr, h->t + (uint64_t)k));
@@ -1009,7 +1013,36 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
         MXV_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     h->was_reset = true;  // an injected state stands in for reset() (parity harness, checkpoint restore)
-    if (state_soa_host) h->state_injected = true;
+    if (state_soa_host) {
+        // The fused rollout's unguarded trigonometry (SAFE = false) rests on invariants the dynamics maintain: CartPole |theta| <= pi/4,
+        // every other trig argument below 2^19.  A state that obeys them — a restored checkpoint — keeps the fast kernels; one that
+        // does not takes the guarded instantiation for the next launch, after which termination + autoreset (CartPole), the wrap
+        // loops (Acrobot) and the position clamps (MountainCar*) have restored them.  Only Pendulum keeps an out-of-range angle
+        // (it is never wrapped, pendulum.py:133) until its episode is truncated: guarded launches until the next full reset.
+        // Non-finite values need no guard (NaN and Inf go through both code paths alike) but are not worth a separate rule.
+        bool in_range = true;
+        const int S = h->S;
+        for (int k = 0; k < S && in_range; ++k) {
+            const double *row = state_soa_host + (size_t)k * n;
+            const double lim = (h->cfg.env_id == MXV_CARTPOLE) ? (k == 2 ? 0.78539816339744830962 : HUGE_VAL) : 65536.0;
+            if (lim == HUGE_VAL) continue;
+            for (size_t i = 0; i < n; ++i)
+                if (!(std::fabs(row[i]) <= lim)) {
+                    in_range = false;
+                    break;
+                }
+        }
+        h->state_injected = !in_range;
+        h->state_out_of_range = !in_range && h->cfg.env_id == MXV_PENDULUM;
+    }
+    return MXV_OK;
+}
+
+int mxv_last_launch(mxv_handle *h, mxv_launch_info *out) {
+    MXV_CHECK_HANDLE(h);
+    if (!out) return fail(h, MXV_ERR_INVALID_ARG, "mxv_last_launch: out is NULL");
+    static_assert(sizeof(mxv_launch_info) == sizeof(LaunchInfo), "mxv_launch_info mirrors LaunchInfo member for member");
+    std::memcpy(out, &h->last_launch, sizeof(*out));
     return MXV_OK;
 }
 

@@ -349,38 +349,58 @@ __device__ __forceinline__ void sincos_small_or_general(double x, double *sn, do
     }
 }
 
-// The reference's clamps — np.clip(x, lo, hi), `if x > hi: x = hi`, min(max(x, lo), hi) — as v_max / v_min: for every x that is not a NaN
-// (the dynamics produce none) `x < lo ? lo : x` IS max(x, lo), bit for bit, but the compiler may not assume that and emits a compare, a
-// wait state for vcc and one select per dword.  (lo and hi are never zeros of opposite sign, the one other case where the forms differ.)
+// The reference's clamps — np.clip(x, lo, hi), `if x > hi: x = hi`, min(max(x, lo), hi) — as v_max / v_min instead of a compare, a wait
+// state for vcc and one select per dword each.  For every x that is not a NaN, `x < lo ? lo : x` IS max(x, lo) bit for bit (lo and hi are
+// never zeros of opposite sign, the one other case where the forms differ); a NaN — which only a caller can bring in: a Box action of a
+// diverged policy, an injected state — passes through every one of the reference's forms unchanged (np.clip propagates it; Python's
+// `NaN > hi`, max(NaN, lo), min(NaN, hi) keep the first operand), whereas v_max / v_min return the OTHER operand.  So the pair is followed
+// by a NaN pass-through: float64 = one v_cmp_u_f64 + one v_cndmask_b32 on the high dword (a NaN is a NaN whatever its low dword);
+// float32 = nothing extra, gfx950 has the IEEE-754-2019 NaN-propagating v_maximum3_f32 / v_minimum3_f32.
 #ifndef MXV_MINMAX_CLAMPS
 #define MXV_MINMAX_CLAMPS 1   // A/B hook: 0 = compare + select
 #endif
-__device__ __forceinline__ double clamp_lo(double x, double lo) {
-#if MXV_MINMAX_CLAMPS
-    return __builtin_fmax(x, lo);
-#else
-    return (x < lo) ? lo : x;
-#endif
+// np.clip(x, lo, hi) = minimum(maximum(x, lo), hi): the lower bound first (the order only shows when a caller sets lo > hi); NaN passes through
+__device__ __forceinline__ double nan_through(double x, double r) {
+    const int rh = (x != x) ? __double2hiint(x) : __double2hiint(r);
+    return __hiloint2double(rh, __double2loint(r));
 }
-__device__ __forceinline__ double clamp_hi(double x, double hi) {
+__device__ __forceinline__ double clamp_range(double x, double lo, double hi) {
 #if MXV_MINMAX_CLAMPS
-    return __builtin_fmin(x, hi);
+    return nan_through(x, __builtin_fmin(__builtin_fmax(x, lo), hi));
 #else
+    x = (x < lo) ? lo : x;
     return (x > hi) ? hi : x;
 #endif
 }
-__device__ __forceinline__ float clamp_lo(float x, float lo) {
+__device__ __forceinline__ float clamp_range(float x, float lo, float hi) {
 #if MXV_MINMAX_CLAMPS
-    return __builtin_fmaxf(x, lo);
+    float r;
+    asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(x), "v"(lo));
+    asm("v_minimum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(r), "v"(hi));
+    return r;
 #else
+    x = (x < lo) ? lo : x;
+    return (x > hi) ? hi : x;
+#endif
+}
+// `if x > hi: x = hi` then `if x < lo: x = lo` (continuous_mountain_car.py:149-157): the upper bound first
+__device__ __forceinline__ double clamp_range_hi_first(double x, double lo, double hi) {
+#if MXV_MINMAX_CLAMPS
+    return nan_through(x, __builtin_fmax(__builtin_fmin(x, hi), lo));
+#else
+    x = (x > hi) ? hi : x;
     return (x < lo) ? lo : x;
 #endif
 }
-__device__ __forceinline__ float clamp_hi(float x, float hi) {
+__device__ __forceinline__ float clamp_range_hi_first(float x, float lo, float hi) {
 #if MXV_MINMAX_CLAMPS
-    return __builtin_fminf(x, hi);
+    float r;
+    asm("v_minimum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(x), "v"(hi));
+    asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(r), "v"(lo));
+    return r;
 #else
-    return (x > hi) ? hi : x;
+    x = (x > hi) ? hi : x;
+    return (x < lo) ? lo : x;
 #endif
 }
 
@@ -524,7 +544,7 @@ struct Env<MXV_PENDULUM> {
         const double th = s[0], thdot = s[1];
         const float lo = (float)(-max_torque), hi = (float)max_torque;  // np.clip(u, -max_torque, max_torque)[0] :127
         float u = a0;
-        u = clamp_hi(clamp_lo(u, lo), hi);
+        u = clamp_range(u, lo, hi);
         const float uterm = (float)0.001 * (u * u);                       // 0.001 * (u**2) in float32 :129
         const double an = (SAFE ? np_remainder(th + kPi, 2 * kPi) : np_remainder_bounded(th + kPi, 2 * kPi)) - kPi;  // angle_normalize :270-271
         const double costs = an * an + 0.1 * (thdot * thdot) + (double)uterm;
@@ -532,7 +552,7 @@ struct Env<MXV_PENDULUM> {
         const float B = (float)(3.0 / (m * (l * l)));
         const float Bu = B * u;                                            // python float * np.float32 -> f32
         double newthdot = thdot + (A * aux[0] + (double)Bu) * dt;         // aux[0] = sin(th)
-        newthdot = clamp_hi(clamp_lo(newthdot, -max_speed), max_speed);    // np.clip :132
+        newthdot = clamp_range(newthdot, -max_speed, max_speed);    // np.clip :132
         const double newth = th + newthdot * dt;                           // :133
         s[0] = newth; s[1] = newthdot;
         reward = -costs;                                                   // :139
@@ -636,7 +656,7 @@ struct Env<MXV_ACROBOT> {
         return x;
     }
     __device__ __forceinline__ static double bound(double x, double m, double M) {  // :399-415 min(max(x, m), M)
-        return clamp_hi(clamp_lo(x, m), M);
+        return clamp_range(x, m, M);
     }
     template <bool GUARD = true>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux = nullptr) {  // :225-230
@@ -754,9 +774,9 @@ struct Env<MXV_MOUNTAINCAR> {
         const double force = P.get(5, 0.001), gravity = P.get(6, 0.0025);
         double position = s[0], velocity = s[1];
         velocity = velocity + ((double)(ai - 1) * force + mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR>()>(3 * position) * (-gravity));  // :133
-        velocity = clamp_hi(clamp_lo(velocity, -max_speed), max_speed);                    // np.clip :134
+        velocity = clamp_range(velocity, -max_speed, max_speed);                           // np.clip :134
         position = position + velocity;                                                    // :135
-        position = clamp_hi(clamp_lo(position, min_position), max_position);               // np.clip :136
+        position = clamp_range(position, min_position, max_position);                      // np.clip :136
         if (position == min_position && velocity < 0) velocity = 0;                        // :137-138
         s[0] = position; s[1] = velocity;
         reward = -1.0;                                                                     // :143
@@ -802,9 +822,9 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
             const double g = 0.0025 * mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR_CONT>()>(3 * position);  // :148
             const double inc = clipped ? (force_py * power - g) : (double)(fp - (float)g);
             velocity = velocity + inc;
-            velocity = clamp_lo(clamp_hi(velocity, max_speed), -max_speed);    // :149-152
+            velocity = clamp_range_hi_first(velocity, -max_speed, max_speed);  // :149-152
             position = position + velocity;                    // :153
-            position = clamp_lo(clamp_hi(position, max_position), min_position);  // :154-157
+            position = clamp_range_hi_first(position, min_position, max_position);  // :154-157
             if (position == min_position && velocity < 0) velocity = 0;  // :158-159
             term = position >= goal_position && velocity >= goal_velocity;  // :162-164
             s[0] = (double)(float)position;  // :171 dtype=np.float32
@@ -815,9 +835,9 @@ struct Env<MXV_MOUNTAINCAR_CONT> {
             const double g = 0.0025 * mx_cos<SAFE, fma3_for<MXV_MOUNTAINCAR_CONT>()>((double)three_p);
             const float inc = clipped ? (float)(force_py * power - g) : (fp - (float)g);
             velocity = velocity + inc;
-            velocity = clamp_lo(clamp_hi(velocity, (float)max_speed), (float)(-max_speed));
+            velocity = clamp_range_hi_first(velocity, (float)(-max_speed), (float)max_speed);
             position = position + velocity;
-            position = clamp_lo(clamp_hi(position, (float)max_position), (float)min_position);
+            position = clamp_range_hi_first(position, (float)min_position, (float)max_position);
             if (position == (float)min_position && velocity < 0) velocity = 0;
             term = position >= (float)goal_position && velocity >= (float)goal_velocity;
             s[0] = (double)position;

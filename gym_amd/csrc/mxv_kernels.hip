@@ -981,7 +981,8 @@ __global__ void __launch_bounds__(kBlock) final_pack_kernel(const CompactArgs a)
 }
 
 template <int ENV, bool DEF, int ER, bool SAFE, int OUT, bool TAPE = false>
-void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
+void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a, LaunchInfo *info) {
+    if (info) *info = LaunchInfo{1, ENV, DEF ? PM_DEFAULT : PM_BROADCAST, ER, SAFE ? 1 : 0, OUT, TAPE ? 1 : 0, a.K, grid, (uint32_t)kWave};
     // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
     // rollout_max_waves) is its LDS footprint: padded with unused dynamic LDS to 9.5 KiB per single-wave workgroup, 16 of
     // them fill the CU's 160 KiB and a 17th does not fit.
@@ -990,7 +991,7 @@ void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a) {
     hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT, TAPE>), dim3(grid), dim3(kWave), pad, stream, a);
 }
 template <int ENV, bool DEF, int ER, bool SAFE>
-void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
+void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a, LaunchInfo *info) {
     // the trajectory-recording shape (all outputs, no final_obs / statistics) has its own straight-line instantiations; a
     // tape-driven launch of that shape records everything but the actions (the caller holds them)
     const bool tape = a.actions != nullptr;
@@ -1001,17 +1002,17 @@ void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a) {
     }
     if constexpr (DEF) {
         if (tape) {  // (tapes exist for default parameters only, launch_step_is_rollout; the compact dtypes take the generic body)
-            if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, true>(grid, stream, a);
-            return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a);
+            if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, true>(grid, stream, a, info);
+            return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a, info);
         }
-        if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a);
-        if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a);
+        if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a, info);
+        if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a, info);
     }
-    launch_rollout_out<ENV, DEF, ER, SAFE, 0>(grid, stream, a);
+    launch_rollout_out<ENV, DEF, ER, SAFE, 0>(grid, stream, a, info);
 }
 
 template <int ENV>
-hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
+hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, LaunchInfo *info) {
     const bool def = pm == PM_DEFAULT;
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
@@ -1026,11 +1027,11 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
             const int64_t rtile = (int64_t)ER * kWave;
             const unsigned rgrid = (unsigned)((a.n + rtile - 1) / rtile);
             if (!def) {
-                launch_rollout<ENV, false, ER, true>(rgrid, stream, a);
+                launch_rollout<ENV, false, ER, true>(rgrid, stream, a, info);
             } else if (fast) {
-                launch_rollout<ENV, true, ER, false>(rgrid, stream, a);
+                launch_rollout<ENV, true, ER, false>(rgrid, stream, a, info);
             } else {
-                launch_rollout<ENV, true, ER, true>(rgrid, stream, a);
+                launch_rollout<ENV, true, ER, true>(rgrid, stream, a, info);
             }
         };
         // Two envs per lane (the tuned choice of the light envs: two independent chains of ILP) only pay when the shard fills
@@ -1049,6 +1050,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream) {
     constexpr bool C = MXV_CONSEC != 0;
     const int64_t tile = (int64_t)E * kBlock;
     const unsigned grid = (unsigned)((a.n + tile - 1) / tile);
+    if (info) *info = LaunchInfo{0, ENV, pm, E, 1, 0, a.actions != nullptr ? 1 : 0, a.K, grid, (uint32_t)kBlock};
     if (a.K > 1) {
         if (pm == PM_DEFAULT)
             hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
@@ -1090,13 +1092,13 @@ bool launch_step_is_rollout(int pm, const StepArgs &a) {
     return sampled_or_tape && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise;
 }
 
-hipError_t launch_step(int env_id, int default_params, const StepArgs &a, hipStream_t stream) {
+hipError_t launch_step(int env_id, int default_params, const StepArgs &a, hipStream_t stream, LaunchInfo *info) {
     switch (env_id) {
-        case MXV_CARTPOLE: return launch_step_env<MXV_CARTPOLE>(default_params, a, stream);
-        case MXV_PENDULUM: return launch_step_env<MXV_PENDULUM>(default_params, a, stream);
-        case MXV_ACROBOT: return launch_step_env<MXV_ACROBOT>(default_params, a, stream);
-        case MXV_MOUNTAINCAR: return launch_step_env<MXV_MOUNTAINCAR>(default_params, a, stream);
-        case MXV_MOUNTAINCAR_CONT: return launch_step_env<MXV_MOUNTAINCAR_CONT>(default_params, a, stream);
+        case MXV_CARTPOLE: return launch_step_env<MXV_CARTPOLE>(default_params, a, stream, info);
+        case MXV_PENDULUM: return launch_step_env<MXV_PENDULUM>(default_params, a, stream, info);
+        case MXV_ACROBOT: return launch_step_env<MXV_ACROBOT>(default_params, a, stream, info);
+        case MXV_MOUNTAINCAR: return launch_step_env<MXV_MOUNTAINCAR>(default_params, a, stream, info);
+        case MXV_MOUNTAINCAR_CONT: return launch_step_env<MXV_MOUNTAINCAR_CONT>(default_params, a, stream, info);
         default: return hipErrorInvalidValue;
     }
 }

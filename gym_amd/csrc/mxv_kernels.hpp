@@ -200,8 +200,20 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #endif
 constexpr int kBlock = 256;
 
+// Which kernel instantiation a step launch took (mxv_last_launch, include/mxv.h: mxv_launch_info has the same members)
+struct LaunchInfo {
+    int32_t kernel;         // 0 = step_kernel, 1 = rollout_kernel_v3
+    int32_t env_id;
+    int32_t param_mode;     // PM_DEFAULT / PM_BROADCAST / PM_PER_ENV
+    int32_t envs_per_lane;
+    int32_t safe;           // guarded trigonometry (state injected / unusual bounds / non-default parameters)
+    int32_t out_mode;       // rollout_kernel_v3: 0 generic body, 1 trajectory outputs float64 + int64, 2 float32 + int32
+    int32_t tape;           // actions from a caller's tape
+    int32_t steps;          // K
+    uint32_t grid, block;
+};
 // param_mode: PM_DEFAULT / PM_BROADCAST / PM_PER_ENV (mxv_device.hpp)
-hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream);
+hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream, LaunchInfo *info = nullptr);
 // true if launch_step(a) runs the fused rollout kernel, which also writes StepArgs::snap_* (other launches: the caller copies)
 bool launch_step_is_rollout(int param_mode, const StepArgs &a);
 hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);

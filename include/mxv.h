@@ -205,6 +205,22 @@ typedef struct mxv_step_outputs {
 int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int32_t K, int32_t per_step, const mxv_step_outputs *outs);
 /* action_space.sample() for the NEXT step index without stepping. */
 int mxv_sample_actions(mxv_handle *h, void *actions_out_dev);
+/* Which kernel instantiation the handle's LAST step / rollout launch took — the library picks among ~150 (one launch per step or K
+ * fused steps, envs per lane by shard size, guarded or unguarded trigonometry, folded or runtime physics parameters, the output-dtype
+ * specialisations of the trajectory launch).  Lets a test or a benchmark state which code it measured (tests/test_gpu_soak.py,
+ * bench.py config.launch_info).  kernel = -1 before the first launch; mxv_rollout_mixed does not update it. */
+typedef struct mxv_launch_info {
+    int32_t kernel;        /* 0 = step_kernel (one launch per step; also EAGER / GRAPH rollouts), 1 = rollout_kernel_v3 (FUSED) */
+    int32_t env_id;
+    int32_t param_mode;    /* 1 = default attributes folded into the code, 0 = common runtime values, 2 = per-env values */
+    int32_t envs_per_lane;
+    int32_t safe;          /* 1 = guarded sin / cos (state injected, unusual reset bounds, non-default attributes) */
+    int32_t out_mode;      /* rollout_kernel_v3: 1 = trajectory outputs float64 rewards + int64 actions, 2 = float32 + int32, 0 = generic */
+    int32_t tape;          /* actions supplied by the caller */
+    int32_t steps;         /* K of the launch */
+    uint32_t grid, block;
+} mxv_launch_info;
+int mxv_last_launch(mxv_handle *h, mxv_launch_info *out);
 
 /* -- host-buffer convenience (what a NumPy-returning gym.vector.VectorEnv adapter calls) -------- */
 /* Copies through library-owned staging buffers and synchronises.  final_obs_host may be NULL. */

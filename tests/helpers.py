@@ -277,3 +277,33 @@ def replay_blackjack(tag, make_engine):
         assert np.array_equal(out["final_obs"][:, done], g["final_obs"][t][:, done]), t
         ndone += int(done.sum())
     return ndone, g
+
+
+def run_p1_nonfinite(engine_cls, name, strict):
+    """<env>_p1_nonfinite.npz (tests/golden/make_golden_nonfinite.py): NaN / +-Inf Box actions and state components through one step.
+    NaNs must sit exactly where the reference's do (no clamp may swallow one, none may appear); everything else to the usual bars:
+    bit-exact for the oracle (strict), float32-ulp / rtol bars for the engine."""
+    g = load_golden(name, "p1_nonfinite")
+    n = len(g["action"])
+    eng = engine_cls(name, n, 0, autoreset=False)
+    elapsed = np.where(g["fresh"] == 1, 0, 5).astype(np.int32)
+    eng.set_state(g["state0"].T, elapsed)
+    with np.errstate(all="ignore"):
+        obs, rew, term, trunc, fin = eng.step(g["action"])
+    st = eng.get_state()[0].T
+    assert np.array_equal(term, g["terminated"].astype(bool)), f"{name}: terminated mask differs on non-finite inputs"
+    assert not trunc.any()
+    for what, got, ref in (("obs", obs, g["obs"]), ("reward", rew, g["reward"]), ("state", st, g["state1"])):
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), \
+            f"{name}: {what}: NaN where the reference has none, or a NaN swallowed, in rows {np.flatnonzero((np.isnan(got) != np.isnan(ref)).reshape(n, -1).any(axis=1))[:8]}"
+        ok = ~np.isnan(ref)
+        assert np.array_equal(np.isinf(got[ok]), np.isinf(ref[ok])) and np.array_equal(np.sign(got[ok][np.isinf(ref[ok])]), np.sign(ref[ok][np.isinf(ref[ok])]))
+        fin_ = ok & ~np.isinf(ref)
+        if strict:
+            assert np.array_equal(got[fin_], ref[fin_]), f"{name}: {what} not bit-exact"
+        elif what == "obs":
+            assert ulps32(got[fin_], ref[fin_]).max() <= MAX_OBS_ULPS
+        else:
+            atol = REWARD_ATOL.get(name, REWARD_ATOL_DEFAULT) if what == "reward" else STATE_ATOL
+            np.testing.assert_allclose(got[fin_], ref[fin_], rtol=REWARD_RTOL if what == "reward" else STATE_RTOL, atol=atol)
+    return int(np.isnan(g["state1"]).any(axis=1).sum())

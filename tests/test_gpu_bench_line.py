@@ -37,11 +37,20 @@ def test_work_check_is_reproduced_by_the_oracle(line):
     o.reset(seed=wc["seed"])
     o.rollout(t0)
     term, trunc, act = (np.zeros((K, n), dtype=np.uint8) for _ in range(3))
+    obs_abs = obs_sq = rew = 0.0
     for k in range(K):
         a = o.sample_actions()
-        _, _, te, tr, _, _ = o.step(a)
+        ob, rw, te, tr, _, _ = o.step(a)
         term[k], trunc[k], act[k] = te, tr, a
+        ob = ob.astype(np.float64)
+        obs_abs, obs_sq, rew = obs_abs + np.abs(ob).sum(), obs_sq + (ob * ob).sum(), rew + rw.sum()
     assert bench.work_checksum(term, trunc, act) == wc["checksum"]
+    # observations and rewards of the same block (the oracle ran 10^4 free steps from the same seeds: last-bit libm differences have
+    # had 22-step episodes to grow in, hence a relative bar instead of bits; tests/test_gpu_soak.py holds the bits of this instantiation)
+    assert wc["reward_sum"] == rew == float(K * n)
+    assert abs(wc["obs_abs_sum"] - obs_abs) <= 1e-6 * obs_abs and abs(wc["obs_sq_sum"] - obs_sq) <= 1e-6 * obs_sq
+    li = line["config"]["launch_info"]
+    assert (li["kernel"], li["envs_per_lane"], li["safe"], li["out_mode"], li["tape"], li["steps"]) == (1, 2, 0, 1, 0, 256), li
     assert abs(wc["autoresets_per_env_step"] - (term | trunc).mean()) < 0.004       # 2^20 envs vs the first 4096 of them
     assert 0.035 < wc["autoresets_per_env_step"] < 0.055                           # random-policy CartPole: ~ 1 / 22 steps
 
@@ -56,9 +65,20 @@ def test_line_carries_what_the_review_asked_for(line):
     assert ref["source"].startswith("profiles/reference_cpu_baseline.json") and ref["value"] > 1e4
     v = line["variants"]
     assert not [k for k, x in v.items() if isinstance(x, dict) and "error" in x], v
-    for key in ("compact_outputs", "configs2_pendulum", "configs2_mountaincar_continuous", "mountaincar", "configs3_acrobot_shard"):
+    for key in ("configs2_pendulum", "configs2_mountaincar_continuous", "mountaincar", "configs3_acrobot_shard", "compact_cartpole",
+                "compact_pendulum", "compact_mountaincar_continuous", "compact_mountaincar", "compact_acrobot"):
         assert v[key]["roofline"]["frac"] > 0.1 and v[key]["write_probe"]["kernel_over_probe"] > 0.9, key
-    assert v["configs3_acrobot_shard"]["roofline_valu"]["frac"] > 0.5
+        li = v[key]["launch_info"]
+        assert li["kernel"] == 1 and li["safe"] == 0 and li["out_mode"] == (2 if key.startswith("compact") else 1), (key, li)
+    # the contract dtypes store what §8(d) prices: 4 O + 4 + 4 + 2 bytes per env-step
+    twins = {"compact_pendulum": ("configs2_pendulum", 3), "compact_mountaincar_continuous": ("configs2_mountaincar_continuous", 2),
+             "compact_mountaincar": ("mountaincar", 2), "compact_acrobot": ("configs3_acrobot_shard", 6)}
+    for key, (ref_key, o) in twins.items():
+        assert v[key]["roofline"]["stored_bytes_per_env_step"] == 4 * o + 10, key
+        assert v[key]["value"] >= 0.97 * v[ref_key]["value"], key            # fewer bytes per env-step cannot be slower
+    assert v["compact_cartpole"]["roofline"]["stored_bytes_per_env_step"] == 26 and v["compact_cartpole"]["value"] >= line["value"]
+    rv = v["configs3_acrobot_shard"]["roofline_valu"]
+    assert rv["source"].startswith("profiles/valu_") and rv["frac"] > 0.5 and 500 < rv["valu_instructions_per_env_step"] < 900
     assert v["configs4_mixed_share"]["value"] > 1e10
     share = v["strong_scaling_share_of_8"]                    # 2^17 envs: what each GPU of an 8-GPU strong-scaling job steps
     assert share["placement"]["balanced"] is True and share["us_per_step"] * 8 < 1.35 * line["ms_per_step"] * 1e3

@@ -8,8 +8,8 @@ within helpers.STATE_RTOL / REWARD_RTOL (device sin/cos and x*x may differ from 
 import numpy as np
 import pytest
 
-from helpers import (DISCRETE, ENV_IDS, ENV_NAMES, LIMITS, MAX_OBS_ULPS, OBS_RTOL, REWARD_ATOL, REWARD_ATOL_DEFAULT, REWARD_RTOL,
-                     HipEngine, OracleEngine, run_p1, run_p2, ulps32)
+from helpers import (DISCRETE, ENV_IDS, ENV_NAMES, GYM_IDS, LIMITS, MAX_OBS_ULPS, OBS_RTOL, REWARD_ATOL, REWARD_ATOL_DEFAULT, REWARD_RTOL,
+                     HipEngine, OracleEngine, run_p1, run_p1_nonfinite, run_p2, ulps32)
 
 pytestmark = pytest.mark.gpu
 
@@ -94,6 +94,49 @@ def test_acrobot_exact_band_inside_a_fused_rollout():
     term = out["terminated"][0].cpu().numpy().astype(bool)
     assert np.array_equal(term, cr["terminated"].astype(bool))
     assert np.array_equal(out["reward"][0].cpu().numpy(), np.where(term, 0.0, -1.0))
+    r.close()
+
+
+@pytest.mark.parametrize("name", ENV_NAMES)
+def test_non_finite_inputs_pass_through_like_the_reference(name):
+    """A NaN Box action (a diverged policy) or state component comes out of the reference as NaN observations / rewards — np.clip and
+    Python's comparisons propagate it — and must not be turned into a bound by the device's v_max / v_min clamps."""
+    assert run_p1_nonfinite(HipEngine, name, strict=False) > 100
+
+
+@pytest.mark.parametrize("name", ["Pendulum", "MountainCarContinuous"])
+def test_non_finite_actions_inside_a_fused_rollout(name):
+    """The same through rollout_kernel_v3 (tape-driven, unguarded trigonometry): two steps with a NaN / Inf action in the first one
+    against the oracle stepping the same tape; the NaN state persists into the second step exactly as in the reference."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    n = 512
+    rng = np.random.default_rng(5)
+    r = DeviceRollout(GYM_IDS[name], n, seed=3, action_seed=4)
+    ref = OracleEngine(name, n, LIMITS[name], seed=3, action_seed=4).o
+    obs0 = r.reset(seed=3).cpu().numpy()
+    robs0 = ref.reset(seed=3)
+    assert ulps32(obs0, robs0).max() <= MAX_OBS_ULPS
+    st, el = r.handle.get_state()
+    ref.state[:] = st
+    tape = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+    tape[0, ::3] = np.nan
+    tape[0, 1::6] = np.inf
+    tape[1, 4::6] = -np.inf
+    out = r.rollout_tape(torch.from_numpy(tape).to(r.device))
+    r.synchronize()
+    with np.errstate(all="ignore"):
+        for k in range(3):
+            o, rw, te, tr, fin, fm = ref.step(tape[k])
+            got_o, got_r = out["obs"][k].cpu().numpy(), out["reward"][k].cpu().numpy()
+            assert np.array_equal(np.isnan(got_o), np.isnan(o)) and np.array_equal(np.isnan(got_r), np.isnan(rw)), f"{name} step {k}"
+            ok = ~np.isnan(o)
+            assert ulps32(got_o[ok], o[ok]).max() <= MAX_OBS_ULPS
+            okr = ~np.isnan(rw)
+            np.testing.assert_allclose(got_r[okr], rw[okr], rtol=REWARD_RTOL, atol=REWARD_ATOL.get(name, REWARD_ATOL_DEFAULT))
+            assert np.array_equal(out["terminated"][k].cpu().numpy().astype(bool), te)
+        assert np.isnan(o).any()
     r.close()
 
 
