@@ -295,6 +295,103 @@ def measure_mixed(torch, envs_per_segment, chunk, launches=8, spin_ms=60.0):
                          "frac": total * b / us / 1e3 / HBM_PEAK_GBS}}
 
 
+def _hbm(us, envs, bytes_per_env_step, **extra):
+    gbs = envs * bytes_per_env_step / us / 1e3
+    return dict({"value": envs / us * 1e6, "unit": "env-steps/s", "us_per_step": us,
+                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": bytes_per_env_step, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}}, **extra)
+
+
+def _event_us(torch, stream, fn, reps, steps_per_call):
+    fn()
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    stream.synchronize()
+    return e0.elapsed_time(e1) / reps / steps_per_call * 1e3
+
+
+def measure_normalize(torch, envs, chunk, reps=6):
+    """NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:57-144) on the [K][N] trajectory tensors of a
+    fused CartPole rollout: per chunk, the batch moments of every step (one streaming read), then the affine map with the statistics as
+    they stood after that step's update (read + write).  Algorithmic bytes per env-step: observations 4 O (sums) + 4 O + 4 O (apply,
+    float32 out) = 48; rewards 8 + 2 (sums: reward + both flags) + 8 + 8 (apply) = 26."""
+    from gym_amd import _native
+    from gym_amd.rollout import DeviceRollout
+
+    dr = DeviceRollout(ENV_ID, envs, seed=0, action_seed=1)
+    dr.reset(seed=0)
+    tr = dr.rollout_per_step(chunk, out=dr.trajectory_buffers(chunk, layout="separate"))
+    dr.synchronize()
+    s, O = dr.stream, dr.O
+    no, nr = _native.Norm(O, envs, stream=s.cuda_stream), _native.Norm(1, envs, stream=s.cuda_stream)
+    with torch.cuda.stream(s):
+        y32 = torch.empty((chunk, envs, O), dtype=torch.float32, device=dr.device)
+        o64 = torch.empty((chunk, envs), dtype=torch.float64, device=dr.device)
+    out = {"workload": f"{ENV_ID}, num_envs={envs}, the [K={chunk}][N] trajectory tensors of one fused launch normalised in place of the "
+                       "reference's per-step wrappers (running mean / var updated once per step, exactly their order)",
+           "normalize_obs": _hbm(_event_us(torch, s, lambda: no.observations(chunk, tr["obs"], y32, True, 1e-8), reps, chunk), envs, 12 * O,
+                                 kernels="mxv_norm.hip: obs sums (read 4 O) + scan + apply (read 4 O, write 4 O float32)"),
+           "normalize_reward": _hbm(_event_us(torch, s, lambda: nr.rewards(chunk, tr["reward"], False, tr["terminated"], tr["truncated"], o64, 0.99, 1e-8),
+                                              reps, chunk), envs, 26, kernels="mxv_norm.hip: discounted-return sums (read 8 + 2) + scan + apply (read 8, write 8)")}
+    no.close(), nr.close(), dr.close()
+    del tr, y32, o64
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_tabular(torch, gid, envs, chunk, reps=6):
+    """a toy_text env as a table-driven kernel (gym/envs/toy_text/frozen_lake.py:247-270, taxi.py:270-278): fused K-step
+    rollouts with sampled actions, every step's obs / actions (int64), reward / prob (float64) and both flags written to [K][N]
+    trajectory tensors.  Contract bytes as SURVEY.md §8(d) prices them (4-byte scalars, 1-byte flags): obs 4 + action 4 + reward 4 +
+    prob 4 + 2 = 18; stored with the reference's dtypes: 34."""
+    from gym_amd.toy_text import TabularRollout
+
+    r = TabularRollout(gid, envs, seed=0, action_seed=1)
+    r.reset(seed=0)
+    out = r.trajectory_buffers(chunk)
+    us = _event_us(torch, r.stream, lambda: r.rollout_per_step(chunk, out=out), reps, chunk)
+    res = _hbm(us, envs, 18, workload=f"{gid}, num_envs={envs}, fused {chunk}-step launches, the reference's dtypes (34 B stored per env-step)",
+               stored_GBs=envs * 34 / us / 1e3, placement=getattr(r, "last_placement", None))
+    r.close()
+    del out
+    torch.cuda.empty_cache()
+    return res
+
+
+def measure_blackjack(torch, envs, chunk, reps=6):
+    """Blackjack-v1 (gym/envs/toy_text/blackjack.py:108-160): fused K-step rollouts, observation = three int64 columns, reward float64,
+    flags, sampled actions int64 -> 42 B stored per env-step; contract bytes (4-byte scalars): 3 x 4 + 4 + 4 + 2 = 22."""
+    from gym_amd import _native
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    h = _native.Blackjack(envs, seed=0, action_seed=1)
+    obs = torch.empty((chunk, 3, envs), dtype=torch.int64, device=dev)
+    rew = torch.empty((chunk, envs), dtype=torch.float64, device=dev)
+    term, trunc = (torch.empty((chunk, envs), dtype=torch.uint8, device=dev) for _ in range(2))
+    act = torch.empty((chunk, envs), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    h.reset()
+    run = lambda: h.rollout(chunk, obs, rew, term, trunc, None, actions_out_dev=act, per_step=True)   # noqa: E731
+    for _ in range(2):
+        run()
+    h.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    h.sync()
+    us = (time.perf_counter() - t0) / reps / chunk * 1e6
+    res = _hbm(us, envs, 22, workload=f"Blackjack-v1, num_envs={envs}, fused {chunk}-step launches, the reference's dtypes (42 B stored per env-step)",
+               stored_GBs=envs * 42 / us / 1e3, episodes_ended_per_env_step=float(((term | trunc) != 0).float().mean().item()))
+    h.close()
+    del obs, rew, term, trunc, act
+    torch.cuda.empty_cache()
+    return res
+
+
 def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
     """The learner-in-the-loop path: DeviceRollout.step(actions) with caller-provided actions, one launch per vector step
     (gym/vector/sync_vector_env.py:131-169 with a policy in the loop).  halves = 2: the batch as two half-size engines (global env
@@ -812,6 +909,11 @@ def main():
             variant("compact_mountaincar_continuous", lambda: measure_fused(torch, "MountainCarContinuous-v0", 1 << 19, args.chunk, compact=True))
             variant("compact_mountaincar", lambda: measure_fused(torch, "MountainCar-v0", 1 << 19, args.chunk, compact=True))
             variant("compact_acrobot", lambda: measure_fused(torch, "Acrobot-v1", 1 << 19, args.chunk, compact=True))
+            # the wrappers and toy_text engines behind the same library
+            variant("normalize", lambda: measure_normalize(torch, ENVS_TOTAL, 128))
+            variant("frozenlake8x8", lambda: measure_tabular(torch, "FrozenLake8x8-v1", ENVS_TOTAL, 128))
+            variant("taxi", lambda: measure_tabular(torch, "Taxi-v3", ENVS_TOTAL, 128))
+            variant("blackjack", lambda: measure_blackjack(torch, ENVS_TOTAL, 128))
             variant("configs4_mixed_share", lambda: measure_mixed(torch, 1 << 15, args.chunk))
             variant("strong_scaling_share_of_8", lambda: measure_fused(torch, ENV_ID, ENVS_TOTAL // 8, args.chunk))
             variant("step_loop", lambda: {

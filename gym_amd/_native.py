@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -323,47 +324,57 @@ def _ptr(x):
     return x.data_ptr()  # torch tensor
 
 
-def _idle_refcount() -> int:
-    """What sys.getrefcount reports for an object that only a list and a `for` loop variable reference — measured, not assumed: the
-    figure is an implementation detail of the interpreter (3 on CPython 3.10-3.13: list, loop variable, getrefcount's argument; borrowed
-    references change it on newer versions).  The pools below compare against THIS value, taken with the same code shape."""
-    lst = [np.empty(1)]
-    for a in lst:
-        return sys.getrefcount(a)
-    return 3
+class _Lease:
+    """One hand-out of a pooled buffer.  The array the caller receives is np.asarray(lease): NumPy makes the lease the `.base` of that
+    array AND of every view later derived from it (a view's base is "the first object that is not an array", so slices and reshapes of
+    the array reference the lease, not the array).  The lease therefore lives exactly as long as anything that can still see the
+    memory, and its finalizer — not a reference COUNT read at some moment — is what returns the buffer to the pool: ownership is
+    explicit, and correct under tracers, debuggers holding frames, other interpreters' refcount conventions."""
+    __slots__ = ("__array_interface__", "_keep", "__weakref__")
 
-
-_IDLE_REFS = _idle_refcount()
+    def __init__(self, ptr: int, shape, typestr: str, keep):
+        self.__array_interface__ = {"data": (ptr, False), "shape": tuple(shape), "typestr": typestr, "version": 3}
+        self._keep = keep            # whatever owns the memory (a NumPy array, a pinned block): alive as long as any lease of it
 
 
 class _ArrayPool:
     """Recycles the host arrays the NumPy adapter returns.  SyncVectorEnv(copy=True) hands the caller a fresh array per call
     (`deepcopy(self.observations)`, gym/vector/sync_vector_env.py:163); allocating one with np.empty means a fresh anonymous
     mapping per step for anything above glibc's mmap threshold — 42 MB of page faults and kernel page zeroing per step at 2^20
-    CartPole envs, which is what made that loop 2-3 ms per step (the DMA itself is 0.9 ms).  The pool keeps a few arrays per
-    (shape, dtype) and hands one out again ONLY when nobody but the pool references it any more (sys.getrefcount: the caller
-    dropped it and every view of it), so the contract the caller sees is unchanged — an array it got is never overwritten while
-    it can still see it — and the pages stay mapped.  If the caller keeps everything, the pool just grows to `limit` and further
-    arrays are plain np.empty."""
+    CartPole envs, which is what made that loop 2-3 ms per step (the DMA itself is 0.9 ms).  The pool keeps a few buffers per
+    (shape, dtype) and hands one out again ONLY once the previous hand-out is unreachable — the array it returned and every view
+    derived from it have been dropped (see _Lease) — so the contract the caller sees is unchanged: an array it got is never
+    overwritten while it can still see it, and the pages stay mapped.  If the caller keeps everything, `limit` buffers per key are out
+    and further arrays are plain np.empty."""
 
     def __init__(self, limit: int = 6):
-        self._free = {}
+        self._free = {}      # key -> buffers nobody sees
+        self._out = {}       # key -> buffers currently leased
         self._limit = limit
 
+    def _give_back(self, key, store):
+        self._out[key] -= 1
+        self._free.setdefault(key, []).append(store)
+
     def take(self, shape, dtype) -> np.ndarray:
-        key = (tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape, np.dtype(dtype).str)
-        lst = self._free.setdefault(key, [])
-        for a in lst:
-            if sys.getrefcount(a) == _IDLE_REFS:   # the list, the loop variable, getrefcount's argument: nobody else
-                return a
-        a = np.empty(shape, dtype=dtype)
-        if len(lst) < self._limit:
-            lst.append(a)
-        return a
+        shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        dt = np.dtype(dtype)
+        key = (shape, dt.str)
+        free = self._free.setdefault(key, [])
+        if free:
+            store = free.pop()
+        elif self._out.get(key, 0) < self._limit:
+            store = np.empty(shape, dtype=dt)
+        else:
+            return np.empty(shape, dtype=dt)      # the caller holds `limit` arrays of this kind: no pooling beyond that
+        self._out[key] = self._out.get(key, 0) + 1
+        lease = _Lease(store.ctypes.data, shape, dt.str, store)
+        weakref.finalize(lease, self._give_back, key, store)
+        return np.asarray(lease)
 
 
 class _PinnedBlock:
-    """One mxv_host_alloc block; freed when the last NumPy view of it is gone."""
+    """One mxv_host_alloc block; freed when the pool and every lease of it are gone."""
 
     def __init__(self, nbytes: int):
         p = C.c_void_p()
@@ -381,26 +392,28 @@ class _PinnedBlock:
 
 class _BlockPool:
     """Pinned output blocks of the NumPy adapter (mxv_step_host_block): the caller gets VIEWS of one block per step; a block is
-    handed out again only when no array derived from it is alive any more (every view holds a reference to the block's byte
-    array, so sys.getrefcount sees them) — the same "never overwritten while the caller can see it" contract as _ArrayPool.
-    A caller that keeps everything makes the pool grow to `limit` blocks; take() then returns None and the step falls back to
-    separate, unpinned arrays."""
+    handed out again only once every array derived from the previous hand-out is gone (see _Lease) — the same "never overwritten
+    while the caller can see it" contract as _ArrayPool.  A caller that keeps everything has `limit` blocks out; take() then returns
+    None and the step falls back to separate, unpinned arrays."""
 
     def __init__(self, nbytes: int, limit: int = 6):
-        self._nbytes, self._limit, self._raw = nbytes, limit, []
+        self._nbytes, self._limit, self._free, self._n_out = nbytes, limit, [], 0
+
+    def _give_back(self, blk):
+        self._n_out -= 1
+        self._free.append(blk)
 
     def take(self):
-        for raw in self._raw:
-            if sys.getrefcount(raw) == _IDLE_REFS:   # the list, the loop variable, getrefcount's argument
-                return raw
-        if len(self._raw) >= self._limit:
+        if self._free:
+            blk = self._free.pop()
+        elif self._n_out < self._limit:
+            blk = _PinnedBlock(self._nbytes)
+        else:
             return None
-        blk = _PinnedBlock(self._nbytes)
-        buf = (C.c_char * self._nbytes).from_address(blk.ptr)
-        buf._keepalive = blk
-        raw = np.frombuffer(buf, dtype=np.uint8)
-        self._raw.append(raw)
-        return raw
+        self._n_out += 1
+        lease = _Lease(blk.ptr, (self._nbytes,), "|u1", blk)
+        weakref.finalize(lease, self._give_back, blk)
+        return np.asarray(lease)
 
 
 def pinned_pool(nbytes: int, limit: int = 6) -> "_BlockPool":

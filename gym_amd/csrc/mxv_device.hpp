@@ -113,6 +113,19 @@ __device__ __forceinline__ uint32_t xor3_vgpr(uint32_t x, uint32_t y, uint32_t z
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(x), "v"(y), "v"(z));
     return d;
 }
+// x ^ (y & mask) in one instruction (mask: a wave-uniform constant, taken from an SGPR)
+#ifndef MXV_BITOP3_SIGNS
+#define MXV_BITOP3_SIGNS 1   // A/B hook (which env kinds use the form: MXV_BITOP3_ENVS below)
+#endif
+__device__ __forceinline__ uint32_t xor_masked(uint32_t x, uint32_t y, uint32_t mask) {
+#if MXV_BITOP3_SIGNS
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x78" : "=v"(d) : "v"(x), "v"(y), "s"(mask));
+    return d;
+#else
+    return x ^ (y & mask);
+#endif
+}
 __device__ __forceinline__ U4 philox4x32_10_vkey(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < MXV_EXP_PHILOX_ROUNDS; ++r) {
@@ -248,11 +261,16 @@ __device__ __forceinline__ double div_par(double x, double c) {
 #ifndef MXV_FMA3_CARTPOLE_E1
 #define MXV_FMA3_CARTPOLE_E1 1
 #endif
+// ... and bit 1 of the same per-kind flag word: the quadrant signs of sincos_medium as v_bitop3_b32 (xor_masked) — Acrobot and Pendulum
+// lose 2 instructions per sincos, MountainCar (cosine only, two envs per lane) gains 15 in its loop: chosen per env kind as well.
+#ifndef MXV_BITOP3_ENVS
+#define MXV_BITOP3_ENVS ((1 << MXV_ACROBOT) | (1 << MXV_PENDULUM))
+#endif
 template <int ENV>
-constexpr int fma3_for() { return ((MXV_FMA3_ENVS >> ENV) & 1) ? 1 : 0; }
+constexpr int fma3_for() { return (((MXV_FMA3_ENVS >> ENV) & 1) ? 1 : 0) | (((MXV_BITOP3_ENVS >> ENV) & 1) ? 2 : 0); }
 template <int F3>
 __device__ __forceinline__ double fma_coef(double a, double b, double k) {
-    if constexpr (F3 == 1) {
+    if constexpr ((F3 & 1) != 0) {
         double r;
         asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(k));
         return r;
@@ -307,9 +325,15 @@ __device__ __forceinline__ void sincos_medium(double x, double *sn, double *cs) 
     const uint32_t q = (uint32_t)(int)k;
     const bool swap = (q & 1u) != 0u;
     const double ss = swap ? c : s, cc = swap ? s : c;
-    // sin changes sign in quadrants 2, 3; cos in quadrants 1, 2
-    *sn = __hiloint2double(__double2hiint(ss) ^ (int)((q & 2u) << 30), __double2loint(ss));
-    *cs = __hiloint2double(__double2hiint(cc) ^ (int)(((q + 1u) & 2u) << 30), __double2loint(cc));
+    // sin changes sign in quadrants 2, 3; cos in quadrants 1, 2: bit 1 of q resp. q + 1, moved to bit 31 and XORed into the high dword —
+    // `hi ^ (shifted & 0x80000000)` is ONE v_bitop3_b32 (truth table 0x78 = a ^ (b & c)) where the compiler emits v_and + v_xor
+    if constexpr ((F3 & 2) != 0) {
+        *sn = __hiloint2double((int)xor_masked(__double2hiint(ss), q << 30, 0x80000000u), __double2loint(ss));
+        *cs = __hiloint2double((int)xor_masked(__double2hiint(cc), (q + 1u) << 30, 0x80000000u), __double2loint(cc));
+    } else {
+        *sn = __hiloint2double(__double2hiint(ss) ^ (int)((q & 2u) << 30), __double2loint(ss));
+        *cs = __hiloint2double(__double2hiint(cc) ^ (int)(((q + 1u) & 2u) << 30), __double2loint(cc));
+    }
 }
 // GUARD = false: the caller knows |x| < 2^19 (the fused rollout on states the dynamics themselves produced: Acrobot wraps its
 // angles to [-pi, pi] and bounds the velocities, MountainCar's argument is 3 * position, a time-limited Pendulum turns at most
@@ -447,7 +471,7 @@ struct Env<MXV_CARTPOLE> {
         const double force = (ai == 1) ? force_mag : -force_mag;  // :135
         double sintheta, costheta;
         if constexpr (DEF == PM_DEFAULT && !SAFE)
-            sincos_kernel<(fma3_for<MXV_CARTPOLE>() || (EPL == 1 && MXV_FMA3_CARTPOLE_E1)) ? 1 : 0>(theta, &sintheta, &costheta);
+            sincos_kernel<((fma3_for<MXV_CARTPOLE>() & 1) || (EPL == 1 && MXV_FMA3_CARTPOLE_E1)) ? 1 : 0>(theta, &sintheta, &costheta);
         else
             sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
         const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
@@ -571,16 +595,20 @@ struct Env<MXV_PENDULUM> {
 // (:252-265), and after the step cos/sin of both angles (:225-230) plus cos(theta1), cos(theta2 + theta1) (:235): 6 sincos +
 // 9 cos per step, each ~70 fp64 instructions, i.e. ~3/4 of this VALU-bound kernel.  Every one of those values is a function
 // of sin/cos of the two stage angles, so each stage takes ONE sincos per angle and rebuilds the shifted / summed cosines by
-// angle addition, carrying the argument roundings of the reference explicitly:
-//     cos(fl(x - p)),  p = fl(pi/2) = pi/2 - delta:   fl(x - p) = x - pi/2 + (delta - e),  e = exact residual of the subtraction
-//                                                      => cos = sin(x + (delta - e)) = sin x + (delta - e) cos x   (+ O(1e-32))
-//     cos(fl(fl(t1 + t2) - p)) = sin(t1 + t2 + eps)  = S12 + eps C12,   S12 = s1 c2 + c1 s2,  C12 = c1 c2 - s1 s2,
-//                                                      eps = delta - e_add - e_sub
-//     cos(fl(t2 + t1))         = cos(t1 + t2 - e_add) = C12 + e_add S12
-// (TwoSum residuals; FMAs only inside these libm-like helpers, as in sincos_kernel).  The results agree with direct
-// evaluation to ~2 ulp of 1.0 — the same size as ocml-vs-glibc differences of the direct calls — and the sin/cos of the
-// post-step angles (the observation) ARE the stage-1 values of the next step, so a fused rollout carries them in
-// registers: 8 sincos per step instead of 6 sincos + 9 cos.
+// angle addition:
+//     cos(t1 - pi/2) = sin t1,   cos(t1 + t2 - pi/2) = sin(t1 + t2) = s1 c2 + c1 s2,   cos(t2 + t1) = c1 c2 - s1 s2
+// and the sin/cos of the post-step angles (the observation) ARE the stage-1 values of the next step, so a fused rollout carries
+// them in registers: 8 sincos per step instead of 6 sincos + 9 cos.
+// What the identities leave out is the ROUNDING OF THE REFERENCE'S ARGUMENTS: it takes the cosine of fl(fl(t1 + t2) - fl(pi/2)), which
+// is off the exact t1 + t2 - pi/2 by up to ~5e-16, i.e. a few ulps of the cosine.  Rounds 2-3 carried those roundings explicitly
+// (three TwoSum residual chains per stage: cos(fl(x - p)) = sin x + (delta - e) cos x, ...; MXV_ACROBOT_CARRY_ARG_ROUNDING = 1): 90 of the
+// kernel's 732 VALU instructions per env-step for agreement to ~2 ulps instead of ~5 per stage cosine — against bars of 1e-12 on the
+// fp64 state and 2 float32 ulps on the observations (golden P1 states: 99 % of post-step state components within 59 fp64 ulps of the
+// reference instead of 16, the worst the same 2.6e-12 relative; tools/acrobot_threshold_ab.c).  Round 4: the mask no longer depends
+// on those ulps (the exact band below decides near the threshold), so the hot path takes the identities as they are.
+#ifndef MXV_ACROBOT_CARRY_ARG_ROUNDING
+#define MXV_ACROBOT_CARRY_ARG_ROUNDING 0   // A/B hook
+#endif
 __device__ __forceinline__ double two_sum_residual(double a, double b, double sum) {  // a + b == sum + residual exactly
     const double bb = sum - a;
     return (a - (sum - bb)) + (b - bb);
@@ -609,21 +637,24 @@ struct Env<MXV_ACROBOT> {
         const double lc1 = P.get(5, 0.5), lc2 = P.get(6, 0.5), I1 = P.get(7, 1.0), I2 = P.get(7, 1.0);
         const bool nips = P.get(11, 0.0) != 0.0;
         const double g = 9.8;  // :245
-        const double theta1 = sa[0], theta2 = sa[1], dtheta1 = sa[2], dtheta2 = sa[3];
+        [[maybe_unused]] const double theta1 = sa[0], theta2 = sa[1];   // (the angles themselves: only the A/B forms below read them)
+        const double dtheta1 = sa[2], dtheta2 = sa[3];
         const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
-        const double halfpi = kPi / 2.0;
-        // cos(theta1 + theta2 - pi / 2.0) :259
+        [[maybe_unused]] const double halfpi = kPi / 2.0;
+        // cos(theta1 + theta2 - pi / 2.0) :259 and cos(theta1 - pi / 2) :264 from the stage's four values (see the trig budget above)
+        const double S12 = __fma_rn(s1, c2, c1 * s2);
+#if MXV_ACROBOT_DIRECT_COS
+        const double cos_t12_shift = mx_cos(theta1 + theta2 - halfpi), cos_t1_shift = mx_cos(theta1 - halfpi);
+#elif MXV_ACROBOT_CARRY_ARG_ROUNDING
         const double t12 = theta1 + theta2;
         const double a12 = t12 - halfpi;
         const double eps12 = kHalfPiTail - two_sum_residual(theta1, theta2, t12) - two_sum_residual(t12, -halfpi, a12);
-        const double S12 = __fma_rn(s1, c2, c1 * s2), C12 = __fma_rn(c1, c2, -(s1 * s2));
-        // cos(theta1 - pi / 2) :264
-        const double a1 = theta1 - halfpi;
-#if MXV_ACROBOT_DIRECT_COS
-        const double cos_t12_shift = mx_cos(a12), cos_t1_shift = mx_cos(a1);
-#else
+        const double C12 = __fma_rn(c1, c2, -(s1 * s2));
         const double cos_t12_shift = __fma_rn(eps12, C12, S12);
+        const double a1 = theta1 - halfpi;
         const double cos_t1_shift = __fma_rn(kHalfPiTail - two_sum_residual(theta1, -halfpi, a1), c1, s1);
+#else
+        const double cos_t12_shift = S12, cos_t1_shift = s1;   // sin(t1 + t2), sin(t1)
 #endif
         const double d1 = m1 * (lc1 * lc1) + m2 * ((l1 * l1) + (lc2 * lc2) + 2 * l1 * lc2 * c2) + I1 + I2;  // :252-257
         const double d2 = m2 * ((lc2 * lc2) + l1 * lc2 * c2) + I2;                                          // :258
@@ -717,11 +748,13 @@ struct Env<MXV_ACROBOT> {
         mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(s[0], &s0, &c0);
         mx_sincos<SAFE, fma3_for<MXV_ACROBOT>()>(s[1], &s1, &c1);
         // cos(s[1] + s[0]) :235 from the same four values
-        const double t21 = s[1] + s[0];
+        [[maybe_unused]] const double t21 = s[1] + s[0];
 #if MXV_ACROBOT_DIRECT_COS
         const double cos21 = mx_cos(t21);
-#else
+#elif MXV_ACROBOT_CARRY_ARG_ROUNDING
         const double cos21 = __fma_rn(two_sum_residual(s[1], s[0], t21), __fma_rn(s0, c1, c0 * s1), __fma_rn(c0, c1, -(s0 * s1)));
+#else
+        const double cos21 = __fma_rn(c0, c1, -(s0 * s1));
 #endif
         const double height = -c0 - cos21;
         bool term = height > 1.0;                            // :235

@@ -79,6 +79,10 @@ def test_line_carries_what_the_review_asked_for(line):
     assert v["compact_cartpole"]["roofline"]["stored_bytes_per_env_step"] == 26 and v["compact_cartpole"]["value"] >= line["value"]
     rv = v["configs3_acrobot_shard"]["roofline_valu"]
     assert rv["source"].startswith("profiles/valu_") and rv["frac"] > 0.5 and 500 < rv["valu_instructions_per_env_step"] < 900
+    for key in ("frozenlake8x8", "taxi", "blackjack"):                    # SURVEY.md §8(f)-4 engines, driver-run
+        assert v[key]["value"] > 2e10 and 0.05 < v[key]["roofline"]["frac"] < 1.0, key
+    for key in ("normalize_obs", "normalize_reward"):                     # §8(f)-2
+        assert v["normalize"][key]["roofline"]["frac"] > 0.15, key
     assert v["configs4_mixed_share"]["value"] > 1e10
     share = v["strong_scaling_share_of_8"]                    # 2^17 envs: what each GPU of an 8-GPU strong-scaling job steps
     assert share["placement"]["balanced"] is True and share["us_per_step"] * 8 < 1.35 * line["ms_per_step"] * 1e3

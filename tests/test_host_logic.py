@@ -243,26 +243,70 @@ def test_bench_accounting_is_a_pure_function_of_the_arguments():
 
 
 def test_array_pool_recycles_only_what_nobody_references():
-    """_ArrayPool (gym_amd/_native.py): an array goes out again only when the caller dropped it and every view of it."""
+    """_ArrayPool (gym_amd/_native.py): a buffer goes out again only when the caller dropped the array it got AND every view of it."""
     from gym_amd._native import _ArrayPool
 
     pool = _ArrayPool(limit=2)
     a = pool.take((1000, 4), np.float32)
     b = pool.take((1000, 4), np.float32)
-    assert a is not b and a.shape == (1000, 4) and a.dtype == np.float32
-    ida, idb = id(a), id(b)
+    assert a.ctypes.data != b.ctypes.data and a.shape == (1000, 4) and a.dtype == np.float32 and a.flags.c_contiguous and a.flags.writeable
+    pa, pb = a.ctypes.data, b.ctypes.data
     view = a[10:20]
     del a
-    c = pool.take((1000, 4), np.float32)          # a is still visible through `view`; b is held: a third array (unpooled: limit 2)
-    assert id(c) not in (ida, idb)
+    c = pool.take((1000, 4), np.float32)          # a's memory is still visible through `view`; b is held: a third array (unpooled: limit 2)
+    assert c.ctypes.data not in (pa, pb)
     del view, c
     d = pool.take((1000, 4), np.float32)
-    assert id(d) == ida                           # now a is free again
+    assert d.ctypes.data == pa                    # now a's buffer is free again
     e = pool.take((1000,), np.float32)            # another shape: its own list
     assert e.shape == (1000,)
     del b
     f = pool.take((1000, 4), np.float32)
-    assert id(f) == idb
+    assert f.ctypes.data == pb
+
+
+def test_pools_do_not_depend_on_reference_counts():
+    """Round 3's pools asked sys.getrefcount whether "nobody holds this array"; a tracer, a debugger holding a frame or an interpreter
+    with different borrowed-reference rules changes that number silently, and a step would have overwritten an array the caller kept
+    (engineering #9).  Ownership is explicit now (a lease object that is the base of the array and of every view, returned
+    by its finalizer): 100 hand-outs kept in a list under sys.settrace, with extra references to each array parked in frames,
+    containers and views, never alias each other or a later hand-out."""
+    import gc
+    import sys
+
+    from gym_amd._native import _ArrayPool
+
+    pool = _ArrayPool(limit=4)
+    kept, events = [], []
+
+    def tracer(frame, event, arg):          # holds frames (and through them locals) alive, as a debugger or coverage tool does
+        events.append(frame)
+        return tracer
+
+    def step(i):
+        arr = pool.take((257, 3), np.float32)
+        arr[:] = i
+        extra = {"alias": arr, "slice": arr[5:7], "T": arr.T}        # more references of every kind
+        return arr, extra
+
+    sys.settrace(tracer)
+    try:
+        for i in range(100):
+            arr, extra = step(i)
+            kept.append(arr if i % 2 else extra["slice"])            # sometimes only a VIEW survives
+            scratch = pool.take((257, 3), np.float32)                # taken and dropped at once: the buffers that do get recycled
+            scratch[:] = -1.0
+            del scratch, arr, extra
+    finally:
+        sys.settrace(None)
+    for i, k in enumerate(kept):
+        assert np.all(k == i), f"hand-out {i} was overwritten while the caller still held it"
+    ptrs = {k.ctypes.data - (0 if i % 2 else 5 * 3 * 4) for i, k in enumerate(kept)}
+    assert len(ptrs) == 100
+    del kept, events
+    gc.collect()
+    again = [pool.take((257, 3), np.float32) for _ in range(4)]       # everything came back: the pool hands out pooled buffers again
+    assert all(type(a.base).__name__ == "_Lease" for a in again)
 
 
 def test_large_env_adapter_paths_on_a_packed_stand_in(monkeypatch):

@@ -39,6 +39,7 @@ static void own_sincos(double x, double *sn, double *cs) {
 }
 static int g_trig = 0;      // 0 = own sincos, 1 = glibc
 static int g_addition = 1;  // 1 = angle addition for shifted cosines (device), 0 = direct evaluation of the reference's arguments
+static int g_carry = 1;     // angle addition: 1 = carries the reference's argument roundings (TwoSum residuals), 0 = cos(t - pi/2) = sin t outright
 static int g_term = 0;      // terminal test: 0 = like the stages (g_addition/g_trig), 1 = direct own, 2 = direct glibc
 static void sc_(double x, double *s, double *c) { if (g_trig) sincos(x, s, c); else own_sincos(x, s, c); }
 static double cos_(double x) { double s, c; sc_(x, &s, &c); return c; }
@@ -53,11 +54,16 @@ static void dsdt(const double *sa, const double *sc, double a, double *out) {
     if (g_addition) {
         const double t12 = theta1 + theta2;
         const double a12 = t12 - halfpi;
-        const double eps12 = kHalfPiTail - two_sum_residual(theta1, theta2, t12) - two_sum_residual(t12, -halfpi, a12);
         const double S12 = fma(s1, c2, c1 * s2), C12 = fma(c1, c2, -(s1 * s2));
-        cos_t12_shift = fma(eps12, C12, S12);
-        const double a1 = theta1 - halfpi;
-        cos_t1_shift = fma(kHalfPiTail - two_sum_residual(theta1, -halfpi, a1), c1, s1);
+        if (g_carry) {
+            const double eps12 = kHalfPiTail - two_sum_residual(theta1, theta2, t12) - two_sum_residual(t12, -halfpi, a12);
+            cos_t12_shift = fma(eps12, C12, S12);
+            const double a1 = theta1 - halfpi;
+            cos_t1_shift = fma(kHalfPiTail - two_sum_residual(theta1, -halfpi, a1), c1, s1);
+        } else {
+            cos_t12_shift = S12;
+            cos_t1_shift = s1;
+        }
     } else {
         cos_t12_shift = cos_(theta1 + theta2 - halfpi);
         cos_t1_shift = cos_(theta1 - halfpi);
@@ -73,6 +79,7 @@ static void dsdt(const double *sa, const double *sc, double a, double *out) {
 static double wrap(double x, double m, double M) { const double diff = M - m; while (x > M) x = x - diff; while (x < m) x = x + diff; return x; }
 static double bound(double x, double m, double M) { return fmin(fmax(x, m), M); }
 void set_mode(int trig, int addition, int term) { g_trig = trig; g_addition = addition; g_term = term; }
+void set_carry(int carry) { g_carry = carry; }
 // s[4] in/out; returns terminated; height out
 int acro_step(double *s, int ai, double *height) {
     const double torque = (double)(ai - 1), dt = 0.2, dt2 = dt / 2.0;
@@ -98,7 +105,7 @@ int acro_step(double *s, int ai, double *height) {
     const double t21 = s[1] + s[0];
     if (g_term == 0) {
         sc_(s[0], &s0, &c0); sc_(s[1], &s1, &c1);
-        if (g_addition) cos21 = fma(two_sum_residual(s[1], s[0], t21), fma(s0, c1, c0 * s1), fma(c0, c1, -(s0 * s1)));
+        if (g_addition) cos21 = g_carry ? fma(two_sum_residual(s[1], s[0], t21), fma(s0, c1, c0 * s1), fma(c0, c1, -(s0 * s1))) : fma(c0, c1, -(s0 * s1));
         else cos21 = cos_(t21);
     } else if (g_term == 1) {
         own_sincos(s[0], &s0, &c0); double d; own_sincos(t21, &d, &cos21);
