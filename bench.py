@@ -573,11 +573,12 @@ def parse_args():
     ap.add_argument("--compact-outputs", action="store_true",
                     help="float32 rewards + int32 actions (MXV_FLAG_REWARD_F32|ACTION_I32: 26 real bytes per env-step "
                          "instead of 34); off by default: the headline keeps the reference's float64 / int64 dtypes")
-    ap.add_argument("--placement", default="sorted", choices=["sorted", "placed", "tuned", "first"],
+    ap.add_argument("--placement", default="sorted", choices=["sorted", "placed", "tuned", "first", "off"],
                     help="trajectory tensors: sorted = ordinary allocations sorted by measured HBM class (the product default, "
                          "DeviceRollout.trajectory_buffers); placed = 256-MiB physical chunks of measured class mapped through the HIP "
                          "virtual-memory API (mxv_placed_alloc); tuned = round 2's timing of --placement-candidates ordinary sets; "
-                         "first = the first ordinary allocation")
+                         "first = the first ordinary allocation; off = first, and MXV_PLACEMENT=off for every measurement of the run "
+                         "(no probe launch, no memory parked anywhere: the setting that cannot fail)")
     ap.add_argument("--placement-candidates", type=int, default=8, help="candidate sets of --placement tuned")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -588,6 +589,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1.  nccl (= RCCL) is the product path; gloo exists to exercise the "
                          "multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="issue the per-chunk all-gather at N = 1 too (with --comm mxv: a real one-rank RCCL communicator and "
+                         "ncclAllGather per output tensor on the side stream) — the gather's launch path measured on one GPU")
     ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds the process group / first collective may take")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds a self-launched job may take in total")
     return ap.parse_args()
@@ -595,6 +599,8 @@ def parse_args():
 
 def main():
     args = parse_args()
+    if args.placement == "off":
+        os.environ["MXV_PLACEMENT"] = "off"      # inherited by self-launched ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
@@ -629,7 +635,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL's kernels run on high-priority streams: a chunk's all-gather gets CUs as soon as rollout waves retire instead of
         # queueing behind the next chunk's (long-running, chip-filling) rollout launch
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        from gym_amd.distributed import prefer_high_priority_collectives
+        prefer_high_priority_collectives()        # TORCH_NCCL_HIGH_PRIORITY=1 unless the caller set it: explicit, this process only
         to = datetime.timedelta(seconds=args.init_timeout)
         try:
             if args.backend == "nccl":
@@ -684,7 +691,7 @@ def main():
         except (RuntimeError, MemoryError) as e:   # e.g. out of device memory: measure on the first allocation instead
             torch.cuda.empty_cache()
             traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"error": f"placement tuning failed: {e}"[:300]}
-    elif args.placement in ("first", "tuned") or mode != "fused":   # (tuned with < 2 candidates, or a one-launch-per-step mode: nothing to place)
+    elif args.placement in ("first", "tuned", "off") or mode != "fused":   # (tuned with < 2 candidates, or a one-launch-per-step mode: nothing to place)
         traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"kind": "first ordinary allocation"}
     else:
         from gym_amd import _native
@@ -704,6 +711,8 @@ def main():
     launches = [0]
     since_gather = [0]
     issued = [0]
+    gathers = [0]
+    gathering = world > 1 or args.force_gather
 
     def run(steps, gather=True):
         """`steps` vector steps as chunk-step launches; at N > 1 the final tensors are all-gathered (asynchronously, overlapping
@@ -716,9 +725,10 @@ def main():
             done += k
             issued[0] += k
             since_gather[0] += k
-            if world > 1 and gather and since_gather[0] >= args.chunk:
+            if gathering and gather and since_gather[0] >= args.chunk:
                 sr.gather_async()
                 since_gather[0] = 0
+                gathers[0] += 1
 
     def fence():
         sr.synchronize()
@@ -743,7 +753,7 @@ def main():
     trace(f"spin-up done ({spin} steps), all ranks at the fence")
     since_gather[0] = 0
     run(max(args.warmup, 1))
-    if world > 1:
+    if gathering:
         sr.gather()
     fence()
     trace("warm-up done (first gather through the transport included)")
@@ -756,11 +766,12 @@ def main():
     fence()
     launches[0] = 0
     since_gather[0] = 0
+    gathers[0] = 0
     t0 = time.perf_counter()
     ev0.record(eng.stream)
     run(timed_steps)
     ev1.record(eng.stream)
-    if world > 1:
+    if gathering:
         sr.wait_gather()
     fence()
     elapsed_local = time.perf_counter() - t0
@@ -769,8 +780,17 @@ def main():
     launch_ms = ev0.elapsed_time(ev1) / launches[0]  # avg step-kernel launch duration on the engine's stream
     steps_per_launch = timed_steps / launches[0]
     t = torch.tensor([elapsed_local], dtype=torch.float64, device="cuda")
+    # what THIS rank's placement sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
+    # the very tensors the timed region wrote: a rank whose tensors ended up in one HBM class shows here, not only in the job's maximum
+    probe_us = None
+    if mode == "fused" and not args.compact_outputs and local_envs % 1024 == 0:
+        from gym_amd import _native
+        torch.cuda.synchronize()
+        probe_us = _native.write_probe(local_rank, local_envs, args.chunk, 20, traj["obs"], traj["reward"], traj["actions"],
+                                       traj["terminated"], traj["truncated"])
     per_rank = [{"rank": rank, "device": local_rank, "kernel_us_per_step": launch_ms * 1e3 / steps_per_launch,
-                 "timed_region_ms": elapsed_local * 1e3,
+                 "timed_region_ms": elapsed_local * 1e3, "write_probe_us_per_step": probe_us,
+                 "kernel_over_probe": (launch_ms * 1e3 / steps_per_launch / probe_us) if probe_us else None,
                  "placement": {k: placement.get(k) for k in ("kind", "balanced", "candidates", "parked_GiB", "chunks_created", "class_chunks",
                                                              "seconds", "peak_GiB", "jumped_GiB", "chosen_us_per_step", "error") if k in placement}}]
     if world > 1:
@@ -846,6 +866,8 @@ def main():
                 "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.chunk} steps "
                                                         f"({args.comm} transport)" if world > 1 else ""),
                 "ranks_seen": comm_info.get("ranks_seen", 1),
+                "gathers_in_timed_region": gathers[0],
+                "gather_transport": (args.comm if gathering else None),
                 "comm": comm_info,
                 "per_rank": per_rank,
                 "work_check": work_check,
@@ -867,13 +889,7 @@ def main():
                 "avg_launch_us": launch_ms * 1e3,
             },
         }
-        if mode == "fused" and not args.compact_outputs and local_envs % 1024 == 0:
-            # what THIS placement sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
-            # the very tensors the timed region wrote
-            from gym_amd import _native
-            torch.cuda.synchronize()
-            probe_us = _native.write_probe(local_rank, local_envs, args.chunk, 20, traj["obs"], traj["reward"], traj["actions"],
-                                           traj["terminated"], traj["truncated"])
+        if probe_us:
             real_b = 34.0 * local_envs
             out["roofline"]["write_probe"] = {
                 "what": "same store pattern, no physics (mxv_write_probe), same tensors",

@@ -754,8 +754,11 @@ class Handle:
         # format 2 (round 2): reset draws are indexed by per-env reset ordinals (`episodes`).  Older snapshots carry no ordinals and
         # were written under the step-indexed reset stream: they cannot continue bit-identically, and restoring them silently would
         # replay reset states — refuse with a message instead of a KeyError
-        if snap.get("format", 1) != SNAPSHOT_FORMAT or "episodes" not in snap:
-            raise ValueError(f"snapshot format {snap.get('format', 1)} (this build reads {SNAPSHOT_FORMAT}): written before the reset "
+        # (snapshots written between the introduction of the ordinals and of the `format` key carry `episodes` and no key: they ARE
+        # format 2 and restore as such)
+        fmt = snap.get("format", SNAPSHOT_FORMAT if "episodes" in snap else 1)
+        if fmt != SNAPSHOT_FORMAT or "episodes" not in snap:
+            raise ValueError(f"snapshot format {fmt} (this build reads {SNAPSHOT_FORMAT}): written before the reset "
                              "stream was indexed by per-env reset ordinals; it cannot be continued bit-identically — re-create the env "
                              "and set_state() from snap['state'] / snap['elapsed'] if an approximate resume is enough")
         for k in ("env_id", "num_envs", "env_offset", "flags", "max_episode_steps"):

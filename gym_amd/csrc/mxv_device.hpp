@@ -229,9 +229,12 @@ __device__ __forceinline__ double div_with_rcp(double x, double d, double r) {
     const double q0 = x * r;
     return __fma_rn(__fma_rn(-d, q0, x), r, q0);
 }
-template <int DEF>
+// FINITE = the caller vouches for a finite dividend (the fused rollout on states the dynamics produced): the Markstein sequence turns
+// an infinite dividend into a NaN (Inf * rc - c * Inf), IEEE division keeps it infinite — and an injected state may hold one
+// (tests/golden/*_p1_nonfinite.npz: the reference's own outputs on such states).
+template <int DEF, bool FINITE = true>
 __device__ __forceinline__ double div_par(double x, double c) {
-    if constexpr (DEF == PM_DEFAULT)
+    if constexpr (DEF == PM_DEFAULT && FINITE)
         return div_by_const(x, c, 1.0 / c);  // c is a literal on this path: 1.0 / c folds at compile time
     else
         return x / c;
@@ -474,15 +477,15 @@ struct Env<MXV_CARTPOLE> {
             sincos_kernel<((fma3_for<MXV_CARTPOLE>() & 1) || (EPL == 1 && MXV_FMA3_CARTPOLE_E1)) ? 1 : 0>(theta, &sintheta, &costheta);
         else
             sincos_small_or_general(theta, &sintheta, &costheta);  // :136-137
-        const double temp = div_par<DEF>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
+        const double temp = div_par<DEF, !SAFE>(force + polemass_length * (theta_dot * theta_dot) * sintheta, total_mass);  // :141-143
         const double ta_num = gravity * sintheta - costheta * temp;
-        const double ta_den = length * (4.0 / 3.0 - div_par<DEF>(masspole * (costheta * costheta), total_mass));  // :144-146
+        const double ta_den = length * (4.0 / 3.0 - div_par<DEF, !SAFE>(masspole * (costheta * costheta), total_mass));  // :144-146
         double thetaacc;
         if constexpr (DEF == PM_DEFAULT && !SAFE && MXV_CARTPOLE_RCP)  // ta_den in [0.62, 0.67], ta_num normal and never -0: the scale / fix-up
             thetaacc = div_with_rcp(ta_num, ta_den, refined_rcp(ta_den));  // steps of `/` are identities (same bits, 3 slots fewer)
         else
             thetaacc = ta_num / ta_den;
-        const double xacc = temp - div_par<DEF>(polemass_length * thetaacc * costheta, total_mass);      // :147
+        const double xacc = temp - div_par<DEF, !SAFE>(polemass_length * thetaacc * costheta, total_mass);      // :147
         if (!semi_implicit) {  // "euler" :149-153
             x = x + tau * x_dot;
             x_dot = x_dot + tau * xacc;

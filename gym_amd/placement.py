@@ -14,6 +14,10 @@ next to it, so no absolute threshold is involved) and, if it lies on the wrong s
 which lies further along in physical memory.  Parked tensors are released at the end.  Typical: a few GiB parked for 0.1 s; a fresh
 device: up to ~90 GiB for ~3 s.  Nothing here touches the results: only WHERE the tensors live.
 
+Safe beside a co-resident learner: what the search may park is capped (half of the memory that is free beyond the set itself, at most
+MXV_PLACEMENT_MAX_PARK_GIB, default 112), an out-of-memory error inside the search ends it with ordinary allocations instead of reaching
+the caller, and MXV_PLACEMENT=off (or layout="separate") switches it off altogether.
+
 What was measured is remembered per device (`_ClassMemo`): torch's caching allocator hands a learner's loop the same blocks again and
 again (`out = r.rollout_per_step(K)` alternates between two sets), and a block keeps its physical memory for as long as its segment is
 not returned to the driver.  The memo is keyed by block address and size and is dropped whenever the allocator's count of segments
@@ -24,6 +28,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 import time
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -35,6 +40,26 @@ MiB = 1 << 20
 WIDE, NARROW = 256 * MiB, 128 * MiB     # what one probe window writes: 16 steps x 2^20 lanes x 16 B / 8 B
 SAME_RATIO = 0.955                      # a different-class pair runs at 0.89-0.91 of the same-class time
 MIN_SET_BYTES = _native.SORTED_MIN_BYTES
+DEFAULT_MAX_PARK_BYTES = 112 << 30      # the search never holds more than this beside the set itself (a fresh device needs ~90 GiB to leave its first class)
+
+
+def enabled() -> bool:
+    """MXV_PLACEMENT=off (or 0 / no / false): trajectory_buffers(layout="auto") never sorts — ordinary allocations, no probe launches, no
+    device synchronisation, no memory parked.  For a process that shares its GPU with a learner that cannot spare the transient memory."""
+    return os.environ.get("MXV_PLACEMENT", "on").strip().lower() not in ("off", "0", "no", "false")
+
+
+def max_park_bytes() -> int:
+    """Upper bound of the memory the search may hold transiently: MXV_PLACEMENT_MAX_PARK_GIB (default 112)."""
+    try:
+        return max(0, int(float(os.environ["MXV_PLACEMENT_MAX_PARK_GIB"]) * (1 << 30)))
+    except (KeyError, ValueError):
+        return DEFAULT_MAX_PARK_BYTES
+
+
+def _is_oom(e: BaseException) -> bool:
+    oom = getattr(torch, "OutOfMemoryError", None)
+    return (oom is not None and isinstance(e, oom)) or isinstance(e, MemoryError) or "out of memory" in str(e).lower()
 
 
 def _nbytes(shape, dtype) -> int:
@@ -84,7 +109,8 @@ class _Device:
 
 class _ClassMemo:
     """Per device: what the probes found out about blocks of the caching allocator.  `single[(ptr, nbytes)]`: the block lies in one HBM
-    class from end to end (anchor-grade); `rel[(anchor ptr, ptr, nbytes)]`: the block's relation to that anchor (+1 / -1 / 0)."""
+    class from end to end (anchor-grade); `rel[(anchor ptr, anchor nbytes, ptr, nbytes)]`: the block's relation to that anchor (+1 / -1 / 0;
+    it is probed at BOTH ends of the anchor, so the anchor's size is part of the key)."""
 
     def __init__(self):
         self.stamp, self.single, self.rel = None, set(), {}
@@ -102,15 +128,39 @@ class _ClassMemo:
 
 
 _MEMO: Dict[object, _ClassMemo] = {}
+_LOCK = threading.Lock()                # one search at a time per process: the memo, the probes' timing and the parked memory are shared
 
 
 def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups: Dict[str, int], device: torch.device,
                    stream: Optional[torch.cuda.Stream] = None, budget_bytes: Optional[int] = None, _backend=None):
     """specs: [(name, shape, dtype, zero_fill)]; groups: {name: 0 | 1} for the tensors that carry long store streams (the others are
     allocated last, wherever).  Returns ({name: tensor}, report).  report["balanced"]: every group-0 tensor shares the anchor's class
-    from end to end and every group-1 tensor lies outside it."""
-    t_begin = time.perf_counter()
+    from end to end and every group-1 tensor lies outside it.
+
+    Never fails because of the SEARCH: the memory it may park is bounded by budget_bytes (default: half of what is free beyond the set
+    itself, at most MXV_PLACEMENT_MAX_PARK_GIB), and an out-of-memory error anywhere inside it — another process took the memory in
+    the meantime, several ranks share the device — drops everything parked and returns ordinary allocations with balanced = False
+    (only if the SET itself does not fit does the error reach the caller, as it would without placement)."""
     be = _backend if _backend is not None else _Device(device, stream)
+    with _LOCK:
+        try:
+            return _sorted_locked(specs, groups, be, budget_bytes)
+        except Exception as e:  # noqa: BLE001
+            if not _is_oom(e):
+                raise
+            note = f"placement search ran out of device memory ({type(e).__name__}): ordinary allocations"
+        # the frames of the failed search (and with them every tensor it held) are gone here
+        getattr(be, "release", lambda: None)()
+        memo = _MEMO.get(be.key() if hasattr(be, "key") else id(be))
+        if memo is not None:
+            memo.seal(None)
+        report = {"kind": "sorted", "balanced": False, "parked_GiB": 0.0, "candidates": 0, "remembered": 0, "note": note,
+                  "requested_GiB": round(sum(_nbytes(shape, dt) for _, shape, dt, _ in specs) / 2**30, 3)}
+        return {n: be.alloc(shape, dt, zero) for n, shape, dt, zero in specs}, report
+
+
+def _sorted_locked(specs, groups, be, budget_bytes):
+    t_begin = time.perf_counter()
     memo = _MEMO.setdefault(be.key() if hasattr(be, "key") else id(be), _ClassMemo())
     frees_of = getattr(be, "segment_frees", lambda: None)
     memo.validate(frees_of())
@@ -122,7 +172,10 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
     report = {"kind": "sorted", "balanced": False, "parked_GiB": 0.0, "candidates": 0, "remembered": 0,
               "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
 
+    dirty = [True]     # allocations (and their zero fills) issued since the last device synchronisation
+
     def alloc(name):
+        dirty[0] = True
         return be.alloc(*spec[name])
 
     def plain(note):
@@ -134,11 +187,16 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
     anchor_name = max(g0, key=lambda n: nbytes[n])
     if nbytes[anchor_name] < WIDE + NARROW or any(nbytes[n] < NARROW for n in g0 + g1):
         return plain("tensors too small to classify: ordinary allocations")
-    budget = min(be.free_bytes() // 2, 112 << 30) if budget_bytes is None else int(budget_bytes)
+    # what may be parked beside the set: half of what is free once the set itself is counted, never more than the cap
+    budget = (min(max(be.free_bytes() - sum(nbytes.values()), 0) // 2, max_park_bytes()) if budget_bytes is None else int(budget_bytes))
+    report["budget_GiB"] = round(budget / 2**30, 2)
     parked, parked_bytes = [], 0
     warmed = [False]
 
     def probe(wide_ptr, narrow_ptr, _warm_at=None):
+        if dirty[0]:                                       # a probe times the device: it must be idle.  A set made of remembered blocks
+            be.sync()                                      # never gets here — no synchronisation at all on a learner's steady loop
+            dirty[0] = False
         if not warmed[0]:                                  # clock ramp + first touch, once per call and only if anything is measured at all
             warmed[0] = True
             w = wide_ptr if _warm_at is None else _warm_at
@@ -157,7 +215,6 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
         # the anchor: one class from end to end (an allocation that straddles a class boundary is parked and replaced)
         anchor = alloc(anchor_name)
         report["candidates"] += 1
-        be.sync()
         a0 = be.ptr(anchor)
         a1 = a0 + nbytes[anchor_name]
         if (a0, nbytes[anchor_name]) in memo.single:
@@ -167,8 +224,11 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             straddles = probe(a0, a1 - NARROW) <= SAME_RATIO * same
             if straddles and parked_bytes + nbytes[anchor_name] <= budget:
                 park((anchor_name, anchor))
+                del anchor
                 continue
-            if not straddles:
+            if straddles:
+                ok = False                                 # no budget left to replace it: the set is built on an anchor that spans two classes
+            else:
                 memo.single.add((a0, nbytes[anchor_name]))
             report["same_class_us"] = round(same, 3)
 
@@ -176,7 +236,8 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             """+1: same class as the anchor at both ends, -1: another class at both ends, 0: mixed."""
             c0 = be.ptr(t)
             c1 = c0 + nbytes[n]
-            known = memo.rel.get((a0, c0, nbytes[n]))
+            key = (a0, a1 - a0, c0, nbytes[n])             # the relation is probed at both ends of the anchor: its size is part of the key
+            known = memo.rel.get(key)
             if known is not None:
                 report["remembered"] += 1
                 return known
@@ -186,7 +247,7 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             if not s0 and not s1:
                 report.setdefault("different_class_us", round(min(p0, p1), 3))
             r = 1 if (s0 and s1) else -1 if (not s0 and not s1) else 0
-            memo.rel[(a0, c0, nbytes[n])] = r
+            memo.rel[key] = r
             return r
 
         out = {anchor_name: anchor}
@@ -196,7 +257,6 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
                 continue
             t = alloc(n)
             report["candidates"] += 1
-            be.sync()
             if relation(t, n) == 1:
                 out[n] = t
             elif parked_bytes + sum(nbytes[m] for m in out) + nbytes[n] <= budget and attempt < 3:
@@ -211,7 +271,6 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             while True:
                 t = alloc(n)
                 report["candidates"] += 1
-                be.sync()
                 r = relation(t, n)
                 if r == -1 or parked_bytes + nbytes[n] > budget:
                     ok = ok and r == -1
@@ -221,6 +280,7 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
         break
     else:   # four starts in a row ran into a class boundary: give up sorting
         ok, out = False, {}
+        anchor = t = None                                  # (the last parked tensors are referenced from here too: let them go with the rest)
         for n in g0 + g1:
             out[n] = alloc(n)
     for n in names:
@@ -228,13 +288,14 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
             out[n] = alloc(n)
     had_parked = bool(parked)
     del parked
+    anchor = t = None
     if had_parked:
         # the parked tensors go back to the driver, not into the allocator's cache — and so does every other unused block the allocator
         # held: only what this call returns is known to keep its memory
         be.release()
         keep = {be.ptr(t) for t in out.values()}
         memo.single = {k for k in memo.single if k[0] in keep}
-        memo.rel = {k: v for k, v in memo.rel.items() if k[0] in keep and k[1] in keep}
+        memo.rel = {k: v for k, v in memo.rel.items() if k[0] in keep and k[2] in keep}
     memo.seal(frees_of())  # the release moved the allocator's count: what survives stays valid from the new count on
     report.update({"balanced": ok, "parked_GiB": round(parked_bytes / 2**30, 2), "seconds": round(time.perf_counter() - t_begin, 3)})
     return {n: out[n] for n in names}, report

@@ -142,7 +142,8 @@ class DeviceRollout:
                 self.handle.set_episode_outputs(*tgt)
                 self._ep_attached = tgt[0]
 
-    def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "auto", seed: int = 0):
+    def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "auto", seed: int = 0,
+                           max_park_bytes: Optional[int] = None):
         """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk).  want_final adds
         `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
         of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content.
@@ -150,7 +151,10 @@ class DeviceRollout:
         layout="sorted" (what "auto" picks for sets of 1 GiB and more): ordinary allocations, but the reward / action tensors are
         made to lie in another third of the HBM address space than the observations (_sorted_buffers): the write-bound rollout then
         runs in its fast mode by construction instead of one time in three; the report is left in
-        `self.last_placement`.  layout="placed": the same goal through HIP's virtual-memory API (mxv_placed_alloc, include/mxv.h:
+        `self.last_placement`.  The search holds extra device memory while it runs (typically a few GiB for 0.1 s): at most
+        `max_park_bytes` (default: half of what is free beyond the set, capped by MXV_PLACEMENT_MAX_PARK_GIB = 112), it never raises
+        on its own account (out of memory inside the search -> ordinary allocations), and MXV_PLACEMENT=off makes "auto" mean
+        "separate" for the whole process (gym_amd/placement.py).  layout="placed": the same goal through HIP's virtual-memory API (mxv_placed_alloc, include/mxv.h:
         256-MiB physical chunks of measured class mapped under the tensors) — less transient memory when the classes are interleaved,
         but the real kernel runs 4-10 % slower on memory mapped that way.  layout="separate": one torch allocation per tensor.  layout="spread": all tensors carved out of ONE allocation in shuffled order
         at irregular offsets (pseudo-random gaps of up to ~60 % of the tensors' size in total, 4-KiB aligned, fixed by `seed`):
@@ -168,9 +172,11 @@ class DeviceRollout:
                   ("actions", (K, n), self.action_dtype, False)]
         if layout == "auto":
             total = sum(math.prod(shape) * torch.empty((), dtype=dt).element_size() for _, shape, dt, _ in specs)
-            layout = "sorted" if total >= _native.SORTED_MIN_BYTES else "separate"
+            from . import placement
+
+            layout = "sorted" if total >= _native.SORTED_MIN_BYTES and placement.enabled() else "separate"   # MXV_PLACEMENT=off: never sort
         if layout == "sorted":
-            return self._sorted_buffers(specs)
+            return self._sorted_buffers(specs, max_park_bytes)
         if layout == "placed":
             npdt = {torch.float32: "<f4", torch.float64: "<f8", torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}
             group = {"obs": 0, "reward": 1, "actions": 1}

@@ -496,7 +496,9 @@ class TabularRollout:
         specs = [("obs", (K, n), t.int64, False), ("reward", (K, n), t.float64, False), ("actions", (K, n), t.int64, False),
                  ("prob", (K, n), t.float64, False), ("terminated", (K, n), t.uint8, False), ("truncated", (K, n), t.uint8, False)]
         if layout == "auto":
-            layout = "sorted" if 34 * K * n >= (2 << 30) else "separate"
+            from . import placement
+
+            layout = "sorted" if 34 * K * n >= (2 << 30) and placement.enabled() else "separate"     # MXV_PLACEMENT=off: never sort
         if layout == "sorted":
             from .placement import sorted_tensors
 

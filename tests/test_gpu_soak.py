@@ -67,7 +67,7 @@ def test_bounded_soak_fused_tape_per_step_and_oracle(name):
 
     # (1) fused == per-step == tape, bit for bit: 65 536 envs x 3 x 128 steps x 3 engines
     n, K, chunks = 1 << 16, 128, 3
-    kw = dict(seed=1234, action_seed=4321, env_offset=5 << 20)
+    kw = dict(seed=1234, action_seed=4321, env_offset=5 << 20, max_episode_steps=min(LIMITS[name], 150))   # episodes end in every kind
     eng = [DeviceRollout(GYM_IDS[name], n, **kw) for _ in range(3)]
     for e in eng:
         e.reset(seed=1234)

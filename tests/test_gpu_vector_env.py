@@ -630,4 +630,9 @@ def test_snapshots_carry_a_format_version_and_old_ones_are_refused_with_a_reason
     old = {k: v for k, v in snap.items() if k not in ("format", "episodes")}
     with pytest.raises(ValueError, match="snapshot format 1"):
         h.restore(old)
+    # written after the ordinals came in but before the `format` key did: semantically format 2, and restored as such
+    keyless = {k: v for k, v in snap.items() if k != "format"}
+    h.step_host(np.zeros(64, dtype=np.int64))
+    h.restore(keyless)
+    assert np.array_equal(h.get_state()[0], snap["state"]) and np.array_equal(h.get_episodes(), snap["episodes"])
     h.close()

@@ -298,3 +298,108 @@ def test_memo_never_claims_a_balance_the_memory_does_not_have():
             held.append(out)
             if len(held) > 3:
                 held.pop(0)
+
+
+# ---- round 4: the search is safe beside a co-resident learner (VERDICT r3 engineering #10) ---------------------------------
+def test_out_of_memory_inside_the_search_falls_back_to_ordinary_allocations():
+    """Another process holds most of the device (or took it while the search was parking): the search must end with ordinary
+    allocations and balanced = False, never with an exception — only a set that does not fit at all may raise."""
+    set_bytes = sum(torch.empty((), dtype=dt).element_size() * K * N * (4 if name == "obs" else 1) for name, _, dt, _ in CARTPOLE)
+
+    class Shrinking(SimDevice):        # a neighbour grabs memory after the third allocation: free space collapses to the set + 1 GiB
+        def alloc(self, shape, dtype, zero):
+            if self.cursor > 12 * GiB and not getattr(self, "robbed", False):
+                self.robbed = True
+                self.free = self.live + 1 * GiB
+            return super().alloc(shape, dtype, zero)
+
+        def release(self):
+            self.released = True
+
+    dev = Shrinking([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")])
+    dev.free = 288 * GiB
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert rep["balanced"] is False and "out of device memory" in rep["note"] and getattr(dev, "released", False)
+    assert dev.live == set_bytes == sum(t.n for t in out.values()) and list(out) == [n for n, *_ in CARTPOLE]
+    # a device that cannot even hold the set: that error is the caller's, as it would be without placement
+    tiny = SimDevice([(288 * GiB, "A")], free=4 * GiB)
+    with pytest.raises(MemoryError):
+        sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=tiny)
+
+
+def test_the_budget_counts_the_set_itself_and_obeys_the_cap(monkeypatch):
+    """200 GiB of the device belong to someone else: the search may park half of what is left AFTER the 9-GiB set, not half of what is free
+    now; MXV_PLACEMENT_MAX_PARK_GIB lowers the cap; peak memory stays inside both."""
+    dev = SimDevice([(291 * GiB, "A"), (387 * GiB, "B")], free=88 * GiB)      # 88 GiB free, one class for all of it
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert rep["balanced"] is False and rep["budget_GiB"] == round((88 - 8.5) / 2, 2)
+    assert dev.peak <= 88 * GiB and dev.live == sum(t.n for t in out.values())
+    monkeypatch.setenv("MXV_PLACEMENT_MAX_PARK_GIB", "4")
+    dev = SimDevice([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")])
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert rep["budget_GiB"] == 4.0 and rep["parked_GiB"] <= 4.0 and rep["balanced"] is False
+    assert dev.peak <= sum(t.n for t in out.values()) + 4 * GiB + 3 * GiB     # the set + the cap + the candidate in hand
+
+
+def test_a_straddling_anchor_without_budget_is_not_reported_as_balanced():
+    dev = SimDevice([(2 * GiB, "A"), (60 * GiB, "B"), (288 * GiB, "A")])     # the first observation tensor is half A, half B
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, budget_bytes=0, _backend=dev)
+    assert rep["balanced"] is False and rep["parked_GiB"] == 0.0
+
+
+def test_a_set_of_remembered_blocks_costs_no_probe_and_no_synchronisation():
+    """The learner's loop: `out = r.rollout_per_step(K)` gets the same allocator blocks again; the second call must neither launch a probe
+    nor synchronise the device (three device-wide synchronisations per call even when the memo hits every block)."""
+    class Recycling(SimDevice):
+        syncs = 0
+
+        def alloc(self, shape, dtype, zero):      # a caching allocator: the same request gets the same block once it is free again
+            n = torch.empty((), dtype=dtype).element_size()
+            for s in shape:
+                n *= s
+            pool = self.__dict__.setdefault("pool", {})
+            if pool.get(n):
+                return SimDevice.T(self, pool[n].pop(0), n)
+            return super().alloc(shape, dtype, zero)
+
+        def give_back(self, tensors):
+            for t in tensors:
+                self.pool.setdefault(t.n, []).append(t.addr)
+
+        def sync(self):
+            Recycling.syncs += 1
+
+        def segment_frees(self):
+            return 0
+
+        def key(self):
+            return "recycling-sim"
+
+    regions, addr = [], 0
+    for i in range(100):
+        addr += 6 * GiB
+        regions.append((addr, "AB"[i % 2]))
+    dev = Recycling(regions)
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert rep["balanced"] is True and dev.probes > 0 and Recycling.syncs > 0
+    first = {k: t.addr for k, t in out.items()}
+    dev.give_back(out.values())
+    del out
+    probes, syncs = dev.probes, Recycling.syncs
+    out2, rep2 = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
+    assert {k: t.addr for k, t in out2.items()} == first
+    assert rep2["balanced"] is True and rep2["remembered"] >= 3
+    assert dev.probes == probes and Recycling.syncs == syncs
+
+
+def test_environment_switch(monkeypatch):
+    from gym_amd import placement
+
+    assert placement.enabled()
+    for v in ("off", "0", "OFF", "no", "false"):
+        monkeypatch.setenv("MXV_PLACEMENT", v)
+        assert not placement.enabled()
+    monkeypatch.setenv("MXV_PLACEMENT", "on")
+    assert placement.enabled()
+    monkeypatch.setenv("MXV_PLACEMENT_MAX_PARK_GIB", "1.5")
+    assert placement.max_park_bytes() == 3 << 29
