@@ -87,6 +87,7 @@ struct mxv_handle {
     EnvParams P{};
     bool default_params = true;
     float *ep_acc = nullptr;        // running episode returns when episode statistics are enabled
+    uint8_t *beyond = nullptr;      // CartPole + MXV_FLAG_NO_AUTORESET: per-env "terminated before" marks (cartpole.py:169-184)
     float *ep_return_out = nullptr; // caller-attached outputs of the statistics (device)
     int32_t *ep_length_out = nullptr;
     float *st_ep_r = nullptr;       // staging for mxv_step_host / mxv_episode_stats_host
@@ -221,6 +222,7 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.slice = 0;
     a.act_slice = 0;
     a.params_pe = h->params_pe;
+    a.beyond = h->beyond;
     a.ep_acc = h->ep_acc;
     a.ep_return_out = h->ep_acc ? h->ep_return_out : nullptr;
     a.ep_length_out = h->ep_acc ? h->ep_length_out : nullptr;
@@ -277,6 +279,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     a.mask = mask_dev;
     a.seeds = h->seeds;
     a.ep_acc = h->ep_acc;
+    a.beyond = h->beyond;
     a.n = h->cfg.num_envs;
     a.env0 = (uint64_t)h->cfg.env_offset;
     a.base_seed = h->base_seed;
@@ -525,6 +528,10 @@ int mxv_create(const mxv_config *cfg, mxv_handle **out) {
     MXV_CREATE_HIP(hipMemsetAsync(h->episodes, 0, n * sizeof(uint32_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->t_dev, 0, sizeof(uint64_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+    if (cfg->env_id == MXV_CARTPOLE && (cfg->flags & MXV_FLAG_NO_AUTORESET)) {   // steps_beyond_terminated marks (cartpole.py:169-184)
+        MXV_CREATE_HIP(hipMalloc((void **)&h->beyond, n));
+        MXV_CREATE_HIP(hipMemsetAsync(h->beyond, 0, n, h->stream));
+    }
     MXV_CREATE_HIP(hipStreamSynchronize(h->stream));
 #undef MXV_CREATE_HIP
     *out = h;
@@ -542,7 +549,8 @@ int mxv_destroy(mxv_handle *h) {
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     if (h->fin_host) (void)hipHostFree(h->fin_host);
     if (h->fin_dev) (void)hipFree(h->fin_dev);
-    void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block};
+    void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block,
+                    h->beyond};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1011,6 +1019,7 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
         MXV_HIP(h, hipMemcpyAsync(h->state, state_soa_host, n * h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (elapsed_host)
         MXV_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (state_soa_host && h->beyond) MXV_HIP(h, hipMemsetAsync(h->beyond, 0, n, h->stream));  // a fresh state: steps_beyond_terminated = None
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     h->was_reset = true;  // an injected state stands in for reset() (parity harness, checkpoint restore)
     if (state_soa_host) {

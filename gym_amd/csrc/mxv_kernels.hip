@@ -237,6 +237,17 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             term[j] = EV::template step<DEF>(P.at(valid[j] ? env_of(j) : 0), s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
+            if constexpr (ENV == MXV_CARTPOLE) {
+                // steps_beyond_terminated (cartpole.py:169-184): an env that is stepped on after it terminated — only possible without
+                // autoreset — pays 1.0 in the step the pole falls and 0.0 in every later step that is (still) terminated
+                if (a.beyond != nullptr && valid[j] && term[j]) {
+                    uint8_t *mark = a.beyond + env_of(j);
+                    if (*mark)
+                        rew[j] = 0.0;
+                    else
+                        *mark = 1;
+                }
+            }
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = autoreset && (term[j] || trunc[j]);
@@ -864,6 +875,7 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
     for (int k = 0; k < S; ++k) a.state[(int64_t)k * a.n + e] = s[k];
     a.elapsed[e] = 0;  // time_limit.py:67
     if (a.ep_acc != nullptr) a.ep_acc[e] = 0.0f;  // record_episode_statistics.py:91-94
+    if (a.beyond != nullptr) a.beyond[e] = 0;     // steps_beyond_terminated = None (cartpole.py:205)
     if (a.obs != nullptr) {
         float o[O];
         double aux_unused[EV::AUX > 0 ? EV::AUX : 1];

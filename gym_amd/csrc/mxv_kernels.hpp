@@ -36,6 +36,7 @@ struct StepArgs {
     int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
     int64_t act_slice;     // action tape advance per step (envs) or 0
     const double *params_pe; // [MXV_MAX_PARAMS][N] per-env physics parameters (PM_PER_ENV launches) or nullptr
+    uint8_t *beyond;         // CartPole without autoreset: [N] "this env has terminated before" (cartpole.py:169-184) or nullptr
     // episode statistics (gym/wrappers/record_episode_statistics.py:96-151), all nullptr when disabled
     float *ep_acc;           // [N] running episode return, float32 like the reference's accumulator
     float *ep_return_out;    // [N] / [K][N]: episode return, written only where terminated | truncated
@@ -64,6 +65,7 @@ struct ResetArgs {
     const uint8_t *mask;   // may be nullptr (all)
     const uint64_t *seeds; // may be nullptr
     float *ep_acc;         // may be nullptr: running episode returns, zeroed for the envs being reset
+    uint8_t *beyond;       // may be nullptr: CartPole's steps_beyond_terminated marks, cleared for the envs being reset
     int64_t n;
     uint64_t env0;
     uint64_t base_seed;

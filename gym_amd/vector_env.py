@@ -14,7 +14,11 @@ from typing import List, Optional, Union
 import numpy as np
 
 from . import _native, error
-from .registration import (CTOR_KWARGS, ENUM_PARAMS, PARAM_NAMES, PENDULUM, single_spaces, spec as _spec)
+from .registration import (CARTPOLE as CARTPOLE_KIND, CTOR_KWARGS, ENUM_PARAMS, MOUNTAINCAR_CONT as MOUNTAINCAR_CONT_KIND, PARAM_NAMES,
+                           PENDULUM, single_spaces, spec as _spec)
+
+# names VectorEnv.call() answers besides the physics attributes (read-only; no arguments)
+READ_ONLY_CALLS = ("state", "_elapsed_steps", "_max_episode_steps", "spec", "render_mode", "action_space", "observation_space")
 from .spaces import Discrete, batch_space
 
 __all__ = ["VectorEnv", "HipVectorEnv", "make"]
@@ -333,13 +337,40 @@ class HipVectorEnv(VectorEnv):
     def call(self, name: str, *args, **kwargs) -> tuple:
         """sync_vector_env.py:171-190: attribute value (or method result) of every sub-env, as a tuple."""
         self._assert_is_running()
-        if args or kwargs:
-            raise NotImplementedError("sub-environment methods are not callable on the device engine")
+        if name in READ_ONLY_CALLS and not args and not kwargs:
+            return self._read_only_call(name)
+        if args or kwargs or name in ("step", "reset", "render", "close", "seed"):
+            raise NotImplementedError(
+                f"call({name!r}, ...): sub-environment METHODS are not callable on the device engine (there are no Python sub-envs); "
+                f"attributes are: {sorted(PARAM_NAMES[self.kind])} (get / set) and {sorted(READ_ONLY_CALLS)} (read-only) — INTEGRATION.md")
         idx = self._param_index(name)
         if self._per_env:
             return tuple(self._decode(name, v) for v in self._handle.get_params_per_env()[idx].tolist())
         value = self._decode(name, self._handle.get_params()[idx])
         return (value,) * self.num_envs
+
+    def _read_only_call(self, name: str) -> tuple:
+        """What the reference's wrapped sub-envs answer for these names (TimeLimit / OrderEnforcing forward unknown attributes to the raw
+        env): `state` — the env's fp64 state (cartpole.py:160 a tuple, the others arrays; MountainCarContinuous float32, :171);
+        `_elapsed_steps`, `_max_episode_steps` (time_limit.py:43-44); `spec`, `render_mode`, `action_space`, `observation_space`."""
+        n = self.num_envs
+        if name == "state":
+            st = self._handle.get_state()[0]
+            if self.kind == CARTPOLE_KIND:
+                return tuple(tuple(float(v) for v in st[:, i]) for i in range(n))
+            dt = np.float32 if self.kind == MOUNTAINCAR_CONT_KIND else np.float64
+            return tuple(st[:, i].astype(dt) for i in range(n))
+        if name == "_elapsed_steps":
+            return tuple(int(v) for v in self._handle.get_state()[1])
+        if name == "_max_episode_steps":
+            return (self._handle.max_episode_steps if self._handle.max_episode_steps > 0 else None,) * n
+        if name == "spec":
+            return (self.spec,) * n
+        if name == "render_mode":
+            return (None,) * n
+        if name == "action_space":
+            return (self.single_action_space,) * n
+        return (self.single_observation_space,) * n
 
     def set_attr(self, name: str, values):
         """sync_vector_env.py:192-214: list/tuple of per-env values or one broadcast value."""

@@ -90,7 +90,10 @@ enum {
 enum {
     MXV_FLAG_ACTION_I32 = 1,   /* discrete actions are int32 instead of int64 */
     MXV_FLAG_REWARD_F32 = 2,   /* rewards are float32 instead of float64 */
-    MXV_FLAG_NO_AUTORESET = 4  /* dynamics + TimeLimit only; finished envs are NOT reset (single-env semantics) */
+    MXV_FLAG_NO_AUTORESET = 4  /* dynamics + TimeLimit only; finished envs are NOT reset (single-env semantics).  CartPole then keeps the
+                                  reference's steps_beyond_terminated bookkeeping (cartpole.py:169-184): the step in which the pole falls
+                                  pays 1.0, every later step of that env that is still terminated pays 0.0, until mxv_reset /
+                                  mxv_set_state touches the env (the reference's one-time logger.warn is not reproduced) */
 };
 
 #define MXV_MAX_PARAMS 12

@@ -536,12 +536,33 @@ static void env_step(int env_id, const double *P, double *s, int fresh, int64_t 
  *   autoreset == 0: dynamics + TimeLimit only (used by "external reset" trajectory tests).
  * Returns the number of envs whose discrete action was out of range (those envs are not
  * stepped): Discrete.contains assert, cartpole.py:131-132 / mountain_car.py:128-130. */
+int64_t orc_vec_step_beyond(int env_id, int64_t n, uint64_t env0, const double *P, int max_episode_steps,
+                            int autoreset, const uint64_t *seeds, uint64_t base_seed, uint64_t t, uint32_t *episodes,
+                            const double *bounds, const int64_t *act_i64, const float *act_f32,
+                            double *state, int32_t *elapsed, float *obs, double *reward,
+                            uint8_t *terminated, uint8_t *truncated, float *final_obs,
+                            uint8_t *final_mask, uint8_t *beyond);
+
 int64_t orc_vec_step(int env_id, int64_t n, uint64_t env0, const double *P, int max_episode_steps,
                      int autoreset, const uint64_t *seeds, uint64_t base_seed, uint64_t t, uint32_t *episodes,
                      const double *bounds, const int64_t *act_i64, const float *act_f32,
                      double *state, int32_t *elapsed, float *obs, double *reward,
                      uint8_t *terminated, uint8_t *truncated, float *final_obs,
                      uint8_t *final_mask) {
+    return orc_vec_step_beyond(env_id, n, env0, P, max_episode_steps, autoreset, seeds, base_seed, t, episodes, bounds, act_i64,
+                               act_f32, state, elapsed, obs, reward, terminated, truncated, final_obs, final_mask, NULL);
+}
+
+/* The same with CartPole's `steps_beyond_terminated` bookkeeping (cartpole.py:169-184) for envs that are stepped on after they
+ * terminated — only possible without autoreset: beyond[i] != 0 = env i has terminated before (steps_beyond_terminated is not None);
+ * the step in which the pole falls still pays 1.0 and sets the mark, every later step that is (still) terminated pays 0.0.  The caller
+ * clears beyond[i] when it resets env i (cartpole.py:205).  beyond == NULL: no bookkeeping (autoreset makes the branch unreachable). */
+int64_t orc_vec_step_beyond(int env_id, int64_t n, uint64_t env0, const double *P, int max_episode_steps,
+                            int autoreset, const uint64_t *seeds, uint64_t base_seed, uint64_t t, uint32_t *episodes,
+                            const double *bounds, const int64_t *act_i64, const float *act_f32,
+                            double *state, int32_t *elapsed, float *obs, double *reward,
+                            uint8_t *terminated, uint8_t *truncated, float *final_obs,
+                            uint8_t *final_mask, uint8_t *beyond) {
     int S = ORC_STATE_DIM[env_id], O = ORC_OBS_DIM[env_id];
     int nact = (env_id == ORC_CARTPOLE) ? 2 : 3;
     int discrete = (env_id == ORC_CARTPOLE || env_id == ORC_ACROBOT || env_id == ORC_MOUNTAINCAR);
@@ -570,6 +591,10 @@ int64_t orc_vec_step(int env_id, int64_t n, uint64_t env0, const double *P, int 
             noise = -P[10] + (P[10] - (-P[10])) * u01(w[0]);       /* np_random.uniform(low, high) = low + (high-low)*u */
         }
         env_step(env_id, P, s, elapsed[i] == 0, ai, af, noise, o, &rew, &term);
+        if (env_id == ORC_CARTPOLE && beyond && term) {            /* cartpole.py:171-184 */
+            if (beyond[i]) rew = 0.0;                              /* steps_beyond_terminated was not None: reward = 0.0 */
+            else beyond[i] = 1;                                    /* "Pole just fell!": reward stays 1.0 */
+        }
         elapsed[i] += 1;                                           /* time_limit.py:51 */
         if (max_episode_steps > 0 && elapsed[i] >= max_episode_steps) trunc = 1; /* :53-54 */
         reward[i] = rew;

@@ -47,6 +47,9 @@ def lib():
         L.orc_vec_step.argtypes = [C.c_int, i64, u64, vp, C.c_int, C.c_int, vp, u64, u64, vp, vp, vp, vp,
                                    vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_vec_step.restype = i64
+        L.orc_vec_step_beyond.argtypes = [C.c_int, i64, u64, vp, C.c_int, C.c_int, vp, u64, u64, vp, vp, vp, vp,
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orc_vec_step_beyond.restype = i64
         L.orc_rollout.argtypes = [C.c_int, i64, u64, vp, C.c_int, u64, u64, u64, vp, C.c_int, vp, vp, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_norm_obs_batches.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, C.c_int, vp]
@@ -115,6 +118,8 @@ class OracleVecEnv:
         self.r = 0  # explicit reset calls since seeding (informational)
         self.episodes = np.zeros(self.n, dtype=np.uint32)  # per-env reset ordinals = position of each env's reset stream
         self.discrete = self.env_id in DISCRETE
+        # CartPole without autoreset: which envs have terminated before (cartpole.py:169-184, steps_beyond_terminated is not None)
+        self.beyond = np.zeros(self.n, dtype=np.uint8) if (self.env_id == 0 and not self.autoreset) else None
 
     # -- RNG-contract helpers ---------------------------------------------------------
     def sample_actions(self, t=None):
@@ -141,6 +146,8 @@ class OracleVecEnv:
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().orc_vec_reset(self.env_id, self.n, self.env0, _p(self.seeds), self.base_seed, _p(self.episodes),
                             _p(b), _p(m), _p(self.state), _p(self.elapsed), _p(obs))
+        if self.beyond is not None:                     # steps_beyond_terminated = None (cartpole.py:205)
+            self.beyond[slice(None) if m is None else m.astype(bool)] = 0
         return obs
 
     def step(self, actions):
@@ -157,10 +164,10 @@ class OracleVecEnv:
         else:
             af = np.ascontiguousarray(actions, dtype=np.float32).reshape(n)
             ai = None
-        bad = lib().orc_vec_step(self.env_id, n, self.env0, _p(self.P), self.max_episode_steps,
-                                 int(self.autoreset), _p(self.seeds), self.base_seed, self.t, _p(self.episodes), _p(self.bounds),
-                                 _p(ai), _p(af), _p(self.state), _p(self.elapsed), _p(obs), _p(reward),
-                                 _p(term), _p(trunc), _p(final_obs), _p(final_mask))
+        bad = lib().orc_vec_step_beyond(self.env_id, n, self.env0, _p(self.P), self.max_episode_steps,
+                                        int(self.autoreset), _p(self.seeds), self.base_seed, self.t, _p(self.episodes), _p(self.bounds),
+                                        _p(ai), _p(af), _p(self.state), _p(self.elapsed), _p(obs), _p(reward),
+                                        _p(term), _p(trunc), _p(final_obs), _p(final_mask), _p(self.beyond))
         if bad:
             raise AssertionError(f"{bad} invalid discrete action(s)")
         self.t += 1

@@ -44,6 +44,8 @@ class OracleEngine:
     def set_state(self, state, elapsed):
         self.o.state[:] = state
         self.o.elapsed[:] = elapsed
+        if self.o.beyond is not None:
+            self.o.beyond[:] = 0           # a fresh state: steps_beyond_terminated = None (what make_golden.set_state does to the reference)
 
     def get_state(self):
         return self.o.state.copy(), self.o.elapsed.copy()
@@ -307,3 +309,30 @@ def run_p1_nonfinite(engine_cls, name, strict):
             atol = REWARD_ATOL.get(name, REWARD_ATOL_DEFAULT) if what == "reward" else STATE_ATOL
             np.testing.assert_allclose(got[fin_], ref[fin_], rtol=REWARD_RTOL if what == "reward" else STATE_RTOL, atol=atol)
     return int(np.isnan(g["state1"]).any(axis=1).sum())
+
+
+def run_cartpole_beyond(engine_cls, strict):
+    """CartPole_p2_beyond.npz (tests/golden/make_golden_cartpole_beyond.py): envs stepped on after they terminated, no reset in between
+    (MXV_FLAG_NO_AUTORESET): the fall pays 1.0, every later terminated step 0.0 (cartpole.py:169-184)."""
+    g = load_golden("CartPole", "p2_beyond")
+    T, n = g["action"].shape
+    eng = engine_cls("CartPole", n, 0, autoreset=False)
+    eng.set_state(g["state0"].T, np.full(n, 3, np.int32))
+    zero = 0
+    for t in range(T):
+        obs, rew, term, trunc, fin = eng.step(g["action"][t])
+        assert np.array_equal(term, g["terminated"][t].astype(bool)), f"step {t}: terminated"
+        assert np.array_equal(rew, g["reward"][t]), f"step {t}: rewards {rew[rew != g['reward'][t]][:4]} vs {g['reward'][t][rew != g['reward'][t]][:4]}"
+        st = eng.get_state()[0].T
+        if strict:
+            assert np.array_equal(obs, g["obs"][t]) and np.array_equal(st, g["state_post"][t])
+        else:
+            assert ulps32(obs, g["obs"][t]).max() <= MAX_OBS_ULPS
+            np.testing.assert_allclose(st, g["state_post"][t], rtol=1e-11, atol=1e-12)
+        zero += int((rew == 0).sum())
+    assert zero > 100
+    # a reset (here: a fresh state) clears the mark: the next fall pays 1.0 again
+    eng.set_state(g["state0"].T, np.full(n, 3, np.int32))
+    obs, rew, term, trunc, fin = eng.step(g["action"][0])
+    assert np.array_equal(rew, g["reward"][0]) and np.all(rew == 1.0)
+    return zero

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from helpers import (DISCRETE, ENV_IDS, ENV_NAMES, GYM_IDS, LIMITS, MAX_OBS_ULPS, OBS_RTOL, REWARD_ATOL, REWARD_ATOL_DEFAULT, REWARD_RTOL,
-                     HipEngine, OracleEngine, run_p1, run_p1_nonfinite, run_p2, ulps32)
+                     HipEngine, OracleEngine, run_cartpole_beyond, run_p1, run_p1_nonfinite, run_p2, ulps32)
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +138,12 @@ def test_non_finite_actions_inside_a_fused_rollout(name):
             assert np.array_equal(out["terminated"][k].cpu().numpy().astype(bool), te)
         assert np.isnan(o).any()
     r.close()
+
+
+def test_cartpole_stepped_on_after_termination():
+    """MXV_FLAG_NO_AUTORESET keeps the reference's steps_beyond_terminated bookkeeping (cartpole.py:169-184): the fall pays 1.0, every
+    later step that is still terminated 0.0, a reset clears the mark."""
+    assert run_cartpole_beyond(HipEngine, strict=False) == 288
 
 
 def test_known_answers_survey_appendix_b():

@@ -49,6 +49,30 @@ def test_reset_and_step_contract(env_id):
         env.reset()
 
 
+def test_call_answers_the_read_only_names_of_the_reference_and_refuses_methods():
+    """VectorEnv.call(name) (sync_vector_env.py:171-190) returns the attribute of every sub-env: besides the physics attributes the
+    device engine answers the names a learner reads off the reference's wrapped sub-envs — state, _elapsed_steps, _max_episode_steps,
+    spec, render_mode, the single spaces — with the reference's container types; sub-env METHODS do not exist here and say so."""
+    env = _make("CartPole-v1", 3)
+    obs, _ = env.reset(seed=5)
+    st = env.call("state")
+    assert isinstance(st, tuple) and len(st) == 3 and all(isinstance(s, tuple) and len(s) == 4 for s in st)      # cartpole.py:160: a tuple
+    assert np.array_equal(np.asarray(st, dtype=np.float32), obs)
+    env.step(env.action_space.sample())
+    assert env.call("_elapsed_steps") == (1, 1, 1) and env.call("_max_episode_steps") == (500,) * 3
+    assert env.call("render_mode") == (None,) * 3 and env.call("spec")[0].id == "CartPole-v1"
+    assert env.call("action_space")[0] == env.single_action_space and env.get_attr("observation_space")[2] == env.single_observation_space
+    for name, args in (("step", (0,)), ("reset", ()), ("render", ()), ("gravity", (1,))):
+        with pytest.raises(NotImplementedError):
+            env.call(name, *args)
+    env.close()
+    mcc = _make("MountainCarContinuous-v0", 2)
+    o, _ = mcc.reset(seed=1)
+    s2 = mcc.call("state")
+    assert all(isinstance(s, np.ndarray) and s.dtype == np.float32 and s.shape == (2,) for s in s2) and np.array_equal(np.stack(s2), o)
+    mcc.close()
+
+
 def test_call_get_attr_set_attr_gravity():
     env = _make("CartPole-v1", 4)
     env.reset(seed=1)
