@@ -248,6 +248,11 @@ def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin
            "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / us / 1e3, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS, "stored_bytes_per_env_step": real_b}}
     out["launch_info"] = r.handle.last_launch()
+    if env_id == ENV_ID and envs == ENVS_TOTAL:      # the headline configuration: the committed PMC pass of this launch shape, if any
+        tr, src = read_traffic("fused", chunk, envs, compact)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, src
+        if tr:
+            out["roofline"]["traffic_over_algorithmic"] = tr / (b * envs * chunk)
     if valu:
         per_env_step, source = read_valu(env_id)     # wave64 VALU instructions a wave issues per env-step of each of its lanes
         if per_env_step:
@@ -488,13 +493,13 @@ def read_traffic(mode: str, steps_per_launch: float, envs: int, compact: bool):
     tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; counters cannot be read from inside the
     process that is being timed), or (None, reason).  The profile's bytes per env-step are only transferable to a launch
     with the same kernel, output dtypes and steps per launch: anything else reports null instead of a mismatched number."""
-    if compact:
-        return None, "no PMC pass of the compact-output kernel committed"
     pdir = os.path.join(ROOT, "profiles")
     try:
         for name in sorted((f for f in os.listdir(pdir) if f.startswith("traffic_") and f.endswith(".json")), reverse=True):
             with open(os.path.join(pdir, name)) as f:
                 j = json.load(f)
+            if bool(j.get("compact_outputs", False)) != bool(compact):      # float32 + int32 outputs: profiles/traffic_compact_*.json
+                continue
             if j.get("mode", "eager") != mode:
                 continue
             if mode == "fused" and abs(float(j.get("chunk", 0)) - steps_per_launch) > 0.5:
@@ -629,7 +634,14 @@ def main():
                          f"(--gpus {args.gpus} with --backend nccl is one process per GPU; --backend gloo shares devices)")
     torch.cuda.set_device(local_rank)
     comm_info = {"backend": None}
-    if world > 1:
+    solo_group = world == 1 and args.force_gather and args.comm == "torch"    # a REAL one-rank process group: torch's RCCL path, minus the links
+    if solo_group and "MASTER_PORT" not in os.environ:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or solo_group:
         import datetime
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -679,6 +691,8 @@ def main():
     local_envs = total_envs // world
     sr = ShardedRollout(ENV_ID, total_envs, rank=rank, world_size=world, device=local_rank, seed=0, action_seed=1,
                         reward_f32=args.compact_outputs, action_i32=args.compact_outputs, comm=args.comm)
+    if solo_group:
+        sr._force_collective = True     # dist.all_gather_into_tensor for real (ShardedRollout short-cuts a one-rank gather to a local copy)
     eng = sr.engine
     mode = "eager" if args.no_graph else args.mode
     sr.reset(seed=0)
@@ -779,32 +793,6 @@ def main():
 
     launch_ms = ev0.elapsed_time(ev1) / launches[0]  # avg step-kernel launch duration on the engine's stream
     steps_per_launch = timed_steps / launches[0]
-    t = torch.tensor([elapsed_local], dtype=torch.float64, device="cuda")
-    # what THIS rank's placement sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
-    # the very tensors the timed region wrote: a rank whose tensors ended up in one HBM class shows here, not only in the job's maximum
-    probe_us = None
-    if mode == "fused" and not args.compact_outputs and local_envs % 1024 == 0:
-        from gym_amd import _native
-        torch.cuda.synchronize()
-        probe_us = _native.write_probe(local_rank, local_envs, args.chunk, 20, traj["obs"], traj["reward"], traj["actions"],
-                                       traj["terminated"], traj["truncated"])
-    per_rank = [{"rank": rank, "device": local_rank, "kernel_us_per_step": launch_ms * 1e3 / steps_per_launch,
-                 "timed_region_ms": elapsed_local * 1e3, "write_probe_us_per_step": probe_us,
-                 "kernel_over_probe": (launch_ms * 1e3 / steps_per_launch / probe_us) if probe_us else None,
-                 "placement": {k: placement.get(k) for k in ("kind", "balanced", "candidates", "parked_GiB", "chunks_created", "class_chunks",
-                                                             "seconds", "peak_GiB", "jumped_GiB", "chosen_us_per_step", "error") if k in placement}}]
-    if world > 1:
-        if args.backend == "gloo":
-            tc = t.cpu()
-            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-            t = tc
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, per_rank[0])
-        per_rank = gathered
-    elapsed = float(t.item())
-
     # what the timed region computed, in a form the oracle can reproduce (tests/test_gpu_bench_line.py): the last launch's flags and
     # actions of the first CHECK_ENVS envs, and how many env-steps of that launch ended an episode
     work_check = None
@@ -825,6 +813,33 @@ def main():
                           "checksum": work_checksum(term[:, :c], trunc[:, :c], act[:, :c]) if eng.NA > 0 else None,
                           "autoresets_per_env_step": ended / float(k_last * local_envs),
                           "seed": 0, "action_seed": 1}
+
+    # (the probe overwrites the trajectory tensors: it runs after work_check has read them)
+    # what THIS rank's placement sustains for the kernel's store pattern with the physics removed (mxv_write_probe, include/mxv.h), into
+    # the very tensors the timed region wrote: a rank whose tensors ended up in one HBM class shows here, not only in the job's maximum
+    probe_us = None
+    if mode == "fused" and not args.compact_outputs and local_envs % 1024 == 0:
+        from gym_amd import _native
+        torch.cuda.synchronize()
+        probe_us = _native.write_probe(local_rank, local_envs, args.chunk, 20, traj["obs"], traj["reward"], traj["actions"],
+                                       traj["terminated"], traj["truncated"])
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device="cuda")
+    per_rank = [{"rank": rank, "device": local_rank, "kernel_us_per_step": launch_ms * 1e3 / steps_per_launch,
+                 "timed_region_ms": elapsed_local * 1e3, "write_probe_us_per_step": probe_us,
+                 "kernel_over_probe": (launch_ms * 1e3 / steps_per_launch / probe_us) if probe_us else None,
+                 "placement": {k: placement.get(k) for k in ("kind", "balanced", "candidates", "parked_GiB", "chunks_created", "class_chunks",
+                                                             "seconds", "peak_GiB", "jumped_GiB", "chosen_us_per_step", "error") if k in placement}}]
+    if world > 1:
+        if args.backend == "gloo":
+            tc = t.cpu()
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            t = tc
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    elapsed = float(t.item())
 
     out = None
     if rank == 0:
@@ -943,7 +958,7 @@ def main():
             out["variants"] = v
         print(json.dumps(out), file=json_out, flush=True)
 
-    if world > 1:
+    if world > 1 or solo_group:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_obs_at(char *base, uint32_t byte_off, cons
 // its own L2.  Handing out tiles in id order makes every XCD write 4-8 KiB crumbs interleaved with the other seven
 // all over each output row; giving XCD x the x-th contiguous eighth of the tiles instead lets each L2 stream long
 // contiguous runs to its memory channels.  Measured on the rollout's store pattern with the physics removed
-// (tools/wbench, profiles/r01_wbench.txt): 4.7 -> 5.7 TB/s.  Works for any tile count (remainder tiles go to the
+// (profiles/r01_wbench.txt; the probe lives on as mxv_write_probe): 4.7 -> 5.7 TB/s.  Works for any tile count (remainder tiles go to the
 // low XCDs, matching how many ids of each residue exist).
 constexpr unsigned kXcds = 8;
 __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned ntiles) {

@@ -66,7 +66,7 @@ class DeviceRollout:
         self.stream.synchronize()
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
         # step(actions) is the learner-in-the-loop call: one launch per policy step, so its host cost is what caps small and
-        # medium vector envs.  Everything it needs per call is looked up once here (tools/step_overhead.py: 17.4 -> ~8 us).
+        # medium vector envs.  Everything it needs per call is looked up once here (17.4 -> ~8 us, profiles/HISTORY.md).
         self._stream_ptr = int(self.stream.cuda_stream)
         self._dev_index = self.device.index
         self._step_ptrs = (self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(), self.truncated.data_ptr(),

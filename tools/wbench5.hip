@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64, 4) twin(float4 *obs, double *rew, int64_t 
     if (x0 + x1 == 12345.678) obs[0] = make_float4((float)x0, 0, 0, 0);  // keep the chains alive when STORE is false
 }
 
-// the same with BLOCK lanes per workgroup (BLOCK / 64 waves, lane `tid` owns envs tile0 + j * BLOCK + tid): what tools/wbench measures
+// the same with BLOCK lanes per workgroup (BLOCK / 64 waves, lane `tid` owns envs tile0 + j * BLOCK + tid): what round 1 measured with 256-lane workgroups
 template <int M, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) twin_block(float4 *obs, double *rew, int64_t *act, uint8_t *term, uint8_t *trunc, int64_t n, int K,
                                                     double seed) {
