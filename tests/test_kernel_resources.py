@@ -151,10 +151,14 @@ def test_the_instruction_forms_this_round_bought_are_still_in_the_loops(build):
     # three-address polynomial steps: 10 per sincos evaluated in the loop body (hot path + reset path), hardly any 64-bit copies left
     assert count(pend, "v_fma_f64") >= 20 and count(pend, "v_mov_b64") <= 10, (count(pend, "v_fma_f64"), count(pend, "v_mov_b64"))
     assert count(mcc, "v_fma_f64") >= 20 and count(mcc, "v_mov_b64") <= 10, (count(mcc, "v_fma_f64"), count(mcc, "v_mov_b64"))
-    # clamps
-    assert count(pend, "v_max_f64") + count(pend, "v_min_f64") >= 2 and (count(pend, "v_med3_f32") + count(pend, "v_max_f32") + count(pend, "v_min_f32")) >= 1
-    assert count(mc, "v_max_f64") + count(mc, "v_min_f64") >= 4 * HOT[3][0] - 2
-    assert count(mcc, "v_max_f32") + count(mcc, "v_min_f32") + count(mcc, "v_med3_f32") >= 2
+    # clamps: v_max / v_min pairs, and since round 4 a NaN passes through them as it does through the reference's (np.clip, `if x > hi`):
+    # float64 = one v_cmp_u_f64 + one v_cndmask on the high dword per pair, float32 = the NaN-propagating v_maximum3 / v_minimum3
+    assert count(pend, "v_max_f64") + count(pend, "v_min_f64") >= 2 and count(pend, "v_cmp_u_f64") >= 1
+    assert count(pend, "v_maximum3_f32") >= 1 and count(pend, "v_minimum3_f32") >= 1
+    assert count(mc, "v_max_f64") + count(mc, "v_min_f64") >= 4 * HOT[3][0] - 2 and count(mc, "v_cmp_u_f64") >= 2 * HOT[3][0]
+    assert count(mcc, "v_maximum3_f32") >= 2 and count(mcc, "v_minimum3_f32") >= 2
+    acro = loop_text(2)
+    assert count(acro, "v_bitop3_b32") >= 12          # quadrant signs of the eight hot sincos (round 4), one instruction each
     # Pendulum's K-step loop: 614 instructions / 27 branches before, 501 / 20 after
     n_instr = sum(1 for l in pend.splitlines() if l.startswith("\t") and not l.strip().startswith((".", ";")))
     assert n_instr <= 540 and sum(1 for l in pend.splitlines() if "s_cbranch" in l) <= 22, n_instr
