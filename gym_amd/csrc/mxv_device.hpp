@@ -235,12 +235,19 @@ __device__ __forceinline__ double div_with_rcp(double x, double d, double r) {
 // state injection) append the hardware's own special-case pass, v_div_fixup_f64 — what the compiler's `/` ends with: the quotient goes
 // through unchanged for ordinary operands, NaN / Inf / 0 operands get IEEE's answers — one instruction instead of the ten of a full division
 // (round 4 first used `/` here: step(actions) 18.5 -> 20.1 us per 2^20-env step).
+#ifndef MXV_GUARDED_DIV_FIXUP
+#define MXV_GUARDED_DIV_FIXUP 1   // A/B hook
+#endif
 template <int DEF, bool FINITE = true>
 __device__ __forceinline__ double div_par(double x, double c) {
     if constexpr (DEF == PM_DEFAULT && FINITE)
         return div_by_const(x, c, 1.0 / c);  // c is a literal on this path: 1.0 / c folds at compile time
     else if constexpr (DEF == PM_DEFAULT)
+#if MXV_GUARDED_DIV_FIXUP
         return __builtin_amdgcn_div_fixup(div_by_const(x, c, 1.0 / c), c, x);
+#else
+        return div_by_const(x, c, 1.0 / c);
+#endif
     else
         return x / c;
 }

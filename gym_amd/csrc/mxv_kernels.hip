@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
             if constexpr (ENV == MXV_CARTPOLE) {
                 // steps_beyond_terminated (cartpole.py:169-184): an env that is stepped on after it terminated — only possible without
                 // autoreset — pays 1.0 in the step the pole falls and 0.0 in every later step that is (still) terminated
-                if (a.beyond != nullptr && valid[j] && term[j]) {
+                if (MXV_CARTPOLE_BEYOND && a.beyond != nullptr && valid[j] && term[j]) {
                     uint8_t *mark = a.beyond + env_of(j);
                     if (*mark)
                         rew[j] = 0.0;

@@ -192,6 +192,10 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_SADDR_STORES
 #define MXV_SADDR_STORES 1
 #endif
+// A/B hook: 0 compiles CartPole's steps_beyond_terminated bookkeeping out of step_kernel
+#ifndef MXV_CARTPOLE_BEYOND
+#define MXV_CARTPOLE_BEYOND 1
+#endif
 // 1: XCD-aware workgroup -> tile map (see xcd_contiguous_tile in mxv_kernels.hip); 0: tiles in workgroup-id order.
 #ifndef MXV_XCD_MAP
 #define MXV_XCD_MAP 1
