@@ -237,17 +237,6 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             term[j] = EV::template step<DEF>(P.at(valid[j] ? env_of(j) : 0), s[j], aux[j], el[j] == 0, ai[j], af[j], rew[j], obs[j]);
-            if constexpr (ENV == MXV_CARTPOLE) {
-                // steps_beyond_terminated (cartpole.py:169-184): an env that is stepped on after it terminated — only possible without
-                // autoreset — pays 1.0 in the step the pole falls and 0.0 in every later step that is (still) terminated
-                if (MXV_CARTPOLE_BEYOND && a.beyond != nullptr && valid[j] && term[j]) {
-                    uint8_t *mark = a.beyond + env_of(j);
-                    if (*mark)
-                        rew[j] = 0.0;
-                    else
-                        *mark = 1;
-                }
-            }
             el[j] += 1;                                              // time_limit.py:51
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = autoreset && (term[j] || trunc[j]);
@@ -326,6 +315,29 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
             }
             if (a.terminated != nullptr) a.terminated[e] = term[j] ? 1 : 0;
             if (a.truncated != nullptr) a.truncated[e] = trunc[j] ? 1 : 0;
+        }
+        if constexpr (ENV == MXV_CARTPOLE) {
+            // steps_beyond_terminated (cartpole.py:169-184): an env that is stepped on after it terminated — only possible without
+            // autoreset, which is when the marks exist — pays 1.0 in the step the pole falls and 0.0 in every later step that is (still)
+            // terminated.  Done BEHIND the step's stores, as a correction of the reward just written (same lane, same address: the later
+            // store stands): a wave-uniform test of the pointer keeps every other launch off this code, and no block boundary cuts
+            // through the step's arithmetic.  (In the middle of the dynamics loop the same lines cost step(actions) 22.1 -> 23.3 us
+            // per 2^20-env step although they never ran: profiles/r4d_step_path_ab.log.)
+            if (MXV_CARTPOLE_BEYOND && a.beyond != nullptr) {
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    if (valid[j] && term[j]) {
+                        uint8_t *mark = a.beyond + env_of(j);
+                        if (landed((uint32_t)*mark) == 0u) {
+                            *mark = 1;
+                        } else if (a.reward != nullptr) {
+                            if (a.flags & MXV_FLAG_REWARD_F32)
+                                static_cast<float *>(a.reward)[so + env_of(j)] = 0.0f;
+                            else
+                                static_cast<double *>(a.reward)[so + env_of(j)] = 0.0;
+                        }
+                    }
+            }
         }
     }
 
