@@ -349,25 +349,24 @@ class _ArrayPool:
 
     def __init__(self, limit: int = 6):
         self._free = {}      # key -> buffers nobody sees
-        self._out = {}       # key -> buffers currently leased
+        self._made = {}      # key -> buffers this pool owns (free or leased): never more than `limit`
         self._limit = limit
 
     def _give_back(self, key, store):
-        self._out[key] -= 1
-        self._free.setdefault(key, []).append(store)
+        self._free[key].append(store)      # (list.append is atomic: finalizers may run on any thread)
 
     def take(self, shape, dtype) -> np.ndarray:
         shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
         dt = np.dtype(dtype)
         key = (shape, dt.str)
         free = self._free.setdefault(key, [])
-        if free:
+        try:
             store = free.pop()
-        elif self._out.get(key, 0) < self._limit:
+        except IndexError:
+            if self._made.get(key, 0) >= self._limit:
+                return np.empty(shape, dtype=dt)      # the caller holds `limit` arrays of this kind: no pooling beyond that
             store = np.empty(shape, dtype=dt)
-        else:
-            return np.empty(shape, dtype=dt)      # the caller holds `limit` arrays of this kind: no pooling beyond that
-        self._out[key] = self._out.get(key, 0) + 1
+            self._made[key] = self._made.get(key, 0) + 1
         lease = _Lease(store.ctypes.data, shape, dt.str, store)
         weakref.finalize(lease, self._give_back, key, store)
         return np.asarray(lease)
@@ -397,20 +396,19 @@ class _BlockPool:
     None and the step falls back to separate, unpinned arrays."""
 
     def __init__(self, nbytes: int, limit: int = 6):
-        self._nbytes, self._limit, self._free, self._n_out = nbytes, limit, [], 0
+        self._nbytes, self._limit, self._free, self._made = nbytes, limit, [], 0
 
     def _give_back(self, blk):
-        self._n_out -= 1
         self._free.append(blk)
 
     def take(self):
-        if self._free:
+        try:
             blk = self._free.pop()
-        elif self._n_out < self._limit:
+        except IndexError:
+            if self._made >= self._limit:
+                return None
             blk = _PinnedBlock(self._nbytes)
-        else:
-            return None
-        self._n_out += 1
+            self._made += 1
         lease = _Lease(blk.ptr, (self._nbytes,), "|u1", blk)
         weakref.finalize(lease, self._give_back, blk)
         return np.asarray(lease)

@@ -1028,13 +1028,13 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
         // does not takes the guarded instantiation for the next launch, after which termination + autoreset (CartPole), the wrap
         // loops (Acrobot) and the position clamps (MountainCar*) have restored them.  Only Pendulum keeps an out-of-range angle
         // (it is never wrapped, pendulum.py:133) until its episode is truncated: guarded launches until the next full reset.
-        // Non-finite values need no guard (NaN and Inf go through both code paths alike) but are not worth a separate rule.
+        // Non-finite values count as outside: NaN goes through both code paths alike, an infinite CartPole velocity does not (above).
         bool in_range = true;
         const int S = h->S;
         for (int k = 0; k < S && in_range; ++k) {
             const double *row = state_soa_host + (size_t)k * n;
-            const double lim = (h->cfg.env_id == MXV_CARTPOLE) ? (k == 2 ? 0.78539816339744830962 : HUGE_VAL) : 65536.0;
-            if (lim == HUGE_VAL) continue;
+            // (CartPole's other components only have to be finite: the unguarded path's quotients turn an infinite dividend into a NaN)
+            const double lim = (h->cfg.env_id == MXV_CARTPOLE) ? (k == 2 ? 0.78539816339744830962 : 1.7976931348623157e308) : 65536.0;
             for (size_t i = 0; i < n; ++i)
                 if (!(std::fabs(row[i]) <= lim)) {
                     in_range = false;

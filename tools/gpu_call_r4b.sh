@@ -16,6 +16,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $GRAFT_REPO_ROOT
 find $O/variants_trace $O/compact_pmc_FETCH_SIZE $O/compact_pmc_WRITE_SIZE -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete 2>/dev/null
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err
+( time timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err ) 2> $O/bench_driver_args.time
 timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo done > $O/finished
