@@ -294,6 +294,9 @@ __device__ __forceinline__ double fma_coef(double a, double b, double k) {
     }
 }
 
+#ifndef MXV_FDLIBM_COS
+#define MXV_FDLIBM_COS 0
+#endif
 template <int F3 = 0>
 __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) {
     const double z = x * x;
@@ -304,15 +307,25 @@ __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) 
     r = fma_coef<F3>(z, r, 8.33333333332248946124e-03);
     r = fma_coef<F3>(z, r, -1.66666666666666324348e-01);
     *sn = __fma_rn(x * z, r, x);
-    // cos: 1 - z/2 + z*z*(C1 + z*(C2 + ... z*C6)), summed so that the rounding error of 1 - z/2 is recovered
+    // cos: 1 + z*(-1/2 + z*(C1 + z*(C2 + ... z*C6))) in plain Horner form.  fdlibm sums 1 - z/2 + z*z*(...) so that the rounding error of
+    // 1 - z/2 is recovered (7 instructions for the last two terms): < 0.751 ulp on |x| <= pi/4 with FMA steps, against < 0.884 ulp for the
+    // two FMAs here (3e7 arguments against 80-bit cosl; 3.6 % vs 4.2 % of the values are not the correctly rounded one).  Five
+    // instructions per evaluation (40 of Acrobot's 622 per env-step) for 0.13 ulp of a function whose medium-range version is bounded by
+    // its argument reduction anyway: sincos_medium's maxima, 1.466 / 1.498 ulp, are the same with either form (tools/fast_sincos_check.c
+    // -DPLAIN).  MXV_FDLIBM_COS = 1 restores the compensated sum (A/B hook).
     double c = fma_coef<F3>(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
     c = fma_coef<F3>(z, c, -2.75573143513906633035e-07);
     c = fma_coef<F3>(z, c, 2.48015872894767294178e-05);
     c = fma_coef<F3>(z, c, -1.38888888888741095749e-03);
     c = fma_coef<F3>(z, c, 4.16666666666666019037e-02);
+#if MXV_FDLIBM_COS
     const double hz = 0.5 * z;
     const double t = 1.0 - hz;
     *cs = t + __fma_rn(z, z * c, (1.0 - t) - hz);
+#else
+    c = __fma_rn(z, c, -0.5);
+    *cs = __fma_rn(z, c, 1.0);
+#endif
 }
 
 // General-range sin/cos.  ocml's sincos costs ~80 VALU instructions per call on gfx950 (a 3-term Cody-Waite reduction kept in

@@ -40,7 +40,9 @@ def report(name, term, state):
 
 def cpu():
     d = tempfile.mkdtemp(prefix="acro_ab_")
-    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC", "-o", f"{d}/hot.so", os.path.join(ROOT, "tools", "acrobot_threshold_ab.c"), "-lm"])
+    # hot.so: the arithmetic of rounds 1-3 (compensated cosine sum; the rows below switch the rest); hot4.so: round 4's hot path
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-DFDLIBM_COS", "-shared", "-fPIC", "-o", f"{d}/hot.so", os.path.join(ROOT, "tools", "acrobot_threshold_ab.c"), "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC", "-o", f"{d}/hot4.so", os.path.join(ROOT, "tools", "acrobot_threshold_ab.c"), "-lm"])
     shim = f"{d}/exact.cpp"
     open(shim, "w").write('#include "%s"\nextern "C" void x_acro(int n, double *st, const long *a, unsigned char *t, double *sc) {\n'
                           '  const double pi = 3.141592653589793, P[12] = {0.2, 1, 1, 1, 1, 0.5, 0.5, 1, 4 * pi, 9 * pi, 0, 0};\n'
@@ -48,7 +50,7 @@ def cpu():
                           % os.path.join(ROOT, "gym_amd", "csrc", "mxv_exact.hpp"))
     subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC", "-o", f"{d}/exact.so", shim])
     hot, ex = ctypes.CDLL(f"{d}/hot.so"), ctypes.CDLL(f"{d}/exact.so")
-    modes = {"engine hot path (own sincos, angle addition) [emulated]": (0, 1, 0),
+    modes = {"round-3 hot path (own sincos, angle addition with the argument roundings carried) [emulated]": (0, 1, 0),
              "own sincos, angle addition in the stages, terminal cosines direct (own sincos)": (0, 1, 1),
              "own sincos, angle addition in the stages, terminal cosines direct (glibc)": (0, 1, 2),
              "own sincos, every cosine direct": (0, 0, 0),
@@ -62,6 +64,13 @@ def cpu():
         t, h = np.zeros(N, np.uint8), np.zeros(N)
         hot.acro_batch(N, st.ctypes.data_as(P), G["action"].ctypes.data_as(P), t.ctypes.data_as(P), h.ctypes.data_as(P))
         report(name, t.astype(bool), st)
+    hot4 = ctypes.CDLL(f"{d}/hot4.so")
+    hot4.set_mode(0, 1, 0)
+    hot4.set_carry(0)
+    st = np.ascontiguousarray(G["state0"].copy())
+    t, h = np.zeros(N, np.uint8), np.zeros(N)
+    hot4.acro_batch(N, st.ctypes.data_as(P), G["action"].ctypes.data_as(P), t.ctypes.data_as(P), h.ctypes.data_as(P))
+    report("round-4 hot path alone (plain angle addition, two-FMA cosine tail; what runs outside the exact band) [emulated]", t.astype(bool), st)
     st = np.ascontiguousarray(G["state0"].copy())
     t, sc = np.zeros(N, np.uint8), np.zeros((N, 4))
     ex.x_acro(N, st.ctypes.data_as(P), G["action"].ctypes.data_as(P), t.ctypes.data_as(P), sc.ctypes.data_as(P))

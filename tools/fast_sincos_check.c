@@ -1,5 +1,6 @@
 // CPU check of gym_amd/csrc/mxv_device.hpp: sincos_medium (same constants, same FMA arithmetic) against 80-bit sinl/cosl:
 //   gcc -O2 -mfma -o /tmp/fast tools/fast_sincos_check.c -lm && /tmp/fast    ->  max ulp err sin 1.466 cos 1.498 over |x| <= 40
+//   (the same maxima with -DFDLIBM_COS, the compensated cosine sum of rounds 1-3: the argument reduction bounds both)
 #define _GNU_SOURCE
 #include <math.h>
 #include <stdio.h>
@@ -21,9 +22,14 @@ static void kern(double x, double *sn, double *cs) {
     c = fma(z, c, 2.48015872894767294178e-05);
     c = fma(z, c, -1.38888888888741095749e-03);
     c = fma(z, c, 4.16666666666666019037e-02);
+#ifdef FDLIBM_COS   /* the compensated sum of rounds 1-3 (MXV_FDLIBM_COS = 1) */
     const double hz = 0.5 * z;
     const double t = 1.0 - hz;
     *cs = t + fma(z, z * c, (1.0 - t) - hz);
+#else               /* round 4: plain Horner, two FMAs */
+    c = fma(z, c, -0.5);
+    *cs = fma(z, c, 1.0);
+#endif
 }
 static void fast_sincos(double x, double *sn, double *cs) {
     const double k = rint(x * TWO_OVER_PI);
