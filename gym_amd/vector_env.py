@@ -14,8 +14,8 @@ from typing import List, Optional, Union
 import numpy as np
 
 from . import _native, error
-from .registration import (CARTPOLE as CARTPOLE_KIND, CTOR_KWARGS, ENUM_PARAMS, MOUNTAINCAR_CONT as MOUNTAINCAR_CONT_KIND, PARAM_NAMES,
-                           PENDULUM, single_spaces, spec as _spec)
+from .registration import (ACROBOT as ACROBOT_KIND, CARTPOLE as CARTPOLE_KIND, CTOR_KWARGS, ENUM_PARAMS, MOUNTAINCAR as MOUNTAINCAR_KIND,
+                           MOUNTAINCAR_CONT as MOUNTAINCAR_CONT_KIND, PARAM_NAMES, PENDULUM, single_spaces, spec as _spec)
 
 # names VectorEnv.call() answers besides the physics attributes (read-only; no arguments)
 READ_ONLY_CALLS = ("state", "_elapsed_steps", "_max_episode_steps", "spec", "render_mode", "action_space", "observation_space")
@@ -355,11 +355,21 @@ class HipVectorEnv(VectorEnv):
         `_elapsed_steps`, `_max_episode_steps` (time_limit.py:43-44); `spec`, `render_mode`, `action_space`, `observation_space`."""
         n = self.num_envs
         if name == "state":
-            st = self._handle.get_state()[0]
-            if self.kind == CARTPOLE_KIND:
-                return tuple(tuple(float(v) for v in st[:, i]) for i in range(n))
-            dt = np.float32 if self.kind == MOUNTAINCAR_CONT_KIND else np.float64
-            return tuple(st[:, i].astype(dt) for i in range(n))
+            # the container is the reference's own, which depends on whether the sub-env was just reset (reset() stores what
+            # np_random.uniform returned) or stepped (step() stores what it computed): cartpole.py:202 ndarray / :160 tuple of floats;
+            # mountain_car.py:160 ndarray / :147 tuple; acrobot.py:188-190 float32 ndarray / :209-218 float64 ndarray;
+            # continuous_mountain_car.py:182 float64 ndarray / :171 float32 ndarray; pendulum.py:153,135 float64 ndarray both times
+            st, el = self._handle.get_state()
+            out = []
+            for i in range(n):
+                fresh, v = el[i] == 0, st[:, i]
+                if self.kind in (CARTPOLE_KIND, MOUNTAINCAR_KIND) and not fresh:
+                    out.append(tuple(float(x) for x in v))
+                elif (self.kind == ACROBOT_KIND and fresh) or (self.kind == MOUNTAINCAR_CONT_KIND and not fresh):
+                    out.append(v.astype(np.float32))
+                else:
+                    out.append(v.astype(np.float64))
+            return tuple(out)
         if name == "_elapsed_steps":
             return tuple(int(v) for v in self._handle.get_state()[1])
         if name == "_max_episode_steps":

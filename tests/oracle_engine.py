@@ -141,6 +141,7 @@ class FakeHandle:
     def __init__(self, kind, num_envs, max_episode_steps, device=0, env_offset=0, seed=0, action_seed=0, flags=0):
         self.o = OracleVecEnv(kind, num_envs, max_episode_steps, seed=seed, action_seed=action_seed, env_offset=env_offset)
         self.env_id, self.num_envs, self.device, self.flags = kind, num_envs, device, flags
+        self.max_episode_steps = int(max_episode_steps)
         self.O, self.S = self.o.O, self.o.S
         self.action_dtype = np.int64 if self.o.discrete else np.float32
         self.closed = False

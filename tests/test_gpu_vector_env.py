@@ -56,9 +56,12 @@ def test_call_answers_the_read_only_names_of_the_reference_and_refuses_methods()
     env = _make("CartPole-v1", 3)
     obs, _ = env.reset(seed=5)
     st = env.call("state")
-    assert isinstance(st, tuple) and len(st) == 3 and all(isinstance(s, tuple) and len(s) == 4 for s in st)      # cartpole.py:160: a tuple
+    assert isinstance(st, tuple) and len(st) == 3 and all(isinstance(s, np.ndarray) and s.dtype == np.float64 for s in st)   # cartpole.py:202
     assert np.array_equal(np.asarray(st, dtype=np.float32), obs)
-    env.step(env.action_space.sample())
+    obs1 = env.step(env.action_space.sample())[0]
+    st1 = env.call("state")                                       # after a step: a tuple of floats (cartpole.py:160)
+    assert all(isinstance(s, tuple) and len(s) == 4 and isinstance(s[0], float) for s in st1)
+    assert np.array_equal(np.asarray(st1, dtype=np.float32), obs1)
     assert env.call("_elapsed_steps") == (1, 1, 1) and env.call("_max_episode_steps") == (500,) * 3
     assert env.call("render_mode") == (None,) * 3 and env.call("spec")[0].id == "CartPole-v1"
     assert env.call("action_space")[0] == env.single_action_space and env.get_attr("observation_space")[2] == env.single_observation_space
@@ -68,8 +71,11 @@ def test_call_answers_the_read_only_names_of_the_reference_and_refuses_methods()
     env.close()
     mcc = _make("MountainCarContinuous-v0", 2)
     o, _ = mcc.reset(seed=1)
+    s2 = mcc.call("state")                                        # float64 right after reset (:182), float32 after a step (:171)
+    assert all(isinstance(s, np.ndarray) and s.dtype == np.float64 and s.shape == (2,) for s in s2) and np.array_equal(np.stack(s2).astype(np.float32), o)
+    o = mcc.step(mcc.action_space.sample())[0]
     s2 = mcc.call("state")
-    assert all(isinstance(s, np.ndarray) and s.dtype == np.float32 and s.shape == (2,) for s in s2) and np.array_equal(np.stack(s2), o)
+    assert all(s.dtype == np.float32 for s in s2) and np.array_equal(np.stack(s2), o)
     mcc.close()
 
 

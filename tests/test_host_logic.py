@@ -597,3 +597,44 @@ def test_vector_utils_without_the_reference():
     assert isinstance(b, Box) and b.shape == (5, 2) and b.dtype == np.int64 and np.array_equal(b.high[0], [2, 3]) and np.all(b.low == 0)
     import gym_amd
     assert gym_amd.vector.utils is mu and gym_amd.vector.make is gym_amd.make
+
+
+@pytest.mark.parametrize("gid", ["CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0"])
+def test_call_state_has_the_references_container_types(gid, monkeypatch):
+    """VectorEnv.call("state") against the LIVE reference (skipped where /root/reference is absent): after reset() and after a step the
+    reference's sub-envs hold their state in different containers (ndarray of the generator's dtype vs tuple / float32 array); the
+    adapter reproduces container, dtype and shape — and `_elapsed_steps`, `_max_episode_steps`, `render_mode` — value for value."""
+    import os
+    if not os.path.isdir("/root/reference/gym"):
+        pytest.skip("the reference tree is not here (GPU box)")
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("make_golden_live2", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mg)
+    from oracle_engine import FakeHandle
+
+    import gym_amd
+    from gym_amd import _native
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    ref = mg.gym.vector.make(gid, num_envs=3, asynchronous=False)
+    env = gym_amd.make(gid, num_envs=3)
+    ref.reset(seed=1), env.reset(seed=1)
+
+    def same_kind(a, b):
+        assert type(a) is type(b) or (isinstance(a, np.ndarray) and isinstance(b, np.ndarray)), (type(a), type(b))
+        if isinstance(a, np.ndarray):
+            assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype)
+        else:
+            assert len(a) == len(b) and all(isinstance(x, float) for x in a)
+
+    for phase in ("after reset", "after a step"):
+        ra, ea = ref.call("state"), env.call("state")
+        assert isinstance(ea, tuple) and len(ea) == 3
+        for a, b in zip(ea, ra):
+            same_kind(a, b)
+        assert env.call("_elapsed_steps") == ref.call("_elapsed_steps") and env.call("_max_episode_steps") == ref.call("_max_episode_steps")
+        assert env.call("render_mode") == ref.call("render_mode")
+        act = ref.action_space.sample()
+        ref.step(act), env.step(act)
+    ref.close(), env.close()
