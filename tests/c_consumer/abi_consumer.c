@@ -136,6 +136,10 @@ int main(int argc, char **argv) {
         OFF(mxv_placed_info, solo_class); OFF(mxv_placed_info, stop_reason); OFF(mxv_placed_info, same_class_us);
         OFF(mxv_placed_info, different_class_us); OFF(mxv_placed_info, seconds); OFF(mxv_placed_info, requested_bytes);
         OFF(mxv_placed_info, held_bytes); OFF(mxv_placed_info, peak_bytes); OFF(mxv_placed_info, jumped_bytes);
+        printf("\nlayout mxv_launch_info %zu", sizeof(mxv_launch_info));
+        OFF(mxv_launch_info, kernel); OFF(mxv_launch_info, env_id); OFF(mxv_launch_info, param_mode); OFF(mxv_launch_info, envs_per_lane);
+        OFF(mxv_launch_info, safe); OFF(mxv_launch_info, out_mode); OFF(mxv_launch_info, tape); OFF(mxv_launch_info, steps);
+        OFF(mxv_launch_info, grid); OFF(mxv_launch_info, block);
         printf("\nlayout mxv_step_outputs %zu\n", sizeof(mxv_step_outputs));
         printf("symbols ok\n");
         return 0;

@@ -52,7 +52,7 @@ def test_c_consumer_links_the_symbols_it_uses_and_agrees_on_the_config_layout(co
     # every struct that crosses the boundary: size and the offset of every field, as the C compiler lays the header's struct out, against
     # the ctypes mirror the Python host uses
     mirrors = {"mxv_config": _native.MxvConfig, "mxv_tab_config": _native.MxvTabConfig, "mxv_bj_config": _native.MxvBjConfig,
-               "mxv_placed_info": _native.MxvPlacedInfo, "mxv_step_outputs": _native.StepOutputs}
+               "mxv_placed_info": _native.MxvPlacedInfo, "mxv_step_outputs": _native.StepOutputs, "mxv_launch_info": _native.MxvLaunchInfo}
     seen = set()
     for line in p.stdout.splitlines():
         if not line.startswith("layout "):
