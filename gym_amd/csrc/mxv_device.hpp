@@ -726,8 +726,9 @@ struct Env<MXV_ACROBOT> {
         obs[4] = (float)s[2]; obs[5] = (float)s[3];
         if (aux) { aux[0] = s0; aux[1] = c0; aux[2] = s1; aux[3] = c1; }
     }
-    // the cold exact path (mxv_exact.hpp) with this launch's parameter values; never inlined: one copy per parameter mode serves every
-    // kernel instantiation, and its registers are not the K-step loop's
+    // the cold exact path (mxv_exact.hpp) with this launch's parameter values.  The step's arithmetic is inlined into the caller's cold
+    // block; cr_sincos, which it calls 21 times, is the one real function call (40 VGPRs, inside the caller-saved range, so the kernel's
+    // register budget stays its own: a fully non-inlined chain pushed the kernel to 198-248 VGPRs through the callee-saved ranges)
     template <int DEF>
     __device__ __forceinline__ static bool acrobot_exact(const Par<DEF> &P, double *s, double torque, double *sc) {
         const double Pv[12] = {P.get(0, 0.2), P.get(1, 1.0), P.get(2, 1.0), P.get(3, 1.0),  P.get(4, 1.0),  P.get(5, 0.5),

@@ -97,6 +97,33 @@ def test_acrobot_exact_band_inside_a_fused_rollout():
     r.close()
 
 
+@pytest.mark.parametrize("mode", ["broadcast", "per_env"])
+def test_acrobot_exact_band_with_runtime_parameters(mode):
+    """The exact path takes the launch's parameter values (Env<ACROBOT>::acrobot_exact builds its vector from Par<DEF>): the threshold
+    states through the runtime-parameter kernels — one common value set, and a per-env table — with LINK_LENGTH_2 changed, an attribute
+    the dynamics never read (acrobot.py:237-277 uses l1 only): the masks must be those of the default-attribute run."""
+    from helpers import load_golden
+
+    g = load_golden("Acrobot", "p1_threshold")
+    cr = load_golden("Acrobot", "p1_threshold_cr")
+    n = len(g["action"])
+    eng = HipEngine("Acrobot", n, 0, autoreset=False)
+    p = eng.h.get_params()
+    if mode == "broadcast":
+        p[2] = 1.5
+        eng.h.set_params(p)
+    else:
+        table = np.repeat(p[:, None], n, axis=1)
+        table[2] = np.linspace(0.5, 2.0, n)
+        eng.h.set_params_per_env(table)
+    eng.set_state(g["state0"].T, np.full(n, 5, np.int32))
+    obs, rew, term, trunc, fin = eng.step(g["action"])
+    assert eng.h.last_launch()["param_mode"] == (0 if mode == "broadcast" else 2)
+    assert np.array_equal(term, cr["terminated"].astype(bool))
+    band = np.abs(g["margin"]) < 2.0 ** -41
+    assert np.array_equal(obs[band], cr["obs"][band])
+
+
 @pytest.mark.parametrize("name", ENV_NAMES)
 def test_non_finite_inputs_pass_through_like_the_reference(name):
     """A NaN Box action (a diverged policy) or state component comes out of the reference as NaN observations / rewards — np.clip and
