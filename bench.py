@@ -12,8 +12,9 @@ gym/vector/sync_vector_env.py:135-169) of every env of the job; EVERY step write
 terminated/truncated flags and the sampled actions to its own slice of [chunk][N] trajectory tensors in HBM (nothing is skipped
 or overwritten in cache).  --mode fused (default) runs a chunk of --chunk steps as ONE kernel launch with the env state in
 registers; --mode graph / eager launch the same kernel once per step.  At N > 1 every rank steps its shard of the logical envs
-with no data-path collective; the final obs/reward/terminated/truncated tensors of each --chunk steps are all-gathered over
-RCCL asynchronously (north_star: all-gather only for the final tensors; the reference's np.stack, gym/vector/utils/numpy_utils.py:49-50).
+with no data-path collective; the final obs/reward/terminated/truncated tensors of every --gather-every steps (the rollout horizon: 1024,
+four launches) are all-gathered over RCCL asynchronously, overlapping the next launches (north_star: all-gather only for the final tensors;
+the reference's np.stack, gym/vector/utils/numpy_utils.py:49-50).
 
 Timing.  The timed region is --steps vector steps, bracketed by barrier + synchronize.  When that is shorter than
 --min-timed-ms (a 20-step region is 0.12 ms: below the resolution of a host fence and of the clock ramp) the region is
@@ -594,6 +595,11 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1.  nccl (= RCCL) is the product path; gloo exists to exercise the "
                          "multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices)")
+    ap.add_argument("--gather-every", type=int, default=1024,
+                    help="steps between all-gathers of the final tensors at N > 1 = the rollout horizon whose final obs / reward / done the "
+                         "learner receives (a multiple of --chunk: the horizon advances in chunk-step launches).  xGMI is per-link bound: "
+                         "an 8-rank all-gather of the 3.4-MB final tensors costs about as much as 256 steps of a 2^17-env shard (0.18 ms), so "
+                         "the horizon, not the launch, sets the cadence — fewer, larger collectives")
     ap.add_argument("--force-gather", action="store_true",
                     help="issue the per-chunk all-gather at N = 1 too (with --comm mxv: a real one-rank RCCL communicator and "
                          "ncclAllGather per output tensor on the side stream) — the gather's launch path measured on one GPU")
@@ -739,7 +745,7 @@ def main():
             done += k
             issued[0] += k
             since_gather[0] += k
-            if gathering and gather and since_gather[0] >= args.chunk:
+            if gathering and gather and since_gather[0] >= args.gather_every:
                 sr.gather_async()
                 since_gather[0] = 0
                 gathers[0] += 1
@@ -878,10 +884,11 @@ def main():
                 "placement": placement,
                 "spinup": f"{warm_s:.2f} s of the workload until its rate settled ({warm_calls} launches; before reset(seed=0)), then {spin} "
                           f"untimed steps (nominally {args.spinup_ms:.0f} ms) before the {args.warmup} warmup steps",
-                "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.chunk} steps "
+                "parallelism": f"env-shard x{world}" + (f", async RCCL all-gather of the final tensors every {args.gather_every} steps "
                                                         f"({args.comm} transport)" if world > 1 else ""),
                 "ranks_seen": comm_info.get("ranks_seen", 1),
                 "gathers_in_timed_region": gathers[0],
+                "gather_every": args.gather_every if gathering else None,
                 "gather_transport": (args.comm if gathering else None),
                 "comm": comm_info,
                 "per_rank": per_rank,

@@ -39,6 +39,8 @@ def test_bench_two_ranks_strong_scaling_is_the_default():
     cfg = out["config"]
     assert cfg["num_envs_per_gpu"] == 1 << 19 and "num_envs=1048576 (524288 per GPU)" in cfg["workload"]
     assert cfg["timed_steps"] == cfg["repeats"] * 512
+    # the final tensors are gathered once per rollout horizon (1024 steps = four launches), not once per launch
+    assert cfg["gather_every"] == 1024 and cfg["gathers_in_timed_region"] == cfg["timed_steps"] // 1024 >= 4
     assert out["value"] == pytest.approx((1 << 20) / (out["ms_per_step"] * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in out and out["roofline"]["bound"] == "hbm"
     assert out["roofline"]["env_steps_per_launch"] == pytest.approx((1 << 19) * out["roofline"]["steps_per_launch"])

@@ -36,7 +36,7 @@ def _one_line(p):
 
 
 def test_bench_with_eight_self_launched_ranks():
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--steps", "256", "--warmup", "256", "--repeats", "2", "--placement",
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--steps", "256", "--warmup", "256", "--repeats", "2", "--gather-every", "256", "--placement",
                         "off", "--warm-max-s", "0.3", "--spinup-ms", "10"], cwd=ROOT, capture_output=True, text=True,
                        timeout=600, env=_env())
     out = _one_line(p)
@@ -75,7 +75,7 @@ def test_configs_3_and_4_with_eight_ranks():
 def test_the_gather_inside_the_timed_region_at_world_size_1(comm):
     """--comm mxv: libmxv.so opens RCCL itself, builds a one-rank communicator and issues the grouped ncclAllGather calls of every chunk
     on its side stream, overlapping the next launch — the code an 8-GPU run executes, minus the links."""
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--comm", comm, "--force-gather", "--steps", "1024", "--warmup", "256",
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--comm", comm, "--force-gather", "--gather-every", "256", "--steps", "1024", "--warmup", "256",
                         "--no-cpu-baseline", "--no-variants", "--placement", "off", "--warm-max-s", "0.4"], cwd=ROOT, capture_output=True,
                        text=True, timeout=300, env=_env())
     out = _one_line(p)
