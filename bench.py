@@ -398,6 +398,31 @@ def measure_blackjack(torch, envs, chunk, reps=6):
     return res
 
 
+def measure_numpy_loop(envs, steps):
+    """SURVEY.md §8(d), the third number: the gym-compatible loop — gym_amd.make(id, num_envs) stepped with NumPy actions, NumPy
+    observations / rewards / flags / infos coming back (gym/vector/sync_vector_env.py:135-169 as a caller sees it) — PCIe and Python
+    inclusive.  This is what a user who swaps gym.vector.SyncVectorEnv for the engine and changes nothing else gets; it is never `value`."""
+    import gym_amd
+
+    env = gym_amd.make(ENV_ID, num_envs=envs)
+    env.reset(seed=0)
+    env.action_space.seed(0)
+    acts = [env.action_space.sample() for _ in range(4)]
+    for i in range(6):
+        env.step(acts[i % 4])
+    t0 = time.perf_counter()
+    ended = 0
+    for i in range(steps):
+        _, _, term, trunc, _ = env.step(acts[i % 4])
+        ended += int(term.sum()) + int(trunc.sum())
+    us = (time.perf_counter() - t0) / steps * 1e6
+    env.close()
+    return {"workload": f"{ENV_ID}, num_envs={envs}, gym_amd.make(...).step(actions) with NumPy arrays in and out (copy=True, infos with "
+                        "final_observation), host loop", "us_per_step": us, "value": envs / us * 1e6, "unit": "env-steps/s",
+            "bytes_over_pcie_per_env_step": 8 + 16 + 8 + 2, "pcie_GBs": envs * 34 / us / 1e3, "episodes_ended": ended,
+            "note": "PCIe- and Python-inclusive; never the bench value"}
+
+
 def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
     """The learner-in-the-loop path: DeviceRollout.step(actions) with caller-provided actions, one launch per vector step
     (gym/vector/sync_vector_env.py:131-169 with a policy in the loop).  halves = 2: the batch as two half-size engines (global env
@@ -962,6 +987,8 @@ def main():
                 "one_engine_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True),
                 "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
                 "kernel": measure_step_kernel(torch, ENVS_TOTAL)})
+            variant("numpy_loop", lambda: {"num_envs_2^20": measure_numpy_loop(ENVS_TOTAL, 60),
+                                           "configs0_num_envs_8": measure_numpy_loop(8, 1000)})    # BASELINE.json configs[0]: the plumbing case
             out["variants"] = v
         print(json.dumps(out), file=json_out, flush=True)
 

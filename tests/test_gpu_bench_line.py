@@ -85,6 +85,8 @@ def test_line_carries_what_the_review_asked_for(line):
         assert v[key]["value"] > 2e10 and 0.05 < v[key]["roofline"]["frac"] < 1.0, key
     for key in ("normalize_obs", "normalize_reward"):                     # §8(f)-2
         assert v["normalize"][key]["roofline"]["frac"] > 0.15, key
+    nl = v["numpy_loop"]                                                  # SURVEY §8(d)'s third number: PCIe- and Python-inclusive
+    assert nl["num_envs_2^20"]["value"] > 2e8 and nl["configs0_num_envs_8"]["value"] > 5e4 and nl["num_envs_2^20"]["episodes_ended"] > 0
     assert v["configs4_mixed_share"]["value"] > 1e10
     share = v["strong_scaling_share_of_8"]                    # 2^17 envs: what each GPU of an 8-GPU strong-scaling job steps
     assert share["placement"]["balanced"] is True and share["us_per_step"] * 8 < 1.35 * line["ms_per_step"] * 1e3
