@@ -122,3 +122,34 @@ def test_bounded_soak_fused_tape_per_step_and_oracle(name):
     r.close()
     assert ndone > n            # every env finished at least one episode (TimeLimit 120 at most)
     print(f"{name}: {compared:.2e} env-steps fused == per-step == tape, {n * K * launches:.2e} fused vs oracle, {ndone} episodes ended")
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("name,n,epl", [("CartPole", 1 << 20, 2), ("Pendulum", 1 << 19, 1), ("Acrobot", 1 << 19, 1), ("MountainCar", 1 << 19, 2),
+                                        ("MountainCarContinuous", 1 << 19, 2), ("CartPole", 1 << 17, 1)])
+def test_every_benchmarked_instantiation_equals_per_step_launches(name, n, epl, compact):
+    """The kernels behind bench.py's variants — every env kind at its BASELINE.json size, both dtype sets (OUT = 1: the reference's
+    float64 rewards / int64 actions, OUT = 2: float32 / int32), plus the 2^17-env share of an 8-GPU job — are the instantiations they
+    are supposed to be (mxv_last_launch) and equal one launch per step (step_kernel, itself held against the oracle at these sizes by
+    tests/test_gpu_parity.py) bit for bit on every output of every step."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    K = 48
+    kw = dict(seed=21, action_seed=22, reward_f32=compact, action_i32=compact, max_episode_steps=min(LIMITS[name], 40))
+    a, b = DeviceRollout(GYM_IDS[name], n, **kw), DeviceRollout(GYM_IDS[name], n, **kw)
+    a.reset(seed=21), b.reset(seed=21)
+    ta, tb = a.trajectory_buffers(K, layout="separate"), b.trajectory_buffers(K, layout="separate")
+    for rep in range(2):
+        fa = a.rollout_per_step(K, mode="fused", out=ta)
+        fb = b.rollout_per_step(K, mode="eager", out=tb)
+        a.synchronize(), b.synchronize()
+        li = a.handle.last_launch()
+        assert (li["kernel"], li["envs_per_lane"], li["safe"], li["out_mode"], li["tape"], li["steps"]) == (1, epl, 0, 2 if compact else 1, 0, K), li
+        assert b.handle.last_launch()["kernel"] == 0
+        for key in ("obs", "reward", "terminated", "truncated", "actions"):
+            assert fa[key].dtype == fb[key].dtype and torch.equal(fa[key], fb[key]), (name, n, compact, rep, key)
+        assert int((fa["terminated"] | fa["truncated"]).sum()) > 0
+    for x, y in zip(a.handle.get_state(), b.handle.get_state()):
+        assert np.array_equal(x, y)
+    a.close(), b.close()
