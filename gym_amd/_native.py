@@ -31,6 +31,7 @@ ERR_UNSUPPORTED = -5
 MAX_PARAMS = 12
 ENV_ALIGN = 4
 ROLLOUT_EAGER, ROLLOUT_GRAPH, ROLLOUT_FUSED = 0, 1, 2
+TAB_FLAG_COMPACT = 1
 COMM_ID_BYTES = 128
 
 EXPORTS = (
@@ -1033,8 +1034,11 @@ class Tab:
     """One mxv_tab handle = one device + one stream + N device-resident copies of a tabular MDP (see include/mxv.h)."""
 
     def __init__(self, num_states, num_actions, cum_prob, prob, next_state, reward, terminated, initial_cum, num_envs,
-                 max_episode_steps, *, device=0, env_offset=0, seed=0, action_seed=0):
+                 max_episode_steps, *, device=0, env_offset=0, seed=0, action_seed=0, compact=False):
+        """compact=True (MXV_TAB_FLAG_COMPACT): rollout() / rollout_tape() take and produce int32 observations / actions and float32
+        rewards / probs; everything else keeps the reference's int64 / float64."""
         S, A = int(num_states), int(num_actions)
+        self.compact = bool(compact)
         cum = np.ascontiguousarray(cum_prob, dtype=np.float64)
         assert cum.ndim == 3 and cum.shape[:2] == (S, A), cum.shape
         M = cum.shape[2]
@@ -1044,7 +1048,7 @@ class Tab:
         te = np.ascontiguousarray(terminated, dtype=np.uint8).reshape(S, A, M)
         ic = np.ascontiguousarray(initial_cum, dtype=np.float64).reshape(S)
         self.S, self.A, self.M, self.num_envs, self.device = S, A, M, int(num_envs), int(device)
-        cfg = MxvTabConfig(self.device, S, A, M, self.num_envs, int(env_offset), int(max_episode_steps), 0,
+        cfg = MxvTabConfig(self.device, S, A, M, self.num_envs, int(env_offset), int(max_episode_steps), TAB_FLAG_COMPACT if compact else 0,
                            int(seed) & (2**64 - 1), int(action_seed) & (2**64 - 1))
         h = C.c_void_p()
         rc = lib.mxv_tab_create(C.byref(cfg), cum.ctypes.data, pr.ctypes.data, nx.ctypes.data, rw.ctypes.data,

@@ -25,6 +25,7 @@
 // word x.  uniform = (word + 0.5) * 2^-32.  A caller may instead inject the uniforms (mxv_tab_step, `uniforms_dev`):
 // that is how the parity tests replay the reference's own PCG64 draws bit for bit.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdarg>
 #include <cstdio>
@@ -56,15 +57,16 @@ struct TabArgs {
     int32_t S, A, M, log2S;
     int32_t single_start;    // >= 0: the initial distribution is a point mass on this state (FrozenLake, CliffWalking): no search
     // step I/O
-    const int64_t *actions;  // [N] (or [K][N] tape) or nullptr -> Philox action stream
-    int64_t *actions_out;    // optional
+    // integer tensors are int64 and real ones float64 — int32 / float32 in a COMPACT launch (MXV_TAB_FLAG_COMPACT, trajectory calls)
+    const void *actions;     // [N] (or [K][N] tape) or nullptr -> Philox action stream
+    void *actions_out;       // optional
     const double *uniforms;  // optional [2][N]: (transition uniform, autoreset uniform) per env; nullptr -> Philox
-    int64_t *obs;            // [N] / [K][N]
-    double *reward_out;      // may be nullptr
+    void *obs;               // [N] / [K][N]
+    void *reward_out;        // may be nullptr
     uint8_t *terminated, *truncated;  // may be nullptr
-    double *prob_out;        // may be nullptr: info["prob"] (1.0 for envs that were reset in this step)
-    int64_t *final_obs;      // may be nullptr: terminal state of finished envs (untouched elsewhere)
-    double *final_prob;      // may be nullptr: info["final_info"]["prob"] of finished envs
+    void *prob_out;          // may be nullptr: info["prob"] (1.0 for envs that were reset in this step)
+    void *final_obs;         // may be nullptr: terminal state of finished envs (untouched elsewhere)
+    void *final_prob;        // may be nullptr: info["final_info"]["prob"] of finished envs
     int32_t *err;
     int64_t n;
     uint64_t env0, base_seed, action_seed, t;
@@ -101,8 +103,10 @@ __device__ __forceinline__ int32_t sample_initial(const double *init_cum, int32_
     return lo < S ? lo : 0;
 }
 
-template <bool LDS_TABLE>
+template <bool LDS_TABLE, bool COMPACT>
 __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
+    using IT = std::conditional_t<COMPACT, int32_t, int64_t>;   // element type of the integer step tensors
+    using RT = std::conditional_t<COMPACT, float, double>;      // ... of the real ones
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
     const int entries = a.S * a.A * a.M;
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
         int64_t act;
         if (a.actions) {
             if (!valid) continue;
-            act = a.actions[(int64_t)k * a.act_slice + e];
+            act = (int64_t) static_cast<const IT *>(a.actions)[(int64_t)k * a.act_slice + e];
             if (act < 0 || act >= a.A) {  // `assert self.action_space.contains(a)`-class error: latch, leave the env unstepped
                 *reinterpret_cast<volatile int32_t *>(a.err) = 1;  // single-bit code: a plain store (the word may live in pinned host memory)
                 continue;
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
             const uint32_t word = j == 0 ? act_word[0] : (j == 1 ? act_word[1] : (j == 2 ? act_word[2] : act_word[3]));
             act = (int64_t)(((uint64_t)word * (uint64_t)a.A) >> 32);
             if (!valid) continue;
-            if (a.actions_out) a.actions_out[o] = act;
+            if (a.actions_out) static_cast<IT *>(a.actions_out)[o] = (IT)act;
         }
         // ---- the step's uniforms ----
         double u_step, u_reset;
@@ -209,17 +213,17 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
         const bool trunc = a.max_steps > 0 && el >= a.max_steps;
         s = ns;
         if (term || trunc) {  // sync_vector_env.py:152-156: the returned observation/info are the reset's
-            if (a.final_obs) a.final_obs[o] = (int64_t)ns;
-            if (a.final_prob) a.final_prob[o] = p;
+            if (a.final_obs) static_cast<IT *>(a.final_obs)[o] = (IT)ns;
+            if (a.final_prob) static_cast<RT *>(a.final_prob)[o] = (RT)p;
             s = a.single_start >= 0 ? a.single_start : sample_initial(init_cum, a.S, a.log2S, u_reset);
             el = 0;
             p = 1.0;                                               // reset() returns {"prob": 1}
         }
-        a.obs[o] = (int64_t)s;
-        if (a.reward_out) a.reward_out[o] = rew;
+        static_cast<IT *>(a.obs)[o] = (IT)s;
+        if (a.reward_out) static_cast<RT *>(a.reward_out)[o] = (RT)rew;
         if (a.terminated) a.terminated[o] = term ? 1 : 0;
         if (a.truncated) a.truncated[o] = trunc ? 1 : 0;
-        if (a.prob_out) a.prob_out[o] = p;
+        if (a.prob_out) static_cast<RT *>(a.prob_out)[o] = (RT)p;
     }
     if (valid) {
         a.state[e] = s;
@@ -320,9 +324,9 @@ int tab_check_latched(mxv_tab *h) {
     return MXV_OK;
 }
 
-int tab_launch(mxv_tab *h, int K, int64_t slice, const int64_t *actions, int64_t act_slice, int64_t *actions_out,
-               const double *uniforms, int64_t *obs, double *reward, uint8_t *term, uint8_t *trunc, double *prob,
-               int64_t *final_obs, double *final_prob) {
+int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t act_slice, void *actions_out,
+               const double *uniforms, void *obs, void *reward, uint8_t *term, uint8_t *trunc, void *prob,
+               void *final_obs, void *final_prob, bool compact = false) {
     if (!h->was_reset)
         return tfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
     if (!obs) return tfail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
@@ -340,10 +344,17 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const int64_t *actions, int64_t
     a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->t;
     a.max_steps = h->cfg.max_episode_steps; a.K = K; a.slice = slice; a.act_slice = act_slice;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
-    if (h->lds_table)
-        hipLaunchKernelGGL(tab_step_kernel<true>, dim3(blocks), dim3(kTabBlock), h->lds_bytes, h->stream, a);
-    else
-        hipLaunchKernelGGL(tab_step_kernel<false>, dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
+    if (h->lds_table) {
+        if (compact)
+            hipLaunchKernelGGL((tab_step_kernel<true, true>), dim3(blocks), dim3(kTabBlock), h->lds_bytes, h->stream, a);
+        else
+            hipLaunchKernelGGL((tab_step_kernel<true, false>), dim3(blocks), dim3(kTabBlock), h->lds_bytes, h->stream, a);
+    } else {
+        if (compact)
+            hipLaunchKernelGGL((tab_step_kernel<false, true>), dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((tab_step_kernel<false, false>), dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
+    }
     TAB_HIP(h, hipGetLastError());
     h->t += (uint64_t)K;
     return MXV_OK;
@@ -542,21 +553,22 @@ int mxv_tab_step(mxv_tab *h, const int64_t *actions_dev, const double *uniforms_
                       prob_dev, final_obs_dev, final_prob_dev);
 }
 
-int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, int64_t *actions_out_dev, int64_t *obs_dev, double *reward_dev,
-                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
-                    double *final_prob_dev) {
+int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, void *actions_out_dev, void *obs_dev, void *reward_dev,
+                    uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev, void *final_obs_dev,
+                    void *final_prob_dev) {
     TAB_CHECK(h);
     return tab_launch(h, K, per_step ? h->cfg.num_envs : 0, nullptr, 0, actions_out_dev, nullptr, obs_dev, reward_dev,
-                      terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev);
+                      terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev, (h->cfg.flags & MXV_TAB_FLAG_COMPACT) != 0);
 }
 
-int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *obs_dev,
-                         double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev,
-                         int64_t *final_obs_dev, double *final_prob_dev) {
+int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const void *actions_tape_dev, void *obs_dev,
+                         void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev,
+                         void *final_obs_dev, void *final_prob_dev) {
     TAB_CHECK(h);
     if (!actions_tape_dev) return tfail(h, MXV_ERR_INVALID_ARG, "actions tape pointer is NULL");
     return tab_launch(h, K, per_step ? h->cfg.num_envs : 0, actions_tape_dev, h->cfg.num_envs, nullptr, nullptr, obs_dev,
-                      reward_dev, terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev);
+                      reward_dev, terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev,
+                      (h->cfg.flags & MXV_TAB_FLAG_COMPACT) != 0);
 }
 
 int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host) {

@@ -276,10 +276,11 @@ def _spec(id: str) -> ToyTextSpec:
         raise error.UnregisteredEnv(f"No HIP tabular engine for id {id!r}; supported: {sorted(TOY_TEXT_REGISTRY)}") from None
 
 
-def _make_handle(mdp: TabularMDP, num_envs: int, limit: Optional[int], device: int, env_offset: int, seed: int, action_seed: int):
+def _make_handle(mdp: TabularMDP, num_envs: int, limit: Optional[int], device: int, env_offset: int, seed: int, action_seed: int,
+                 compact: bool = False):
     return _native.Tab(mdp.num_states, mdp.num_actions, mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated,
                        mdp.initial_cum, num_envs, -1 if limit is None else int(limit), device=device,
-                       env_offset=env_offset, seed=seed, action_seed=action_seed)
+                       env_offset=env_offset, seed=seed, action_seed=action_seed, compact=compact)
 
 
 class HipTabularVectorEnv(VectorEnv):
@@ -460,10 +461,11 @@ class HipTabularVectorEnv(VectorEnv):
 
 class TabularRollout:
     """Device-resident front-end: K sampled steps per launch into [K, N] torch tensors (obs / actions int64, reward / prob
-    float64, terminated / truncated uint8), state resident on the device between calls."""
+    float64, terminated / truncated uint8), state resident on the device between calls.  compact=True: the trajectory tensors hold the
+    contract dtypes of SURVEY.md §8(d) — int32 obs / actions, float32 reward / prob: 18 instead of 34 bytes per env-step, same values."""
 
     def __init__(self, id: str, num_envs: int, *, device: int = 0, env_offset: int = 0, seed: int = 0, action_seed: int = 0,
-                 max_episode_steps: Optional[int] = None, **kwargs):
+                 max_episode_steps: Optional[int] = None, compact: bool = False, **kwargs):
         import torch
 
         if not torch.cuda.is_available():
@@ -474,7 +476,9 @@ class TabularRollout:
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", device)
         limit = self.spec.max_episode_steps if max_episode_steps is None else max_episode_steps
-        self.handle = _make_handle(self.mdp, num_envs, limit, device, env_offset, seed, action_seed)
+        self.compact = bool(compact)
+        self.int_dtype, self.real_dtype = (torch.int32, torch.float32) if compact else (torch.int64, torch.float64)
+        self.handle = _make_handle(self.mdp, num_envs, limit, device, env_offset, seed, action_seed, compact=compact)
         self.stream = torch.cuda.Stream(device=self.device)
         self.handle.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
@@ -493,12 +497,14 @@ class TabularRollout:
         over two classes (profiles/r3g_tab_class_ab.jsonl) — obs + reward on one, actions + prob on another.  layout="separate":
         ordinary allocations.  The report is left in self.last_placement."""
         t, n, dev = self._torch, self.num_envs, self.device
-        specs = [("obs", (K, n), t.int64, False), ("reward", (K, n), t.float64, False), ("actions", (K, n), t.int64, False),
-                 ("prob", (K, n), t.float64, False), ("terminated", (K, n), t.uint8, False), ("truncated", (K, n), t.uint8, False)]
+        it, rt = self.int_dtype, self.real_dtype
+        specs = [("obs", (K, n), it, False), ("reward", (K, n), rt, False), ("actions", (K, n), it, False),
+                 ("prob", (K, n), rt, False), ("terminated", (K, n), t.uint8, False), ("truncated", (K, n), t.uint8, False)]
         if layout == "auto":
             from . import placement
 
-            layout = "sorted" if 34 * K * n >= (2 << 30) and placement.enabled() else "separate"     # MXV_PLACEMENT=off: never sort
+            stored = 18 if self.compact else 34
+            layout = "sorted" if stored * K * n >= (2 << 30) and placement.enabled() else "separate"     # MXV_PLACEMENT=off: never sort
         if layout == "sorted":
             from .placement import sorted_tensors
 
@@ -561,7 +567,7 @@ class TabularRollout:
 
     def rollout_tape(self, actions, out: Optional[dict] = None):
         K = actions.shape[0]
-        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self._torch.int64
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self.int_dtype
         out = self.trajectory_buffers(K) if out is None else out
         self.stream.wait_stream(self._torch.cuda.current_stream(self.device))   # the tape was produced on the caller's stream
         self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"],

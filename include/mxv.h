@@ -384,10 +384,14 @@ typedef struct mxv_tab_config {
     int64_t num_envs;
     int64_t env_offset;        /* global index of local env 0 (multiple of MXV_ENV_ALIGN) */
     int32_t max_episode_steps; /* TimeLimit; <= 0 disables (CliffWalking-v0 has none) */
-    int32_t flags;             /* reserved, 0 */
+    int32_t flags;             /* MXV_TAB_FLAG_* */
     uint64_t seed;
     uint64_t action_seed;
 } mxv_tab_config;
+/* MXV_TAB_FLAG_COMPACT: the trajectory calls (mxv_tab_rollout, mxv_tab_rollout_tape) take and produce the contract dtypes of SURVEY.md
+ * §8(d) — int32 observations / actions (tape included), float32 rewards / probs: 18 B per env-step instead of 34 — on the device tensors;
+ * every other call (mxv_tab_step, reset, the host calls) keeps the reference's int64 / float64.  Same values, narrower stores. */
+enum { MXV_TAB_FLAG_COMPACT = 1 };
 int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const double *prob_host,
                    const int32_t *next_state_host, const double *reward_host, const uint8_t *terminated_host,
                    const double *initial_cum_host, mxv_tab **out);
@@ -405,13 +409,14 @@ int mxv_tab_step(mxv_tab *h, const int64_t *actions_dev, const double *uniforms_
                  uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
                  double *final_prob_dev);
 /* K steps in ONE launch (state + TimeLimit counter in registers), actions sampled on device (Discrete(A).sample()) or read
- * from a tape int64 [K][N]; per_step != 0: outputs are [K][N] trajectories, else overwritten K times. */
-int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, int64_t *actions_out_dev, int64_t *obs_dev, double *reward_dev,
-                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
-                    double *final_prob_dev);
-int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *obs_dev,
-                         double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev,
-                         int64_t *final_obs_dev, double *final_prob_dev);
+ * from a tape int64 [K][N]; per_step != 0: outputs are [K][N] trajectories, else overwritten K times.  Integer tensors are int64 and
+ * real ones float64 — int32 / float32 with MXV_TAB_FLAG_COMPACT. */
+int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, void *actions_out_dev, void *obs_dev, void *reward_dev,
+                    uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev, void *final_obs_dev,
+                    void *final_prob_dev);
+int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const void *actions_tape_dev, void *obs_dev,
+                         void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev,
+                         void *final_obs_dev, void *final_prob_dev);
 /* host-buffer convenience (staged copies, synchronising) */
 int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host);
 int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uniforms_host, int64_t *obs_host,
