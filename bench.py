@@ -349,21 +349,22 @@ def measure_normalize(torch, envs, chunk, reps=6):
     return out
 
 
-def measure_tabular(torch, gid, envs, chunk, reps=6, compact=False):
+def measure_tabular(torch, gid, envs, chunk, reps=6, compact=False, general_kernel=False):
     """a toy_text env as a table-driven kernel (gym/envs/toy_text/frozen_lake.py:247-270, taxi.py:270-278): fused K-step
     rollouts with sampled actions, every step's obs / actions (int64), reward / prob (float64) and both flags written to [K][N]
     trajectory tensors.  Contract bytes as SURVEY.md §8(d) prices them (4-byte scalars, 1-byte flags): obs 4 + action 4 + reward 4 +
     prob 4 + 2 = 18; stored with the reference's dtypes: 34."""
     from gym_amd.toy_text import TabularRollout
 
-    r = TabularRollout(gid, envs, seed=0, action_seed=1, compact=compact)
+    r = TabularRollout(gid, envs, seed=0, action_seed=1, compact=compact, general_kernel=general_kernel)
     r.reset(seed=0)
     out = r.trajectory_buffers(chunk)
     us = _event_us(torch, r.stream, lambda: r.rollout_per_step(chunk, out=out), reps, chunk)
     stored = 18 if compact else 34
     res = _hbm(us, envs, 18, workload=f"{gid}, num_envs={envs}, fused {chunk}-step launches, "
                                       + ("int32 obs / actions + float32 reward / prob" if compact else "the reference's dtypes") + f" ({stored} B stored per env-step)",
-               stored_GBs=envs * stored / us / 1e3, placement=getattr(r, "last_placement", None))
+               stored_GBs=envs * stored / us / 1e3, placement=getattr(r, "last_placement", None),
+               kernel={1: "tab_step_kernel (general)", 2: "tab_traj_kernel (integer thresholds, packed table)"}.get(r.handle.last_kernel()))
     r.close()
     del out
     torch.cuda.empty_cache()

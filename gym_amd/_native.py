@@ -32,6 +32,8 @@ MAX_PARAMS = 12
 ENV_ALIGN = 4
 ROLLOUT_EAGER, ROLLOUT_GRAPH, ROLLOUT_FUSED = 0, 1, 2
 TAB_FLAG_COMPACT = 1
+TAB_FLAG_GENERAL_KERNEL = 2
+TAB_KERNEL_NONE, TAB_KERNEL_GENERAL, TAB_KERNEL_TRAJECTORY = 0, 1, 2
 COMM_ID_BYTES = 128
 
 EXPORTS = (
@@ -47,7 +49,7 @@ EXPORTS = (
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
-    "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_set_stream",
+    "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_stream",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
     "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error", "mxv_hbm_pair_probe",
@@ -259,6 +261,8 @@ def _load():
         "mxv_tab_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_tab_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_tab_sync": ([vp], C.c_int),
+        "mxv_tab_last_kernel": ([vp], C.c_int),
+        "mxv_tab_word_threshold": ([C.c_double], u64),
         "mxv_tab_set_stream": ([vp, vp], C.c_int),
         "mxv_bj_create": ([C.POINTER(MxvBjConfig), C.POINTER(vp)], C.c_int),
         "mxv_bj_destroy": ([vp], C.c_int),
@@ -1034,9 +1038,10 @@ class Tab:
     """One mxv_tab handle = one device + one stream + N device-resident copies of a tabular MDP (see include/mxv.h)."""
 
     def __init__(self, num_states, num_actions, cum_prob, prob, next_state, reward, terminated, initial_cum, num_envs,
-                 max_episode_steps, *, device=0, env_offset=0, seed=0, action_seed=0, compact=False):
+                 max_episode_steps, *, device=0, env_offset=0, seed=0, action_seed=0, compact=False, general_kernel=False):
         """compact=True (MXV_TAB_FLAG_COMPACT): rollout() / rollout_tape() take and produce int32 observations / actions and float32
-        rewards / probs; everything else keeps the reference's int64 / float64."""
+        rewards / probs; everything else keeps the reference's int64 / float64.  general_kernel=True (MXV_TAB_FLAG_GENERAL_KERNEL):
+        trajectory rollouts stay on the general kernel even where the specialised one applies (the tests' A/B switch)."""
         S, A = int(num_states), int(num_actions)
         self.compact = bool(compact)
         cum = np.ascontiguousarray(cum_prob, dtype=np.float64)
@@ -1048,7 +1053,8 @@ class Tab:
         te = np.ascontiguousarray(terminated, dtype=np.uint8).reshape(S, A, M)
         ic = np.ascontiguousarray(initial_cum, dtype=np.float64).reshape(S)
         self.S, self.A, self.M, self.num_envs, self.device = S, A, M, int(num_envs), int(device)
-        cfg = MxvTabConfig(self.device, S, A, M, self.num_envs, int(env_offset), int(max_episode_steps), TAB_FLAG_COMPACT if compact else 0,
+        cfg = MxvTabConfig(self.device, S, A, M, self.num_envs, int(env_offset), int(max_episode_steps),
+                           (TAB_FLAG_COMPACT if compact else 0) | (TAB_FLAG_GENERAL_KERNEL if general_kernel else 0),
                            int(seed) & (2**64 - 1), int(action_seed) & (2**64 - 1))
         h = C.c_void_p()
         rc = lib.mxv_tab_create(C.byref(cfg), cum.ctypes.data, pr.ctypes.data, nx.ctypes.data, rw.ctypes.data,
@@ -1103,6 +1109,10 @@ class Tab:
         self.seed_actions(snap["action_seed"])
         self.set_state(snap["state"], snap["elapsed"])
         self.set_counters(snap["t"], snap["r"])
+
+    def last_kernel(self) -> int:
+        """TAB_KERNEL_GENERAL / TAB_KERNEL_TRAJECTORY: which kernel the last step / rollout call launched (mxv_tab_last_kernel)."""
+        return int(lib.mxv_tab_last_kernel(self._h))
 
     def reset(self, obs_dev=None, mask_dev=None):
         self._check(lib.mxv_tab_reset(self._h, _ptr(mask_dev), _ptr(obs_dev)))

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -231,6 +232,183 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
     }
 }
 
+// ---- the trajectory fast path: sampled actions, every per-step output present (what mxv_tab_rollout's [K][N] launches of the registered
+// envs are) -------------------------------------------------------------------------------------------------------------------------
+// Same streams and the same values as tab_step_kernel, bit for bit (tests/test_gpu_toytext.py holds the two against each other and
+// against the CPU restatement); what differs is the work per env-step:
+//   * categorical_sample in the integer domain.  cum > u with u = (w + 0.5) * 2^-32 (exact in fp64) <=> w < T, T = ceil(cum * 2^32 - 0.5)
+//     (cum * 2^32 - 0.5 is exact too).  The host packs T - 1 per transition; the index of the first cumulative probability that exceeds
+//     u is then the NUMBER of thresholds below w: M - 1 unsigned compares, no fp64 conversion, no loop.  Lists whose last cumulative
+//     probability does not reach 1 - 2^-33, zero-probability heads, or rewards that are not float32 values keep the general kernel
+//     (pack_fast_table decides at create time).
+//   * one LDS read per table level: {thresholds} -> {next state | terminated, reward, prob} packed in 16 (M > 1) or 8 bytes (M == 1);
+//   * M == 1 (Taxi, CliffWalking, non-slippery lakes): the transition uniform is never used, so the env's Philox call is made only in the
+//     steps where some env of the wave needs its autoreset uniform — and never for a point-mass initial distribution;
+//   * the four action words of a quad change lanes through two DPP butterfly stages (a 4 x 4 transpose) instead of three shuffles and
+//     select chains; the step loop is unrolled over the aligned block of four steps those words serve;
+//   * no pointer tests in the loop, stores with the block's scalar base + one 32-bit lane offset each.
+struct TabTrajArgs {
+    int32_t *state, *elapsed;
+    const uint64_t *seeds;
+    const uint32_t *table;   // packed by pack_fast_table
+    int32_t table_words;     // multiple of 4
+    int32_t A;
+    int32_t ent_off;         // word offset of the transition entries
+    int32_t init_off, S1, init_iters;  // initial distribution that is no point mass: thresholds [S1 + 1], search iterations
+    int32_t start;           // point mass: the start state
+    char *actions, *obs, *reward, *prob;  // [K][N]
+    uint8_t *terminated, *truncated;
+    int64_t n;
+    uint64_t env0, base_seed, action_seed, t;
+    int32_t max_steps, K;
+    uint32_t tile_base;      // ALLV == false: the (one) ragged block's tile index
+};
+
+__device__ __forceinline__ uint32_t tab_pin32(uint32_t v) {  // see pin32 in mxv_kernels.hip: keeps the store's saddr + 32-bit voffset form
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
+// b[j] at lane L of a quad = a[L] at lane j of the quad
+__device__ __forceinline__ void quad_transpose(uint32_t (&a)[4], uint32_t q) {
+    const bool odd = (q & 1u) != 0, hi = (q & 2u) != 0;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {  // lanes L and L ^ 1 trade a[p + 1] of the even lane for a[p] of the odd one
+        const uint32_t recv = quad_perm<0xB1>(odd ? a[p] : a[p + 1]);
+        a[p] = odd ? recv : a[p];
+        a[p + 1] = odd ? a[p + 1] : recv;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {     // lanes L and L ^ 2: a[p + 2] of the low pair for a[p] of the high pair
+        const uint32_t recv = quad_perm<0x4E>(hi ? a[p] : a[p + 2]);
+        a[p] = hi ? recv : a[p];
+        a[p + 2] = hi ? a[p + 2] : recv;
+    }
+}
+
+template <int M_T, bool COMPACT, bool SINGLE, bool ALLV>
+__global__ void __launch_bounds__(kTabBlock) tab_traj_kernel(TabTrajArgs a) {
+    static_assert(M_T == 1 || M_T == 3, "instantiated for the transition-list lengths of the registered envs");
+    constexpr uint32_t IB = COMPACT ? 4u : 8u;  // bytes of an integer / a real element of the trajectory tensors
+    extern __shared__ uint32_t tbl[];
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.table);
+        uint4 *dst = reinterpret_cast<uint4 *>(tbl);
+        for (int i = (int)tid; i < a.table_words / 4; i += kTabBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    const unsigned tile = ALLV ? tab_tile(blockIdx.x, gridDim.x) : a.tile_base;
+    const int64_t tile0 = (int64_t)tile * kTabBlock;
+    const int64_t e = tile0 + tid;
+    const bool valid = ALLV || e < a.n;  // lanes past the end keep stepping (their quad partners need their action words)
+    const uint64_t ge = a.env0 + (uint64_t)e;
+    uint64_t seed = a.base_seed + ge;
+    int32_t s = 0, el = 0;
+    if (valid) {
+        if (a.seeds) seed = a.seeds[e];
+        s = a.state[e];
+        el = a.elapsed[e];
+    }
+    const uint32_t q = (uint32_t)(ge & 3);
+    const int32_t max_eff = a.max_steps > 0 ? a.max_steps : 0x7fffffff;
+    char *p_act = a.actions + tile0 * IB, *p_obs = a.obs + tile0 * IB, *p_rew = a.reward + tile0 * IB, *p_prob = a.prob + tile0 * IB;
+    uint8_t *p_term = a.terminated + tile0, *p_trunc = a.truncated + tile0;
+    const int64_t slice_w = a.n * (int64_t)IB, slice_b = a.n;
+    const uint32_t off_w = tid * IB, off_b = tid;
+    const uint64_t t0 = a.t, t1 = a.t + (uint64_t)a.K;
+    mxv::settle_entry_loads();
+    for (uint64_t blk = t0 >> 2; blk <= ((t1 - 1) >> 2); ++blk) {
+        uint32_t aw[4];
+        {
+            const U4 w = action_words(a.action_seed, (blk << 2) + q, ge >> 2);  // this lane: step q of the block, the quad's 4 envs
+            aw[0] = w.x; aw[1] = w.y; aw[2] = w.z; aw[3] = w.w;
+            quad_transpose(aw, q);                                                // -> this lane's env at steps 0..3 of the block
+        }
+        U4 tw{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t t = (blk << 2) + (uint64_t)j;
+            if (M_T > 1 && (j & 1) == 0) tw = transition_words(seed, t >> 1);
+            if (t < t0 || t >= t1) continue;  // wave-uniform: only the first and the last block of a launch can be partial
+            const uint32_t act = __umulhi(aw[j], (uint32_t)a.A);
+            const uint32_t sa = (uint32_t)s * (uint32_t)a.A + act;
+            uint32_t nt, rew_bits, p_lo = 0, p_hi = 0;
+            if constexpr (M_T == 1) {
+                const uint2 en = *reinterpret_cast<const uint2 *>(&tbl[a.ent_off + sa * 2u]);
+                nt = en.x; rew_bits = en.y;
+            } else {
+                const uint32_t w = (j & 1) ? tw.z : tw.x;
+                const uint2 th = *reinterpret_cast<const uint2 *>(&tbl[sa * 2u]);
+                const uint32_t idx = (w > th.x ? 1u : 0u) + (w > th.y ? 1u : 0u);
+                const uint4 en = *reinterpret_cast<const uint4 *>(&tbl[a.ent_off + (sa * 3u + idx) * 4u]);
+                nt = en.x; rew_bits = en.y; p_lo = en.z; p_hi = en.w;
+            }
+            el += 1;                                                   // TimeLimit.step, time_limit.py:50-53
+            const bool trunc = el >= max_eff;
+            const bool term = (int32_t)nt < 0;
+            const bool done = term || trunc;
+            int32_t ns = (int32_t)(nt & 0x7fffffffu);
+            if constexpr (SINGLE) {
+                ns = done ? a.start : ns;                              // sync_vector_env.py:152-156: the reset's observation
+            } else {
+                if (__any(done)) {
+                    uint32_t wr;
+                    if constexpr (M_T == 1) {
+                        // the env's Philox call of this step pair, made HERE only (the asm keeps the compiler from speculating the ten
+                        // rounds into the path every step takes)
+                        const U4 x = transition_words(((uint64_t)tab_pin32((uint32_t)(seed >> 32)) << 32) | tab_pin32((uint32_t)seed), t >> 1);
+                        wr = (j & 1) ? x.w : x.y;
+                    } else {
+                        wr = (j & 1) ? tw.w : tw.y;
+                    }
+                    int32_t lo = 0, hi = a.S1;                         // first state whose cumulative probability exceeds u
+                    for (int it = 0; it < a.init_iters; ++it) {
+                        const int32_t mid = (lo + hi) >> 1;
+                        const bool live = lo < hi, hit = wr < tbl[a.init_off + mid];
+                        hi = (live && hit) ? mid : hi;
+                        lo = (live && !hit) ? mid + 1 : lo;
+                    }
+                    ns = done ? lo : ns;
+                }
+            }
+            s = ns;
+            el = done ? 0 : el;
+            if (ALLV || valid) {
+                const float rew = __uint_as_float(rew_bits);
+                if constexpr (COMPACT) {
+                    *reinterpret_cast<int32_t *>(p_act + tab_pin32(off_w)) = (int32_t)act;
+                    *reinterpret_cast<float *>(p_rew + tab_pin32(off_w)) = rew;
+                    *reinterpret_cast<int32_t *>(p_obs + tab_pin32(off_w)) = s;
+                    float p = 1.0f;
+                    if constexpr (M_T > 1) p = done ? 1.0f : __uint_as_float(p_lo);
+                    *reinterpret_cast<float *>(p_prob + tab_pin32(off_w)) = p;
+                } else {
+                    *reinterpret_cast<int64_t *>(p_act + tab_pin32(off_w)) = (int64_t)act;
+                    *reinterpret_cast<double *>(p_rew + tab_pin32(off_w)) = (double)rew;
+                    *reinterpret_cast<int64_t *>(p_obs + tab_pin32(off_w)) = (int64_t)s;
+                    double p = 1.0;
+                    if constexpr (M_T > 1) p = done ? 1.0 : __hiloint2double((int)p_hi, (int)p_lo);
+                    *reinterpret_cast<double *>(p_prob + tab_pin32(off_w)) = p;
+                }
+                p_term[tab_pin32(off_b)] = term ? 1 : 0;
+                p_trunc[tab_pin32(off_b)] = trunc ? 1 : 0;
+            }
+            p_act += slice_w; p_obs += slice_w; p_rew += slice_w; p_prob += slice_w;
+            p_term += slice_b; p_trunc += slice_b;
+        }
+    }
+    if (valid) {
+        a.state[e] = s;
+        a.elapsed[e] = el;
+    }
+}
+
 struct TabResetArgs {
     int32_t *state, *elapsed;
     const uint64_t *seeds;
@@ -269,6 +447,10 @@ struct mxv_tab {
     double *cum = nullptr, *prob = nullptr, *reward = nullptr, *init_cum = nullptr;
     size_t lds_bytes = 0;
     bool lds_table = false;
+    // trajectory fast path (tab_traj_kernel): the packed table and where its parts start; fast_M == 0: not eligible
+    uint32_t *fast_tbl = nullptr;
+    int fast_M = 0, fast_words = 0, fast_ent_off = 0, fast_init_off = 0, fast_S1 = 0, fast_iters = 0;
+    int last_kernel = MXV_TAB_KERNEL_NONE;
     int log2S = 0;
     int single_start = -1;
     uint64_t base_seed = 0, action_seed = 0, t = 0;
@@ -357,6 +539,130 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t ac
     }
     TAB_HIP(h, hipGetLastError());
     h->t += (uint64_t)K;
+    h->last_kernel = MXV_TAB_KERNEL_GENERAL;
+    return MXV_OK;
+}
+
+// T = ceil(cum * 2^32 - 0.5) clamped to [0, 2^32]: cum > (w + 0.5) * 2^-32  <=>  w < T for every 32-bit word w (both sides of the
+// rewrite are exact in fp64: cum * 2^32 is a scaling, the subtraction of 0.5 from a value below 2^33 loses nothing).
+uint64_t word_threshold(double cum) {
+    const double x = cum * 4294967296.0 - 0.5;
+    if (!(x > 0.0)) return 0;
+    if (x > 4294967295.0) return 1ull << 32;
+    return (uint64_t)std::ceil(x);
+}
+
+// The packed table of tab_traj_kernel, or an empty vector when this MDP has to stay on the general kernel.
+std::vector<uint32_t> pack_fast_table(const mxv_tab_config &cfg, const double *cum, const double *prob, const int32_t *next,
+                                      const double *reward, const uint8_t *term, const double *init_cum, int single_start, bool all_one,
+                                      bool compact, int *ent_off, int *init_off, int *S1_out, int *iters) {
+    const int S = cfg.num_states, A = cfg.num_actions, M = cfg.max_transitions;
+    std::vector<uint32_t> w;
+    if (!(M == 1 || M == 3) || (M == 1 && !all_one)) return {};
+    const size_t SA = (size_t)S * A;
+    if (M > 1) w.assign(SA * 2, 0xFFFFFFFFu);
+    *ent_off = (int)w.size();
+    w.resize(w.size() + SA * (M == 1 ? 2 : 12), 0u);
+    for (size_t sa = 0; sa < SA; ++sa) {
+        int nvalid = 0;
+        while (nvalid < M && cum[sa * M + nvalid] >= 0.0) nvalid += 1;
+        if (nvalid == 0) return {};
+        for (int i = nvalid; i < M; ++i)
+            if (cum[sa * M + i] >= 0.0) return {};                       // padding must be a suffix
+        double prev = 0.0;
+        for (int i = 0; i < nvalid; ++i) {
+            const double c = cum[sa * M + i];
+            if (!(c >= prev)) return {};                                 // cumulative sums are non-decreasing (NaN fails too)
+            prev = c;
+            const uint64_t T = word_threshold(c);
+            if (T == 0) return {};                                       // a head no word selects: not encodable as T - 1
+            if (i == nvalid - 1 && T != (1ull << 32)) return {};         // "none exceeds u" (argmax of all-False = 0) must be impossible
+            if (i < M - 1) w[sa * 2 + i] = (uint32_t)(T - 1);            // (M == 3 only: i in {0, 1})
+        }
+        for (int i = 0; i < nvalid; ++i) {
+            const size_t k = sa * M + i;
+            const float rf = (float)reward[k];
+            if ((double)rf != reward[k]) return {};
+            uint32_t rb;
+            std::memcpy(&rb, &rf, 4);
+            const uint32_t nt = (uint32_t)next[k] | (term[k] ? 0x80000000u : 0u);
+            if (M == 1) {
+                w[*ent_off + sa * 2] = nt;
+                w[*ent_off + sa * 2 + 1] = rb;
+            } else {
+                uint32_t *en = &w[*ent_off + k * 4];
+                en[0] = nt;
+                en[1] = rb;
+                if (compact) {
+                    const float pf = (float)prob[k];                     // what the general kernel's (float)p stores
+                    std::memcpy(&en[2], &pf, 4);
+                } else {
+                    std::memcpy(&en[2], &prob[k], 8);
+                }
+            }
+        }
+    }
+    *init_off = (int)w.size();
+    *S1_out = 0;
+    *iters = 0;
+    if (single_start < 0) {
+        int S1 = -1;
+        double prev = 0.0;
+        for (int i = 0; i < S; ++i) {
+            if (!(init_cum[i] >= prev)) return {};
+            prev = init_cum[i];
+            if (S1 < 0 && word_threshold(init_cum[i]) == (1ull << 32)) S1 = i;
+        }
+        if (S1 < 1) return {};                                           // never reaches 1 (S1 == 0 would be a point mass: single_start)
+        for (int i = 0; i < S1; ++i) w.push_back((uint32_t)word_threshold(init_cum[i]));
+        w.push_back(0xFFFFFFFFu);                                        // index S1: read (never used) when the search has converged there
+        *S1_out = S1;
+        while ((1 << *iters) <= S1) *iters += 1;                         // bit_length(S1) halvings settle an interval of S1 states
+    }
+    while (w.size() % 4) w.push_back(0u);
+    if (w.size() * 4 > 64 * 1024) return {};
+    return w;
+}
+
+template <int M_T, bool COMPACT, bool SINGLE>
+void launch_traj(mxv_tab *h, const TabTrajArgs &a0) {
+    TabTrajArgs a = a0;
+    const unsigned full = (unsigned)(a.n / kTabBlock);
+    const size_t lds = (size_t)a.table_words * 4;
+    if (full) hipLaunchKernelGGL((tab_traj_kernel<M_T, COMPACT, SINGLE, true>), dim3(full), dim3(kTabBlock), lds, h->stream, a);
+    if (a.n % kTabBlock) {
+        a.tile_base = full;
+        hipLaunchKernelGGL((tab_traj_kernel<M_T, COMPACT, SINGLE, false>), dim3(1), dim3(kTabBlock), lds, h->stream, a);
+    }
+}
+
+int tab_launch_traj(mxv_tab *h, int K, void *actions_out, void *obs, void *reward, uint8_t *term, uint8_t *trunc, void *prob, bool compact) {
+    if (!h->was_reset)
+        return tfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    TabTrajArgs a{};
+    a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds;
+    a.table = h->fast_tbl; a.table_words = h->fast_words; a.A = h->cfg.num_actions; a.ent_off = h->fast_ent_off;
+    a.init_off = h->fast_init_off; a.S1 = h->fast_S1; a.init_iters = h->fast_iters; a.start = h->single_start;
+    a.actions = (char *)actions_out; a.obs = (char *)obs; a.reward = (char *)reward; a.prob = (char *)prob;
+    a.terminated = term; a.truncated = trunc;
+    a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->t;
+    a.max_steps = h->cfg.max_episode_steps; a.K = K;
+    const bool single = h->single_start >= 0;
+    const int sel = (h->fast_M == 3 ? 4 : 0) | (compact ? 2 : 0) | (single ? 1 : 0);
+    switch (sel) {
+        case 0: launch_traj<1, false, false>(h, a); break;
+        case 1: launch_traj<1, false, true>(h, a); break;
+        case 2: launch_traj<1, true, false>(h, a); break;
+        case 3: launch_traj<1, true, true>(h, a); break;
+        case 4: launch_traj<3, false, false>(h, a); break;
+        case 5: launch_traj<3, false, true>(h, a); break;
+        case 6: launch_traj<3, true, false>(h, a); break;
+        default: launch_traj<3, true, true>(h, a); break;
+    }
+    TAB_HIP(h, hipGetLastError());
+    h->t += (uint64_t)K;
+    h->last_kernel = MXV_TAB_KERNEL_TRAJECTORY;
     return MXV_OK;
 }
 
@@ -488,6 +794,22 @@ int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const
 #undef TAB_CREATE_HIP
     h->lds_bytes = entries * (sizeof(double) * (1 + (need_cum ? 1 : 0) + (all_one ? 0 : 1)) + sizeof(int32_t)) + (size_t)S * sizeof(double);
     h->lds_table = h->lds_bytes <= 64 * 1024;  // larger MDPs (custom maps) read the table through L2 instead
+    if (!(cfg->flags & MXV_TAB_FLAG_GENERAL_KERNEL)) {
+        const std::vector<uint32_t> w = pack_fast_table(*cfg, cum_prob_host, prob_host, next_state_host, reward_host, terminated_host,
+                                                        initial_cum_host, h->single_start, all_one, (cfg->flags & MXV_TAB_FLAG_COMPACT) != 0,
+                                                        &h->fast_ent_off, &h->fast_init_off, &h->fast_S1, &h->fast_iters);
+        if (!w.empty()) {
+            hipError_t e1 = hipMalloc((void **)&h->fast_tbl, w.size() * 4);
+            if (e1 == hipSuccess) e1 = hipMemcpy(h->fast_tbl, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+            if (e1 != hipSuccess) {
+                tfail(nullptr, MXV_ERR_HIP, "packed transition table: %s", hipGetErrorString(e1));
+                mxv_tab_destroy(h);
+                return MXV_ERR_HIP;
+            }
+            h->fast_M = M;
+            h->fast_words = (int)w.size();
+        }
+    }
     *out = h;
     return MXV_OK;
 }
@@ -496,7 +818,7 @@ int mxv_tab_destroy(mxv_tab *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->fast_tbl};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->hostmap) {
@@ -557,8 +879,12 @@ int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, void *actions_out_d
                     uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev, void *final_obs_dev,
                     void *final_prob_dev) {
     TAB_CHECK(h);
+    const bool compact = (h->cfg.flags & MXV_TAB_FLAG_COMPACT) != 0;
+    if (h->fast_M != 0 && per_step && K > 0 && actions_out_dev && obs_dev && reward_dev && terminated_dev && truncated_dev && prob_dev &&
+        !final_obs_dev && !final_prob_dev)
+        return tab_launch_traj(h, K, actions_out_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, prob_dev, compact);
     return tab_launch(h, K, per_step ? h->cfg.num_envs : 0, nullptr, 0, actions_out_dev, nullptr, obs_dev, reward_dev,
-                      terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev, (h->cfg.flags & MXV_TAB_FLAG_COMPACT) != 0);
+                      terminated_dev, truncated_dev, prob_dev, final_obs_dev, final_prob_dev, compact);
 }
 
 int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const void *actions_tape_dev, void *obs_dev,
@@ -681,6 +1007,10 @@ int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r) {
     h->r = r;
     return MXV_OK;
 }
+
+uint64_t mxv_tab_word_threshold(double cum_prob) { return word_threshold(cum_prob); }
+
+int mxv_tab_last_kernel(const mxv_tab *h) { return h ? h->last_kernel : MXV_TAB_KERNEL_NONE; }
 
 int mxv_tab_sync(mxv_tab *h) {
     TAB_CHECK(h);

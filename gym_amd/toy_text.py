@@ -277,10 +277,10 @@ def _spec(id: str) -> ToyTextSpec:
 
 
 def _make_handle(mdp: TabularMDP, num_envs: int, limit: Optional[int], device: int, env_offset: int, seed: int, action_seed: int,
-                 compact: bool = False):
+                 compact: bool = False, general_kernel: bool = False):
     return _native.Tab(mdp.num_states, mdp.num_actions, mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated,
                        mdp.initial_cum, num_envs, -1 if limit is None else int(limit), device=device,
-                       env_offset=env_offset, seed=seed, action_seed=action_seed, compact=compact)
+                       env_offset=env_offset, seed=seed, action_seed=action_seed, compact=compact, general_kernel=general_kernel)
 
 
 class HipTabularVectorEnv(VectorEnv):
@@ -465,7 +465,7 @@ class TabularRollout:
     contract dtypes of SURVEY.md §8(d) — int32 obs / actions, float32 reward / prob: 18 instead of 34 bytes per env-step, same values."""
 
     def __init__(self, id: str, num_envs: int, *, device: int = 0, env_offset: int = 0, seed: int = 0, action_seed: int = 0,
-                 max_episode_steps: Optional[int] = None, compact: bool = False, **kwargs):
+                 max_episode_steps: Optional[int] = None, compact: bool = False, general_kernel: bool = False, **kwargs):
         import torch
 
         if not torch.cuda.is_available():
@@ -478,7 +478,8 @@ class TabularRollout:
         limit = self.spec.max_episode_steps if max_episode_steps is None else max_episode_steps
         self.compact = bool(compact)
         self.int_dtype, self.real_dtype = (torch.int32, torch.float32) if compact else (torch.int64, torch.float64)
-        self.handle = _make_handle(self.mdp, num_envs, limit, device, env_offset, seed, action_seed, compact=compact)
+        self.handle = _make_handle(self.mdp, num_envs, limit, device, env_offset, seed, action_seed, compact=compact,
+                                   general_kernel=general_kernel)
         self.stream = torch.cuda.Stream(device=self.device)
         self.handle.set_stream(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):

@@ -391,7 +391,14 @@ typedef struct mxv_tab_config {
 /* MXV_TAB_FLAG_COMPACT: the trajectory calls (mxv_tab_rollout, mxv_tab_rollout_tape) take and produce the contract dtypes of SURVEY.md
  * §8(d) — int32 observations / actions (tape included), float32 rewards / probs: 18 B per env-step instead of 34 — on the device tensors;
  * every other call (mxv_tab_step, reset, the host calls) keeps the reference's int64 / float64.  Same values, narrower stores. */
-enum { MXV_TAB_FLAG_COMPACT = 1 };
+enum { MXV_TAB_FLAG_COMPACT = 1, MXV_TAB_FLAG_GENERAL_KERNEL = 2 };
+/* mxv_tab_rollout launches with every per-step output present (actions, obs, reward, both flags, prob; no final_* tensors) run a
+ * kernel specialised for them (gym_amd/csrc/mxv_tab.hip: tab_traj_kernel — categorical_sample as integer compares against thresholds
+ * packed at create time) whenever the MDP allows the packing: transition lists of length 1 or 3 whose cumulative probabilities end at
+ * 1, float32-representable rewards, 64 KiB of table at most.  Same streams, same values, bit for bit.  MXV_TAB_FLAG_GENERAL_KERNEL
+ * keeps such a handle on the general kernel (the tests' A/B switch); mxv_tab_last_kernel reports which one the last step / rollout
+ * call launched. */
+enum { MXV_TAB_KERNEL_NONE = 0, MXV_TAB_KERNEL_GENERAL = 1, MXV_TAB_KERNEL_TRAJECTORY = 2 };
 int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const double *prob_host,
                    const int32_t *next_state_host, const double *reward_host, const uint8_t *terminated_host,
                    const double *initial_cum_host, mxv_tab **out);
@@ -428,6 +435,10 @@ int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elap
 int mxv_tab_get_counters(mxv_tab *h, uint64_t *t, uint32_t *r);
 int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r);
 int mxv_tab_sync(mxv_tab *h);
+int mxv_tab_last_kernel(const mxv_tab *h);
+/* The integer form of categorical_sample's comparison (host function, no device needed): T in [0, 2^32] with
+ * cum_prob > (w + 0.5) * 2^-32  <=>  w < T  for every 32-bit word w. */
+uint64_t mxv_tab_word_threshold(double cum_prob);
 int mxv_tab_set_stream(mxv_tab *h, void *stream);
 
 /* -- Blackjack-v1 (gym/envs/toy_text/blackjack.py:48-160), the toy_text env that is not a P table ------------

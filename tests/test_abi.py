@@ -154,6 +154,8 @@ def test_ctypes_signatures_agree_with_the_header_prototypes():
                 assert got == want, (name, i, a, t)
         if "char" in ret:
             assert f.restype is ctypes.c_char_p, name
+        elif "uint64_t" in ret:
+            assert f.restype is ctypes.c_uint64, name
         else:
             assert f.restype in (ctypes.c_int, ctypes.c_int32), (name, ret)
     assert not undeclared, f"exported by the header, but gym_amd/_native.py declares no signature: {undeclared}"

@@ -83,6 +83,8 @@ def test_line_carries_what_the_review_asked_for(line):
     assert rv["source"].startswith("profiles/valu_") and rv["frac"] > 0.5 and 500 < rv["valu_instructions_per_env_step"] < 900
     for key in ("compact_frozenlake8x8", "compact_taxi"):                # the table engine with the contract dtypes: 18 B stored
         assert v[key]["value"] >= 0.95 * v[key.replace("compact_", "")]["value"] and v[key]["roofline"]["frac"] > 0.4, key
+    for key in ("frozenlake8x8", "taxi", "compact_frozenlake8x8", "compact_taxi"):
+        assert v[key]["kernel"].startswith("tab_traj_kernel"), key          # the specialised trajectory kernel is the one measured
     for key in ("frozenlake8x8", "taxi", "blackjack"):                    # SURVEY.md §8(f)-4 engines, driver-run
         assert v[key]["value"] > 2e10 and 0.05 < v[key]["roofline"]["frac"] < 1.0, key
     for key in ("normalize_obs", "normalize_reward"):                     # §8(f)-2

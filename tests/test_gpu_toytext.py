@@ -62,6 +62,8 @@ def test_philox_mode_equals_oracle_twin_and_fused_equals_single_steps(gid, limit
         else:
             out = r.rollout_tape(torch.from_numpy(runs["fused"][1]["actions"]).cuda())
         r.synchronize()
+        from gym_amd import _native
+        assert r.handle.last_kernel() == (_native.TAB_KERNEL_TRAJECTORY if mode == "fused" else _native.TAB_KERNEL_GENERAL), mode
         runs[mode] = (obs0, {k: v.cpu().numpy() for k, v in out.items()}, r.handle.get_state())
         r.close()
     for mode in ("single", "tape"):
@@ -306,3 +308,83 @@ def test_compact_trajectories_hold_the_same_values(gid):
     for x, y in zip(wide.handle.get_state(), comp.handle.get_state()):
         assert np.array_equal(x, y)
     wide.close(), comp.close()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("gid,limit", [("FrozenLake-v1", 100), ("FrozenLake8x8-v1", 11), ("Taxi-v3", 7), ("CliffWalking-v0", 23),
+                                       ("FrozenLake-v1:det", 9)])
+def test_trajectory_kernel_equals_general_kernel(gid, limit, compact):
+    """tab_traj_kernel (integer thresholds, packed table, DPP word transpose, lazily drawn reset uniforms) against tab_step_kernel on
+    the same handle configuration: every output of every step, state and counters, over launches that start and end inside the
+    four-step blocks of the action stream (K = 3, 50, 1, 64, 6) and a ragged last workgroup (n = 70 001); per-env seeds included."""
+    import torch
+    from gym_amd import _native
+    from gym_amd.toy_text import TabularRollout
+
+    kw = {"is_slippery": False} if gid.endswith(":det") else {}
+    gid = gid.split(":")[0]
+    n = 70001
+    fast = TabularRollout(gid, n, seed=5, action_seed=6, max_episode_steps=limit, compact=compact, **kw)
+    gen = TabularRollout(gid, n, seed=5, action_seed=6, max_episode_steps=limit, compact=compact, general_kernel=True, **kw)
+    seeds = np.random.default_rng(3).integers(0, 2 ** 63, n, dtype=np.uint64)
+    ended = 0
+    for rnd, per_env in enumerate((False, True)):
+        for r in (fast, gen):
+            r.handle.seed(5 + rnd, seeds if per_env else None)
+            r.reset()
+        for K in (3, 50, 1, 64, 6):
+            a, b = fast.rollout_per_step(K), gen.rollout_per_step(K)
+            fast.synchronize(), gen.synchronize()
+            assert fast.handle.last_kernel() == _native.TAB_KERNEL_TRAJECTORY and gen.handle.last_kernel() == _native.TAB_KERNEL_GENERAL
+            for key in ("obs", "actions", "reward", "prob", "terminated", "truncated"):
+                assert a[key].dtype == b[key].dtype and torch.equal(a[key], b[key]), (gid, compact, per_env, K, key)
+            ended += int((a["terminated"] | a["truncated"]).sum())
+        for x, y in zip(fast.handle.get_state(), gen.handle.get_state()):
+            assert np.array_equal(x, y)
+        assert fast.handle.get_counters() == gen.handle.get_counters()
+    assert ended > n
+    fast.close(), gen.close()
+
+
+def test_mdps_the_packing_refuses_stay_on_the_general_kernel():
+    """A transition list of length 2, a reward that is no float32 value, a cumulative sum that stops short of 1: the handle keeps the
+    general kernel for trajectory launches too — and agrees with the CPU twin."""
+    import torch
+    from gym_amd import _native
+    from gym_amd.toy_text import frozen_lake_mdp
+    from oracle.oracle import OracleTabEnv
+
+    base = frozen_lake_mdp(map_name="4x4")
+    S, A, M = base.num_states, base.num_actions, base.max_transitions
+    cases = []
+    rew = np.array(base.reward, np.float64).copy(); rew[rew == 1.0] = 0.1
+    cases.append(("reward 0.1", dict(reward=rew)))
+    cum = np.array(base.cum_prob, np.float64).copy(); cum[cum == 1.0] = 1.0 - 2.0 ** -30
+    cases.append(("cum stops short of 1", dict(cum_prob=cum)))
+    cum2, prob2 = np.array(base.cum_prob)[:, :, :2].copy(), np.array(base.prob)[:, :, :2].copy()
+    full = cum2[:, :, 1] >= 0
+    cum2[:, :, 1][full] = 1.0; prob2[:, :, 1][full] = 2.0 / 3.0
+    cases.append(("M = 2", dict(cum_prob=cum2, prob=prob2, next_state=np.array(base.next_state)[:, :, :2].copy(),
+                                reward=np.array(base.reward)[:, :, :2].copy(), terminated=np.array(base.terminated)[:, :, :2].copy())))
+    n, K = 5000, 40
+    for what, over in cases:
+        t = dict(cum_prob=base.cum_prob, prob=base.prob, next_state=base.next_state, reward=base.reward, terminated=base.terminated)
+        t.update(over)
+        h = _native.Tab(S, A, t["cum_prob"], t["prob"], t["next_state"], t["reward"], t["terminated"], base.initial_cum, n, 30, seed=1,
+                        action_seed=2)
+        orc = OracleTabEnv(t["cum_prob"], t["prob"], t["next_state"], t["reward"], t["terminated"], base.initial_cum, n, 30, seed=1,
+                           action_seed=2)
+        dev = torch.device("cuda", 0)
+        out = {k: torch.empty((K, n), dtype=dt, device=dev) for k, dt in (("obs", torch.int64), ("reward", torch.float64), ("actions", torch.int64),
+                                                                           ("prob", torch.float64), ("terminated", torch.uint8), ("truncated", torch.uint8))}
+        torch.cuda.synchronize()
+        assert np.array_equal(h.reset_host(), orc.reset())
+        h.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"], actions_out_dev=out["actions"], per_step=True)
+        h.sync()
+        assert h.last_kernel() == _native.TAB_KERNEL_GENERAL, what
+        for k in range(K):
+            o = orc.step()
+            for name in ("actions", "obs", "reward", "prob"):
+                assert np.array_equal(o[name], out[name][k].cpu().numpy()), (what, k, name)
+            assert np.array_equal(o["terminated"], out["terminated"][k].cpu().numpy().astype(bool)), (what, k)
+        h.close()
