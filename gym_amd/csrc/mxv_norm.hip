@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mxv.h"
@@ -42,10 +43,48 @@ constexpr int kRewLeafEnvs = 256;   // envs per leaf of the return-sum tree (one
 constexpr int kTreeFan = 1024;      // leaves folded per workgroup per tree level (a complete 10-level subtree)
 constexpr int kMaxWorld = 64;
 
+#ifndef MXV_NORM_DPP_REDUCE
+#define MXV_NORM_DPP_REDUCE 1  // A/B hook: 0 = the six ds_bpermute stages of __shfl_xor
+#endif
+#ifndef MXV_NORM_XCD_MAP
+#define MXV_NORM_XCD_MAP 1     // A/B hook: 0 = leaf = workgroup id
+#endif
+#ifndef MXV_NORM_VEC4
+#define MXV_NORM_VEC4 1        // A/B hook: 0 = lane L of a return leaf owns envs L, L + 64, L + 128, L + 192 (twelve loads per step)
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_tree_sum(double v) {
     // xor butterfly = the binary tree over lane index (addition is commutative, so every lane holds the tree's value)
+#if MXV_NORM_DPP_REDUCE
+    // The same tree without LDS round trips.  Stages 1, 2: quad permutes (lane ^ 1, lane ^ 2).  Stages 4, 8: after them every lane of
+    // a quad (of a half row) holds the same partial sum, so the mirror permutes of the DPP unit — lane 7 - i of the half row, lane
+    // 15 - i of the row — deliver what lane ^ 4 (lane ^ 8) holds.  Stages 16, 32: gfx950's v_permlane16_swap / v_permlane32_swap.
+    // a + b == b + a exactly, so the value is the __shfl_xor butterfly's, bit for bit.
+    v += dpp_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);   // rows (0, 1), (2, 3)
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);   // lower half + upper half
+    }
+#else
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+#endif
     return v;
 }
 
@@ -108,22 +147,35 @@ __global__ void __launch_bounds__(kThreads) obs_sums_kernel(const float *__restr
 }
 
 // ---- 1b. rewards: discounted-return recurrence + per-(step, leaf) sums ----------------------------------------------
-// One wave per workgroup, leaf = 256 consecutive envs, lane L owns envs leaf*256 + j*64 + L (j < 4): dense 512-B
-// bursts of rewards, 64-B bursts of flags.  partials [K][leaves][2] = (sum, sumsq) of the returns AFTER the update of
-// step k and BEFORE the zeroing of finished envs (normalize.py:132-136).
+// One wave per workgroup, leaf = 256 consecutive envs, lane L owns envs leaf*256 + 4*L + j (j < 4): per step one 32-byte (float32
+// rewards: 16-byte) load of rewards and one dword of each flag array per lane — four load instructions per wave-step where a lane
+// that owned envs L, L + 64, ... issued twelve, eight of them 64-byte bursts of flag bytes.  (Vector loads need n % 4 == 0: the
+// steps of a [K][n] tensor then start on multiples of four elements; other sizes load element by element, same lanes, same order.)
+// partials [K][leaves][2] = (sum, sumsq) of the returns AFTER the update of step k and BEFORE the zeroing of finished envs
+// (normalize.py:132-136).
 template <typename RT>
 __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__ rew, const uint8_t *__restrict__ term,
                                                           const uint8_t *__restrict__ trunc, double *__restrict__ returns,
                                                           int64_t n, int K, double gamma, int64_t leaves,
                                                           double *__restrict__ partials) {
     const int lane = threadIdx.x;
+#if MXV_NORM_XCD_MAP
+    // workgroup ids are dealt round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the leaves (as the rollout kernels'
+    // tiles), so that the lines one L2 fetches at a step are neighbours in memory
+    int64_t leaf;
+    {
+        const unsigned bid = blockIdx.x, nb = gridDim.x, x = bid % 8u, idx = bid / 8u, base = nb / 8u, rem = nb % 8u;
+        leaf = (int64_t)(x * base + (x < rem ? x : rem) + idx);
+    }
+#else
     const int64_t leaf = blockIdx.x;
+#endif
     int64_t e[4];
     bool live[4];
     double ret[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        e[j] = leaf * kRewLeafEnvs + j * 64 + lane;
+        e[j] = MXV_NORM_VEC4 ? leaf * kRewLeafEnvs + 4 * lane + j : leaf * kRewLeafEnvs + j * 64 + lane;
         live[j] = e[j] < n;
         ret[j] = live[j] ? returns[e[j]] : 0.0;
     }
@@ -132,48 +184,79 @@ __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__
     // the four waves of a SIMD still spent most of a step waiting: 3.5 us per 2^20-env step for 10 B per env-step = 3 TB/s).  A ring
     // of D register sets, the loop unrolled by D so that every set has a fixed name; the arithmetic and its order are unchanged.
     constexpr int D = 4;
-    RT r_ring[D][4];
-    uint8_t f_ring[D][4];
-    auto fetch = [&](int k, RT *r, uint8_t *f) {
-        const int64_t off = (int64_t)k * n;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool on = live[j] && k < K;
-            r[j] = on ? rew[off + e[j]] : (RT)0;
-            f[j] = on ? (uint8_t)(term[off + e[j]] | trunc[off + e[j]]) : (uint8_t)0;
-        }
+    // A ring entry holds what the loads RETURN (rewards, the two flag words or bytes) and nothing derived from it: OR-ing the flags at
+    // fetch time — rounds 1-4a — made every fetch wait for its own flag loads, a full HBM round trip per step with the "prefetched"
+    // rewards of the later steps queued behind it (3.5 TB/s for 10 B per env-step).
+    struct Slot {
+        RT r[4];
+        uint32_t ft[4], fu[4];   // VEC: element 0 = the dword of four flag bytes; else one byte each
     };
+    Slot ring[D];
+    // wave-uniform: the whole leaf exists and every step of the [K][n] tensors starts on a multiple of four elements
+    const bool vec = MXV_NORM_VEC4 && (n & 3) == 0 && (leaf + 1) * kRewLeafEnvs <= n;
+    auto run = [&](auto vec_tag) __attribute__((always_inline)) {
+        constexpr bool VEC = decltype(vec_tag)::value;
+        auto fetch = [&](int k, Slot &sl) {
+            const int64_t off = (int64_t)(k < K ? k : K - 1) * n;   // past the end: the last step once more (never used)
+            if constexpr (VEC) {
+                if constexpr (sizeof(RT) == 8) {
+                    const double2 a = reinterpret_cast<const double2 *>(rew + off + e[0])[0], b = reinterpret_cast<const double2 *>(rew + off + e[0])[1];
+                    sl.r[0] = a.x; sl.r[1] = a.y; sl.r[2] = b.x; sl.r[3] = b.y;
+                } else {
+                    const float4 a = *reinterpret_cast<const float4 *>(rew + off + e[0]);
+                    sl.r[0] = a.x; sl.r[1] = a.y; sl.r[2] = a.z; sl.r[3] = a.w;
+                }
+                sl.ft[0] = *reinterpret_cast<const uint32_t *>(term + off + e[0]);
+                sl.fu[0] = *reinterpret_cast<const uint32_t *>(trunc + off + e[0]);
+            } else {
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) fetch(d, r_ring[d], f_ring[d]);
-    auto one_step = [&](int k, const RT *r_cur, const uint8_t *f_cur) {
-        double s = 0.0, q = 0.0;
+                for (int j = 0; j < 4; ++j) {
+                    sl.r[j] = live[j] ? rew[off + e[j]] : (RT)0;
+                    sl.ft[j] = live[j] ? (uint32_t)term[off + e[j]] : 0u;
+                    sl.fu[j] = live[j] ? (uint32_t)trunc[off + e[j]] : 0u;
+                }
+            }
+        };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (live[j]) {
-                ret[j] = ret[j] * gamma + (double)r_cur[j];  // :132 (two roundings; contraction is off)
-                s += ret[j];
-                q = __fma_rn(ret[j], ret[j], q);
+        for (int d = 0; d < D - 1; ++d) fetch(d, ring[d]);
+        auto one_step = [&](int k, const Slot &sl) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (VEC || live[j]) {
+                    ret[j] = ret[j] * gamma + (double)sl.r[j];  // :132 (two roundings; contraction is off)
+                    s += ret[j];
+                    q = __fma_rn(ret[j], ret[j], q);
+                }
+            }
+            s = wave_tree_sum(s);
+            q = wave_tree_sum(q);
+            if (lane == 0) {
+                partials[((int64_t)k * leaves + leaf) * 2 + 0] = s;
+                partials[((int64_t)k * leaves + leaf) * 2 + 1] = q;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // :135-136
+                const bool done = VEC ? (((sl.ft[0] | sl.fu[0]) >> (8 * j)) & 0xffu) != 0 : (sl.ft[j] | sl.fu[j]) != 0;
+                if (done) ret[j] = 0.0;
+            }
+        };
+        // full groups of D steps: a body without exits (a `break` between the unrolled steps splits it into blocks, and the waits the
+        // compiler then places at the joins drain the ring once per group); the last K % D steps find their slots already loaded
+        int k0 = 0;
+        for (; k0 + D <= K; k0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                fetch(k0 + d + D - 1, ring[(d + D - 1) % D]);   // the slot step k-1 has just released
+                one_step(k0 + d, ring[d]);
             }
         }
-        s = wave_tree_sum(s);
-        q = wave_tree_sum(q);
-        if (lane == 0) {
-            partials[((int64_t)k * leaves + leaf) * 2 + 0] = s;
-            partials[((int64_t)k * leaves + leaf) * 2 + 1] = q;
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (f_cur[j]) ret[j] = 0.0;  // :135-136
+        for (int d = 0; d < D - 1; ++d)
+            if (k0 + d < K) one_step(k0 + d, ring[d]);
     };
-    for (int k0 = 0; k0 < K; k0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int k = k0 + d;
-            if (k >= K) break;
-            fetch(k + D - 1, r_ring[(d + D - 1) % D], f_ring[(d + D - 1) % D]);   // the set step k-1 has just released
-            one_step(k, r_ring[d], f_ring[d]);
-        }
-    }
+    if (vec) run(std::true_type{});
+    else run(std::false_type{});
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (live[j]) returns[e[j]] = ret[j];
@@ -201,55 +284,92 @@ __global__ void __launch_bounds__(kThreads) tree_kernel(const double *__restrict
 
 // ---- 3. the running update, sequential over the K steps (normalize.py:17-47) ------------------------------------------
 // all_sums [W][K][2*O]; stat = mean[O], var[O], count; coef [K][O][2] = (mean_k, sqrt(var_k + epsilon)).
-__global__ void scan_kernel(const double *__restrict__ all_sums, int W, int K, int O, double total_rows, double epsilon,
-                            int obs_dtype_f32, double *__restrict__ stat, double *__restrict__ coef) {
-    const int j = threadIdx.x;
-    if (j >= O) return;
-    double mean = stat[j], var = stat[O + j], count = stat[2 * O];
+// One workgroup, chunks of kScanChunk steps, three phases per chunk:
+//   A (all threads, one (step, column) pair each): the tree over the ranks' sums and the batch moments — nothing here depends on the
+//     running statistics — into LDS;
+//   B (thread j = column j): the Chan merge itself, the only sequential part: three divisions per step, operands read from LDS
+//     (addresses known in advance: the reads of the next steps are in flight while a step's divisions run);
+//   C (all threads): coef_k = (mean_k, sqrt(var_k + epsilon)) out to HBM.
+// Rounds 1-4a walked the steps with one thread per column doing everything: a dependent HBM round trip, the moments' divisions and a
+// square root per step — 84 us for 128 steps (8 % of a NormalizeReward pass).  Every value is computed by the same operations in the
+// same order as before.
+constexpr int kScanChunk = 256, kScanMaxDim = 6;
+__global__ void __launch_bounds__(kThreads) scan_kernel(const double *__restrict__ all_sums, int W, int K, int O, double total_rows,
+                                                        double epsilon, int obs_dtype_f32, double *__restrict__ stat,
+                                                        double *__restrict__ coef) {
+    __shared__ double l_bm[kScanChunk * kScanMaxDim], l_mb[kScanChunk * kScanMaxDim];   // batch mean, m_b; then mean_k, var_k
+    const int tid = threadIdx.x;
     const double N = total_rows;
-    for (int k = 0; k < K; ++k) {
-        double bs[kMaxWorld], bq[kMaxWorld];
-        for (int w = 0; w < W; ++w) {
-            bs[w] = all_sums[((int64_t)w * K + k) * (2 * O) + j];
-            bq[w] = all_sums[((int64_t)w * K + k) * (2 * O) + O + j];
-        }
-        for (int stride = 1; stride < W; stride <<= 1)  // binary tree over the rank index
-            for (int w = 0; w + stride < W; w += 2 * stride) {
-                bs[w] += bs[w + stride];
-                bq[w] += bq[w + stride];
-            }
-        const double S = bs[0], Q = bq[0];
-        double batch_mean, m_b;
-        if (obs_dtype_f32) {
-            // np.mean / np.var of a float32 array are float32 (the division itself runs in double: _methods.py _mean/_var);
-            // var = mean((x - mean32)^2) expanded over the exact sums
-            const float mean32 = (float)(S / N);
-            const double m = (double)mean32;
-            double v = ((Q - 2.0 * m * S) + N * m * m) / N;
-            v = v > 0.0 ? v : 0.0;
-            const float var32 = (float)v;
-            batch_mean = m;
-            m_b = (double)__fmul_rn(var32, (float)N);  // float32 array * python int stays float32 (:41)
-        } else {
-            batch_mean = S / N;
-            double v = Q / N - batch_mean * batch_mean;
-            v = v > 0.0 ? v : 0.0;
-            m_b = v * N;
-        }
-        const double delta = batch_mean - mean;                                  // :36
-        const double tot = count + N;                                            // :37
-        const double new_mean = mean + delta * N / tot;                          // :39
-        const double m_a = var * count;                                          // :40
-        const double M2 = m_a + m_b + delta * delta * count * N / tot;           // :42
-        mean = new_mean;
-        var = M2 / tot;                                                          // :43
-        count = tot;                                                             // :44
-        coef[((int64_t)k * O + j) * 2 + 0] = mean;
-        coef[((int64_t)k * O + j) * 2 + 1] = sqrt(var + epsilon);                // np.sqrt(var + epsilon), :93 / :145
+    double mean = 0.0, var = 0.0, count = 0.0;
+    if (tid < O) {
+        mean = stat[tid];
+        var = stat[O + tid];
+        count = stat[2 * O];
     }
-    stat[j] = mean;
-    stat[O + j] = var;
-    if (j == 0) stat[2 * O] = count;
+    for (int c0 = 0; c0 < K; c0 += kScanChunk) {
+        const int steps = (K - c0) < kScanChunk ? (K - c0) : kScanChunk;
+        for (int i = tid; i < steps * O; i += kThreads) {  // ---- A
+            const int k = c0 + i / O, j = i % O;
+            double bs[kMaxWorld], bq[kMaxWorld];
+            for (int w = 0; w < W; ++w) {
+                bs[w] = all_sums[((int64_t)w * K + k) * (2 * O) + j];
+                bq[w] = all_sums[((int64_t)w * K + k) * (2 * O) + O + j];
+            }
+            for (int stride = 1; stride < W; stride <<= 1)  // binary tree over the rank index
+                for (int w = 0; w + stride < W; w += 2 * stride) {
+                    bs[w] += bs[w + stride];
+                    bq[w] += bq[w + stride];
+                }
+            const double S = bs[0], Q = bq[0];
+            double batch_mean, m_b;
+            if (obs_dtype_f32) {
+                // np.mean / np.var of a float32 array are float32 (the division itself runs in double: _methods.py _mean/_var);
+                // var = mean((x - mean32)^2) expanded over the exact sums
+                const float mean32 = (float)(S / N);
+                const double m = (double)mean32;
+                double v = ((Q - 2.0 * m * S) + N * m * m) / N;
+                v = v > 0.0 ? v : 0.0;
+                const float var32 = (float)v;
+                batch_mean = m;
+                m_b = (double)__fmul_rn(var32, (float)N);  // float32 array * python int stays float32 (:41)
+            } else {
+                batch_mean = S / N;
+                double v = Q / N - batch_mean * batch_mean;
+                v = v > 0.0 ? v : 0.0;
+                m_b = v * N;
+            }
+            l_bm[i] = batch_mean;
+            l_mb[i] = m_b;
+        }
+        __syncthreads();
+        if (tid < O) {  // ---- B
+#pragma unroll 4
+            for (int kk = 0; kk < steps; ++kk) {
+                const double batch_mean = l_bm[kk * O + tid], m_b = l_mb[kk * O + tid];
+                const double delta = batch_mean - mean;                                  // :36
+                const double tot = count + N;                                            // :37
+                const double new_mean = mean + delta * N / tot;                          // :39
+                const double m_a = var * count;                                          // :40
+                const double M2 = m_a + m_b + delta * delta * count * N / tot;           // :42
+                mean = new_mean;
+                var = M2 / tot;                                                          // :43
+                count = tot;                                                             // :44
+                l_bm[kk * O + tid] = mean;
+                l_mb[kk * O + tid] = var;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < steps * O; i += kThreads) {  // ---- C
+            coef[((int64_t)c0 * O + i) * 2 + 0] = l_bm[i];
+            coef[((int64_t)c0 * O + i) * 2 + 1] = sqrt(l_mb[i] + epsilon);             // np.sqrt(var + epsilon), :93 / :145
+        }
+        __syncthreads();
+    }
+    if (tid < O) {
+        stat[tid] = mean;
+        stat[O + tid] = var;
+        if (tid == 0) stat[2 * O] = count;
+    }
 }
 
 // ---- 4a. (obs - mean) / sqrt(var + epsilon): one row per lane, grid (ceil(N/256), K) -----------------------------------
@@ -413,7 +533,7 @@ int checks(mxv_norm *nm, int K) {
 int run_scan(mxv_norm *nm, int K, const double *all_sums, int world, int64_t total_rows, double epsilon, int obs) {
     if (world < 1 || world > kMaxWorld) return nfail(nm, MXV_ERR_INVALID_ARG, "world must be in [1, %d]", kMaxWorld);
     if (total_rows <= 0) return nfail(nm, MXV_ERR_INVALID_ARG, "total_rows must be positive");
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, nm->stream, all_sums, world, K, nm->dim, (double)total_rows, epsilon,
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kThreads), 0, nm->stream, all_sums, world, K, nm->dim, (double)total_rows, epsilon,
                        obs, nm->stat, nm->coef);
     NRM_HIP(nm, hipGetLastError());
     return MXV_OK;
