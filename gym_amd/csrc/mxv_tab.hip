@@ -561,6 +561,7 @@ std::vector<uint32_t> pack_fast_table(const mxv_tab_config &cfg, const double *c
     if (!(M == 1 || M == 3) || (M == 1 && !all_one)) return {};
     const size_t SA = (size_t)S * A;
     if (M > 1) w.assign(SA * 2, 0xFFFFFFFFu);
+    while (w.size() % 4) w.push_back(0u);                               // the 16-byte entries are read with ds_read_b128
     *ent_off = (int)w.size();
     w.resize(w.size() + SA * (M == 1 ? 2 : 12), 0u);
     for (size_t sa = 0; sa < SA; ++sa) {

@@ -388,3 +388,62 @@ def test_mdps_the_packing_refuses_stay_on_the_general_kernel():
                 assert np.array_equal(o[name], out[name][k].cpu().numpy()), (what, k, name)
             assert np.array_equal(o["terminated"], out["terminated"][k].cpu().numpy().astype(bool)), (what, k)
         h.close()
+
+
+@pytest.mark.parametrize("S,A,M,point_mass", [(5, 3, 3, False), (7, 1, 3, True), (11, 5, 1, False), (3, 3, 1, True)])
+def test_trajectory_kernel_on_synthetic_mdps(S, A, M, point_mass):
+    """Tables no registered env has — odd S * A (the packed entries' alignment), unequal transition probabilities, lists of one, two and
+    three entries side by side, an initial distribution with zero-probability states at both ends and M = 3 — through the trajectory
+    kernel, the general kernel and the CPU twin."""
+    import torch
+    from gym_amd import _native
+    from oracle.oracle import OracleTabEnv
+
+    rng = np.random.default_rng(S * 100 + A * 10 + M)
+    cum = np.full((S, A, M), -1.0)
+    prob = np.zeros((S, A, M))
+    for s in range(S):
+        for a in range(A):
+            n = 1 if M == 1 else int(rng.integers(1, M + 1))
+            p = {1: [1.0], 2: [[0.25, 0.75], [0.5, 0.5], [0.875, 0.125]][int(rng.integers(3))],
+                 3: [[0.25, 0.25, 0.5], [1.0 / 3.0] * 3, [0.125, 0.5, 0.375]][int(rng.integers(3))]}[n]
+            prob[s, a, :n] = p
+            cum[s, a, :n] = np.cumsum(p)
+    nxt = rng.integers(0, S, (S, A, M)).astype(np.int32)
+    rew = rng.integers(-3, 4, (S, A, M)).astype(np.float64) * 0.5
+    term = (rng.random((S, A, M)) < 0.15).astype(np.uint8)
+    if point_mass:
+        init = np.zeros(S); init[S // 2] = 1.0
+    else:
+        init = np.zeros(S); k = rng.choice(np.arange(1, S - 1), size=min(3, S - 2), replace=False); init[k] = 1.0 / len(k)
+    icum = np.cumsum(init)
+    icum[np.flatnonzero(init)[-1]:] = 1.0
+    n, K = 4097, 37
+    dev = torch.device("cuda", 0)
+    outs = []
+    for general in (False, True):
+        h = _native.Tab(S, A, cum, prob, nxt, rew, term, icum, n, 9, seed=3, action_seed=4, general_kernel=general)
+        out = {k: torch.empty((K, n), dtype=dt, device=dev) for k, dt in (("obs", torch.int64), ("reward", torch.float64), ("actions", torch.int64),
+                                                                           ("prob", torch.float64), ("terminated", torch.uint8), ("truncated", torch.uint8))}
+        torch.cuda.synchronize()
+        obs0 = h.reset_host()
+        h.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"], actions_out_dev=out["actions"], per_step=True)
+        h.sync()
+        assert h.last_kernel() == (_native.TAB_KERNEL_GENERAL if general else _native.TAB_KERNEL_TRAJECTORY)
+        outs.append((obs0, {k: v.cpu().numpy() for k, v in out.items()}, h.get_state()))
+        h.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    assert all(np.array_equal(x, y) for x, y in zip(outs[0][2], outs[1][2]))
+    orc = OracleTabEnv(cum, prob, nxt, rew, term, icum, n, 9, seed=3, action_seed=4)
+    assert np.array_equal(orc.reset(), outs[0][0])
+    ended = 0
+    for k in range(K):
+        o = orc.step()
+        for name in ("actions", "obs", "reward", "prob"):
+            assert np.array_equal(o[name], outs[0][1][name][k]), (k, name)
+        assert np.array_equal(o["terminated"], outs[0][1]["terminated"][k].astype(bool))
+        assert np.array_equal(o["truncated"], outs[0][1]["truncated"][k].astype(bool))
+        ended += int(o["final_mask"].sum())
+    assert ended > n
