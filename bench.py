@@ -475,6 +475,55 @@ def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
                          "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS}}
 
 
+def measure_policy_loop(torch, envs, per_graph=32, steps=1920):
+    """The learner-in-the-loop path where launches, not kernels, bound it: CartPole-v1, `envs` envs (a PPO-sized batch), a linear
+    policy's three kernels between the steps.  (i) the loop as a caller writes it: one ctypes call and three torch ops per step;
+    (ii) the same loop recorded ONCE into a hipGraph of the caller's — DeviceRollout.enable_graph_capture() moves the step index into
+    device memory, so replays continue the streams (tests/test_gpu_graph_capture.py: == single calls, bit for bit) — and replayed."""
+    from gym_amd.rollout import DeviceRollout
+
+    def loop(captured):
+        r = DeviceRollout(ENV_ID, envs, seed=0, action_seed=1)
+        r.reset(seed=0)
+        torch.manual_seed(0)
+        W = torch.randn(r.O, 2, device=r.device)
+
+        def one():
+            r.step((r.obs @ W).argmax(dim=1), want_final=False)
+
+        with torch.cuda.stream(r.stream):
+            for _ in range(64):
+                one()
+            r.stream.synchronize()
+            if captured:
+                r.enable_graph_capture()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=r.stream):
+                    for _ in range(per_graph):
+                        one()
+                run, calls = g.replay, steps // per_graph
+            else:
+                run, calls = one, steps
+            for _ in range(max(2, calls // 8)):
+                run()
+            r.stream.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                run()
+            r.stream.synchronize()
+            us = (time.perf_counter() - t0) / steps * 1e6
+        ended = int(r.handle.get_episodes().sum())
+        r.close()
+        return us, ended
+
+    eager, e1 = loop(False)
+    graph, e2 = loop(True)
+    return {"workload": f"{ENV_ID}, num_envs={envs}, obs @ W -> argmax -> step(actions), host wall time per vector step",
+            "one_call_per_step": {"us_per_step": eager, "value": envs / eager * 1e6, "unit": "env-steps/s"},
+            "recorded_in_a_hipgraph": {"steps_per_graph": per_graph, "us_per_step": graph, "value": envs / graph * 1e6, "unit": "env-steps/s"},
+            "speedup": eager / graph, "episodes_ended": [e1, e2]}
+
+
 def measure_step_kernel(torch, envs, launches=400, compact=False):
     """The step kernel itself (HIP events around back-to-back launches are dominated by the inter-launch gap, so the kernel time
     is taken with one event pair PER launch on a few launches and the minimum-gap figure is the loop's)."""
@@ -996,7 +1045,8 @@ def main():
                 "one_engine": measure_step_loop(torch, ENVS_TOTAL),
                 "one_engine_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True),
                 "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
-                "kernel": measure_step_kernel(torch, ENVS_TOTAL)})
+                "kernel": measure_step_kernel(torch, ENVS_TOTAL),
+                "policy_loop_4096_envs": measure_policy_loop(torch, 4096)})
             variant("numpy_loop", lambda: {"num_envs_2^20": measure_numpy_loop(ENVS_TOTAL, 60),
                                            "configs0_num_envs_8": measure_numpy_loop(8, 1000)})    # BASELINE.json configs[0]: the plumbing case
             out["variants"] = v

@@ -40,7 +40,7 @@ EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_last_launch", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
-    "mxv_set_counters", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_set_counters", "mxv_set_device_clock", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_write_probe_env", "mxv_host_alloc", "mxv_host_free",
                 "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream", "mxv_staging_view",
@@ -198,6 +198,7 @@ def _load():
         "mxv_set_state": ([vp, vp, vp], C.c_int),
         "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
+        "mxv_set_device_clock": ([vp, i32], C.c_int),
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
         "mxv_write_probe": ([C.c_int32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double)], C.c_int),
@@ -692,6 +693,11 @@ class Handle:
 
     def set_counters(self, t: int, r: int):
         self._check(lib.mxv_set_counters(self._h, int(t), int(r)))
+
+    def set_device_clock(self, on: bool = True):
+        """The step index lives in device memory and advances on the stream (mxv_set_device_clock): calls of this handle can then be
+        recorded into a caller's hipGraph and replayed."""
+        self._check(lib.mxv_set_device_clock(self._h, 1 if on else 0))
 
     def get_episodes(self) -> np.ndarray:
         """Per-env reset ordinals (uint32 [N]): how many resets each env has had since seeding = the position of its reset

@@ -75,6 +75,8 @@ struct mxv_handle {
     uint32_t *episodes = nullptr;  // [N] resets of each env since seeding = index of its next draw from the reset stream
     uint64_t *seeds = nullptr;  // optional per-env seeds
     uint64_t *t_dev = nullptr;  // device-resident step index for graph replay
+    uint32_t *clock_ticket = nullptr;  // finished-workgroup counter of launches that advance the device clock themselves
+    bool dev_clock = false;     // mxv_set_device_clock: every launch reads the step index from t_dev and a one-thread kernel advances it
     int32_t *err = nullptr;     // latched kernel error word
     uint64_t base_seed = 0, action_seed = 0;
     uint64_t t = 0;
@@ -200,6 +202,16 @@ int take_block_error(mxv_handle *h) {  // after the stream drained
     return fail(h, MXV_ERR_INVALID_ARG, "kernel error word 0x%x", e);
 }
 
+// The handle has just launched `delta` vector steps (negative: a step that is being taken back).  Device-clock mode: the device word
+// follows through a one-thread kernel on the same stream — captured with the launch when a caller's hipGraph is being recorded.
+constexpr int64_t kClockInKernelEnvs = 65536;
+
+int clock_add(mxv_handle *h, int64_t delta) {
+    h->t += (uint64_t)delta;
+    if (h->dev_clock) MXV_HIP(h, launch_add_word(h->t_dev, (uint64_t)delta, h->stream));
+    return MXV_OK;
+}
+
 void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.state = h->state;
     a.elapsed = h->elapsed;
@@ -212,6 +224,10 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.base_seed = h->base_seed;
     a.action_seed = h->action_seed;
     a.t = h->t;
+    if (h->dev_clock) {  // the step index lives on the device (a caller's hipGraph replays this launch at other step indices)
+        a.t_dev = h->t_dev;
+        a.t = 0;
+    }
     a.b0 = h->bounds[0];
     a.b1 = h->bounds[1];
     a.max_steps = h->cfg.max_episode_steps;
@@ -247,10 +263,20 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
+    // device clock, batches of at most kClockInKernelEnvs envs (a few hundred workgroups: one returning atomic each is nothing; at
+    // 2^20 envs thousands of same-address atomics would cost more than the one-thread kernel they replace): the launch advances it
+    const bool self_clock = h->dev_clock && h->cfg.num_envs <= kClockInKernelEnvs && h->param_mode() == PM_DEFAULT;   // (step_kernel<..., CLOCK = true> exists for these)
+    if (self_clock) {
+        a.clock_out = h->t_dev;
+        a.clock_ticket = h->clock_ticket;
+    }
     MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
     h->state_injected = false;
-    h->t += 1;
-    return MXV_OK;
+    if (self_clock) {
+        h->t += 1;
+        return MXV_OK;
+    }
+    return clock_add(h, 1);
 }
 
 int parse_bounds(mxv_handle *h, const double *b, double *out) {
@@ -522,11 +548,13 @@ int mxv_create(const mxv_config *cfg, mxv_handle **out) {
     MXV_CREATE_HIP(hipMalloc((void **)&h->elapsed, n * sizeof(int32_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->episodes, n * sizeof(uint32_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->t_dev, sizeof(uint64_t)));
+    MXV_CREATE_HIP(hipMalloc((void **)&h->clock_ticket, sizeof(uint32_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->err, sizeof(int32_t)));
     MXV_CREATE_HIP(hipMemsetAsync(h->state, 0, n * h->S * sizeof(double), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->elapsed, 0, n * sizeof(int32_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->episodes, 0, n * sizeof(uint32_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->t_dev, 0, sizeof(uint64_t), h->stream));
+    MXV_CREATE_HIP(hipMemsetAsync(h->clock_ticket, 0, sizeof(uint32_t), h->stream));
     MXV_CREATE_HIP(hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
     if (cfg->env_id == MXV_CARTPOLE && (cfg->flags & MXV_FLAG_NO_AUTORESET)) {   // steps_beyond_terminated marks (cartpole.py:169-184)
         MXV_CREATE_HIP(hipMalloc((void **)&h->beyond, n));
@@ -549,7 +577,7 @@ int mxv_destroy(mxv_handle *h) {
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     if (h->fin_host) (void)hipHostFree(h->fin_host);
     if (h->fin_dev) (void)hipFree(h->fin_dev);
-    void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block,
+    void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->clock_ticket, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block,
                     h->beyond};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -566,6 +594,7 @@ int mxv_seed(mxv_handle *h, uint64_t base_seed, const uint64_t *per_env_seeds_ho
     h->base_seed = base_seed;
     h->t = 0;
     h->r = 0;
+    if (h->dev_clock) MXV_HIP(h, launch_set_word(h->t_dev, 0, h->stream));
     // a (re)seeded env starts its reset stream from the beginning: reset ordinals back to 0
     MXV_HIP(h, hipMemsetAsync(h->episodes, 0, (size_t)h->cfg.num_envs * sizeof(uint32_t), h->stream));
     if (per_env_seeds_host) {
@@ -657,7 +686,7 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     }
     MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
     h->state_injected = false;
-    h->t += (uint64_t)K;
+    if (int rc = clock_add(h, K)) return rc;
     if (h->snap_obs && !in_kernel) return copy_final_snapshot(h, K, per_step, obs, reward, term, trunc);
     return MXV_OK;
 }
@@ -695,8 +724,11 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         a.ep_length_out = (int32_t *)slice(a.ep_length_out, sizeof(int32_t), k);
         return launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch);
     };
-    if (mode == MXV_ROLLOUT_EAGER) {
-        for (int k = 0; k < K; ++k) MXV_HIP(h, launch_k(k, nullptr, h->t + (uint64_t)k));
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(h->stream, &capturing);   // inside a caller's capture: plain launches (they are being recorded already)
+    if (mode == MXV_ROLLOUT_EAGER || capturing != hipStreamCaptureStatusNone) {
+        for (int k = 0; k < K; ++k)
+            MXV_HIP(h, launch_k(k, h->dev_clock ? h->t_dev : nullptr, h->dev_clock ? (uint64_t)k : h->t + (uint64_t)k));
     } else {
         // The captured launches read the base step index from device memory (t_dev) and add their
         // own offset k, so one instantiated graph replays for any t.  Seeds, bounds and params are
@@ -720,11 +752,11 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
             MXV_HIP(h, ie);
             it = h->graphs.emplace(key, exec).first;
         }
-        MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
+        if (!h->dev_clock) MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
         MXV_HIP(h, hipGraphLaunch(it->second, h->stream));
     }
     h->state_injected = false;
-    h->t += (uint64_t)K;
+    if (int rc = clock_add(h, K)) return rc;
     if (h->snap_obs) return copy_final_snapshot(h, K, per_step, obs_dev, reward_dev, terminated_dev, truncated_dev);
     return MXV_OK;
 }
@@ -760,6 +792,10 @@ int mxv_sample_actions(mxv_handle *h, void *actions_out_dev) {
     a.env0 = (uint64_t)h->cfg.env_offset;
     a.action_seed = h->action_seed;
     a.t = h->t;
+    if (h->dev_clock) {
+        a.t_dev = h->t_dev;
+        a.t = 0;
+    }
     a.flags = h->cfg.flags;
     a.params_pe = h->params_pe;
     a.P = h->P;
@@ -820,7 +856,7 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
         if (truncated_host) std::memcpy(truncated_host, h->st_trunc, n);
         if (final_obs_host) std::memcpy(final_obs_host, h->st_final, n * h->O * sizeof(float));
         const int rc = take_block_error(h);
-        if (rc != MXV_OK) h->t -= 1;  // the reference raises before stepping anything further
+        if (rc != MXV_OK) (void)clock_add(h, -1);  // the reference raises before stepping anything further
         return rc;
     }
     // the packed final rows go first: their DMAs target pinned memory and are truly asynchronous, the copies into the caller's
@@ -839,7 +875,7 @@ int mxv_step_host(mxv_handle *h, const void *actions_host, float *obs_host, void
     if (!packed && final_obs_host)
         MXV_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * h->O * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     int rc = check_latched(h);  // synchronises
-    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
+    if (rc == MXV_ERR_INVALID_ACTION) (void)clock_add(h, -1);  // the reference raises before stepping anything further
     if (rc == MXV_OK && packed)                   // packed rows of the finished envs: left packed (mxv_final_packed_view) or scattered
         rc = finish_final_rows(h, first, h->fin_packed ? nullptr : final_obs_host);
     return rc;
@@ -919,7 +955,7 @@ int mxv_step_host_block(mxv_handle *h, const void *actions_host, void *block_hos
         rc = check_latched(h);  // synchronises
         if (rc == MXV_OK && packed) rc = finish_final_rows(h, first, nullptr);
     }
-    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;  // the reference raises before stepping anything further
+    if (rc == MXV_ERR_INVALID_ACTION) (void)clock_add(h, -1);  // the reference raises before stepping anything further
     return rc;
 }
 
@@ -960,7 +996,7 @@ int mapped_finish(mxv_handle *h, bool stepped) {
         MXV_HIP(h, hipStreamSynchronize(h->stream));
     }
     const int rc = take_block_error(h);
-    if (rc != MXV_OK && stepped) h->t -= 1;  // the reference raises before stepping anything further
+    if (rc != MXV_OK && stepped) (void)clock_add(h, -1);  // the reference raises before stepping anything further
     return rc;
 }
 
@@ -1057,6 +1093,11 @@ int mxv_last_launch(mxv_handle *h, mxv_launch_info *out) {
 
 int mxv_get_counters(mxv_handle *h, uint64_t *t, uint32_t *r) {
     MXV_CHECK_HANDLE(h);
+    if (h->dev_clock) {  // graphs the caller replays advance the device word only: read it (synchronises the handle's stream)
+        if (int rc = use_device(h)) return rc;
+        MXV_HIP(h, hipMemcpyAsync(&h->t, h->t_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+    }
     if (t) *t = h->t;
     if (r) *r = h->r;
     return MXV_OK;
@@ -1066,6 +1107,24 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
     MXV_CHECK_HANDLE(h);
     h->t = t;
     h->r = r;
+    if (h->dev_clock) {
+        if (int rc = use_device(h)) return rc;
+        MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
+    }
+    return MXV_OK;
+}
+
+int mxv_set_device_clock(mxv_handle *h, int32_t on) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (on && !h->dev_clock) {
+        MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
+        h->dev_clock = true;
+    } else if (!on && h->dev_clock) {
+        MXV_HIP(h, hipMemcpyAsync(&h->t, h->t_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        MXV_HIP(h, hipStreamSynchronize(h->stream));
+        h->dev_clock = false;
+    }
     return MXV_OK;
 }
 
@@ -1392,11 +1451,11 @@ extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int3
     for (int i = 0; i < count; ++i) {
         mxv_handle *h = handles[i];
         h->state_injected = false;
-        h->t += (uint64_t)K;
         if (i > 0 && h->stream != h0->stream) {
             MXV_HIP(h0, hipEventRecord(h->ev_mixed, h0->stream));
             MXV_HIP(h0, hipStreamWaitEvent(h->stream, h->ev_mixed, 0));
         }
+        if (int rc = clock_add(h, K)) return rc;   // (device-clock mode: on the segment's own stream, behind the launch)
     }
     return MXV_OK;
 }

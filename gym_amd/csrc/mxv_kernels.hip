@@ -108,7 +108,10 @@ __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned n
 //                   Philox action words are transposed through LDS (one call = 4 consecutive envs).
 //   CONSEC = true : lane owns the E consecutive envs tile0 + tid*E + j: a Philox action group is
 //                   lane-private (no LDS, no barrier) and the flag bytes of a lane are contiguous.
-template <int ENV, int DEF, int E, bool CONSEC, bool MULTI>
+//   CLOCK = true  : the launch advances the device clock itself (single steps with default parameters of a handle in device-clock mode,
+//                   small grids).  An instantiation of its own: as a run-time branch at the exit of the one kernel it cost every
+//                   launch 1.1 us per 2^20-env step (18.6 -> 19.8, profiles/r4q_step_clock_tail_ab.txt).
+template <int ENV, int DEF, int E, bool CONSEC, bool MULTI, bool CLOCK = false>
 __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -351,6 +354,18 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         a.elapsed[e] = el[j];
         if (ep[j] != ep_in[j]) a.episodes[e] = ep[j];
         if (a.ep_acc) a.ep_acc[e] = er[j];
+    }
+    // ---- device clock (mxv_set_device_clock, small grids): the LAST workgroup to get here advances the step index, so that a launch
+    // recorded in a caller's hipGraph needs no second kernel behind it.  Every workgroup read *t_dev before it took its ticket, and
+    // the next launch of the stream starts after this one has finished.
+    if constexpr (CLOCK) {
+        if (tid == 0) {
+            const uint32_t ticket = atomicAdd(a.clock_ticket, 1u);
+            if (ticket == gridDim.x - 1) {
+                *a.clock_ticket = 0u;
+                *a.clock_out = t0 - a.t + (uint64_t)a.K;
+            }
+        }
     }
 }
 
@@ -925,6 +940,7 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const SampleArgs a) {
 }
 
 __global__ void set_word_kernel(uint64_t *dst, uint64_t value) { *dst = value; }
+__global__ void add_word_kernel(uint64_t *dst, uint64_t delta) { *dst += delta; }
 
 // info["final_observation"] for a host caller: of the dense [N][O] final_obs rows only those of the envs that finished this step
 // (terminated | truncated: ~5 % of a random-policy CartPole batch) are meaningful.  Instead of sending the whole array over PCIe
@@ -1083,7 +1099,9 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
         else
             hipLaunchKernelGGL((step_kernel<ENV, PM_PER_ENV, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
     } else {
-        if (pm == PM_DEFAULT)
+        if (pm == PM_DEFAULT && a.clock_ticket != nullptr)
+            hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, false, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+        else if (pm == PM_DEFAULT)
             hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
         else if (pm == PM_BROADCAST)
             hipLaunchKernelGGL((step_kernel<ENV, PM_BROADCAST, E, C, false>), dim3(grid), dim3(kBlock), 0, stream, a);
@@ -1260,6 +1278,11 @@ hipError_t launch_write_probe_env(int env_id, int flags, float *obs, void *rew, 
 
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream) {
     hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, stream, dst, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_word(uint64_t *dst, uint64_t delta, hipStream_t stream) {
+    hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, stream, dst, delta);
     return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@ struct StepArgs {
     float *final_obs;      // [N][O], rows of finished envs only; may be nullptr
     const uint64_t *seeds; // per-env seeds or nullptr (base_seed + global index)
     const uint64_t *t_dev; // optional device-resident base step index (hipGraph replay)
+    uint64_t *clock_out;   // device clock advanced by the launch itself (step_kernel, small grids): = t_dev, with clock_ticket; or nullptr
+    uint32_t *clock_ticket; // workgroups that have finished (zero between launches)
     int32_t *err;          // latched error word (bit 0: invalid discrete action)
     int64_t n;             // local envs
     uint64_t env0;         // global index of local env 0
@@ -231,5 +233,6 @@ hipError_t launch_write_probe(float *obs, double *rew, int64_t *act, uint8_t *te
 hipError_t launch_write_probe_env(int env_id, int flags, float *obs, void *rew, void *act, uint8_t *term, uint8_t *trunc, int64_t n, int K,
                                   hipStream_t stream);
 hipError_t launch_set_word(uint64_t *dst, uint64_t value, hipStream_t stream);
+hipError_t launch_add_word(uint64_t *dst, uint64_t delta, hipStream_t stream);   // *dst += delta (two's complement: a negative delta subtracts)
 
 }  // namespace mxv

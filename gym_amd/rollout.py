@@ -106,6 +106,25 @@ class DeviceRollout:
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
         return self._last
 
+    def enable_graph_capture(self, on: bool = True):
+        """Make this engine's calls recordable into a hipGraph of the CALLER's (torch.cuda.graph, hipStreamBeginCapture): the vector-step
+        index moves into device memory and advances on the stream (mxv_set_device_clock), so that a replayed graph continues the
+        action / noise streams where single calls would instead of repeating its capture-time step.  Typical use — a policy in the
+        loop at a batch size where launches, not kernels, bound the loop:
+
+            r.enable_graph_capture()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(r.stream):
+                step_once()                                   # warm-up outside the capture (allocations, lazy initialisation)
+                with torch.cuda.graph(g, stream=r.stream):
+                    for _ in range(32):
+                        r.step(policy(r.obs))                 # r.obs / r.reward / ... are the engine's own (static) tensors
+            for _ in range(1000):
+                g.replay()                                    # 32 000 vector steps, 1 000 host calls
+
+        synchronize() / get_counters() still work (outside captures); turning it off reads the index back."""
+        self.handle.set_device_clock(on)
+
     def step_sampled(self, want_final: bool = False, record_actions: bool = True):
         """One vector step with actions drawn on device (action_space.sample())."""
         self._attach_episode_outputs(None)

@@ -289,6 +289,17 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
  * mxv_set_counters when resuming. */
 int mxv_get_counters(mxv_handle *h, uint64_t *t, uint32_t *r);
 int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r);
+/* Device clock: the vector-step index (counter of the action and step-noise streams) normally travels to every launch as a kernel
+ * argument, which a hipGraph would freeze at its capture-time value.  With the device clock on, every launch of this handle reads the
+ * index from a device word and a one-thread kernel behind it advances the word — both are ordinary stream work, so a caller may
+ * RECORD calls of this handle into its own hipGraph (hipStreamBeginCapture / torch.cuda.graph on the handle's stream, or on a stream
+ * the handle's stream is joined to) — mxv_step with a policy in between, mxv_step_sampled, mxv_rollout, mxv_rollout_tape — and replay
+ * the graph any number of times: the replays continue the streams exactly where single calls would (tests/test_gpu_graph_capture.py:
+ * replayed graphs == the same calls made one by one, bit for bit, including Acrobot's step-indexed torque noise).  The host's copy of
+ * the index is refreshed from the device by mxv_get_counters (which then synchronises the stream).  on = 0 reads the index back and
+ * returns to argument passing.  Calls that synchronise or copy to the host (the *_host calls, mxv_sync, mxv_get_state) cannot be
+ * captured, as with any stream. */
+int mxv_set_device_clock(mxv_handle *h, int32_t on);
 /* per-env reset ordinals (position of each env's reset stream, see RNG contract): uint32[N].  Synchronises. */
 int mxv_get_episodes(mxv_handle *h, uint32_t *episodes_host);
 int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host);

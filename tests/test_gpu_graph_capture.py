@@ -1,0 +1,127 @@
+"""A caller's hipGraph around the engine (mxv_set_device_clock, DeviceRollout.enable_graph_capture): the learner-in-the-loop path
+(SyncVectorEnv.step with a policy between the steps, gym/vector/sync_vector_env.py:131-169) recorded ONCE with torch.cuda.graph —
+policy kernels and env steps together — and replayed.  A replayed graph must continue every Philox stream where single calls would:
+the step index travels in device memory, not as a capture-time kernel argument.  Held against the same calls made one by one, bit for
+bit, for the env kinds whose step reads the index (sampled actions: all; step(actions): Acrobot with torque noise) and for CartPole
+with a policy in the loop."""
+import numpy as np
+import pytest
+
+from helpers import ENV_IDS, GYM_IDS, LIMITS
+
+pytestmark = pytest.mark.gpu
+
+
+def _policy(torch, obs, W):
+    return (obs @ W).argmax(dim=1)
+
+
+def _run(kind, n, per_graph, replays, captured, noise=0.0, sampled=False):
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout(GYM_IDS[kind], n, seed=3, action_seed=4, max_episode_steps=min(LIMITS[kind], 60))
+    if noise:
+        p = r.handle.get_params()
+        p[10] = noise
+        r.handle.set_params(p)
+    r.reset(seed=3)
+    dev = r.device
+    torch.manual_seed(0)
+    W = torch.randn(r.O, max(r.NA, 2), device=dev)
+    steps = per_graph * replays
+    log = {k: [] for k in ("obs", "reward", "terminated", "truncated", "actions")}
+
+    def one():
+        if sampled:
+            r.step_sampled(record_actions=True)
+            acts = r.actions
+        else:
+            acts = _policy(torch, r.obs, W).to(r.action_dtype)
+            r.step(acts)
+        return acts
+
+    with torch.cuda.stream(r.stream):
+        if captured:
+            r.enable_graph_capture()
+            # static logs: every step of the graph writes its own row
+            bufs = {"obs": torch.empty((per_graph, n, r.O), device=dev), "reward": torch.empty((per_graph, n), dtype=torch.float64, device=dev),
+                    "terminated": torch.empty((per_graph, n), dtype=torch.uint8, device=dev), "truncated": torch.empty((per_graph, n), dtype=torch.uint8, device=dev),
+                    "actions": torch.empty((per_graph, n), dtype=r.action_dtype, device=dev)}
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=r.stream):
+                for k in range(per_graph):
+                    a = one()
+                    bufs["obs"][k].copy_(r.obs); bufs["reward"][k].copy_(r.reward); bufs["terminated"][k].copy_(r.terminated)
+                    bufs["truncated"][k].copy_(r.truncated); bufs["actions"][k].copy_(a.reshape(n))
+            for _ in range(replays):
+                g.replay()
+                for k in log:
+                    log[k].append(bufs[k].clone())
+            out = {k: torch.cat(v) for k, v in log.items()}
+        else:
+            for _ in range(steps):
+                a = one()
+                for k, v in (("obs", r.obs), ("reward", r.reward), ("terminated", r.terminated), ("truncated", r.truncated), ("actions", a.reshape(n))):
+                    log[k].append(v.clone())
+            out = {k: torch.stack(v) for k, v in log.items()}
+    r.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items()}
+    res["state"] = r.handle.get_state()
+    res["t"] = r.handle.get_counters()[0]
+    res["episodes"] = r.handle.get_episodes()
+    r.close()
+    return res
+
+
+@pytest.mark.parametrize("kind,noise,sampled", [("CartPole", 0.0, False), ("Acrobot", 0.4, False), ("CartPole", 0.0, True), ("Pendulum", 0.0, True),
+                                                ("MountainCar", 0.0, True)])
+def test_replayed_graph_equals_single_calls(kind, noise, sampled):
+    n, per_graph, replays = 4096, 8, 12
+    a = _run(kind, n, per_graph, replays, captured=False, noise=noise, sampled=sampled)
+    b = _run(kind, n, per_graph, replays, captured=True, noise=noise, sampled=sampled)
+    assert a["t"] == b["t"] == per_graph * replays          # the device clock, read back through mxv_get_counters
+    for k in ("obs", "reward", "terminated", "truncated", "actions"):
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (kind, k)
+    assert np.array_equal(a["state"][0], b["state"][0]) and np.array_equal(a["state"][1], b["state"][1])
+    assert np.array_equal(a["episodes"], b["episodes"])
+    assert int((a["terminated"] | a["truncated"]).sum()) > 0
+    if sampled:
+        assert len(np.unique(a["actions"][:8], axis=0)) > 1     # the sampled actions change from step to step (the clock runs)
+
+
+def test_device_clock_round_trips_and_fused_rollouts_follow_it():
+    """Clock on -> calls -> off: the host index picks up where the device left it; fused, eager and internal-graph rollouts and a
+    seed() in between behave as without the clock."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    runs = []
+    for clock in (False, True):
+        r = DeviceRollout("CartPole-v1", 2048, seed=9, action_seed=10)
+        r.reset(seed=9)
+        if clock:
+            r.enable_graph_capture()
+        seq = []
+        for mode in ("fused", "eager", "graph", "fused"):
+            r.rollout(5, mode=mode, record_actions=True)
+            r.synchronize()
+            seq.append((r.obs.cpu().numpy().copy(), r.actions.cpu().numpy().copy()))
+        assert r.handle.get_counters()[0] == 20
+        r.handle.set_counters(100, 0)
+        r.step_sampled()
+        r.synchronize()
+        seq.append((r.obs.cpu().numpy().copy(), r.actions.cpu().numpy().copy()))
+        assert r.handle.get_counters()[0] == 101
+        if clock:
+            r.enable_graph_capture(False)
+            assert r.handle.get_counters()[0] == 101
+        r.step_sampled()
+        r.synchronize()
+        seq.append((r.obs.cpu().numpy().copy(), r.actions.cpu().numpy().copy()))
+        r.handle.seed(9)
+        assert r.handle.get_counters()[0] == 0
+        runs.append(seq)
+        r.close()
+    for (o1, a1), (o2, a2) in zip(*runs):
+        assert np.array_equal(o1, o2) and np.array_equal(a1, a2)
