@@ -1045,10 +1045,10 @@ def main():
                 "one_engine": measure_step_loop(torch, ENVS_TOTAL),
                 "one_engine_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True),
                 "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
-                "kernel": measure_step_kernel(torch, ENVS_TOTAL),
-                "policy_loop_4096_envs": measure_policy_loop(torch, 4096)})
+                "kernel": measure_step_kernel(torch, ENVS_TOTAL)})
             variant("numpy_loop", lambda: {"num_envs_2^20": measure_numpy_loop(ENVS_TOTAL, 60),
                                            "configs0_num_envs_8": measure_numpy_loop(8, 1000)})    # BASELINE.json configs[0]: the plumbing case
+            variant("policy_loop_4096_envs", lambda: measure_policy_loop(torch, 4096))   # last: records a hipGraph
             out["variants"] = v
         print(json.dumps(out), file=json_out, flush=True)
 

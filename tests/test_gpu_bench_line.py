@@ -98,6 +98,6 @@ def test_line_carries_what_the_review_asked_for(line):
     assert sl["one_engine"]["roofline"]["algorithmic_bytes_per_env_step"] == 66
     assert sl["one_engine"]["roofline"]["frac"] > 0.38        # round 2's loop: 0.34 (a cross-stream wait per step), kernel 0.44
     assert sl["one_engine_compact"]["value"] >= 0.97 * sl["one_engine"]["value"]
-    pl = sl["policy_loop_4096_envs"]                          # the launch-bound regime: the loop recorded once in a caller's hipGraph
+    pl = v["policy_loop_4096_envs"]                          # the launch-bound regime: the loop recorded once in a caller's hipGraph
     assert pl["recorded_in_a_hipgraph"]["us_per_step"] < pl["one_call_per_step"]["us_per_step"] and pl["speedup"] > 1.3
     assert min(pl["episodes_ended"]) > 0
