@@ -125,6 +125,34 @@ class DeviceRollout:
         synchronize() / get_counters() still work (outside captures); turning it off reads the index back."""
         self.handle.set_device_clock(on)
 
+    def graphed_loop(self, policy, steps_per_graph: int = 32, *, warmup: int = 3, on_step=None):
+        """`steps_per_graph` iterations of  actions = policy(self.obs); self.step(actions)  recorded once into a hipGraph and returned
+        as a torch.cuda.CUDAGraph: every `.replay()` advances the vector env by that many steps with one host call.  `policy` maps the
+        engine's observation tensor [N, O] to an action tensor of the engine's dtype/shape using torch ops only (no host
+        synchronisation, no data-dependent Python control flow: the rules of torch.cuda.graph); `on_step(k)` (optional) runs after
+        step k inside the recording — e.g. to copy self.obs / self.reward / ... into the k-th row of the caller's own static
+        trajectory tensors.  Everything is recorded on the engine's stream; call self.ready() (or synchronize()) before reading
+        results on another stream."""
+        self.enable_graph_capture()
+
+        def one(k):
+            a = policy(self.obs)
+            if a.dtype != self.action_dtype:
+                a = a.to(self.action_dtype)
+            self.step(a.contiguous(), want_final=False)
+            if on_step is not None:
+                on_step(k)
+
+        with torch.cuda.stream(self.stream):
+            for k in range(warmup):                          # lazy initialisation and the caching allocator's first blocks stay outside
+                one(k % steps_per_graph)
+            self.stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                for k in range(steps_per_graph):
+                    one(k)
+        return g
+
     def step_sampled(self, want_final: bool = False, record_actions: bool = True):
         """One vector step with actions drawn on device (action_space.sample())."""
         self._attach_episode_outputs(None)

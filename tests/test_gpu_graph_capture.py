@@ -125,3 +125,45 @@ def test_device_clock_round_trips_and_fused_rollouts_follow_it():
         r.close()
     for (o1, a1), (o2, a2) in zip(*runs):
         assert np.array_equal(o1, o2) and np.array_equal(a1, a2)
+
+
+def test_graphed_loop_helper_records_a_trajectory():
+    """DeviceRollout.graphed_loop: policy + step recorded once; the on_step hook fills the caller's static [K, N] tensors; three
+    replays == 3 K single calls (the warm-up steps of the helper included in both)."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    n, K = 2048, 16
+    torch.manual_seed(1)
+    W = torch.randn(4, 2, device="cuda")
+    policy = lambda obs: (obs @ W).argmax(dim=1)   # noqa: E731
+
+    a = DeviceRollout("CartPole-v1", n, seed=11, action_seed=12, max_episode_steps=20)   # (this policy balances: let TimeLimit end episodes)
+    a.reset(seed=11)
+    traj = {"obs": torch.empty((K, n, 4), device="cuda"), "done": torch.empty((K, n), dtype=torch.uint8, device="cuda")}
+
+    def record(k):
+        traj["obs"][k].copy_(a.obs)
+        torch.bitwise_or(a.terminated, a.truncated, out=traj["done"][k])
+
+    g = a.graphed_loop(policy, K, warmup=3, on_step=record)
+    got = []
+    for _ in range(3):
+        g.replay()
+        a.synchronize()
+        got.append((traj["obs"].cpu().numpy().copy(), traj["done"].cpu().numpy().copy()))
+    assert a.handle.get_counters()[0] == 3 + 3 * K
+
+    b = DeviceRollout("CartPole-v1", n, seed=11, action_seed=12, max_episode_steps=20)
+    b.reset(seed=11)
+    with torch.cuda.stream(b.stream):
+        for _ in range(3):
+            b.step(policy(b.obs))
+        for rep in range(3):
+            for k in range(K):
+                b.step(policy(b.obs))
+                b.stream.synchronize()
+                assert np.array_equal(got[rep][0][k], b.obs.cpu().numpy()), (rep, k)
+                assert np.array_equal(got[rep][1][k], (b.terminated | b.truncated).cpu().numpy()), (rep, k)
+    assert sum(int(d.sum()) for _, d in got) > 0
+    a.close(), b.close()
