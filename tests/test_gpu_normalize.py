@@ -133,7 +133,7 @@ def test_one_call_forms_chunking_and_float32_output(name):
         h.close()
 
 
-@pytest.mark.parametrize("n,T", [(96, 60), (70_000, 14)])
+@pytest.mark.parametrize("n,T", [(96, 60), (70_000, 14), (70_003, 14), (1022, 14)])   # whole + ragged leaves; n % 4 != 0 (element-wise loads), n % 4 == 2
 @pytest.mark.parametrize("name", ["CartPole", "Pendulum"])
 def test_wrappers_on_hip_vector_env(name, n, T):
     """gym_amd.wrappers.NormalizeReward(NormalizeObservation(HipVectorEnv)) — the reference's stacking — against the
