@@ -343,6 +343,31 @@ def measure_normalize(torch, envs, chunk, reps=6):
                                  kernels="mxv_norm.hip: obs sums (read 4 O) + scan + apply (read 4 O, write 4 O float32)"),
            "normalize_reward": _hbm(_event_us(torch, s, lambda: nr.rewards(chunk, tr["reward"], False, tr["terminated"], tr["truncated"], o64, 0.99, 1e-8),
                                               reps, chunk), envs, 26, kernels="mxv_norm.hip: discounted-return sums (read 8 + 2) + scan + apply (read 8, write 8)")}
+    # the batch moments formed by the rollout itself (mxv_set_obs_partials): what NormalizeObservation then costs ON TOP of the rollout
+    try:
+        trp = dr.trajectory_buffers(chunk, layout="separate", obs_partials=True)
+        plain = {k: t for k, t in trp.items() if k != "obs_partials"}
+        nf = _native.Norm(O, envs, stream=s.cuda_stream)
+        r0 = _event_us(torch, s, lambda: dr.rollout_per_step(chunk, out=plain), reps, chunk)
+        r1 = _event_us(torch, s, lambda: dr.rollout_per_step(chunk, out=trp), reps, chunk)
+        sums = torch.empty((chunk, 2 * O), dtype=torch.float64, device=dr.device)
+
+        def fused():
+            nf.obs_sums_partials(chunk, trp["obs_partials"], trp["obs_partials"].shape[1], sums)
+            nf.obs_apply(chunk, trp["obs"], y32, True, 1e-8, sums.unsqueeze(0), 1, envs)
+
+        nfu = _event_us(torch, s, fused, reps, chunk)
+        inc = nfu + (r1 - r0)
+        b = 8 * O + 2 * 16 * O * trp["obs_partials"].shape[1] / envs   # apply: read 4 O + write 4 O; partials: 2 O doubles per tile, written + read
+        out["normalize_obs_fused_moments"] = dict(_hbm(inc, envs, b, kernels="rollout_kernel_v3<..., STATS> writes per-tile column sums; mxv_norm.hip: tree over the "
+                                                                              "partials + scan + apply (read 4 O, write 4 O float32); no pass reads the observations back"),
+                                                  rollout_us_per_step=r0, rollout_with_partials_us_per_step=r1, normalize_from_partials_us_per_step=nfu,
+                                                  separate_us_per_step=out["normalize_obs"]["us_per_step"],
+                                                  note="us_per_step = what normalisation adds to the rollout: (rollout with partials - rollout) + tree + scan + apply")
+        nf.close()
+        del trp, plain, sums
+    except Exception as e:  # noqa: BLE001
+        out["normalize_obs_fused_moments"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     no.close(), nr.close(), dr.close()
     del tr, y32, o64
     torch.cuda.empty_cache()

@@ -75,6 +75,7 @@ struct mxv_handle {
     uint32_t *episodes = nullptr;  // [N] resets of each env since seeding = index of its next draw from the reset stream
     uint64_t *seeds = nullptr;  // optional per-env seeds
     uint64_t *t_dev = nullptr;  // device-resident step index for graph replay
+    double *obs_part = nullptr;        // mxv_set_obs_partials: where trajectory launches leave the observations' column sums (caller's memory)
     uint32_t *clock_ticket = nullptr;  // finished-workgroup counter of launches that advance the device clock themselves
     bool dev_clock = false;     // mxv_set_device_clock: every launch reads the step index from t_dev and a one-thread kernel advances it
     int32_t *err = nullptr;     // latched kernel error word
@@ -677,6 +678,13 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
+    if (h->obs_part && per_step && !actions_tape) {  // fused batch moments of NormalizeObservation (mxv_set_obs_partials)
+        a.obs_part = h->obs_part;
+        if (!launch_step_supports_stats(h->cfg.env_id, h->param_mode(), a))
+            return fail(h, MXV_ERR_UNSUPPORTED, "observation partial sums are attached (mxv_set_obs_partials), but this launch cannot produce them: they "
+                                                "exist for sampled [K][N] trajectory launches (K >= 2) with every per-step output, default physics "
+                                                "parameters, autoreset and a state the engine produced itself; detach (NULL) and use mxv_norm_obs_sums");
+    }
     const bool in_kernel = h->snap_obs && launch_step_is_rollout(h->param_mode(), a);
     if (in_kernel) {
         a.snap_obs = h->snap_obs;
@@ -1111,6 +1119,21 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
         if (int rc = use_device(h)) return rc;
         MXV_HIP(h, launch_set_word(h->t_dev, h->t, h->stream));
     }
+    return MXV_OK;
+}
+
+int mxv_set_obs_partials(mxv_handle *h, double *partials_dev) {
+    MXV_CHECK_HANDLE(h);
+    h->obs_part = partials_dev;
+    return MXV_OK;
+}
+
+int mxv_obs_partials_layout(mxv_handle *h, int64_t *leaves, int64_t *envs_per_leaf, int32_t *values) {
+    MXV_CHECK_HANDLE(h);
+    const int64_t per = stats_leaf_envs(h->cfg.env_id);
+    if (leaves) *leaves = (h->cfg.num_envs + per - 1) / per;
+    if (envs_per_leaf) *envs_per_leaf = per;
+    if (values) *values = 2 * h->O;
     return MXV_OK;
 }
 

@@ -416,6 +416,69 @@ constexpr int rollout_min_waves() {
     return (!DEF || (ENV == MXV_CARTPOLE && SAFE)) ? 1 : 4;
 }
 
+// ---- wave-level sums of V values per lane (the fused batch moments of NormalizeObservation, STATS launches) ------------------------
+// V per-lane doubles -> V wave totals in one pass of a fixed binary tree over the lane index.  Bits 0, 1 (and 3 for V = 8) HALVE the
+// value set: a lane and its partner split the values between them — each keeps the half whose index bit equals its lane bit and adds
+// the partner's copy of that half — so after log2(V) stages every lane holds ONE value, the sum over its 2^log2(V) partners; the
+// remaining lane bits (2, 4, 5; and 3 for V = 4) are plain butterfly stages.  V + V/2 + ... additions instead of 6 V, and the tree is
+// the same for every launch shape: totals are bit-reproducible and do not depend on how a vector env is sharded.
+template <int CTRL>
+__device__ __forceinline__ double stat_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double stat_xor4(double v) {  // lane ^ 4 through the swizzle crossbar (bit-mask mode: and 0x1f, or 0, xor 4)
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int N>
+__device__ __forceinline__ void stat_halve(double (&v)[N], bool bit) {  // N values -> N / 2 in v[0 .. N/2)
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) {
+        const double lo = v[2 * p], hi = v[2 * p + 1];
+        v[p] = (bit ? hi : lo) + stat_dpp<CTRL>(bit ? lo : hi);
+    }
+}
+// returns the lane's total; the total of value i sits in the lanes with (lane & 3) | (lane >> 3 & 1) << 2 == i (V = 8) resp. (lane & 3) == i
+template <int V>
+__device__ __forceinline__ double wave_sums(double (&v)[V], uint32_t lane) {
+    static_assert(V == 4 || V == 8, "batches of 4 or 8 values");
+    stat_halve<0xB1, V>(v, (lane & 1u) != 0);             // quad_perm [1, 0, 3, 2]
+    if constexpr (V == 8) {
+        double w[4] = {v[0], v[1], v[2], v[3]};
+        stat_halve<0x4E, 4>(w, (lane & 2u) != 0);         // quad_perm [2, 3, 0, 1]
+        double u[2] = {w[0], w[1]};
+        stat_halve<0x128, 2>(u, (lane & 8u) != 0);        // row_ror:8 = lane ^ 8
+        v[0] = u[0];
+    } else {
+        double w[2] = {v[0], v[1]};
+        stat_halve<0x4E, 2>(w, (lane & 2u) != 0);
+        v[0] = w[0] + stat_dpp<0x128>(w[0]);              // lane ^ 8
+    }
+    double x = v[0];
+    x += stat_xor4(x);
+    {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return x;
+}
+// One batch: `count` (<= V) values summed over the wave, value i stored to dst[i] by the lane that holds it.
+template <int V>
+__device__ __forceinline__ void wave_sums_store(double (&v)[V], uint32_t lane, double *dst, int count) {
+    const double x = wave_sums<V>(v, lane);
+    const uint32_t idx = V == 8 ? ((lane & 3u) | ((lane >> 1) & 4u)) : (lane & 3u);
+    const bool holder = V == 8 ? (lane & 0x34u) == 0 : (lane & 0x3Cu) == 0;
+    if (holder && (int)idx < count) dst[idx] = x;
+}
+
 // LDS of one rollout workgroup (= one wave): the ring of action words and the lane-private reset entries.
 template <int ENV, int E>
 struct RolloutLds {
@@ -428,7 +491,7 @@ struct RolloutLds {
 
 // The kernel body as a device function of (arguments, workgroup index, workgroups of this segment, LDS): rollout_kernel_v3 runs
 // it for one homogeneous vector env, mixed_rollout_kernel for the segment a workgroup belongs to.
-template <int ENV, bool DEF, int E, bool SAFE, int OUT, bool TAPE = false>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT, bool TAPE = false, bool STATS = false>
 __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigned bid, const unsigned nblk, RolloutLds<ENV, E> &lds) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -559,6 +622,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
     char *p_term = reinterpret_cast<char *>(a.terminated);
     char *p_trunc = reinterpret_cast<char *>(a.truncated);
     char *p_fin = FULL ? nullptr : reinterpret_cast<char *>(a.final_obs);
+    [[maybe_unused]] double *p_part = STATS ? a.obs_part + (int64_t)tile * (2 * O) : nullptr;   // [K][tiles][2 O], tile = leaf index
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
     uint32_t lo[E];  // index of the lane's env slot inside one step's slice of every output array
@@ -739,6 +803,48 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 #pragma unroll
         for (int j = 0; j < E; ++j)
             if (ALLV || valid[j]) store_obs_at<O>(p_obs, pin32(lo[j] * (uint32_t)(O * sizeof(float))), obs[j]);
+        // ---- STATS: this tile's column sums and sums of squares of the observations just stored (NormalizeObservation's batch
+        //      moments, gym/wrappers/normalize.py:17-29, as partials [K][tiles][2 O] for mxv_norm's tree) — the pass that would read
+        //      them back from HBM is not launched
+        if constexpr (STATS) {
+            double sm[O], sq[O];
+#pragma unroll
+            for (int k = 0; k < O; ++k) sm[k] = sq[k] = 0.0;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    const double x = (ALLV || valid[j]) ? (double)obs[j][k] : 0.0;
+                    sm[k] += x;
+                    sq[k] = __fma_rn(x, x, sq[k]);  // x * x is exact in fp64
+                }
+            }
+            if constexpr (2 * O <= 8) {
+                constexpr int V = 2 * O <= 4 ? 4 : 8;
+                double v[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) v[k] = 0.0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    v[k] = sm[k];
+                    v[O + k] = sq[k];
+                }
+                wave_sums_store<V>(v, (uint32_t)lane, p_part, 2 * O);
+            } else {
+                static_assert(O <= 8, "two batches of at most 8 values");
+                double v[8], w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = w[k] = 0.0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    v[k] = sm[k];
+                    w[k] = sq[k];
+                }
+                wave_sums_store<8>(v, (uint32_t)lane, p_part, O);
+                wave_sums_store<8>(w, (uint32_t)lane, p_part + O, O);
+            }
+            p_part += (int64_t)nblk * (2 * O);
+        }
         // ---- the chunk's FINAL tensors once more, into the caller's snapshot (what a sharded vector env all-gathers while the
         //      next chunk runs: written here, no copy kernels between rollout and gather) ----
         if (step + 1 == a.K && a.snap_obs != nullptr) {
@@ -834,12 +940,12 @@ constexpr int rollout_max_waves() {
     return rollout_min_waves<ENV, DEF, SAFE>() == 1 ? 8 : rollout_min_waves<ENV, DEF, SAFE>();
 }
 
-template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, bool TAPE = false>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, bool TAPE = false, bool STATS = false>
 __global__ void __launch_bounds__(kWave)
     __attribute__((amdgpu_waves_per_eu(rollout_min_waves<ENV, DEF, SAFE>(), rollout_max_waves<ENV, DEF, SAFE>())))
     rollout_kernel_v3(const StepArgs a) {
     __shared__ RolloutLds<ENV, E> lds;
-    rollout_body_v3<ENV, DEF, E, SAFE, OUT, TAPE>(a, blockIdx.x, gridDim.x, lds);
+    rollout_body_v3<ENV, DEF, E, SAFE, OUT, TAPE, STATS>(a, blockIdx.x, gridDim.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1020,7 +1126,7 @@ __global__ void __launch_bounds__(kBlock) final_pack_kernel(const CompactArgs a)
     }
 }
 
-template <int ENV, bool DEF, int ER, bool SAFE, int OUT, bool TAPE = false>
+template <int ENV, bool DEF, int ER, bool SAFE, int OUT, bool TAPE = false, bool STATS = false>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a, LaunchInfo *info) {
     if (info) *info = LaunchInfo{1, ENV, DEF ? PM_DEFAULT : PM_BROADCAST, ER, SAFE ? 1 : 0, OUT, TAPE ? 1 : 0, a.K, grid, (uint32_t)kWave};
     // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
@@ -1028,7 +1134,7 @@ void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a, La
     // them fill the CU's 160 KiB and a 17th does not fit.
     constexpr size_t kLdsPerWorkgroup = 9728, kStatic = sizeof(RolloutLds<ENV, ER>);
     const size_t pad = (rollout_min_waves<ENV, DEF, SAFE>() == 4 && kStatic < kLdsPerWorkgroup) ? kLdsPerWorkgroup - kStatic : 0;
-    hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT, TAPE>), dim3(grid), dim3(kWave), pad, stream, a);
+    hipLaunchKernelGGL((rollout_kernel_v3<ENV, DEF, ER, SAFE, OUT, TAPE, STATS>), dim3(grid), dim3(kWave), pad, stream, a);
 }
 template <int ENV, bool DEF, int ER, bool SAFE>
 void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a, LaunchInfo *info) {
@@ -1044,6 +1150,10 @@ void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a, Launch
         if (tape) {  // (tapes exist for default parameters only, launch_step_is_rollout; the compact dtypes take the generic body)
             if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, true>(grid, stream, a, info);
             return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a, info);
+        }
+        if constexpr (!SAFE && ER == rollout_envs_per_lane(ENV)) {   // STATS instantiations: launch_step_supports_stats
+            if (a.obs_part != nullptr && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, true>(grid, stream, a, info);
+            if (a.obs_part != nullptr && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, true>(grid, stream, a, info);
         }
         if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a, info);
         if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a, info);
@@ -1080,7 +1190,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
         // at 2^17 itself, one E = 2 wave per SIMD: 0.92 vs 1.01, profiles/r3k_small_shard_e1_ab.jsonl) — the shard sizes of an 8-GPU
         // strong-scaling or mixed-batch job.
         constexpr int ER = rollout_envs_per_lane(ENV);
-        if (ER > 1 && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
+        if (ER > 1 && a.obs_part == nullptr && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
             go(std::integral_constant<int, 1>{});
         else
             go(std::integral_constant<int, ER>{});
@@ -1132,6 +1242,26 @@ hipError_t launch_sample_env(int pm, const SampleArgs &a, hipStream_t stream) {
 bool launch_step_is_rollout(int pm, const StepArgs &a) {
     const bool sampled_or_tape = a.actions == nullptr || (a.act_slice != 0 && pm == PM_DEFAULT);
     return sampled_or_tape && !(a.flags & MXV_FLAG_NO_AUTORESET) && a.K > 1 && pm != PM_PER_ENV && !a.step_noise;
+}
+
+// STATS (StepArgs::obs_part) exists for the sampled trajectory-recording launch with default parameters, a state inside the invariants,
+// every per-step output present and one dtype set — and always with the env kind's own envs-per-lane, so that the leaves of the sum
+// tree (one per tile) are the same however small the shard is.
+bool launch_step_supports_stats(int env_id, int pm, const StepArgs &a) {
+    if (!launch_step_is_rollout(pm, a) || pm != PM_DEFAULT || a.actions != nullptr || a.state_injected || !MXV_FAST_TRIG) return false;
+    if (env_id == MXV_PENDULUM && !(a.max_steps > 0 && a.max_steps < 1000000)) return false;
+    if (!(a.reward && a.actions_out && a.terminated && a.truncated && !a.final_obs && !a.ep_acc) || a.slice == 0) return false;
+    const int f = a.flags & (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32);
+    return f == 0 || f == (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32);
+}
+int64_t stats_leaf_envs(int env_id) {
+    switch (env_id) {
+        case MXV_CARTPOLE: return (int64_t)rollout_envs_per_lane(MXV_CARTPOLE) * kWave;
+        case MXV_PENDULUM: return (int64_t)rollout_envs_per_lane(MXV_PENDULUM) * kWave;
+        case MXV_ACROBOT: return (int64_t)rollout_envs_per_lane(MXV_ACROBOT) * kWave;
+        case MXV_MOUNTAINCAR: return (int64_t)rollout_envs_per_lane(MXV_MOUNTAINCAR) * kWave;
+        default: return (int64_t)rollout_envs_per_lane(MXV_MOUNTAINCAR_CONT) * kWave;
+    }
 }
 
 hipError_t launch_step(int env_id, int default_params, const StepArgs &a, hipStream_t stream, LaunchInfo *info) {

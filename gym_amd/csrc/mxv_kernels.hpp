@@ -21,6 +21,7 @@ struct StepArgs {
     float *final_obs;      // [N][O], rows of finished envs only; may be nullptr
     const uint64_t *seeds; // per-env seeds or nullptr (base_seed + global index)
     const uint64_t *t_dev; // optional device-resident base step index (hipGraph replay)
+    double *obs_part;      // STATS launches: [K][tiles][2 O] column sums / sums of squares of every step's observations, or nullptr
     uint64_t *clock_out;   // device clock advanced by the launch itself (step_kernel, small grids): = t_dev, with clock_ticket; or nullptr
     uint32_t *clock_ticket; // workgroups that have finished (zero between launches)
     int32_t *err;          // latched error word (bit 0: invalid discrete action)
@@ -224,6 +225,9 @@ struct LaunchInfo {
 hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream, LaunchInfo *info = nullptr);
 // true if launch_step(a) runs the fused rollout kernel, which also writes StepArgs::snap_* (other launches: the caller copies)
 bool launch_step_is_rollout(int param_mode, const StepArgs &a);
+// true if launch_step(a) with a.obs_part set runs a STATS instantiation (fused observation sums); envs per leaf of those partials
+bool launch_step_supports_stats(int env_id, int param_mode, const StepArgs &a);
+int64_t stats_leaf_envs(int env_id);
 hipError_t launch_reset(int env_id, const ResetArgs &a, hipStream_t stream);
 hipError_t launch_sample(int env_id, int param_mode, const SampleArgs &a, hipStream_t stream);
 hipError_t launch_mixed_rollout(const MixedArgs &m, hipStream_t stream);

@@ -270,20 +270,25 @@ __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__
 // Missing leaves count as +0.0 (x + 0.0 == x): an odd leftover passes through unchanged, as a pairwise tree does.
 __global__ void __launch_bounds__(kThreads) tree_kernel(const double *__restrict__ in, double *__restrict__ out,
                                                         int64_t leaves, int V) {
+    constexpr int kMaxV = 12;  // 2 * dim, dim <= 6
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t k = blockIdx.y, group = blockIdx.x, groups = gridDim.x;
     const int64_t l0 = group * kTreeFan + (int64_t)tid * 4;
-    __shared__ double sm[kThreads / 64];
-    for (int v = 0; v < V; ++v) {
-        double a[4];
+    __shared__ double sm[kThreads / 64][kMaxV];
+    // all V values of a lane's four leaves in one go (4 V contiguous doubles), ONE barrier per workgroup: the per-value loop with two
+    // barriers each cost the fused-moments path (8192 leaves of 8 values per step) more than the scan; same tree, same bits
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = (l0 + i < leaves) ? in[(k * leaves + l0 + i) * V + v] : 0.0;
-        double t = wave_tree_sum((a[0] + a[1]) + (a[2] + a[3]));
-        if (lane == 0) sm[wave] = t;
-        __syncthreads();
-        if (tid == 0) out[(k * groups + group) * V + v] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-        __syncthreads();
+    for (int v = 0; v < kMaxV; ++v) {
+        if (v < V) {
+            double a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = (l0 + i < leaves) ? in[(k * leaves + l0 + i) * V + v] : 0.0;
+            const double t = wave_tree_sum((a[0] + a[1]) + (a[2] + a[3]));
+            if (lane == 0) sm[wave][v] = t;
+        }
     }
+    __syncthreads();
+    if (tid < V) out[(k * groups + group) * V + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
 }
 
 // ---- 3. the running update, sequential over the K steps (normalize.py:17-47) ------------------------------------------
@@ -490,9 +495,10 @@ int ensure_capacity(mxv_norm *nm, int K, int64_t leaves, int V) {
     return MXV_OK;
 }
 
-// folds partials [K][leaves][V] (in part_a) down to [K][V] written to dst (device)
-int run_tree(mxv_norm *nm, int K, int64_t leaves, int V, double *dst) {
-    double *in = nm->part_a, *out = nm->part_b;
+// folds partials [K][leaves][V] (in part_a, or the caller's `from`, which is only read) down to [K][V] written to dst (device)
+int run_tree(mxv_norm *nm, int K, int64_t leaves, int V, double *dst, const double *from = nullptr) {
+    const double *in = from ? from : nm->part_a;
+    double *out = from ? nm->part_a : nm->part_b;
     while (true) {
         const int64_t groups = ceil_div(leaves, kTreeFan);
         double *target = groups == 1 ? dst : out;
@@ -500,9 +506,8 @@ int run_tree(mxv_norm *nm, int K, int64_t leaves, int V, double *dst) {
         NRM_HIP(nm, hipGetLastError());
         if (groups == 1) break;
         leaves = groups;
-        double *t = in;
         in = out;
-        out = t;
+        out = out == nm->part_a ? nm->part_b : nm->part_a;
     }
     return MXV_OK;
 }
@@ -655,6 +660,14 @@ int mxv_norm_obs_sums(mxv_norm *nm, int32_t K, const float *x_dev, double *sums_
     if (int rc = ensure_capacity(nm, K, leaves, 2 * nm->dim)) return rc;
     if (int rc = dispatch_obs_sums(nm, K, x_dev, leaves)) return rc;
     return run_tree(nm, K, leaves, 2 * nm->dim, sums_dev);
+}
+
+int mxv_norm_obs_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev) {
+    if (int rc = checks(nm, K)) return rc;
+    if (!partials_dev || !sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "partials/sums pointer is NULL");
+    if (leaves < 1) return nfail(nm, MXV_ERR_INVALID_ARG, "leaves must be positive");
+    if (int rc = ensure_capacity(nm, K, ceil_div(leaves, kTreeFan), 2 * nm->dim)) return rc;
+    return run_tree(nm, K, leaves, 2 * nm->dim, sums_dev, partials_dev);
 }
 
 int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon,

@@ -37,6 +37,9 @@ class HipNormBackend:
     def obs_sums(self, K, x, sums):
         self.obs.obs_sums(K, x, sums)
 
+    def obs_sums_partials(self, K, partials, sums):
+        self.obs.obs_sums_partials(K, partials, partials.shape[-2], sums)
+
     def obs_apply(self, K, x, y, epsilon, all_sums, world, total_rows):
         self.obs.obs_apply(K, x, y, y.dtype == torch.float32, epsilon, all_sums, world, total_rows)
 
@@ -98,7 +101,10 @@ class RunningNormalizer:
         dist.all_gather_into_tensor(out.view(-1), sums.view(-1), group=self.group)
         return out
 
-    def normalize_obs(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_dtype=torch.float64) -> torch.Tensor:
+    def normalize_obs(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_dtype=torch.float64,
+                      partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """partials: the [K, leaves, 2 O] float64 column sums the rollout that wrote `x` left behind (DeviceRollout.trajectory_buffers(
+        obs_partials=True)): the pass that would read x once more to form them is skipped."""
         assert x.dtype == torch.float32 and x.is_contiguous()
         K = x.shape[0] if x.dim() == 3 else 1
         assert x.numel() == K * self.num_envs * self.obs_dim, (tuple(x.shape), self.num_envs, self.obs_dim)
@@ -107,7 +113,12 @@ class RunningNormalizer:
                 out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
             assert out.is_contiguous() and out.shape == x.shape and out.dtype in (torch.float64, torch.float32)
             sums = torch.empty((K, 2 * self.obs_dim), dtype=torch.float64, device=x.device)
-            self.backend.obs_sums(K, x, sums)
+            if partials is not None:
+                assert partials.dtype == torch.float64 and partials.is_contiguous() and partials.dim() == 3
+                assert partials.shape[0] >= K and partials.shape[2] == 2 * self.obs_dim, tuple(partials.shape)
+                self.backend.obs_sums_partials(K, partials, sums)
+            else:
+                self.backend.obs_sums(K, x, sums)
             self.backend.obs_apply(K, x, out, self.obs_epsilon, self._all_sums(sums), self.world_size, self.total_envs)
         return out
 

@@ -190,7 +190,7 @@ class DeviceRollout:
                 self._ep_attached = tgt[0]
 
     def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "auto", seed: int = 0,
-                           max_park_bytes: Optional[int] = None):
+                           max_park_bytes: Optional[int] = None, obs_partials: bool = False):
         """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk).  want_final adds
         `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
         of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content.
@@ -208,6 +208,15 @@ class DeviceRollout:
         on the boxes where placement matters the speed mode of the write-bound rollout is a function of the ADDRESSES — packed
         back to back (which is also what consecutive separate allocations are) can hit the slow mode, eight of eight such
         irregular layouts measured fast (profiles/r02q_placement_scan_one_allocation.jsonl)."""
+        if obs_partials:
+            # + "obs_partials" [K, leaves, 2 O] float64: rollout_per_step then also leaves every step's column sums / sums of squares
+            # of the observations per tile of envs (mxv_set_obs_partials) — RunningNormalizer.normalize_obs(x, partials=...) folds them
+            # instead of reading the observations a second time
+            out = self.trajectory_buffers(K, want_final, layout, seed, max_park_bytes)
+            leaves, _, vals = self.handle.obs_partials_layout()
+            with torch.cuda.stream(self.stream):
+                out["obs_partials"] = torch.empty((K, leaves, vals), dtype=torch.float64, device=self.device)
+            return out
         n, dev = self.num_envs, self.device
         specs = []
         if want_final:
@@ -387,6 +396,10 @@ class DeviceRollout:
         out = self.trajectory_buffers(K) if out is None else out
         assert out["obs"].shape[0] >= K
         self._attach_episode_outputs(out)
+        part = out.get("obs_partials")
+        if part is not getattr(self, "_partials_attached", None):
+            self.handle.set_obs_partials(part)
+            self._partials_attached = part
         self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
                             out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])

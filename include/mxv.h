@@ -300,6 +300,16 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r);
  * returns to argument passing.  Calls that synchronise or copy to the host (the *_host calls, mxv_sync, mxv_get_state) cannot be
  * captured, as with any stream. */
 int mxv_set_device_clock(mxv_handle *h, int32_t on);
+/* NormalizeObservation's batch moments, fused into the rollout (gym/wrappers/normalize.py:17-29: every step's batch mean / var are the
+ * only cross-env reduction on the path).  With a buffer attached, every sampled trajectory launch (mxv_rollout, MXV_ROLLOUT_FUSED,
+ * per_step != 0, K >= 2, all per-step outputs, default physics parameters) also leaves, for each of its K steps and each tile of
+ * envs_per_leaf consecutive envs, the fp64 column sums and sums of squares of the observations it wrote:
+ * partials_dev[K][leaves][values], values = 2 O (sums, then sums of squares) — 0.5 B per env-step instead of a second pass that reads
+ * the 4 O bytes back.  mxv_norm_obs_sums_partials folds them (fixed binary tree: bit-reproducible, the same for any power-of-two
+ * sharding) into the [K][2 O] sums mxv_norm_obs_apply takes.  A launch that cannot produce them fails with MXV_ERR_UNSUPPORTED
+ * (nothing is skipped silently); NULL detaches.  The caller owns the buffer. */
+int mxv_set_obs_partials(mxv_handle *h, double *partials_dev);
+int mxv_obs_partials_layout(mxv_handle *h, int64_t *leaves, int64_t *envs_per_leaf, int32_t *values);
 /* per-env reset ordinals (position of each env's reset stream, see RNG contract): uint32[N].  Synchronises. */
 int mxv_get_episodes(mxv_handle *h, uint32_t *episodes_host);
 int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host);
@@ -367,6 +377,8 @@ int mxv_norm_rewards(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t re
  * running update with batch_count = total_rows and applies the map to this shard's rows.  world <= 64.
  * The one-call forms above are *_sums + *_apply with world = 1. */
 int mxv_norm_obs_sums(mxv_norm *nm, int32_t K, const float *x_dev, double *sums_dev);
+/* the same sums from partials a rollout left behind (mxv_set_obs_partials): [K][leaves][2 dim] -> sums_dev [K][2 dim] */
+int mxv_norm_obs_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev);
 int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon,
                        const double *all_sums_dev, int32_t world, int64_t total_rows);
 int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,

@@ -89,6 +89,8 @@ def test_line_carries_what_the_review_asked_for(line):
         assert v[key]["value"] > 2e10 and 0.05 < v[key]["roofline"]["frac"] < 1.0, key
     for key in ("normalize_obs", "normalize_reward"):                     # §8(f)-2
         assert v["normalize"][key]["roofline"]["frac"] > 0.15, key
+    fm = v["normalize"]["normalize_obs_fused_moments"]                    # the batch moments formed by the rollout: cheaper than the second pass
+    assert "error" not in fm and fm["us_per_step"] < fm["separate_us_per_step"] and fm["rollout_with_partials_us_per_step"] < 1.35 * fm["rollout_us_per_step"]
     nl = v["numpy_loop"]                                                  # SURVEY §8(d)'s third number: PCIe- and Python-inclusive
     assert nl["num_envs_2^20"]["value"] > 2e8 and nl["configs0_num_envs_8"]["value"] > 5e4 and nl["num_envs_2^20"]["episodes_ended"] > 0
     assert v["configs4_mixed_share"]["value"] > 1e10

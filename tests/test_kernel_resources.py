@@ -56,7 +56,7 @@ def _resources(remarks):
 
 
 def _symbol(env, e):
-    return f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi1ELb0EEEvNS_8StepArgsE"
+    return f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi1ELb0ELb0EEEvNS_8StepArgsE"
 
 
 def _function_body(asm, sym):
@@ -98,6 +98,22 @@ def test_hot_rollout_kernels_keep_their_resource_budget(build):
         assert r["Occupancy"] == occ, (env, r)
         assert r["VGPRs"] <= 128, (env, r)
         assert r["VGPRs Spill"] <= spill_bound, (env, r)          # today's figures; a larger spill is one step from scratch traffic in the loop
+
+
+def test_the_instantiations_with_fused_observation_moments_keep_four_waves(build):
+    """rollout_kernel_v3<..., STATS = true> (mxv_set_obs_partials): the column sums of a step's observations and the wave-level tree on
+    top of the trajectory kernel — still inside the 128-VGPR budget, nothing spilled, for every env kind and both dtype sets."""
+    remarks, asm = build
+    res = _resources(remarks)
+    for env, (e, occ, _) in HOT.items():
+        for out in (1, 2):
+            r = res[f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi{out}ELb0ELb1EEEvNS_8StepArgsE"]
+            assert r["Occupancy"] == occ and r["VGPRs"] <= 128 and r["VGPRs Spill"] == 0, (env, out, r)
+    body = _function_body(asm, "_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi0ELb1ELi2ELb0ELi1ELb0ELb1EEEvNS_8StepArgsE")
+    loops = [(h, t) for h, t in _inner_loops(body) if "global_store" in t]
+    text = max(loops, key=lambda ht: ht[1].count("global_store"))[1]
+    assert text.count("v_permlane16_swap") == 2 and text.count("v_permlane32_swap") == 2 and text.count("ds_swizzle") == 2   # ONE value left at these stages
+    assert 10 <= sum(1 for l in text.splitlines() if "_dpp" in l) <= 20                                                    # 8 -> 4 -> 2 -> 1 values: 14 moves
 
 
 # Round 3: with scalar-base stores (pin32, mxv_kernels.hip) no kernel spills a vector register any more; round 2's CartPole kernel parked

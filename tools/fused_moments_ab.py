@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""rollout + NormalizeObservation per 2^20-env CartPole step, the batch moments formed (a) by the stand-alone pass that reads the
+observations back, (b) by the rollout itself (mxv_set_obs_partials): event-timed on the engine's stream, alternating, one process."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gym_amd.rollout import DeviceRollout  # noqa: E402
+
+n, K = 1 << 20, 128
+for env_id, nn in (("CartPole-v1", n), ("Pendulum-v1", n >> 1), ("Acrobot-v1", n >> 1)):
+    r = DeviceRollout(env_id, nn, seed=0, action_seed=1)
+    r.reset(seed=0)
+    out = r.trajectory_buffers(K, obs_partials=True)
+    plain = {k: v for k, v in out.items() if k != "obs_partials"}
+    nz = r.make_normalizer()
+    y = torch.empty((K, nn, r.O), dtype=torch.float32, device=r.device)
+
+    def timed(fn, reps=5):
+        for _ in range(2):
+            fn()
+        r.stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(r.stream)
+        for _ in range(reps):
+            fn()
+        e1.record(r.stream)
+        r.stream.synchronize()
+        return e0.elapsed_time(e1) / reps / K * 1e3
+
+    for rep in range(3):
+        res = {"env": env_id, "num_envs": nn,
+               "rollout": timed(lambda: r.rollout_per_step(K, out=plain)),
+               "rollout_with_partials": timed(lambda: r.rollout_per_step(K, out=out)),
+               "normalize_obs": timed(lambda: nz.normalize_obs(out["obs"], out=y)),
+               "normalize_obs_from_partials": timed(lambda: nz.normalize_obs(out["obs"], out=y, partials=out["obs_partials"]))}
+        res["pipeline_separate"] = res["rollout"] + res["normalize_obs"]
+        res["pipeline_fused"] = res["rollout_with_partials"] + res["normalize_obs_from_partials"]
+        print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+    r.close()
+    del out, plain, y
+    torch.cuda.empty_cache()
