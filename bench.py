@@ -364,10 +364,34 @@ def measure_normalize(torch, envs, chunk, reps=6):
                                                   rollout_us_per_step=r0, rollout_with_partials_us_per_step=r1, normalize_from_partials_us_per_step=nfu,
                                                   separate_us_per_step=out["normalize_obs"]["us_per_step"],
                                                   note="us_per_step = what normalisation adds to the rollout: (rollout with partials - rollout) + tree + scan + apply")
-        nf.close()
-        del trp, plain, sums
+        # ... and NormalizeReward's discounted returns (mxv_set_return_partials), alone and together with the observation moments
+        nrf = _native.Norm(1, envs, stream=s.cuda_stream)
+        dr._fused_returns = (nrf.returns_ptr(), 0.99)
+        dr._ret_partials_attached = None
+        leaves = trp["obs_partials"].shape[1]
+        with torch.cuda.stream(s):
+            rp = torch.empty((chunk, leaves, 2), dtype=torch.float64, device=dr.device)
+        rets, both = dict(plain, ret_partials=rp), dict(trp, ret_partials=rp)
+        r2 = _event_us(torch, s, lambda: dr.rollout_per_step(chunk, out=rets), reps, chunk)
+        r3 = _event_us(torch, s, lambda: dr.rollout_per_step(chunk, out=both), reps, chunk)
+        rsums = torch.empty((chunk, 2), dtype=torch.float64, device=dr.device)
+
+        def fused_reward():
+            nrf.reward_sums_partials(chunk, rp, leaves, rsums)
+            nrf.reward_apply(chunk, trp["reward"], False, o64, 1e-8, rsums.unsqueeze(0), 1, envs)
+
+        nru = _event_us(torch, s, fused_reward, reps, chunk)
+        out["normalize_reward_fused_moments"] = dict(_hbm(nru + (r2 - r0), envs, 16 + 2 * 16 * leaves / envs,
+                                                          kernels="rollout_kernel_v3<..., STATS = 2> advances the discounted returns; tree + scan + apply (read 8, write 8)"),
+                                                     rollout_with_partials_us_per_step=r2, normalize_from_partials_us_per_step=nru,
+                                                     separate_us_per_step=out["normalize_reward"]["us_per_step"])
+        out["rollout_and_both_normalisations"] = {"separate_us_per_step": r0 + out["normalize_obs"]["us_per_step"] + out["normalize_reward"]["us_per_step"],
+                                                  "fused_us_per_step": r3 + nfu + nru, "rollout_with_both_partials_us_per_step": r3}
+        nf.close(), nrf.close()
+        del trp, plain, sums, rp, rets, both, rsums
     except Exception as e:  # noqa: BLE001
-        out["normalize_obs_fused_moments"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out.setdefault("normalize_obs_fused_moments", {"error": f"{type(e).__name__}: {e}"[:300]})
+        out.setdefault("normalize_reward_fused_moments", {"error": f"{type(e).__name__}: {e}"[:300]})
     no.close(), nr.close(), dr.close()
     del tr, y32, o64
     torch.cuda.empty_cache()

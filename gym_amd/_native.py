@@ -40,12 +40,12 @@ EXPORTS = (
     "mxv_env_dims", "mxv_default_params", "mxv_default_reset_bounds", "mxv_version", "mxv_create", "mxv_destroy",
     "mxv_last_error", "mxv_seed", "mxv_seed_actions", "mxv_reset", "mxv_step", "mxv_step_sampled", "mxv_rollout",
     "mxv_rollout_tape", "mxv_sample_actions", "mxv_last_launch", "mxv_reset_host", "mxv_step_host", "mxv_get_state", "mxv_set_state", "mxv_get_counters",
-    "mxv_set_counters", "mxv_set_device_clock", "mxv_set_obs_partials", "mxv_obs_partials_layout", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
+    "mxv_set_counters", "mxv_set_device_clock", "mxv_set_obs_partials", "mxv_set_return_partials", "mxv_obs_partials_layout", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_write_probe_env", "mxv_host_alloc", "mxv_host_free",
                 "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream", "mxv_staging_view",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
-    "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_sums_partials", "mxv_norm_obs_apply",
+    "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_sums_partials", "mxv_norm_reward_sums_partials", "mxv_norm_returns_ptr", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
@@ -200,6 +200,7 @@ def _load():
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_set_device_clock": ([vp, i32], C.c_int),
         "mxv_set_obs_partials": ([vp, vp], C.c_int),
+        "mxv_set_return_partials": ([vp, vp, C.c_double, vp], C.c_int),
         "mxv_obs_partials_layout": ([vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxv_rollout_mixed": ([vp, C.c_int32, C.c_int32, C.c_int32, vp], C.c_int),
         "mxv_set_final_snapshot": ([vp, vp, vp, vp, vp], C.c_int),
@@ -246,6 +247,8 @@ def _load():
         "mxv_norm_rewards": ([vp, i32, vp, i32, vp, vp, vp, C.c_double, C.c_double], C.c_int),
         "mxv_norm_obs_sums": ([vp, i32, vp, vp], C.c_int),
         "mxv_norm_obs_sums_partials": ([vp, i32, vp, i64, vp], C.c_int),
+        "mxv_norm_reward_sums_partials": ([vp, i32, vp, i64, vp], C.c_int),
+        "mxv_norm_returns_ptr": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_norm_obs_apply": ([vp, i32, vp, vp, i32, C.c_double, vp, i32, i64], C.c_int),
         "mxv_norm_reward_sums": ([vp, i32, vp, i32, vp, vp, C.c_double, vp], C.c_int),
         "mxv_norm_reward_apply": ([vp, i32, vp, i32, vp, C.c_double, vp, i32, i64], C.c_int),
@@ -702,6 +705,11 @@ class Handle:
         sums of squares of the observations they write (mxv_set_obs_partials)."""
         self._check(lib.mxv_set_obs_partials(self._h, _ptr(partials_dev)))
 
+    def set_return_partials(self, returns_state_ptr=None, gamma: float = 0.99, partials_dev=None):
+        """NormalizeReward's running returns advanced by the rollout, their per-tile sums left in partials_dev [K][leaves][2]
+        (mxv_set_return_partials); partials_dev None detaches."""
+        self._check(lib.mxv_set_return_partials(self._h, _ptr(returns_state_ptr), float(gamma), _ptr(partials_dev)))
+
     def obs_partials_layout(self):
         """(leaves, envs per leaf, values per leaf = 2 O) of that buffer."""
         lv, per, vals = C.c_int64(), C.c_int64(), C.c_int32()
@@ -1040,6 +1048,15 @@ class Norm:
 
     def obs_sums(self, K, x_dev, sums_dev):
         self._check(lib.mxv_norm_obs_sums(self._h, int(K), _ptr(x_dev), _ptr(sums_dev)))
+
+    def reward_sums_partials(self, K, partials_dev, leaves: int, sums_dev):
+        self._check(lib.mxv_norm_reward_sums_partials(self._h, int(K), _ptr(partials_dev), int(leaves), _ptr(sums_dev)))
+
+    def returns_ptr(self) -> int:
+        """Device address of the running discounted returns [N] float64 (mxv_norm_returns_ptr)."""
+        p = C.c_void_p()
+        self._check(lib.mxv_norm_returns_ptr(self._h, C.byref(p)))
+        return int(p.value)
 
     def obs_sums_partials(self, K, partials_dev, leaves: int, sums_dev):
         """[K][leaves][2 dim] partial sums a rollout left behind (Handle.set_obs_partials) -> sums_dev [K][2 dim]."""

@@ -75,6 +75,8 @@ struct mxv_handle {
     uint32_t *episodes = nullptr;  // [N] resets of each env since seeding = index of its next draw from the reset stream
     uint64_t *seeds = nullptr;  // optional per-env seeds
     uint64_t *t_dev = nullptr;  // device-resident step index for graph replay
+    double *ret_state = nullptr, *ret_part = nullptr;   // mxv_set_return_partials: NormalizeReward's running returns and their per-tile sums
+    double ret_gamma = 0.0;
     double *obs_part = nullptr;        // mxv_set_obs_partials: where trajectory launches leave the observations' column sums (caller's memory)
     uint32_t *clock_ticket = nullptr;  // finished-workgroup counter of launches that advance the device clock themselves
     bool dev_clock = false;     // mxv_set_device_clock: every launch reads the step index from t_dev and a one-thread kernel advances it
@@ -678,12 +680,17 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
-    if (h->obs_part && per_step && !actions_tape) {  // fused batch moments of NormalizeObservation (mxv_set_obs_partials)
+    if ((h->obs_part || h->ret_part) && per_step && !actions_tape) {  // fused batch moments (mxv_set_obs_partials / mxv_set_return_partials)
         a.obs_part = h->obs_part;
+        if (h->ret_part) {
+            a.ret_part = h->ret_part;
+            a.ret_state = h->ret_state;
+            a.ret_gamma = h->ret_gamma;
+        }
         if (!launch_step_supports_stats(h->cfg.env_id, h->param_mode(), a))
-            return fail(h, MXV_ERR_UNSUPPORTED, "observation partial sums are attached (mxv_set_obs_partials), but this launch cannot produce them: they "
+            return fail(h, MXV_ERR_UNSUPPORTED, "partial sums are attached (mxv_set_obs_partials / mxv_set_return_partials), but this launch cannot produce them: they "
                                                 "exist for sampled [K][N] trajectory launches (K >= 2) with every per-step output, default physics "
-                                                "parameters, autoreset and a state the engine produced itself; detach (NULL) and use mxv_norm_obs_sums");
+                                                "parameters, autoreset and a state the engine produced itself; detach (NULL) and use mxv_norm_obs_sums / mxv_norm_reward_sums");
     }
     const bool in_kernel = h->snap_obs && launch_step_is_rollout(h->param_mode(), a);
     if (in_kernel) {
@@ -1125,6 +1132,15 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r) {
 int mxv_set_obs_partials(mxv_handle *h, double *partials_dev) {
     MXV_CHECK_HANDLE(h);
     h->obs_part = partials_dev;
+    return MXV_OK;
+}
+
+int mxv_set_return_partials(mxv_handle *h, double *returns_state_dev, double gamma, double *partials_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (partials_dev && !returns_state_dev) return fail(h, MXV_ERR_INVALID_ARG, "mxv_set_return_partials: the running returns [N] are required");
+    h->ret_part = partials_dev;
+    h->ret_state = partials_dev ? returns_state_dev : nullptr;
+    h->ret_gamma = gamma;
     return MXV_OK;
 }
 

@@ -491,7 +491,7 @@ struct RolloutLds {
 
 // The kernel body as a device function of (arguments, workgroup index, workgroups of this segment, LDS): rollout_kernel_v3 runs
 // it for one homogeneous vector env, mixed_rollout_kernel for the segment a workgroup belongs to.
-template <int ENV, bool DEF, int E, bool SAFE, int OUT, bool TAPE = false, bool STATS = false>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT, bool TAPE = false, int STATS = 0>
 __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigned bid, const unsigned nblk, RolloutLds<ENV, E> &lds) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
@@ -622,7 +622,13 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
     char *p_term = reinterpret_cast<char *>(a.terminated);
     char *p_trunc = reinterpret_cast<char *>(a.truncated);
     char *p_fin = FULL ? nullptr : reinterpret_cast<char *>(a.final_obs);
-    [[maybe_unused]] double *p_part = STATS ? a.obs_part + (int64_t)tile * (2 * O) : nullptr;   // [K][tiles][2 O], tile = leaf index
+    // STATS bit 0: per-tile column sums of the observations ([K][tiles][2 O]); bit 1: the discounted returns of NormalizeReward
+    // (normalize.py:132-136) advanced in registers, their per-tile sum and sum of squares per step ([K][tiles][2]); tile = leaf index
+    [[maybe_unused]] double *p_part = (STATS & 1) ? a.obs_part + (int64_t)tile * (2 * O) : nullptr;
+    [[maybe_unused]] double *p_rpart = (STATS & 2) ? a.ret_part + (int64_t)tile * 2 : nullptr;
+    [[maybe_unused]] double ret[E], ret_s = 0.0, ret_q = 0.0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) ret[j] = ((STATS & 2) && valid[j]) ? a.ret_state[le[j]] : 0.0;
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
     uint32_t lo[E];  // index of the lane's env slot inside one step's slice of every output array
@@ -741,6 +747,19 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             trunc[j] = (a.max_steps > 0) && (el[j] >= a.max_steps);  // time_limit.py:53-54
             pend[j] = (ALLV || valid[j]) && (term[j] || trunc[j]);
         }
+        if constexpr ((STATS & 2) != 0) {  // returns = returns * gamma + rews; (sums for return_rms.update); returns[dones] = 0
+            ret_s = ret_q = 0.0;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double r = rew_f32 ? (double)(float)rew[j] : rew[j];   // what NormalizeReward reads from the reward tensor
+                ret[j] = ret[j] * a.ret_gamma + r;
+                if (ALLV || valid[j]) {
+                    ret_s += ret[j];
+                    ret_q = __fma_rn(ret[j], ret[j], ret_q);
+                }
+                if (term[j] || trunc[j]) ret[j] = 0.0;
+            }
+        }
         if (ep_on) {  // record_episode_statistics.py:119-143
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -806,7 +825,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         // ---- STATS: this tile's column sums and sums of squares of the observations just stored (NormalizeObservation's batch
         //      moments, gym/wrappers/normalize.py:17-29, as partials [K][tiles][2 O] for mxv_norm's tree) — the pass that would read
         //      them back from HBM is not launched
-        if constexpr (STATS) {
+        if constexpr ((STATS & 1) != 0) {
             double sm[O], sq[O];
 #pragma unroll
             for (int k = 0; k < O; ++k) sm[k] = sq[k] = 0.0;
@@ -844,6 +863,11 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
                 wave_sums_store<8>(w, (uint32_t)lane, p_part + O, O);
             }
             p_part += (int64_t)nblk * (2 * O);
+        }
+        if constexpr ((STATS & 2) != 0) {
+            double v[4] = {ret_s, ret_q, 0.0, 0.0};
+            wave_sums_store<4>(v, (uint32_t)lane, p_rpart, 2);
+            p_rpart += (int64_t)nblk * 2;
         }
         // ---- the chunk's FINAL tensors once more, into the caller's snapshot (what a sharded vector env all-gathers while the
         //      next chunk runs: written here, no copy kernels between rollout and gather) ----
@@ -927,6 +951,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         a.elapsed[le[j]] = el[j];
         a.episodes[le[j]] = ep[j];
         if (ep_on) a.ep_acc[le[j]] = er[j];
+        if constexpr ((STATS & 2) != 0) a.ret_state[le[j]] = ret[j];
     }
 }
 
@@ -940,7 +965,7 @@ constexpr int rollout_max_waves() {
     return rollout_min_waves<ENV, DEF, SAFE>() == 1 ? 8 : rollout_min_waves<ENV, DEF, SAFE>();
 }
 
-template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, bool TAPE = false, bool STATS = false>
+template <int ENV, bool DEF, int E, bool SAFE, int OUT = 0, bool TAPE = false, int STATS = 0>
 __global__ void __launch_bounds__(kWave)
     __attribute__((amdgpu_waves_per_eu(rollout_min_waves<ENV, DEF, SAFE>(), rollout_max_waves<ENV, DEF, SAFE>())))
     rollout_kernel_v3(const StepArgs a) {
@@ -1126,7 +1151,7 @@ __global__ void __launch_bounds__(kBlock) final_pack_kernel(const CompactArgs a)
     }
 }
 
-template <int ENV, bool DEF, int ER, bool SAFE, int OUT, bool TAPE = false, bool STATS = false>
+template <int ENV, bool DEF, int ER, bool SAFE, int OUT, bool TAPE = false, int STATS = 0>
 void launch_rollout_out(unsigned grid, hipStream_t stream, const StepArgs &a, LaunchInfo *info) {
     if (info) *info = LaunchInfo{1, ENV, DEF ? PM_DEFAULT : PM_BROADCAST, ER, SAFE ? 1 : 0, OUT, TAPE ? 1 : 0, a.K, grid, (uint32_t)kWave};
     // amdgpu_waves_per_eu only budgets registers; what physically keeps a 5-wave-sized kernel at 4 waves per SIMD (see
@@ -1152,8 +1177,13 @@ void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a, Launch
             return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a, info);
         }
         if constexpr (!SAFE && ER == rollout_envs_per_lane(ENV)) {   // STATS instantiations: launch_step_supports_stats
-            if (a.obs_part != nullptr && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, true>(grid, stream, a, info);
-            if (a.obs_part != nullptr && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, true>(grid, stream, a, info);
+            const int st = (a.obs_part != nullptr ? 1 : 0) | (a.ret_part != nullptr ? 2 : 0);
+            if (st == 1 && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, 1>(grid, stream, a, info);
+            if (st == 1 && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, 1>(grid, stream, a, info);
+            if (st == 2 && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, 2>(grid, stream, a, info);
+            if (st == 2 && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, 2>(grid, stream, a, info);
+            if (st == 3 && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, 3>(grid, stream, a, info);
+            if (st == 3 && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, 3>(grid, stream, a, info);
         }
         if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a, info);
         if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a, info);
@@ -1190,7 +1220,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
         // at 2^17 itself, one E = 2 wave per SIMD: 0.92 vs 1.01, profiles/r3k_small_shard_e1_ab.jsonl) — the shard sizes of an 8-GPU
         // strong-scaling or mixed-batch job.
         constexpr int ER = rollout_envs_per_lane(ENV);
-        if (ER > 1 && a.obs_part == nullptr && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
+        if (ER > 1 && a.obs_part == nullptr && a.ret_part == nullptr && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
             go(std::integral_constant<int, 1>{});
         else
             go(std::integral_constant<int, ER>{});

@@ -21,6 +21,9 @@ struct StepArgs {
     float *final_obs;      // [N][O], rows of finished envs only; may be nullptr
     const uint64_t *seeds; // per-env seeds or nullptr (base_seed + global index)
     const uint64_t *t_dev; // optional device-resident base step index (hipGraph replay)
+    double *ret_state;     // STATS bit 1: [N] NormalizeReward's running discounted returns (read at entry, written at exit), with
+    double *ret_part;      //   [K][tiles][2] their per-tile sum / sum of squares after every step's update, and
+    double ret_gamma;      //   the discount
     double *obs_part;      // STATS launches: [K][tiles][2 O] column sums / sums of squares of every step's observations, or nullptr
     uint64_t *clock_out;   // device clock advanced by the launch itself (step_kernel, small grids): = t_dev, with clock_ticket; or nullptr
     uint32_t *clock_ticket; // workgroups that have finished (zero between launches)

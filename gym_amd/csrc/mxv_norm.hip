@@ -670,6 +670,21 @@ int mxv_norm_obs_sums_partials(mxv_norm *nm, int32_t K, const double *partials_d
     return run_tree(nm, K, leaves, 2 * nm->dim, sums_dev, partials_dev);
 }
 
+int mxv_norm_reward_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev) {
+    if (int rc = checks(nm, K)) return rc;
+    if (nm->dim != 1) return nfail(nm, MXV_ERR_INVALID_ARG, "reward sums need a 1-column mxv_norm");
+    if (!partials_dev || !sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "partials/sums pointer is NULL");
+    if (leaves < 1) return nfail(nm, MXV_ERR_INVALID_ARG, "leaves must be positive");
+    if (int rc = ensure_capacity(nm, K, ceil_div(leaves, kTreeFan), 2)) return rc;
+    return run_tree(nm, K, leaves, 2, sums_dev, partials_dev);
+}
+
+int mxv_norm_returns_ptr(mxv_norm *nm, double **returns_dev) {
+    if (!nm || !returns_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "NULL mxv_norm or output pointer");
+    *returns_dev = nm->returns;
+    return MXV_OK;
+}
+
 int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon,
                        const double *all_sums_dev, int32_t world, int64_t total_rows) {
     if (int rc = checks(nm, K)) return rc;

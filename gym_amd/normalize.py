@@ -40,6 +40,12 @@ class HipNormBackend:
     def obs_sums_partials(self, K, partials, sums):
         self.obs.obs_sums_partials(K, partials, partials.shape[-2], sums)
 
+    def reward_sums_partials(self, K, partials, sums):
+        self.rew.reward_sums_partials(K, partials, partials.shape[-2], sums)
+
+    def returns_ptr(self) -> int:
+        return self.rew.returns_ptr()
+
     def obs_apply(self, K, x, y, epsilon, all_sums, world, total_rows):
         self.obs.obs_apply(K, x, y, y.dtype == torch.float32, epsilon, all_sums, world, total_rows)
 
@@ -123,7 +129,9 @@ class RunningNormalizer:
         return out
 
     def normalize_rewards(self, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor,
-                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          out: Optional[torch.Tensor] = None, partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """partials: the [K, leaves, 2] float64 sums of the discounted returns the rollout that wrote `reward` left behind (it advanced
+        this normaliser's running returns itself: DeviceRollout.fuse_reward_normalizer): the pass over rewards and flags is skipped."""
         assert reward.dtype in (torch.float64, torch.float32) and reward.is_contiguous()
         K = reward.shape[0] if reward.dim() == 2 else 1
         assert reward.numel() == K * self.num_envs
@@ -135,7 +143,12 @@ class RunningNormalizer:
                 out = torch.empty_like(reward)
             assert out.is_contiguous() and out.shape == reward.shape and out.dtype == reward.dtype
             sums = torch.empty((K, 2), dtype=torch.float64, device=reward.device)
-            self.backend.reward_sums(K, reward, terminated, truncated, self.gamma, sums)
+            if partials is not None:
+                assert partials.dtype == torch.float64 and partials.is_contiguous() and partials.dim() == 3
+                assert partials.shape[0] >= K and partials.shape[2] == 2, tuple(partials.shape)
+                self.backend.reward_sums_partials(K, partials, sums)
+            else:
+                self.backend.reward_sums(K, reward, terminated, truncated, self.gamma, sums)
             self.backend.reward_apply(K, reward, out, self.reward_epsilon, self._all_sums(sums), self.world_size,
                                       self.total_envs)
         return out

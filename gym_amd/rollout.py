@@ -190,7 +190,7 @@ class DeviceRollout:
                 self._ep_attached = tgt[0]
 
     def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "auto", seed: int = 0,
-                           max_park_bytes: Optional[int] = None, obs_partials: bool = False):
+                           max_park_bytes: Optional[int] = None, obs_partials: bool = False, ret_partials: bool = False):
         """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk).  want_final adds
         `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
         of that step is set (what a learner bootstraps from when an episode was truncated), other rows keep their content.
@@ -208,14 +208,18 @@ class DeviceRollout:
         on the boxes where placement matters the speed mode of the write-bound rollout is a function of the ADDRESSES — packed
         back to back (which is also what consecutive separate allocations are) can hit the slow mode, eight of eight such
         irregular layouts measured fast (profiles/r02q_placement_scan_one_allocation.jsonl)."""
-        if obs_partials:
+        if obs_partials or ret_partials:
             # + "obs_partials" [K, leaves, 2 O] float64: rollout_per_step then also leaves every step's column sums / sums of squares
             # of the observations per tile of envs (mxv_set_obs_partials) — RunningNormalizer.normalize_obs(x, partials=...) folds them
-            # instead of reading the observations a second time
+            # instead of reading the observations a second time;  + "ret_partials" [K, leaves, 2]: the same for NormalizeReward's
+            # discounted returns, which the rollout then advances itself (after fuse_reward_normalizer(normalizer))
             out = self.trajectory_buffers(K, want_final, layout, seed, max_park_bytes)
             leaves, _, vals = self.handle.obs_partials_layout()
             with torch.cuda.stream(self.stream):
-                out["obs_partials"] = torch.empty((K, leaves, vals), dtype=torch.float64, device=self.device)
+                if obs_partials:
+                    out["obs_partials"] = torch.empty((K, leaves, vals), dtype=torch.float64, device=self.device)
+                if ret_partials:
+                    out["ret_partials"] = torch.empty((K, leaves, 2), dtype=torch.float64, device=self.device)
             return out
         n, dev = self.num_envs, self.device
         specs = []
@@ -400,6 +404,13 @@ class DeviceRollout:
         if part is not getattr(self, "_partials_attached", None):
             self.handle.set_obs_partials(part)
             self._partials_attached = part
+        rpart = out.get("ret_partials")
+        if rpart is not getattr(self, "_ret_partials_attached", None):
+            if rpart is not None and getattr(self, "_fused_returns", None) is None:
+                raise RuntimeError("'ret_partials' needs fuse_reward_normalizer(normalizer) first: the rollout advances THAT normaliser's returns")
+            ptr, gamma = self._fused_returns if rpart is not None else (None, 0.0)
+            self.handle.set_return_partials(ptr, gamma, rpart)
+            self._ret_partials_attached = rpart
         self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
                             out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
@@ -417,6 +428,13 @@ class DeviceRollout:
                                  out.get("final_obs"), per_step=True)
         self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
         return out
+
+    def fuse_reward_normalizer(self, normalizer):
+        """Let trajectory rollouts whose buffers carry "ret_partials" advance `normalizer`'s running discounted returns
+        (NormalizeReward, normalize.py:132-136) and leave their per-step sums behind (mxv_set_return_partials); feed them back with
+        normalizer.normalize_rewards(reward, terminated, truncated, partials=out["ret_partials"])."""
+        self._fused_returns = (normalizer.backend.returns_ptr(), float(normalizer.gamma))
+        self._ret_partials_attached = None
 
     def make_normalizer(self, **kw):
         """RunningNormalizer (NormalizeObservation / NormalizeReward on device tensors) sized for this

@@ -310,6 +310,11 @@ int mxv_set_device_clock(mxv_handle *h, int32_t on);
  * (nothing is skipped silently); NULL detaches.  The caller owns the buffer. */
 int mxv_set_obs_partials(mxv_handle *h, double *partials_dev);
 int mxv_obs_partials_layout(mxv_handle *h, int64_t *leaves, int64_t *envs_per_leaf, int32_t *values);
+/* The same for NormalizeReward (normalize.py:127-145): the running discounted returns `returns = returns * gamma + rews`, zeroed where
+ * an episode ended, are advanced by the rollout in registers (returns_state_dev [N] float64: read at entry, written at exit — the array
+ * mxv_norm_returns_ptr gives), and every step's per-tile sum and sum of squares of the updated returns are left in
+ * partials_dev[K][leaves][2] for mxv_norm_reward_sums_partials.  Same launches, same leaves as above; both may be attached. */
+int mxv_set_return_partials(mxv_handle *h, double *returns_state_dev, double gamma, double *partials_dev);
 /* per-env reset ordinals (position of each env's reset stream, see RNG contract): uint32[N].  Synchronises. */
 int mxv_get_episodes(mxv_handle *h, uint32_t *episodes_host);
 int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host);
@@ -379,6 +384,9 @@ int mxv_norm_rewards(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t re
 int mxv_norm_obs_sums(mxv_norm *nm, int32_t K, const float *x_dev, double *sums_dev);
 /* the same sums from partials a rollout left behind (mxv_set_obs_partials): [K][leaves][2 dim] -> sums_dev [K][2 dim] */
 int mxv_norm_obs_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev);
+int mxv_norm_reward_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev);
+/* device address of the running discounted returns [N] (float64) this object keeps for NormalizeReward */
+int mxv_norm_returns_ptr(mxv_norm *nm, double **returns_dev);
 int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon,
                        const double *all_sums_dev, int32_t world, int64_t total_rows);
 int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,

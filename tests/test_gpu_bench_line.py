@@ -91,6 +91,8 @@ def test_line_carries_what_the_review_asked_for(line):
         assert v["normalize"][key]["roofline"]["frac"] > 0.15, key
     fm = v["normalize"]["normalize_obs_fused_moments"]                    # the batch moments formed by the rollout: cheaper than the second pass
     assert "error" not in fm and fm["us_per_step"] < fm["separate_us_per_step"] and fm["rollout_with_partials_us_per_step"] < 1.35 * fm["rollout_us_per_step"]
+    fr, fb = v["normalize"]["normalize_reward_fused_moments"], v["normalize"]["rollout_and_both_normalisations"]
+    assert "error" not in fr and fr["us_per_step"] < fr["separate_us_per_step"] and fb["fused_us_per_step"] < fb["separate_us_per_step"]
     nl = v["numpy_loop"]                                                  # SURVEY §8(d)'s third number: PCIe- and Python-inclusive
     assert nl["num_envs_2^20"]["value"] > 2e8 and nl["configs0_num_envs_8"]["value"] > 5e4 and nl["num_envs_2^20"]["episodes_ended"] > 0
     assert v["configs4_mixed_share"]["value"] > 1e10

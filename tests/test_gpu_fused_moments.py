@@ -116,3 +116,44 @@ def test_a_launch_that_cannot_produce_them_fails_loudly():
     r.rollout_per_step(8, out=plain)                         # detached: the ordinary launch
     r.synchronize()
     r.close()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("name,both", [("CartPole", True), ("CartPole", False), ("Pendulum", True), ("MountainCarContinuous", False), ("Acrobot", True)])
+def test_discounted_returns_advanced_by_the_rollout(name, both, compact):
+    """NormalizeReward fused the same way (mxv_set_return_partials): the rollout advances the normaliser's running returns and leaves
+    their per-step sums; normalised rewards, running statistics and the returns array equal the stand-alone path's (the recurrence is
+    IEEE-exact, so the returns are bit-identical; the sums differ in summation order only)."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    n, K = 70_000, 32
+    kw = dict(seed=4, action_seed=5, reward_f32=compact, action_i32=compact, max_episode_steps=min(LIMITS[name], 21))
+    a, b = DeviceRollout(GYM_IDS[name], n, **kw), DeviceRollout(GYM_IDS[name], n, **kw)
+    a.reset(seed=4), b.reset(seed=4)
+    na, nb = a.make_normalizer(gamma=0.97), b.make_normalizer(gamma=0.97)
+    a.fuse_reward_normalizer(na)
+    oa = a.trajectory_buffers(K, layout="separate", obs_partials=both, ret_partials=True)
+    ob = b.trajectory_buffers(K, layout="separate")
+    for rep in range(3):
+        a.rollout_per_step(K, out=oa)
+        b.rollout_per_step(K, out=ob)
+        ra = na.normalize_rewards(oa["reward"], oa["terminated"], oa["truncated"], partials=oa["ret_partials"])
+        rb = nb.normalize_rewards(ob["reward"], ob["terminated"], ob["truncated"])
+        a.synchronize(), b.synchronize()
+        for key in ("obs", "reward", "terminated", "truncated", "actions"):
+            assert torch.equal(oa[key], ob[key]), (name, key)
+        np.testing.assert_allclose(ra.cpu().numpy(), rb.cpu().numpy(), rtol=(2e-6 if compact else 1e-11), atol=0)
+        if both:
+            ya = na.normalize_obs(oa["obs"], partials=oa["obs_partials"])
+            yb = nb.normalize_obs(ob["obs"])
+            a.synchronize(), b.synchronize()
+            np.testing.assert_allclose(ya.cpu().numpy(), yb.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    sa, sb = na.backend.reward_state(), nb.backend.reward_state()
+    assert np.array_equal(sa[3], sb[3]) and (sa[3] != 0).any()       # the running returns themselves: bit-identical
+    assert int((oa["terminated"] | oa["truncated"]).sum()) > 0
+    np.testing.assert_allclose(sa[1], sb[1], rtol=1e-12)
+    assert sa[2] == sb[2]
+    li = a.handle.last_launch()
+    assert li["kernel"] == 1 and li["out_mode"] == (2 if compact else 1)
+    a.close(), b.close()

@@ -56,7 +56,7 @@ def _resources(remarks):
 
 
 def _symbol(env, e):
-    return f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi1ELb0ELb0EEEvNS_8StepArgsE"
+    return f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi1ELb0ELi0EEEvNS_8StepArgsE"
 
 
 def _function_body(asm, sym):
@@ -106,10 +106,10 @@ def test_the_instantiations_with_fused_observation_moments_keep_four_waves(build
     remarks, asm = build
     res = _resources(remarks)
     for env, (e, occ, _) in HOT.items():
-        for out in (1, 2):
-            r = res[f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi{out}ELb0ELb1EEEvNS_8StepArgsE"]
-            assert r["Occupancy"] == occ and r["VGPRs"] <= 128 and r["VGPRs Spill"] == 0, (env, out, r)
-    body = _function_body(asm, "_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi0ELb1ELi2ELb0ELi1ELb0ELb1EEEvNS_8StepArgsE")
+        for out, st in ((1, 1), (2, 1), (1, 2), (2, 2), (1, 3), (2, 3)):      # st: 1 observation moments, 2 discounted returns, 3 both
+            r = res[f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{e}ELb0ELi{out}ELb0ELi{st}EEEvNS_8StepArgsE"]
+            assert r["Occupancy"] == occ and r["VGPRs"] <= 128 and r["VGPRs Spill"] <= (8 if (env, st) == (0, 3) else 0), (env, out, st, r)   # CartPole with both: 6 parked around the loop
+    body = _function_body(asm, "_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi0ELb1ELi2ELb0ELi1ELb0ELi1EEEvNS_8StepArgsE")
     loops = [(h, t) for h, t in _inner_loops(body) if "global_store" in t]
     text = max(loops, key=lambda ht: ht[1].count("global_store"))[1]
     assert text.count("v_permlane16_swap") == 2 and text.count("v_permlane32_swap") == 2 and text.count("ds_swizzle") == 2   # ONE value left at these stages

@@ -31,15 +31,28 @@ for env_id, nn in (("CartPole-v1", n), ("MountainCar-v0", n >> 1), ("MountainCar
         r.stream.synchronize()
         return e0.elapsed_time(e1) / reps / K * 1e3
 
+    nz.normalize_rewards(out["reward"], out["terminated"], out["truncated"])
+    r.fuse_reward_normalizer(nz)
+    both = r.trajectory_buffers(K, obs_partials=True, ret_partials=True)
+    rets = {k: v for k, v in both.items() if k != "obs_partials"}
+    ro = torch.empty_like(both["reward"])
     for rep in range(3):
         res = {"env": env_id, "num_envs": nn,
+               "rollout_with_return_partials": timed(lambda: r.rollout_per_step(K, out=rets)),
+               "rollout_with_both": timed(lambda: r.rollout_per_step(K, out=both)),
+               "normalize_reward": timed(lambda: nz.normalize_rewards(both["reward"], both["terminated"], both["truncated"], out=ro)),
+               "normalize_reward_from_partials": timed(lambda: nz.normalize_rewards(both["reward"], both["terminated"], both["truncated"], out=ro, partials=both["ret_partials"])),
                "rollout": timed(lambda: r.rollout_per_step(K, out=plain)),
                "rollout_with_partials": timed(lambda: r.rollout_per_step(K, out=out)),
                "normalize_obs": timed(lambda: nz.normalize_obs(out["obs"], out=y)),
                "normalize_obs_from_partials": timed(lambda: nz.normalize_obs(out["obs"], out=y, partials=out["obs_partials"]))}
         res["pipeline_separate"] = res["rollout"] + res["normalize_obs"]
         res["pipeline_fused"] = res["rollout_with_partials"] + res["normalize_obs_from_partials"]
+        res["both_separate"] = res["rollout"] + res["normalize_obs"] + res["normalize_reward"]
+        res["both_fused"] = res["rollout_with_both"] + res["normalize_obs_from_partials"] + res["normalize_reward_from_partials"]
+        res["reward_only_fused"] = res["rollout_with_return_partials"] + res["normalize_reward_from_partials"]
+        res["reward_only_separate"] = res["rollout"] + res["normalize_reward"]
         print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
     r.close()
-    del out, plain, y
+    del out, plain, y, both, rets, ro
     torch.cuda.empty_cache()

@@ -28,7 +28,7 @@ NAMES = ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuou
 EPL = {0: 2, 1: 1, 2: 1, 3: 2, 4: 2}
 for env in range(5):
     for out in (1, 2):
-        sym = f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{EPL[env]}ELb0ELi{out}ELb0ELb0EEEvNS_8StepArgsE"
+        sym = f"_ZN3mxv12_GLOBAL__N_117rollout_kernel_v3ILi{env}ELb1ELi{EPL[env]}ELb0ELi{out}ELb0ELi0EEEvNS_8StepArgsE"
         if sym not in res:
             continue
         body = tk._function_body(asm, sym)
