@@ -49,7 +49,7 @@ EXPORTS = (
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
-    "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_stream",
+    "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_device_clock", "mxv_bj_set_device_clock", "mxv_tab_set_stream",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
     "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error", "mxv_hbm_pair_probe",
@@ -269,6 +269,8 @@ def _load():
         "mxv_tab_set_counters": ([vp, u64, u32], C.c_int),
         "mxv_tab_sync": ([vp], C.c_int),
         "mxv_tab_last_kernel": ([vp], C.c_int),
+        "mxv_tab_set_device_clock": ([vp, i32], C.c_int),
+        "mxv_bj_set_device_clock": ([vp, i32], C.c_int),
         "mxv_tab_word_threshold": ([C.c_double], u64),
         "mxv_tab_set_stream": ([vp, vp], C.c_int),
         "mxv_bj_create": ([C.POINTER(MxvBjConfig), C.POINTER(vp)], C.c_int),
@@ -1151,6 +1153,10 @@ class Tab:
         self.set_state(snap["state"], snap["elapsed"])
         self.set_counters(snap["t"], snap["r"])
 
+    def set_device_clock(self, on: bool = True):
+        """The step index in device memory, advanced on the stream: step / rollout calls become recordable in a caller's hipGraph."""
+        self._check(lib.mxv_tab_set_device_clock(self._h, 1 if on else 0))
+
     def last_kernel(self) -> int:
         """TAB_KERNEL_GENERAL / TAB_KERNEL_TRAJECTORY: which kernel the last step / rollout call launched (mxv_tab_last_kernel)."""
         return int(lib.mxv_tab_last_kernel(self._h))
@@ -1273,6 +1279,10 @@ class Blackjack:
         self._base_seed = int(base_seed) & (2**64 - 1)
         self._per_env_seeds = None if per_env_seeds is None else per_env_seeds.copy()
         self._action_seed = int(action_seed) & (2**64 - 1)
+
+    def set_device_clock(self, on: bool = True):
+        """The step index in device memory, advanced on the stream: step / rollout calls become recordable in a caller's hipGraph."""
+        self._check(lib.mxv_bj_set_device_clock(self._h, 1 if on else 0))
 
     def get_counters(self):
         t, r = C.c_uint64(), C.c_uint32()

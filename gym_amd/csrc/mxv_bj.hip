@@ -68,6 +68,7 @@ struct BjArgs {
     int32_t *err;
     int64_t n;
     uint64_t env0, base_seed, action_seed, t;
+    const uint64_t *t_dev;    // device clock (mxv_bj_set_device_clock): the step index = t + *t_dev; nullptr: t
     int32_t max_steps, K, natural, sab;
     int64_t slice, act_slice;
 };
@@ -163,9 +164,10 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
     const uint32_t q = (uint32_t)(ge & 3);
     uint64_t act_block = ~0ull;
     uint32_t act_word[4] = {0, 0, 0, 0};
+    const uint64_t t_base = a.t + (a.t_dev ? *a.t_dev : 0);
     mxv::settle_entry_loads();
     for (int k = 0; k < a.K; ++k) {
-        const uint64_t t = a.t + (uint64_t)k;
+        const uint64_t t = t_base + (uint64_t)k;
         const int64_t o = (int64_t)k * a.slice * 3 + e;   // observation columns: o, o + slice', ...
         const int64_t o1 = (int64_t)k * a.slice + e;
         const int64_t col = a.slice ? a.slice : a.n;      // distance between the three observation columns
@@ -261,8 +263,12 @@ struct BjResetArgs {
     int64_t *obs;
     int64_t n;
     uint64_t env0, base_seed, t;
+    const uint64_t *t_dev;
     uint32_t r;
 };
+
+__global__ void bj_set_word_kernel(uint64_t *dst, uint64_t v) { *dst = v; }
+__global__ void bj_add_word_kernel(uint64_t *dst, uint64_t d) { *dst += d; }
 
 __global__ void __launch_bounds__(kBjBlock) bj_reset_kernel(BjResetArgs a) {
     const int64_t e = (int64_t)blockIdx.x * kBjBlock + threadIdx.x;
@@ -277,7 +283,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_reset_kernel(BjResetArgs a) {
             for (int i = 0; i < 4; ++i) c[i] = a.cards[e * 4 + i];
         } else {
             const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
-            const U4 w = reset_words(seed, a.t, a.r);
+            const U4 w = reset_words(seed, a.t + (a.t_dev ? *a.t_dev : 0), a.r);
             c[0] = card_of(w.x); c[1] = card_of(w.y); c[2] = card_of(w.z); c[3] = card_of(w.w);
         }
         deal(c[0], c[1], d);
@@ -302,6 +308,8 @@ struct mxv_bj {
     int32_t *state = nullptr, *elapsed = nullptr, *err = nullptr;
     uint64_t *seeds = nullptr;
     uint64_t base_seed = 0, action_seed = 0, t = 0;
+    uint64_t *t_dev = nullptr;   // device clock (mxv_bj_set_device_clock)
+    bool dev_clock = false;
     uint32_t r = 0;
     bool was_reset = false;
     // staging of the *_host calls
@@ -352,6 +360,23 @@ int bj_latched(mxv_bj *h) {
     return MXV_OK;
 }
 
+// see mxv_set_device_clock (include/mxv.h): the step index on the device, advanced on the stream
+int bj_clock_add(mxv_bj *h, int64_t delta) {
+    h->t += (uint64_t)delta;
+    if (h->dev_clock) {
+        hipLaunchKernelGGL(bj_add_word_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, (uint64_t)delta);
+        BJ_HIP(h, hipGetLastError());
+    }
+    return MXV_OK;
+}
+int bj_clock_set(mxv_bj *h) {
+    if (h->dev_clock) {
+        hipLaunchKernelGGL(bj_set_word_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, h->t);
+        BJ_HIP(h, hipGetLastError());
+    }
+    return MXV_OK;
+}
+
 int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t act_slice, int64_t *actions_out,
               const int8_t *cards, int64_t *obs, double *reward, uint8_t *term, uint8_t *trunc, int64_t *final_obs) {
     if (!h->was_reset) return bfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
@@ -363,13 +388,13 @@ int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t a
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.actions = actions; a.actions_out = actions_out;
     a.cards = cards; a.obs = obs; a.reward = reward; a.terminated = term; a.truncated = trunc; a.final_obs = final_obs;
     a.err = h->err_in_block ? h->hm_err : h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed;
-    a.action_seed = h->action_seed; a.t = h->t; a.max_steps = h->cfg.max_episode_steps; a.K = K;
+    a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr;
+    a.max_steps = h->cfg.max_episode_steps; a.K = K;
     a.natural = h->cfg.natural; a.sab = h->cfg.sab; a.slice = slice; a.act_slice = act_slice;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock);
     hipLaunchKernelGGL(bj_step_kernel, dim3(blocks), dim3(kBjBlock), 0, h->stream, a);
     BJ_HIP(h, hipGetLastError());
-    h->t += (uint64_t)K;
-    return MXV_OK;
+    return bj_clock_add(h, K);
 }
 
 int bj_do_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int64_t *obs_dev) {
@@ -377,7 +402,7 @@ int bj_do_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int
     h->r += 1;
     BjResetArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.mask = mask_dev; a.cards = cards_dev; a.obs = obs_dev;
-    a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->t; a.r = h->r;
+    a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr; a.r = h->r;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock);
     hipLaunchKernelGGL(bj_reset_kernel, dim3(blocks), dim3(kBjBlock), 0, h->stream, a);
     BJ_HIP(h, hipGetLastError());
@@ -445,9 +470,11 @@ int mxv_bj_create(const mxv_bj_config *cfg, mxv_bj **out) {
     if (err == hipSuccess) err = hipMalloc((void **)&h->state, n * 4);
     if (err == hipSuccess) err = hipMalloc((void **)&h->elapsed, n * 4);
     if (err == hipSuccess) err = hipMalloc((void **)&h->err, 4);
+    if (err == hipSuccess) err = hipMalloc((void **)&h->t_dev, 8);
     if (err == hipSuccess) err = hipMemsetAsync(h->state, 0, n * 4, h->stream);
     if (err == hipSuccess) err = hipMemsetAsync(h->elapsed, 0, n * 4, h->stream);
     if (err == hipSuccess) err = hipMemsetAsync(h->err, 0, 4, h->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(h->t_dev, 0, 8, h->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
     if (err != hipSuccess) {
         bfail(nullptr, MXV_ERR_HIP, "mxv_bj_create: %s", hipGetErrorString(err));
@@ -462,7 +489,7 @@ int mxv_bj_destroy(mxv_bj *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->seeds};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->seeds, h->t_dev};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->hostmap) {
@@ -487,6 +514,7 @@ int mxv_bj_seed(mxv_bj *h, uint64_t base_seed, const uint64_t *per_env_seeds_hos
     h->action_seed = action_seed;
     h->t = 0;
     h->r = 0;
+    if (int rc = bj_clock_set(h)) return rc;
     if (per_env_seeds_host) {
         const size_t bytes = (size_t)h->cfg.num_envs * sizeof(uint64_t);
         if (!h->seeds) BJ_HIP(h, hipMalloc((void **)&h->seeds, bytes));
@@ -560,7 +588,7 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
         if (final_obs_host) std::memcpy(final_obs_host, h->st_final, 3 * n * 8);
         if (*h->hm_err != 0) {
             *h->hm_err = 0;
-            h->t -= 1;
+            (void)bj_clock_add(h, -1);
             return bfail(h, MXV_ERR_INVALID_ACTION, "action outside {0, 1} (Discrete(2).contains assert, blackjack.py:122)");
         }
         return MXV_OK;
@@ -576,7 +604,7 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
     if (truncated_host) BJ_HIP(h, hipMemcpyAsync(truncated_host, h->st_trunc, n, hipMemcpyDeviceToHost, h->stream));
     if (final_obs_host) BJ_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, 3 * n * 8, hipMemcpyDeviceToHost, h->stream));
     int rc = bj_latched(h);
-    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;
+    if (rc == MXV_ERR_INVALID_ACTION) (void)bj_clock_add(h, -1);
     return rc;
 }
 
@@ -592,6 +620,11 @@ int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host) {
 
 int mxv_bj_get_counters(mxv_bj *h, uint64_t *t, uint32_t *r) {
     BJ_CHECK(h);
+    if (h->dev_clock) {
+        BJ_HIP(h, hipSetDevice(h->cfg.device));
+        BJ_HIP(h, hipMemcpyAsync(&h->t, h->t_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        BJ_HIP(h, hipStreamSynchronize(h->stream));
+    }
     if (t) *t = h->t;
     if (r) *r = h->r;
     return MXV_OK;
@@ -607,6 +640,21 @@ int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapse
     h->t = t;
     h->r = r;
     h->was_reset = true;
+    return bj_clock_set(h);
+}
+
+int mxv_bj_set_device_clock(mxv_bj *h, int32_t on) {
+    BJ_CHECK(h);
+    BJ_HIP(h, hipSetDevice(h->cfg.device));
+    if (on && !h->dev_clock) {
+        h->dev_clock = true;
+        return bj_clock_set(h);
+    }
+    if (!on && h->dev_clock) {
+        BJ_HIP(h, hipMemcpyAsync(&h->t, h->t_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        BJ_HIP(h, hipStreamSynchronize(h->stream));
+        h->dev_clock = false;
+    }
     return MXV_OK;
 }
 

@@ -71,6 +71,7 @@ struct TabArgs {
     int32_t *err;
     int64_t n;
     uint64_t env0, base_seed, action_seed, t;
+    const uint64_t *t_dev;   // device clock (mxv_tab_set_device_clock): the step index = t + *t_dev; nullptr: t
     int32_t max_steps, K;
     int64_t slice;           // 0 or N (per-step trajectory outputs)
     int64_t act_slice;       // 0 or N (action tape)
@@ -143,9 +144,10 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
     uint64_t act_block = ~0ull, tr_block = ~0ull;
     uint32_t act_word[4] = {0, 0, 0, 0};
     U4 tw{0, 0, 0, 0};
+    const uint64_t t_base = a.t + (a.t_dev ? *a.t_dev : 0);
     mxv::settle_entry_loads();
     for (int k = 0; k < a.K; ++k) {
-        const uint64_t t = a.t + (uint64_t)k;
+        const uint64_t t = t_base + (uint64_t)k;
         const int64_t o = (int64_t)k * a.slice + e;
         // ---- action: caller's, or Discrete(A).sample() from the Philox action stream ----
         int64_t act;
@@ -260,6 +262,7 @@ struct TabTrajArgs {
     uint8_t *terminated, *truncated;
     int64_t n;
     uint64_t env0, base_seed, action_seed, t;
+    const uint64_t *t_dev;
     int32_t max_steps, K;
     uint32_t tile_base;      // ALLV == false: the (one) ragged block's tile index
 };
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_traj_kernel(TabTrajArgs a) {
     uint8_t *p_term = a.terminated + tile0, *p_trunc = a.truncated + tile0;
     const int64_t slice_w = a.n * (int64_t)IB, slice_b = a.n;
     const uint32_t off_w = tid * IB, off_b = tid;
-    const uint64_t t0 = a.t, t1 = a.t + (uint64_t)a.K;
+    const uint64_t t0 = a.t + (a.t_dev ? *a.t_dev : 0), t1 = t0 + (uint64_t)a.K;
     mxv::settle_entry_loads();
     for (uint64_t blk = t0 >> 2; blk <= ((t1 - 1) >> 2); ++blk) {
         uint32_t aw[4];
@@ -409,6 +412,9 @@ __global__ void __launch_bounds__(kTabBlock) tab_traj_kernel(TabTrajArgs a) {
     }
 }
 
+__global__ void tab_set_word_kernel(uint64_t *dst, uint64_t v) { *dst = v; }
+__global__ void tab_add_word_kernel(uint64_t *dst, uint64_t d) { *dst += d; }
+
 struct TabResetArgs {
     int32_t *state, *elapsed;
     const uint64_t *seeds;
@@ -418,6 +424,7 @@ struct TabResetArgs {
     int32_t S, log2S;
     int64_t n;
     uint64_t env0, base_seed, t;
+    const uint64_t *t_dev;
     uint32_t r;
 };
 
@@ -429,7 +436,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_reset_kernel(TabResetArgs a) {
         return;
     }
     const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + a.env0 + (uint64_t)e;
-    const U4 w = reset_words(seed, a.t, a.r);
+    const U4 w = reset_words(seed, a.t + (a.t_dev ? *a.t_dev : 0), a.r);
     const int32_t s = sample_initial(a.init_cum, a.S, a.log2S, u01(w.x));
     a.state[e] = s;
     a.elapsed[e] = 0;
@@ -454,6 +461,8 @@ struct mxv_tab {
     int log2S = 0;
     int single_start = -1;
     uint64_t base_seed = 0, action_seed = 0, t = 0;
+    uint64_t *t_dev = nullptr;   // device clock (mxv_tab_set_device_clock)
+    bool dev_clock = false;
     uint32_t r = 0;
     bool was_reset = false;
     // staging for *_host calls
@@ -495,6 +504,23 @@ int tfail(mxv_tab *h, int code, const char *fmt, ...) {
 #define TAB_CHECK(h) \
     if (!(h)) return tfail(nullptr, MXV_ERR_INVALID_ARG, "NULL mxv_tab")
 
+// see mxv_set_device_clock (include/mxv.h): the step index on the device, advanced on the stream
+int tab_clock_add(mxv_tab *h, int64_t delta) {
+    h->t += (uint64_t)delta;
+    if (h->dev_clock) {
+        hipLaunchKernelGGL(tab_add_word_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, (uint64_t)delta);
+        TAB_HIP(h, hipGetLastError());
+    }
+    return MXV_OK;
+}
+int tab_clock_set(mxv_tab *h) {
+    if (h->dev_clock) {
+        hipLaunchKernelGGL(tab_set_word_kernel, dim3(1), dim3(1), 0, h->stream, h->t_dev, h->t);
+        TAB_HIP(h, hipGetLastError());
+    }
+    return MXV_OK;
+}
+
 int tab_check_latched(mxv_tab *h) {
     int32_t e = 0;
     TAB_HIP(h, hipMemcpyAsync(&e, h->err, sizeof e, hipMemcpyDeviceToHost, h->stream));
@@ -523,7 +549,7 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t ac
     a.obs = obs; a.reward_out = reward; a.terminated = term; a.truncated = trunc; a.prob_out = prob;
     a.final_obs = final_obs; a.final_prob = final_prob;
     a.err = h->err_in_block ? h->hm_err : h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset;
-    a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->t;
+    a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr;
     a.max_steps = h->cfg.max_episode_steps; a.K = K; a.slice = slice; a.act_slice = act_slice;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
     if (h->lds_table) {
@@ -538,9 +564,8 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t ac
             hipLaunchKernelGGL((tab_step_kernel<false, false>), dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
     }
     TAB_HIP(h, hipGetLastError());
-    h->t += (uint64_t)K;
     h->last_kernel = MXV_TAB_KERNEL_GENERAL;
-    return MXV_OK;
+    return tab_clock_add(h, K);
 }
 
 // T = ceil(cum * 2^32 - 0.5) clamped to [0, 2^32]: cum > (w + 0.5) * 2^-32  <=>  w < T for every 32-bit word w (both sides of the
@@ -647,7 +672,8 @@ int tab_launch_traj(mxv_tab *h, int K, void *actions_out, void *obs, void *rewar
     a.init_off = h->fast_init_off; a.S1 = h->fast_S1; a.init_iters = h->fast_iters; a.start = h->single_start;
     a.actions = (char *)actions_out; a.obs = (char *)obs; a.reward = (char *)reward; a.prob = (char *)prob;
     a.terminated = term; a.truncated = trunc;
-    a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->t;
+    a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t;
+    a.t_dev = h->dev_clock ? h->t_dev : nullptr;
     a.max_steps = h->cfg.max_episode_steps; a.K = K;
     const bool single = h->single_start >= 0;
     const int sel = (h->fast_M == 3 ? 4 : 0) | (compact ? 2 : 0) | (single ? 1 : 0);
@@ -662,9 +688,8 @@ int tab_launch_traj(mxv_tab *h, int K, void *actions_out, void *obs, void *rewar
         default: launch_traj<3, true, true>(h, a); break;
     }
     TAB_HIP(h, hipGetLastError());
-    h->t += (uint64_t)K;
     h->last_kernel = MXV_TAB_KERNEL_TRAJECTORY;
-    return MXV_OK;
+    return tab_clock_add(h, K);
 }
 
 int tab_do_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
@@ -673,7 +698,7 @@ int tab_do_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
     TabResetArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.mask = mask_dev; a.init_cum = h->init_cum;
     a.obs = obs_dev; a.S = h->cfg.num_states; a.log2S = h->log2S; a.n = h->cfg.num_envs;
-    a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->t; a.r = h->r;
+    a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr; a.r = h->r;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
     hipLaunchKernelGGL(tab_reset_kernel, dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
     TAB_HIP(h, hipGetLastError());
@@ -778,6 +803,7 @@ int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const
     TAB_CREATE_HIP(hipMalloc((void **)&h->state, n * sizeof(int32_t)));
     TAB_CREATE_HIP(hipMalloc((void **)&h->elapsed, n * sizeof(int32_t)));
     TAB_CREATE_HIP(hipMalloc((void **)&h->err, sizeof(int32_t)));
+    TAB_CREATE_HIP(hipMalloc((void **)&h->t_dev, sizeof(uint64_t)));
     TAB_CREATE_HIP(hipMalloc((void **)&h->reward, entries * sizeof(double)));
     TAB_CREATE_HIP(hipMalloc((void **)&h->nt, entries * sizeof(int32_t)));
     TAB_CREATE_HIP(hipMalloc((void **)&h->init_cum, (size_t)S * sizeof(double)));
@@ -786,6 +812,7 @@ int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const
     TAB_CREATE_HIP(hipMemsetAsync(h->state, 0, n * sizeof(int32_t), h->stream));
     TAB_CREATE_HIP(hipMemsetAsync(h->elapsed, 0, n * sizeof(int32_t), h->stream));
     TAB_CREATE_HIP(hipMemsetAsync(h->err, 0, sizeof(int32_t), h->stream));
+    TAB_CREATE_HIP(hipMemsetAsync(h->t_dev, 0, sizeof(uint64_t), h->stream));
     TAB_CREATE_HIP(hipMemcpyAsync(h->reward, reward_host, entries * sizeof(double), hipMemcpyHostToDevice, h->stream));
     TAB_CREATE_HIP(hipMemcpyAsync(h->nt, packed.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     TAB_CREATE_HIP(hipMemcpyAsync(h->init_cum, initial_cum_host, (size_t)S * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -819,7 +846,7 @@ int mxv_tab_destroy(mxv_tab *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->fast_tbl};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->fast_tbl, h->t_dev};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->hostmap) {
@@ -844,6 +871,7 @@ int mxv_tab_seed(mxv_tab *h, uint64_t base_seed, const uint64_t *per_env_seeds_h
     h->base_seed = base_seed;
     h->t = 0;
     h->r = 0;
+    if (int rc = tab_clock_set(h)) return rc;
     if (per_env_seeds_host) {
         const size_t bytes = (size_t)h->cfg.num_envs * sizeof(uint64_t);
         if (!h->seeds) TAB_HIP(h, hipMalloc((void **)&h->seeds, bytes));
@@ -945,7 +973,7 @@ int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uni
         if (final_prob_host) std::memcpy(final_prob_host, h->st_fprob, n * 8);
         if (*h->hm_err != 0) {
             *h->hm_err = 0;
-            h->t -= 1;
+            (void)tab_clock_add(h, -1);
             return tfail(h, MXV_ERR_INVALID_ACTION, "discrete action outside [0, %d) (Discrete.contains)", h->cfg.num_actions);
         }
         return MXV_OK;
@@ -965,7 +993,7 @@ int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uni
     if (final_obs_host) TAB_HIP(h, hipMemcpyAsync(final_obs_host, h->st_final, n * 8, hipMemcpyDeviceToHost, h->stream));
     if (final_prob_host) TAB_HIP(h, hipMemcpyAsync(final_prob_host, h->st_fprob, n * 8, hipMemcpyDeviceToHost, h->stream));
     int rc = tab_check_latched(h);
-    if (rc == MXV_ERR_INVALID_ACTION) h->t -= 1;
+    if (rc == MXV_ERR_INVALID_ACTION) (void)tab_clock_add(h, -1);
     return rc;
 }
 
@@ -997,6 +1025,11 @@ int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elap
 
 int mxv_tab_get_counters(mxv_tab *h, uint64_t *t, uint32_t *r) {
     TAB_CHECK(h);
+    if (h->dev_clock) {  // a caller's graph replays advance the device word only
+        TAB_HIP(h, hipSetDevice(h->cfg.device));
+        TAB_HIP(h, hipMemcpyAsync(&h->t, h->t_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        TAB_HIP(h, hipStreamSynchronize(h->stream));
+    }
     if (t) *t = h->t;
     if (r) *r = h->r;
     return MXV_OK;
@@ -1006,6 +1039,21 @@ int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r) {
     TAB_CHECK(h);
     h->t = t;
     h->r = r;
+    return tab_clock_set(h);
+}
+
+int mxv_tab_set_device_clock(mxv_tab *h, int32_t on) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    if (on && !h->dev_clock) {
+        h->dev_clock = true;
+        return tab_clock_set(h);
+    }
+    if (!on && h->dev_clock) {
+        TAB_HIP(h, hipMemcpyAsync(&h->t, h->t_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        TAB_HIP(h, hipStreamSynchronize(h->stream));
+        h->dev_clock = false;
+    }
     return MXV_OK;
 }
 

@@ -466,6 +466,9 @@ int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elap
 int mxv_tab_get_counters(mxv_tab *h, uint64_t *t, uint32_t *r);
 int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r);
 int mxv_tab_sync(mxv_tab *h);
+/* the device clock of mxv_set_device_clock for this engine: mxv_tab_step / mxv_tab_rollout / mxv_tab_rollout_tape become recordable in a
+ * caller's hipGraph (explicit resets are not: their ordinal travels by value) */
+int mxv_tab_set_device_clock(mxv_tab *h, int32_t on);
 int mxv_tab_last_kernel(const mxv_tab *h);
 /* The integer form of categorical_sample's comparison (host function, no device needed): T in [0, 2^32] with
  * cum_prob > (w + 0.5) * 2^-32  <=>  w < T  for every 32-bit word w. */
@@ -512,6 +515,7 @@ int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host);
 int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapsed_host, uint64_t t, uint32_t r);
 /* step index / reset ordinal of the draw streams (checkpointing: what mxv_bj_set_state takes back) */
 int mxv_bj_get_counters(mxv_bj *h, uint64_t *t, uint32_t *r);
+int mxv_bj_set_device_clock(mxv_bj *h, int32_t on);   /* as mxv_tab_set_device_clock: mxv_bj_step / mxv_bj_rollout recordable in a caller's hipGraph */
 int mxv_bj_sync(mxv_bj *h);
 int mxv_bj_set_stream(mxv_bj *h, void *stream);
 

@@ -167,3 +167,85 @@ def test_graphed_loop_helper_records_a_trajectory():
                 assert np.array_equal(got[rep][1][k], (b.terminated | b.truncated).cpu().numpy()), (rep, k)
     assert sum(int(d.sum()) for _, d in got) > 0
     a.close(), b.close()
+
+
+@pytest.mark.parametrize("gid,compact", [("FrozenLake8x8-v1", False), ("Taxi-v3", True)])
+def test_tabular_rollouts_in_a_callers_graph(gid, compact):
+    """mxv_tab_set_device_clock: K-step sampled rollouts of the table engine (trajectory kernel) and single general-kernel steps recorded
+    in a torch.cuda.graph and replayed == the same calls one by one."""
+    import torch
+    from gym_amd.toy_text import TabularRollout
+
+    n, K, replays = 8192, 6, 7          # K = 6: launches start and end inside the four-step action blocks, at a different phase every replay
+    runs = []
+    for captured in (False, True):
+        r = TabularRollout(gid, n, seed=3, action_seed=4, max_episode_steps=9, compact=compact)
+        r.reset(seed=3)
+        out = r.trajectory_buffers(K, layout="separate")
+        log = []
+        with torch.cuda.stream(r.stream):
+            if captured:
+                r.handle.set_device_clock(True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=r.stream):
+                    r.rollout_per_step(K, out=out)
+                    r.handle.rollout(1, out["obs"][0], out["reward"][0], out["terminated"][0], out["truncated"][0], out["prob"][0],
+                                     actions_out_dev=out["actions"][0], per_step=False)          # the general kernel, one step
+                for _ in range(replays):
+                    g.replay()
+                    log.append({k: v.clone() for k, v in out.items()})
+            else:
+                for _ in range(replays):
+                    r.rollout_per_step(K, out=out)
+                    r.handle.rollout(1, out["obs"][0], out["reward"][0], out["terminated"][0], out["truncated"][0], out["prob"][0],
+                                     actions_out_dev=out["actions"][0], per_step=False)
+                    log.append({k: v.clone() for k, v in out.items()})
+        r.synchronize()
+        assert r.handle.get_counters()[0] == replays * (K + 1)
+        runs.append(([{k: v.cpu().numpy() for k, v in d.items()} for d in log], r.handle.get_state()))
+        r.close()
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (gid, k)
+    assert all(np.array_equal(x, y) for x, y in zip(runs[0][1], runs[1][1]))
+    assert len({tuple(d["actions"][1][:64]) for d in runs[1][0]}) > 1        # the action stream moves from replay to replay
+
+
+def test_blackjack_rollouts_in_a_callers_graph():
+    import torch
+    from gym_amd import _native
+
+    n, K, replays = 4096, 5, 6
+    dev = torch.device("cuda", 0)
+    runs = []
+    for captured in (False, True):
+        h = _native.Blackjack(n, seed=5, action_seed=6)
+        st = torch.cuda.Stream()
+        h.set_stream(st.cuda_stream)
+        obs = torch.empty((K, 3, n), dtype=torch.int64, device=dev)
+        rew = torch.empty((K, n), dtype=torch.float64, device=dev)
+        term, trunc = (torch.empty((K, n), dtype=torch.uint8, device=dev) for _ in range(2))
+        act = torch.empty((K, n), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        h.reset()
+        log = []
+        with torch.cuda.stream(st):
+            if captured:
+                h.set_device_clock(True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    h.rollout(K, obs, rew, term, trunc, None, actions_out_dev=act, per_step=True)
+                for _ in range(replays):
+                    g.replay()
+                    log.append([x.clone() for x in (obs, rew, term, act)])
+            else:
+                for _ in range(replays):
+                    h.rollout(K, obs, rew, term, trunc, None, actions_out_dev=act, per_step=True)
+                    log.append([x.clone() for x in (obs, rew, term, act)])
+        h.sync()
+        assert h.get_counters()[0] == replays * K
+        runs.append(([[x.cpu().numpy() for x in row] for row in log], h.get_state()))
+        h.close()
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert all(np.array_equal(x, y) for x, y in zip(runs[0][1], runs[1][1]))
