@@ -161,7 +161,7 @@ template <typename RT>
 __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__ rew, const uint8_t *__restrict__ term,
                                                           const uint8_t *__restrict__ trunc, double *__restrict__ returns,
                                                           int64_t n, int K, double gamma, int64_t leaves,
-                                                          double *__restrict__ partials) {
+                                                          double *__restrict__ partials, int aligned) {
     const int lane = threadIdx.x;
 #if MXV_NORM_XCD_MAP
     // workgroup ids are dealt round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the leaves (as the rollout kernels'
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64) returns_sums_kernel(const RT *__restrict__
     };
     Slot ring[D];
     // wave-uniform: the whole leaf exists and every step of the [K][n] tensors starts on a multiple of four elements
-    const bool vec = MXV_NORM_VEC4 && (n & 3) == 0 && (leaf + 1) * kRewLeafEnvs <= n;
+    const bool vec = MXV_NORM_VEC4 && aligned && (n & 3) == 0 && (leaf + 1) * kRewLeafEnvs <= n;   // aligned: the host checked the tensors' addresses
     auto run = [&](auto vec_tag) __attribute__((always_inline)) {
         constexpr bool VEC = decltype(vec_tag)::value;
         auto fetch = [&](int k, Slot &sl) {
@@ -711,12 +711,15 @@ int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_
         return nfail(nm, MXV_ERR_INVALID_ARG, "reward/terminated/truncated/sums pointer is NULL");
     const int64_t leaves = ceil_div(nm->n, kRewLeafEnvs);
     if (int rc = ensure_capacity(nm, K, leaves, 2)) return rc;
+    // the vector loads (16 / 32 bytes of rewards, 4 of each flag array per lane) need tensors that start on those boundaries — true of
+    // whole allocations, not of every view a caller may pass
+    const int aligned = (uintptr_t)reward_dev % 32 == 0 && (uintptr_t)terminated_dev % 4 == 0 && (uintptr_t)truncated_dev % 4 == 0;
     if (reward_f32)
         hipLaunchKernelGGL(returns_sums_kernel<float>, dim3((unsigned)leaves), dim3(64), 0, nm->stream, (const float *)reward_dev,
-                           terminated_dev, truncated_dev, nm->returns, nm->n, (int)K, gamma, leaves, nm->part_a);
+                           terminated_dev, truncated_dev, nm->returns, nm->n, (int)K, gamma, leaves, nm->part_a, aligned);
     else
         hipLaunchKernelGGL(returns_sums_kernel<double>, dim3((unsigned)leaves), dim3(64), 0, nm->stream, (const double *)reward_dev,
-                           terminated_dev, truncated_dev, nm->returns, nm->n, (int)K, gamma, leaves, nm->part_a);
+                           terminated_dev, truncated_dev, nm->returns, nm->n, (int)K, gamma, leaves, nm->part_a, aligned);
     NRM_HIP(nm, hipGetLastError());
     return run_tree(nm, K, leaves, 2, sums_dev);
 }

@@ -379,3 +379,37 @@ def test_public_normalize_works_on_the_array_it_is_given():
     np.testing.assert_allclose(o1, rn.normalize_obs(b1), rtol=1e-12, atol=1e-12)               # the statistics include `other`
     env.close()
     bare.close()
+
+
+def test_reward_normalisation_of_views_that_start_anywhere():
+    """The return-sum and reward-map kernels use 16 / 32-byte vector loads where the tensors allow it; a caller's VIEW that starts one
+    element into an allocation (8-byte aligned rewards, odd flag addresses) must take the element-wise path and give the same bits."""
+    import torch
+    from gym_amd import _native
+
+    n, K = 8192, 12
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rew = torch.rand((K, n), generator=g, device="cuda", dtype=torch.float64)
+    te = (torch.rand((K, n), generator=g, device="cuda") < 0.05).to(torch.uint8)
+    tr = (torch.rand((K, n), generator=g, device="cuda") < 0.02).to(torch.uint8)
+
+    def shifted(t):
+        flat = torch.empty(t.numel() + 1, dtype=t.dtype, device="cuda")
+        v = flat[1:].view(t.shape)
+        v.copy_(t)
+        return v
+
+    outs = []
+    for views in (False, True):
+        r, a, b = (shifted(rew), shifted(te), shifted(tr)) if views else (rew, te, tr)
+        if views:
+            assert r.data_ptr() % 16 == 8 and a.data_ptr() % 4 == 1
+        nm = _native.Norm(1, n)
+        out = shifted(torch.empty_like(rew)) if views else torch.empty_like(rew)
+        nm.rewards(K, r, False, a, b, out, 0.99, 1e-8)
+        torch.cuda.synchronize()
+        outs.append((out.cpu().numpy().copy(), nm.get_state(want_returns=True)))
+        nm.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
