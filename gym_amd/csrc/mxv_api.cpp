@@ -251,10 +251,19 @@ void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.P = h->P;
 }
 
+// launches that never form the fused batch moments: with a buffer attached they fail instead of leaving it stale
+int no_partials_here(mxv_handle *h, const char *what) {
+    if (h->obs_part || h->ret_part)
+        return fail(h, MXV_ERR_UNSUPPORTED, "partial sums are attached (mxv_set_obs_partials / mxv_set_return_partials), but %s does not produce "
+                                            "them (only sampled [K][N] trajectory launches of mxv_rollout, MXV_ROLLOUT_FUSED, do): detach first", what);
+    return MXV_OK;
+}
+
 int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, void *reward, uint8_t *term,
             uint8_t *trunc, float *final_obs) {
     if (!h->was_reset)
         return fail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
+    if (int rc = no_partials_here(h, "a single step")) return rc;
     if (!obs) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
     if (int rc = use_device(h)) return rc;
     StepArgs a{};
@@ -680,7 +689,7 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
     a.terminated = term;
     a.truncated = trunc;
     a.final_obs = final_obs;
-    if ((h->obs_part || h->ret_part) && per_step && !actions_tape) {  // fused batch moments (mxv_set_obs_partials / mxv_set_return_partials)
+    if (h->obs_part || h->ret_part) {  // fused batch moments (mxv_set_obs_partials / mxv_set_return_partials): produced, or the call fails
         a.obs_part = h->obs_part;
         if (h->ret_part) {
             a.ret_part = h->ret_part;
@@ -718,6 +727,7 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         return fused_launch(h, K, per_step, nullptr, actions_out_dev, obs_dev, reward_dev, terminated_dev,
                             truncated_dev, final_obs_dev);
     if (mode != MXV_ROLLOUT_EAGER && mode != MXV_ROLLOUT_GRAPH) return fail(h, MXV_ERR_INVALID_ARG, "unknown rollout mode %d", mode);
+    if (int rc = no_partials_here(h, "a rollout of single-step launches (MXV_ROLLOUT_EAGER / _GRAPH)")) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
     auto slice = [&](void *p, size_t elem_bytes, int k) -> void * {
         if (!p) return nullptr;
@@ -1452,6 +1462,10 @@ extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int3
         for (int j = 0; j < i; ++j)
             if (handles[j] == h) return fail(h0, MXV_ERR_INVALID_ARG, "handle listed twice (segments %d and %d)", j, i);
         if (int rc = rollout_checks(h, K, outs[i].obs)) {
+            if (h != h0) h0->error = h->error;
+            return rc;
+        }
+        if (int rc = no_partials_here(h, "mxv_rollout_mixed")) {
             if (h != h0) h0->error = h->error;
             return rc;
         }

@@ -101,6 +101,7 @@ class DeviceRollout:
         self._order_after_caller()                                        # the actions were produced on the caller's stream
         if getattr(self, "episode_stats", False):
             self._attach_episode_outputs(None)
+        self._attach_partials(None, None)
         p = self._step_ptrs
         self.handle.step(actions.data_ptr(), p[0], p[1], p[2], p[3], p[4] if want_final else None)
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
@@ -156,6 +157,7 @@ class DeviceRollout:
     def step_sampled(self, want_final: bool = False, record_actions: bool = True):
         """One vector step with actions drawn on device (action_space.sample())."""
         self._attach_episode_outputs(None)
+        self._attach_partials(None, None)
         self.handle.step_sampled(self.obs, self.reward, self.terminated, self.truncated,
                                  self.final_obs if want_final else None, self.actions if record_actions else None)
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
@@ -165,6 +167,7 @@ class DeviceRollout:
         """K sampled steps back to back; the output tensors hold the last step ("final tensors" of the chunk).
         mode: "fused" (one launch, state in registers), "graph" (K launches from a hipGraph) or "eager"."""
         self._attach_episode_outputs(None)
+        self._attach_partials(None, None)
         self.handle.rollout(K, self.obs, self.reward, self.terminated, self.truncated,
                             self.final_obs if want_final else None, self.actions if record_actions else None,
                             per_step=False, mode=MODES[mode])
@@ -400,21 +403,23 @@ class DeviceRollout:
         out = self.trajectory_buffers(K) if out is None else out
         assert out["obs"].shape[0] >= K
         self._attach_episode_outputs(out)
-        part = out.get("obs_partials")
+        self._attach_partials(out.get("obs_partials"), out.get("ret_partials"))
+        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
+                            out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
+        self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
+        return out
+
+    def _attach_partials(self, part, rpart):
+        """Attach / detach the buffers of the fused batch moments (mxv_set_obs_partials, mxv_set_return_partials) when they change."""
         if part is not getattr(self, "_partials_attached", None):
             self.handle.set_obs_partials(part)
             self._partials_attached = part
-        rpart = out.get("ret_partials")
         if rpart is not getattr(self, "_ret_partials_attached", None):
             if rpart is not None and getattr(self, "_fused_returns", None) is None:
                 raise RuntimeError("'ret_partials' needs fuse_reward_normalizer(normalizer) first: the rollout advances THAT normaliser's returns")
             ptr, gamma = self._fused_returns if rpart is not None else (None, 0.0)
             self.handle.set_return_partials(ptr, gamma, rpart)
             self._ret_partials_attached = rpart
-        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
-                            out["actions"] if record_actions else None, per_step=True, mode=MODES[mode])
-        self._last = (out["obs"][K - 1], out["reward"][K - 1], out["terminated"][K - 1], out["truncated"][K - 1])
-        return out
 
     def rollout_tape(self, actions: torch.Tensor, *, out: Optional[dict] = None):
         """One fused launch driven by an action tape actions[K, N] (the engine's action dtype)."""
@@ -422,6 +427,9 @@ class DeviceRollout:
         assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self.action_dtype
         assert actions.numel() == K * self.num_envs
         out = self.trajectory_buffers(K) if out is None else out
+        if "obs_partials" in out or "ret_partials" in out:
+            raise ValueError("tape-driven launches do not form the batch moments (obs_partials / ret_partials): use buffers without them")
+        self._attach_partials(None, None)
         self._order_after_caller()                                        # the tape was produced on the caller's stream
         self._attach_episode_outputs(out)
         self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"],

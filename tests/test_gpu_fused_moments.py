@@ -157,3 +157,37 @@ def test_discounted_returns_advanced_by_the_rollout(name, both, compact):
     li = a.handle.last_launch()
     assert li["kernel"] == 1 and li["out_mode"] == (2 if compact else 1)
     a.close(), b.close()
+
+
+def test_attached_partials_never_go_stale_silently():
+    """C ABI: with a partials buffer attached, every launch that does not fill it fails (single steps, tape launches, eager rollouts,
+    final-tensor rollouts); the Python front-end detaches by itself when a call shape without partials follows."""
+    import torch
+    from gym_amd import _native
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout("CartPole-v1", 2048, seed=1, action_seed=2)
+    r.reset(seed=1)
+    out = r.trajectory_buffers(4, layout="separate", obs_partials=True)
+    r.rollout_per_step(4, out=out)
+    r.synchronize()
+    h = r.handle
+    dev_a = torch.zeros(2048, dtype=torch.int64, device="cuda")
+    for call in (lambda: h.step(dev_a.data_ptr(), r.obs, r.reward, r.terminated, r.truncated, None),
+                 lambda: h.rollout(4, r.obs, r.reward, r.terminated, r.truncated, None, None, per_step=False, mode=_native.ROLLOUT_FUSED),
+                 lambda: h.rollout(4, out["obs"], out["reward"], out["terminated"], out["truncated"], None, out["actions"], per_step=True, mode=_native.ROLLOUT_EAGER),
+                 lambda: h.rollout_tape(4, out["actions"], out["obs"], out["reward"], out["terminated"], out["truncated"], None, per_step=True)):
+        with pytest.raises(_native.MxvError) as e:
+            call()
+        assert e.value.code == _native.ERR_UNSUPPORTED
+    # the front-end: other call shapes detach first
+    r.step(dev_a)
+    r.rollout(3)
+    plain = {k: v for k, v in out.items() if k != "obs_partials"}
+    r.rollout_tape(out["actions"].clone(), out=plain)
+    with pytest.raises(ValueError):
+        r.rollout_tape(out["actions"].clone(), out=out)
+    r.rollout_per_step(4, out=out)                      # and re-attach
+    r.synchronize()
+    assert torch.isfinite(out["obs_partials"]).all()
+    r.close()
