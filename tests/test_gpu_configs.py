@@ -276,3 +276,4 @@ def test_gym_amd_first_torch_second_share_one_hip_runtime():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "import_order.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok: gym_amd first" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    print(r.stderr[-600:])       # the script's own timestamps (pytest -rP / a failure shows them)
