@@ -249,3 +249,20 @@ def test_blackjack_rollouts_in_a_callers_graph():
     for a, b in zip(runs[0][0], runs[1][0]):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert all(np.array_equal(x, y) for x, y in zip(runs[0][1], runs[1][1]))
+
+
+def test_the_graphed_policy_gradient_example_learns():
+    """examples/policy_gradient_graphed.py: REINFORCE with the 64-step sampling loop (policy, env steps, trajectory copies, fused
+    episode statistics) replayed from one hipGraph; the policy improves, and the recorded loop is faster than one call per step."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("policy_gradient_graphed", os.path.join(root, "examples", "policy_gradient_graphed.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    h = mod.train(iterations=14, verbose=False)
+    assert h[0]["mean_episode_length"] < 30 and h[-1]["mean_episode_length"] > 45, [round(x["mean_episode_length"], 1) for x in h]
+    e = mod.train(iterations=4, graphed=False, verbose=False)
+    fast = min(x["us_per_step"] for x in h[2:])
+    assert fast < 0.8 * min(x["us_per_step"] for x in e[1:]), (fast, [x["us_per_step"] for x in e])
