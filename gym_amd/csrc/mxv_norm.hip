@@ -47,9 +47,6 @@ constexpr int kMaxWorld = 64;
 #ifndef MXV_NORM_DPP_REDUCE
 #define MXV_NORM_DPP_REDUCE 1  // A/B hook: 0 = the six ds_bpermute stages of __shfl_xor
 #endif
-#ifndef MXV_NORM_OBS_UNROLL
-#define MXV_NORM_OBS_UNROLL 4  // rows in flight per lane of obs_sums_kernel (A/B hook)
-#endif
 #ifndef MXV_NORM_XCD_MAP
 #define MXV_NORM_XCD_MAP 1     // A/B hook: 0 = leaf = workgroup id
 #endif
@@ -124,7 +121,7 @@ __global__ void __launch_bounds__(kThreads) obs_sums_kernel(const float *__restr
 #pragma unroll
     for (int j = 0; j < O; ++j) s[j] = q[j] = 0.0;
     // a lane's rows are tid, tid+256, ...: every wave load is a dense burst (64 rows x 4*O bytes)
-#pragma unroll MXV_NORM_OBS_UNROLL
+#pragma unroll 4   // (8 or 16 rows in flight per lane measured the same: profiles/r4n_normalize_variants.txt)
     for (int r = tid; r < rows; r += kThreads) {
         float f[O];
         load_row<O>(base + (int64_t)r * O, f);

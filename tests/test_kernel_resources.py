@@ -178,3 +178,54 @@ def test_the_instruction_forms_this_round_bought_are_still_in_the_loops(build):
     # Pendulum's K-step loop: 614 instructions / 27 branches before, 501 / 20 after
     n_instr = sum(1 for l in pend.splitlines() if l.startswith("\t") and not l.strip().startswith((".", ";")))
     assert n_instr <= 540 and sum(1 for l in pend.splitlines() if "s_cbranch" in l) <= 22, n_instr
+
+
+# ---- the other engines' trajectory kernels (seconds to compile) -------------------------------------------------------------------------
+def _compile(src_name):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    d = tempfile.mkdtemp(prefix="mxv_kres2_")
+    try:
+        p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c",
+                            os.path.join(ROOT, "gym_amd", "csrc", src_name), "-o", os.path.join(d, "k.o"),
+                            "-Rpass-analysis=kernel-resource-usage", "-save-temps"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        asm = [f for f in os.listdir(d) if f.endswith("gfx950.s")]
+        return p.stderr, open(os.path.join(d, asm[0])).read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_tabular_trajectory_kernel_stays_lean():
+    """tab_traj_kernel (gym_amd/csrc/mxv_tab.hip): every instantiation at 8 waves per SIMD without scratch; the step loop of the two
+    shapes the bench measures holds exactly the six per-step stores of four unrolled steps, one LDS read per table level, no fp64
+    conversion of the Philox words (the integer thresholds), and the quad transpose in DPP moves instead of ds_bpermute."""
+    remarks, asm = _compile("mxv_tab.hip")
+    res = _resources(remarks)
+    traj = {k: v for k, v in res.items() if "tab_traj_kernel" in k}
+    assert len(traj) == 16
+    for k, r in traj.items():
+        assert r["Occupancy"] == 8 and r["VGPRs"] <= 64 and r["ScratchSize"] == 0, (k, r)
+    for sym, lds_reads in (("_ZN12_GLOBAL__N_115tab_traj_kernelILi1ELb1ELb0ELb1EEEvNS_11TabTrajArgsE", 4),      # Taxi: M = 1, search in a cold block
+                           ("_ZN12_GLOBAL__N_115tab_traj_kernelILi3ELb1ELb1ELb1EEEvNS_11TabTrajArgsE", 8)):     # FrozenLake8x8: M = 3, point-mass start
+        body = _function_body(asm, sym)
+        assert body.count("ds_bpermute") == 0 and body.count("v_cvt_f64_u32") == 0, sym
+        assert sum(1 for l in body.splitlines() if "_dpp" in l and "quad_perm" in l) >= 4, sym
+        loops = [t for _, t in _inner_loops(body) if "global_store" in t]
+        main = max(loops, key=lambda t: t.count("global_store"))
+        assert main.count("global_store") == 24, (sym, main.count("global_store"))                 # 6 outputs x 4 unrolled steps
+        hot_reads = sum(1 for l in main.splitlines() if re.match(r"\s+ds_read", l))
+        assert hot_reads >= lds_reads, (sym, hot_reads)
+
+
+def test_normalisation_kernels_keep_their_pipelines():
+    """mxv_norm.hip: the vector path of returns_sums_kernel waits for its ring with vmcnt(>= 9) — a derived value in the ring, or an exit
+    between the unrolled steps, shows up here as vmcnt(0..4) (round 4) — and reduces through DPP / permlane, not ds_bpermute."""
+    remarks, asm = _compile("mxv_norm.hip")
+    for sym, floor in (("_ZN12_GLOBAL__N_119returns_sums_kernelIdEEvPKT_PKhS5_PdlidlS6_i", 12), ("_ZN12_GLOBAL__N_119returns_sums_kernelIfEEvPKT_PKhS5_PdlidlS6_i", 9)):
+        body = _function_body(asm, sym)
+        assert body.count("ds_bpermute") == 0 and body.count("v_permlane32_swap") >= 4, sym
+        vec = [t for _, t in _inner_loops(body) if "global_load_dwordx4" in t and "global_load_ubyte" not in t]
+        assert len(vec) == 1, (sym, len(vec))
+        waits = [int(m) for m in re.findall(r"s_waitcnt vmcnt\((\d+)\)", vec[0])]
+        assert waits and min(waits) >= floor, (sym, waits)
