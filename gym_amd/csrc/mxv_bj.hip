@@ -32,6 +32,9 @@ namespace {
 #ifndef MXV_BJ_QUAD_ACTIONS
 #define MXV_BJ_QUAD_ACTIONS 1   // 1: the lanes of a quad share one action-word Philox call per four steps; 0: one call per lane per step (A/B hook)
 #endif
+#ifndef MXV_BJ_DPP_TRANSPOSE
+#define MXV_BJ_DPP_TRANSPOSE 1   // 1: the quad's action words change lanes by quad_transpose (DPP); 0: three shuffles and select chains (A/B hook)
+#endif
 #ifndef MXV_BJ_PACKED_DRAWS
 #define MXV_BJ_PACKED_DRAWS 1   // 1: the step's first eight cards evaluated up front (CardSource); 0: a Philox call at every draw (A/B hook)
 #endif
@@ -188,11 +191,13 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
             if (MXV_BJ_QUAD_ACTIONS && (t >> 2) != act_block) {  // uniform across the launch: every lane refills its cache at the same step
                 act_block = t >> 2;
                 const U4 w = action_words(a.action_seed, (act_block << 2) + q, ge >> 2);
+#if MXV_BJ_DPP_TRANSPOSE
+                act_word[0] = w.x; act_word[1] = w.y; act_word[2] = w.z; act_word[3] = w.w;
+                quad_transpose(act_word, q);   // lane q evaluated step q of the block for the quad's four envs -> its own env's words for steps 0..3
+#else
                 const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (uint32_t r = 0; r < 4; ++r) {
-                    // lane q sends the word of env (q ^ r) and receives, from lane q ^ r (which evaluated step q ^ r of the block), the
-                    // word of env (q ^ r) ^ r = q: its own word for step q ^ r
                     const uint32_t i = q ^ r;
                     const uint32_t send = i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
                     const uint32_t recv = r == 0 ? send : (uint32_t)__shfl_xor((int)send, (int)r, 64);
@@ -201,6 +206,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
                     act_word[2] = i == 2 ? recv : act_word[2];
                     act_word[3] = i == 3 ? recv : act_word[3];
                 }
+#endif
             }
             const uint32_t j = (uint32_t)(t & 3);
             const uint32_t word = j == 0 ? act_word[0] : (j == 1 ? act_word[1] : (j == 2 ? act_word[2] : act_word[3]));

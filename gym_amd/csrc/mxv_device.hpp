@@ -163,6 +163,31 @@ __device__ __forceinline__ U4 action_words(uint64_t action_seed, uint64_t t, uin
     return philox4x32_10(c, (uint32_t)action_seed, (uint32_t)(action_seed >> 32));
 }
 
+// The four action words of a quad change lanes (tabular and Blackjack engines: lane q of a quad evaluates step q of an aligned block of
+// four steps for the quad's four envs; afterwards lane q holds its own env's words for steps 0..3): a 4 x 4 transpose in two DPP
+// butterfly stages.
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
+// b[j] at lane L of a quad = a[L] at lane j of the quad
+__device__ __forceinline__ void quad_transpose(uint32_t (&a)[4], uint32_t q) {
+    const bool odd = (q & 1u) != 0, hi = (q & 2u) != 0;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {  // lanes L and L ^ 1 trade a[p + 1] of the even lane for a[p] of the odd one
+        const uint32_t recv = quad_perm<0xB1>(odd ? a[p] : a[p + 1]);
+        a[p] = odd ? recv : a[p];
+        a[p + 1] = odd ? a[p + 1] : recv;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {     // lanes L and L ^ 2: a[p + 2] of the low pair for a[p] of the high pair
+        const uint32_t recv = quad_perm<0x4E>(hi ? a[p] : a[p + 2]);
+        a[p] = hi ? recv : a[p];
+        a[p + 2] = hi ? a[p + 2] : recv;
+    }
+}
+
 // Step-indexed reset words (explicit resets of the tabular and Blackjack engines: step t, ordinal r of the reset call).
 __device__ __forceinline__ U4 reset_words(uint64_t seed, uint64_t t, uint32_t r) {
     U4 c;

@@ -162,19 +162,8 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
             if ((t >> 2) != act_block) {  // uniform across the launch: every lane refills its cache at the same step
                 act_block = t >> 2;
                 const U4 w = action_words(a.action_seed, (act_block << 2) + q, ge >> 2);
-                const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                for (uint32_t r = 0; r < 4; ++r) {
-                    // lane q sends the word of env (q ^ r); it receives, from lane q ^ r (which evaluated step q ^ r of
-                    // the block), the word of env (q ^ r) ^ r = q: its own word for step q ^ r
-                    const uint32_t i = q ^ r;
-                    const uint32_t send = i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
-                    const uint32_t recv = r == 0 ? send : (uint32_t)__shfl_xor((int)send, (int)r, 64);
-                    act_word[0] = i == 0 ? recv : act_word[0];
-                    act_word[1] = i == 1 ? recv : act_word[1];
-                    act_word[2] = i == 2 ? recv : act_word[2];
-                    act_word[3] = i == 3 ? recv : act_word[3];
-                }
+                act_word[0] = w.x; act_word[1] = w.y; act_word[2] = w.z; act_word[3] = w.w;
+                quad_transpose(act_word, q);   // lane q evaluated step q of the block for the quad's four envs -> its own env's words for steps 0..3
             }
             const uint32_t j = (uint32_t)(t & 3);
             const uint32_t word = j == 0 ? act_word[0] : (j == 1 ? act_word[1] : (j == 2 ? act_word[2] : act_word[3]));
@@ -270,28 +259,6 @@ struct TabTrajArgs {
 __device__ __forceinline__ uint32_t tab_pin32(uint32_t v) {  // see pin32 in mxv_kernels.hip: keeps the store's saddr + 32-bit voffset form
     asm volatile("" : "+v"(v));
     return v;
-}
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
-}
-
-// b[j] at lane L of a quad = a[L] at lane j of the quad
-__device__ __forceinline__ void quad_transpose(uint32_t (&a)[4], uint32_t q) {
-    const bool odd = (q & 1u) != 0, hi = (q & 2u) != 0;
-#pragma unroll
-    for (int p = 0; p < 4; p += 2) {  // lanes L and L ^ 1 trade a[p + 1] of the even lane for a[p] of the odd one
-        const uint32_t recv = quad_perm<0xB1>(odd ? a[p] : a[p + 1]);
-        a[p] = odd ? recv : a[p];
-        a[p + 1] = odd ? a[p + 1] : recv;
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {     // lanes L and L ^ 2: a[p + 2] of the low pair for a[p] of the high pair
-        const uint32_t recv = quad_perm<0x4E>(hi ? a[p] : a[p + 2]);
-        a[p] = hi ? recv : a[p];
-        a[p + 2] = hi ? a[p + 2] : recv;
-    }
 }
 
 template <int M_T, bool COMPACT, bool SINGLE, bool ALLV>
