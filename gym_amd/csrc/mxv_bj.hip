@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
     unpack(valid ? a.state[e] : 0, p, d, dfirst);
     int32_t el = valid ? a.elapsed[e] : 0;
     // Action words: one Philox call yields the words of the 4 envs of group g = env >> 2 at ONE step.  The four lanes of a quad (= one
-    // group) each evaluate a different step of the aligned block 4 * (t >> 2) .. + 3 and trade words through quad shuffles: one call per
+    // group) each evaluate a different step of the aligned block 4 * (t >> 2) .. + 3 and trade words through quad_transpose (two DPP butterfly stages): one call per
     // lane per four steps instead of one per step (the same stream, the same words: mxv_tab.hip's scheme).
     const uint32_t q = (uint32_t)(ge & 3);
     uint64_t act_block = ~0ull;

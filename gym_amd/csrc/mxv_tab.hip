@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
     int32_t s = valid ? a.state[e] : 0, el = valid ? a.elapsed[e] : 0;
     // Philox caches.  Actions: one call yields the words of the 4 envs of group g = env >> 2 at ONE step, so the four
     // lanes of a quad (= one group) each evaluate a different step of the aligned block 4*(t >> 2) .. +3 and trade words
-    // through quad shuffles: one call per lane per four steps.  Transitions: one call per two steps (see the contract).
+    // through a 4 x 4 transpose inside the quad (quad_transpose: two DPP butterfly stages): one call per lane per four steps.  Transitions: one call per two steps (see the contract).
     const uint32_t q = (uint32_t)(ge & 3);
     uint64_t act_block = ~0ull, tr_block = ~0ull;
     uint32_t act_word[4] = {0, 0, 0, 0};
