@@ -151,7 +151,14 @@ __device__ __forceinline__ void deal(int c1, int c2, Hand &h) {
     h.sum = c1 + c2; h.ace = (c1 == 1) | (c2 == 1); h.two = 1;
 }
 
-__global__ void __launch_bounds__(kBjBlock) bj_step_kernel(BjArgs a) {
+#ifndef MXV_BJ_WAVES
+#define MXV_BJ_WAVES 0   // 0: the register allocator's choice (89 VGPRs: 5 waves per SIMD); 6 / 8: a budget of 80 / 64 VGPRs (A/B hook)
+#endif
+__global__ void __launch_bounds__(kBjBlock)
+#if MXV_BJ_WAVES > 0
+    __attribute__((amdgpu_waves_per_eu(MXV_BJ_WAVES, MXV_BJ_WAVES)))
+#endif
+    bj_step_kernel(BjArgs a) {
     const int64_t e = (int64_t)blockIdx.x * kBjBlock + threadIdx.x;
     const bool valid = e < a.n;  // sampled actions: lanes past the end stay in the loop, their quad partners need their action words
     if (!valid && a.actions) return;
