@@ -447,3 +447,39 @@ def test_trajectory_kernel_on_synthetic_mdps(S, A, M, point_mass):
         assert np.array_equal(o["truncated"], outs[0][1]["truncated"][k].astype(bool))
         ended += int(o["final_mask"].sum())
     assert ended > n
+
+
+def test_trajectory_kernel_randomised_launch_shapes():
+    """24 random cases (env, batch size incl. ragged and sub-workgroup ones, TimeLimit, dtype set, a sequence of launch lengths that
+    walks through every phase of the four-step action blocks, per-env seeds or not, a counter set far beyond 2^32): trajectory kernel ==
+    general kernel on every output of every step, state and counters."""
+    import torch
+    from gym_amd import _native
+    from gym_amd.toy_text import TabularRollout
+
+    rng = np.random.default_rng(2024)
+    gids = ["FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "CliffWalking-v0"]
+    for case in range(24):
+        gid = gids[case % 4]
+        n = int(rng.choice([1, 63, 64, 255, 256, 257, 1000, 4097, 20_000]))
+        limit = int(rng.integers(2, 40))
+        compact = bool(rng.integers(2))
+        kw = dict(seed=int(rng.integers(1 << 30)), action_seed=int(rng.integers(1 << 30)), max_episode_steps=limit, compact=compact)
+        fast, gen = TabularRollout(gid, n, **kw), TabularRollout(gid, n, general_kernel=True, **kw)
+        seeds = rng.integers(0, 2 ** 63, n, dtype=np.uint64) if rng.integers(2) else None
+        t0 = int(rng.integers(1 << 33, 1 << 40))
+        for r in (fast, gen):
+            r.handle.seed(kw["seed"], seeds)
+            r.reset()
+            if case % 5 == 0:
+                r.handle.set_counters(t0, r.handle.get_counters()[1])
+        for K in [int(k) for k in rng.integers(1, 23, size=5)]:
+            a, b = fast.rollout_per_step(K), gen.rollout_per_step(K)
+            fast.synchronize(), gen.synchronize()
+            assert fast.handle.last_kernel() == _native.TAB_KERNEL_TRAJECTORY and gen.handle.last_kernel() == _native.TAB_KERNEL_GENERAL
+            for key in ("obs", "actions", "reward", "prob", "terminated", "truncated"):
+                assert torch.equal(a[key], b[key]), (case, gid, n, limit, compact, K, key)
+        for x, y in zip(fast.handle.get_state(), gen.handle.get_state()):
+            assert np.array_equal(x, y), (case, gid, n)
+        assert fast.handle.get_counters() == gen.handle.get_counters()
+        fast.close(), gen.close()
