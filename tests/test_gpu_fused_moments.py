@@ -191,3 +191,38 @@ def test_attached_partials_never_go_stale_silently():
     r.synchronize()
     assert torch.isfinite(out["obs_partials"]).all()
     r.close()
+
+
+@pytest.mark.parametrize("name,n", [("CartPole", 1), ("CartPole", 130), ("Pendulum", 65), ("Acrobot", 3), ("MountainCar", 257)])
+def test_partials_of_batches_smaller_than_a_tile(name, n):
+    """One env, one env more than a tile: the lanes without an env contribute zeros; both moment sets; odd launch lengths."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout(GYM_IDS[name], n, seed=8, action_seed=9, max_episode_steps=min(LIMITS[name], 7))
+    r.reset(seed=8)
+    nz = r.make_normalizer(gamma=0.9)
+    r.fuse_reward_normalizer(nz)
+    leaves, per, vals = r.handle.obs_partials_layout()
+    ret = np.zeros(n)
+    for K in (2, 5, 3):
+        out = r.trajectory_buffers(K, layout="separate", obs_partials=True, ret_partials=True)
+        r.rollout_per_step(K, out=out)
+        r.synchronize()
+        x = out["obs"].cpu().numpy().astype(np.float64)
+        pad = leaves * per - n
+        xp = np.concatenate([x, np.zeros((K, pad, r.O))], axis=1).reshape(K, leaves, per, r.O)
+        p = out["obs_partials"].cpu().numpy()
+        np.testing.assert_allclose(p[:, :, :r.O], xp.sum(axis=2), rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(p[:, :, r.O:], (xp * xp).sum(axis=2), rtol=1e-13, atol=1e-300)
+        rew = out["reward"].cpu().numpy().astype(np.float64)
+        done = (out["terminated"] | out["truncated"]).cpu().numpy().astype(bool)
+        rp = out["ret_partials"].cpu().numpy()
+        for k in range(K):                                    # normalize.py:132-136 restated
+            ret = ret * 0.9 + rew[k]
+            rpad = np.concatenate([ret, np.zeros(pad)]).reshape(leaves, per)
+            np.testing.assert_allclose(rp[k, :, 0], rpad.sum(axis=1), rtol=1e-13, atol=1e-300)
+            np.testing.assert_allclose(rp[k, :, 1], (rpad * rpad).sum(axis=1), rtol=1e-13, atol=1e-300)
+            ret[done[k]] = 0.0
+    assert np.array_equal(nz.backend.reward_state()[3], ret)
+    r.close()
