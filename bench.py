@@ -366,8 +366,12 @@ def measure_normalize(torch, envs, chunk, reps=6):
                                                   note="us_per_step = what normalisation adds to the rollout: (rollout with partials - rollout) + tree + scan + apply")
         # ... and NormalizeReward's discounted returns (mxv_set_return_partials), alone and together with the observation moments
         nrf = _native.Norm(1, envs, stream=s.cuda_stream)
-        dr._fused_returns = (nrf.returns_ptr(), 0.99)
-        dr._ret_partials_attached = None
+
+        class _Returns:      # what DeviceRollout.fuse_reward_normalizer needs of a normaliser: its returns array and its discount
+            gamma = 0.99
+            backend = nrf
+
+        dr.fuse_reward_normalizer(_Returns)
         leaves = trp["obs_partials"].shape[1]
         with torch.cuda.stream(s):
             rp = torch.empty((chunk, leaves, 2), dtype=torch.float64, device=dr.device)
@@ -387,6 +391,8 @@ def measure_normalize(torch, envs, chunk, reps=6):
                                                      separate_us_per_step=out["normalize_reward"]["us_per_step"])
         out["rollout_and_both_normalisations"] = {"separate_us_per_step": r0 + out["normalize_obs"]["us_per_step"] + out["normalize_reward"]["us_per_step"],
                                                   "fused_us_per_step": r3 + nfu + nru, "rollout_with_both_partials_us_per_step": r3}
+        dr.handle.set_obs_partials(None)
+        dr.handle.set_return_partials(None, 0.0, None)            # nothing may point into nrf's returns any more
         nf.close(), nrf.close()
         del trp, plain, sums, rp, rets, both, rsums
     except Exception as e:  # noqa: BLE001

@@ -441,7 +441,10 @@ class DeviceRollout:
         """Let trajectory rollouts whose buffers carry "ret_partials" advance `normalizer`'s running discounted returns
         (NormalizeReward, normalize.py:132-136) and leave their per-step sums behind (mxv_set_return_partials); feed them back with
         normalizer.normalize_rewards(reward, terminated, truncated, partials=out["ret_partials"])."""
+        self._fused_normalizer = normalizer                      # keeps the returns array the kernels write alive
         self._fused_returns = (normalizer.backend.returns_ptr(), float(normalizer.gamma))
+        if getattr(self, "_ret_partials_attached", None) is not None:
+            self.handle.set_return_partials(None, 0.0, None)     # re-attached with the new array by the next rollout_per_step
         self._ret_partials_attached = None
 
     def make_normalizer(self, **kw):
