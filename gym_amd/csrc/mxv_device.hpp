@@ -606,10 +606,10 @@ struct Env<MXV_PENDULUM> {
     template <bool GUARD = true>
     __device__ __forceinline__ static void prime(const double *s, double *aux) { aux[0] = mx_sin<GUARD, fma3_for<MXV_PENDULUM>()>(s[0]); }
     // aux[0] = sin(theta): `sin(th)` of step t+1 (:131) is the sine _get_obs took at the end of step t (:162)
-    template <bool GUARD = true>
+    template <bool GUARD = true, int F3 = fma3_for<MXV_PENDULUM>()>
     __device__ __forceinline__ static void observe(const double *s, float *obs, double *aux) {  // :161-163
         double sn, cs;
-        mx_sincos<GUARD, fma3_for<MXV_PENDULUM>()>(s[0], &sn, &cs);
+        mx_sincos<GUARD, F3>(s[0], &sn, &cs);
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1];
         aux[0] = sn;
     }
@@ -633,7 +633,10 @@ struct Env<MXV_PENDULUM> {
         const double newth = th + newthdot * dt;                           // :133
         s[0] = newth; s[1] = newthdot;
         reward = -costs;                                                   // :139
-        observe<SAFE>(s, obs, aux);
+        // two envs per lane (the launches with fused batch moments only) run at the 128-VGPR cap: the polynomial coefficients the
+        // three-address FMA form keeps in ~40 registers across the loop came back from scratch every step there; the compiler's own
+        // form (literals materialised where used) costs instructions instead.  Same operations, same bits.
+        observe<SAFE, (EPL == 2 ? (fma3_for<MXV_PENDULUM>() & ~1) : fma3_for<MXV_PENDULUM>())>(s, obs, aux);
         return false;
     }
     // high = (x_init, y_init), low = -high; np_random.uniform(low, high) :141-154

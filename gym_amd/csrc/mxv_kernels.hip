@@ -1176,19 +1176,31 @@ void launch_rollout(unsigned grid, hipStream_t stream, const StepArgs &a, Launch
             if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, true>(grid, stream, a, info);
             return launch_rollout_out<ENV, DEF, ER, SAFE, 0, true>(grid, stream, a, info);
         }
-        if constexpr (!SAFE && ER == rollout_envs_per_lane(ENV)) {   // STATS instantiations: launch_step_supports_stats
-            const int st = (a.obs_part != nullptr ? 1 : 0) | (a.ret_part != nullptr ? 2 : 0);
-            if (st == 1 && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, 1>(grid, stream, a, info);
-            if (st == 1 && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, 1>(grid, stream, a, info);
-            if (st == 2 && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, 2>(grid, stream, a, info);
-            if (st == 2 && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, 2>(grid, stream, a, info);
-            if (st == 3 && out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1, false, 3>(grid, stream, a, info);
-            if (st == 3 && out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2, false, 3>(grid, stream, a, info);
-        }
         if (out == 1) return launch_rollout_out<ENV, DEF, ER, SAFE, 1>(grid, stream, a, info);
         if (out == 2) return launch_rollout_out<ENV, DEF, ER, SAFE, 2>(grid, stream, a, info);
     }
     launch_rollout_out<ENV, DEF, ER, SAFE, 0>(grid, stream, a, info);
+}
+
+// STATS launches (fused batch moments: StepArgs::obs_part / ret_part; the host has checked launch_step_supports_stats): default
+// parameters, unguarded trigonometry, the trajectory-recording shape — and ALWAYS stats_envs_per_lane(ENV) envs per lane, whatever the
+// shard size: the leaves of the sum tree (one per tile) must not depend on it, and two envs per lane halve the wave-level tree's cost per
+// env (Pendulum, one env per lane otherwise, takes two here).
+constexpr int stats_envs_per_lane(int env_id) { return env_id == MXV_ACROBOT ? 1 : 2; }
+template <int ENV>
+hipError_t launch_rollout_stats(const StepArgs &a, hipStream_t stream, LaunchInfo *info) {
+    constexpr int SE = stats_envs_per_lane(ENV);
+    const int64_t rtile = (int64_t)SE * kWave;
+    const unsigned grid = (unsigned)((a.n + rtile - 1) / rtile);
+    const int st = (a.obs_part != nullptr ? 1 : 0) | (a.ret_part != nullptr ? 2 : 0);
+    const bool compact = (a.flags & (MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32)) != 0;
+    if (st == 1 && !compact) launch_rollout_out<ENV, true, SE, false, 1, false, 1>(grid, stream, a, info);
+    else if (st == 1) launch_rollout_out<ENV, true, SE, false, 2, false, 1>(grid, stream, a, info);
+    else if (st == 2 && !compact) launch_rollout_out<ENV, true, SE, false, 1, false, 2>(grid, stream, a, info);
+    else if (st == 2) launch_rollout_out<ENV, true, SE, false, 2, false, 2>(grid, stream, a, info);
+    else if (!compact) launch_rollout_out<ENV, true, SE, false, 1, false, 3>(grid, stream, a, info);
+    else launch_rollout_out<ENV, true, SE, false, 2, false, 3>(grid, stream, a, info);
+    return hipGetLastError();
 }
 
 template <int ENV>
@@ -1196,6 +1208,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
     const bool def = pm == PM_DEFAULT;
     // Sampled actions + autoreset, several steps per launch: the fused fast path.  (Single-step launches stay on
     // step_kernel: they are latency-bound and its 58 VGPRs give twice the occupancy.)
+    if ((a.obs_part != nullptr || a.ret_part != nullptr) && launch_step_supports_stats(ENV, pm, a)) return launch_rollout_stats<ENV>(a, stream, info);
     if (launch_step_is_rollout(pm, a)) {
         // SAFE = false: the state obeys the invariants the dynamics maintain (CartPole: |theta| <= pi/4; the others: trig arguments
         // below 2^19), so sin/cos need no range check.  A state injection (mxv_set_state) or unusual explicit-reset bounds break
@@ -1220,7 +1233,7 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
         // at 2^17 itself, one E = 2 wave per SIMD: 0.92 vs 1.01, profiles/r3k_small_shard_e1_ab.jsonl) — the shard sizes of an 8-GPU
         // strong-scaling or mixed-batch job.
         constexpr int ER = rollout_envs_per_lane(ENV);
-        if (ER > 1 && a.obs_part == nullptr && a.ret_part == nullptr && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
+        if (ER > 1 && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)
             go(std::integral_constant<int, 1>{});
         else
             go(std::integral_constant<int, ER>{});
@@ -1286,11 +1299,11 @@ bool launch_step_supports_stats(int env_id, int pm, const StepArgs &a) {
 }
 int64_t stats_leaf_envs(int env_id) {
     switch (env_id) {
-        case MXV_CARTPOLE: return (int64_t)rollout_envs_per_lane(MXV_CARTPOLE) * kWave;
-        case MXV_PENDULUM: return (int64_t)rollout_envs_per_lane(MXV_PENDULUM) * kWave;
-        case MXV_ACROBOT: return (int64_t)rollout_envs_per_lane(MXV_ACROBOT) * kWave;
-        case MXV_MOUNTAINCAR: return (int64_t)rollout_envs_per_lane(MXV_MOUNTAINCAR) * kWave;
-        default: return (int64_t)rollout_envs_per_lane(MXV_MOUNTAINCAR_CONT) * kWave;
+        case MXV_CARTPOLE: return (int64_t)stats_envs_per_lane(MXV_CARTPOLE) * kWave;
+        case MXV_PENDULUM: return (int64_t)stats_envs_per_lane(MXV_PENDULUM) * kWave;
+        case MXV_ACROBOT: return (int64_t)stats_envs_per_lane(MXV_ACROBOT) * kWave;
+        case MXV_MOUNTAINCAR: return (int64_t)stats_envs_per_lane(MXV_MOUNTAINCAR) * kWave;
+        default: return (int64_t)stats_envs_per_lane(MXV_MOUNTAINCAR_CONT) * kWave;
     }
 }
 

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gym_amd.rollout import DeviceRollout  # noqa: E402
 
 n, K = 1 << 20, 128
-for env_id, nn in (("CartPole-v1", n), ("MountainCar-v0", n >> 1), ("MountainCarContinuous-v0", n >> 1), ("Pendulum-v1", n >> 1), ("Acrobot-v1", n >> 1)):
+for env_id, nn in [(e, n if e == "CartPole-v1" else n >> 1) for e in (sys.argv[1:] or ["CartPole-v1", "MountainCar-v0", "MountainCarContinuous-v0", "Pendulum-v1", "Acrobot-v1"])]:
     r = DeviceRollout(env_id, nn, seed=0, action_seed=1)
     r.reset(seed=0)
     out = r.trajectory_buffers(K, obs_partials=True)
