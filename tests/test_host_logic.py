@@ -638,3 +638,98 @@ def test_call_state_has_the_references_container_types(gid, monkeypatch):
         act = ref.action_space.sample()
         ref.step(act), env.step(act)
     ref.close(), env.close()
+
+
+def test_partials_are_attached_and_detached_by_call_shape():
+    """DeviceRollout's bookkeeping of the fused-moment buffers (mxv_set_obs_partials / mxv_set_return_partials) on a stand-in handle:
+    attached when a trajectory call brings them, detached before every call shape that does not fill them (the C ABI would refuse),
+    re-attached when the normaliser behind the returns changes, refused without one."""
+    from gym_amd.rollout import DeviceRollout
+
+    calls = []
+
+    class H:
+        def set_obs_partials(self, p):
+            calls.append(("obs", p))
+
+        def set_return_partials(self, ptr, gamma, p):
+            calls.append(("ret", ptr, gamma, p))
+
+    r = object.__new__(DeviceRollout)
+    r.handle = H()
+    P, Q = object(), object()
+    r._attach_partials(None, None)
+    assert calls == []                                            # nothing attached, nothing to do
+    r._attach_partials(P, None)
+    r._attach_partials(P, None)
+    assert calls == [("obs", P)]                                  # once per change
+    with pytest.raises(RuntimeError):
+        r._attach_partials(P, Q)                                  # returns need a normaliser first
+
+    class Backend:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def returns_ptr(self):
+            return self.ptr
+
+    class Nz:
+        def __init__(self, ptr, gamma):
+            self.backend, self.gamma = Backend(ptr), gamma
+
+    a = Nz(0x1000, 0.9)
+    r.fuse_reward_normalizer(a)
+    r._attach_partials(P, Q)
+    assert calls[-1] == ("ret", 0x1000, 0.9, Q) and r._fused_normalizer is a
+    b = Nz(0x2000, 0.5)
+    r.fuse_reward_normalizer(b)                                   # another normaliser: detach now, attach its array at the next rollout
+    assert calls[-1] == ("ret", None, 0.0, None)
+    r._attach_partials(P, Q)
+    assert calls[-1] == ("ret", 0x2000, 0.5, Q)
+    n = len(calls)
+    r._attach_partials(None, None)                                # what step() / rollout() / rollout_tape() do first
+    assert calls[n:] == [("obs", None), ("ret", None, 0.0, None)]
+
+
+def test_normaliser_folds_partials_instead_of_reading_the_batch_again():
+    """RunningNormalizer.normalize_obs / normalize_rewards with `partials=`: the backend's *_sums_partials is called with the leaf count of
+    the buffer, the pass over the batch is not."""
+    import torch
+
+    from gym_amd.normalize import RunningNormalizer
+
+    log = []
+
+    class B:
+        stream, torch_device = None, torch.device("cpu")
+
+        def obs_sums(self, K, x, sums):
+            log.append("obs_sums")
+
+        def obs_sums_partials(self, K, partials, sums):
+            log.append(("obs_partials", K, partials.shape[-2]))
+
+        def obs_apply(self, K, x, y, eps, all_sums, world, total):
+            log.append(("obs_apply", tuple(all_sums.shape)))
+
+        def reward_sums(self, K, r, te, tr, gamma, sums):
+            log.append("reward_sums")
+
+        def reward_sums_partials(self, K, partials, sums):
+            log.append(("ret_partials", K, partials.shape[-2]))
+
+        def reward_apply(self, K, r, out, eps, all_sums, world, total):
+            log.append(("reward_apply", tuple(all_sums.shape)))
+
+    n, K, O, leaves = 256, 3, 4, 2
+    nz = RunningNormalizer(n, O, backend=B())
+    x = torch.zeros((K, n, O), dtype=torch.float32)
+    nz.normalize_obs(x, partials=torch.zeros((K, leaves, 2 * O), dtype=torch.float64))
+    nz.normalize_obs(x)
+    r, f = torch.zeros((K, n), dtype=torch.float64), torch.zeros((K, n), dtype=torch.uint8)
+    nz.normalize_rewards(r, f, f, partials=torch.zeros((K, leaves, 2), dtype=torch.float64))
+    nz.normalize_rewards(r, f, f)
+    assert log == [("obs_partials", K, leaves), ("obs_apply", (1, K, 2 * O)), "obs_sums", ("obs_apply", (1, K, 2 * O)),
+                   ("ret_partials", K, leaves), ("reward_apply", (1, K, 2)), "reward_sums", ("reward_apply", (1, K, 2))]
+    with pytest.raises(AssertionError):
+        nz.normalize_obs(x, partials=torch.zeros((K, leaves, 2 * O + 1), dtype=torch.float64))
