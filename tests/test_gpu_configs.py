@@ -273,7 +273,15 @@ def test_gym_amd_first_torch_second_share_one_hip_runtime():
     import subprocess
     import sys
 
+    import time
+    import warnings
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "import_order.py")], capture_output=True, text=True, timeout=900)
+    dt = time.time() - t0
     assert r.returncode == 0 and "ok: gym_amd first" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
-    print(r.stderr[-600:])       # the script's own timestamps (pytest -rP / a failure shows them)
+    stamps = " | ".join(l for l in r.stderr.splitlines() if l.startswith("[import_order]"))
+    print(stamps)                # the script's own timestamps (pytest -rP / a failure shows them)
+    if dt > 30:                  # seen: 8-11 s alone, 110-270 s inside some full-suite runs — say where the time went
+        warnings.warn(f"import_order.py took {dt:.0f} s (spawn to exit); inside the child: {stamps}")
