@@ -345,7 +345,9 @@ def measure_normalize(torch, envs, chunk, reps=6):
                                               reps, chunk), envs, 26, kernels="mxv_norm.hip: discounted-return sums (read 8 + 2) + scan + apply (read 8, write 8)")}
     # the batch moments formed by the rollout itself (mxv_set_obs_partials): what NormalizeObservation then costs ON TOP of the rollout
     try:
-        trp = dr.trajectory_buffers(chunk, layout="separate", obs_partials=True)
+        tr = None                                                  # (the set normalised above: its numbers are taken, its 9 GiB are needed)
+        torch.cuda.empty_cache()
+        trp = dr.trajectory_buffers(chunk, obs_partials=True)     # sorted by HBM class, as a caller gets them by default
         plain = {k: t for k, t in trp.items() if k != "obs_partials"}
         nf = _native.Norm(O, envs, stream=s.cuda_stream)
         r0 = _event_us(torch, s, lambda: dr.rollout_per_step(chunk, out=plain), reps, chunk)
