@@ -108,7 +108,7 @@ SNAPSHOT_FORMAT = 2   # Handle.snapshot(): 2 = per-env reset ordinals (`episodes
 PLACED_CHUNK_BYTES = 256 << 20
 PLACED_MIN_BYTES = 2 << 30      # mxv_placed_alloc (HIP virtual-memory mappings): sets below it get ordinary allocations
 SORTED_MIN_BYTES = 1 << 30      # placement.sorted_tensors (ordinary allocations sorted by class): "auto" sorts sets of 1 GiB and more — the 2^17-env
-                                # shard of an 8-GPU strong-scaling job runs 0.79-0.82 us per step sorted, 0.87-0.93 unsorted (profiles/r3k_*)
+                                # shard of an 8-GPU strong-scaling job runs 0.79-0.82 us per step sorted, 0.87-0.93 unsorted (profiles/r3/r3k_*)
 PLACED_PLAIN, PLACED_NO_JUMP = 1, 2
 
 

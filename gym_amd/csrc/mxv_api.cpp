@@ -400,7 +400,7 @@ int ensure_staging(mxv_handle *h, bool want_pinned = false) {
 // Actions of a host step, caller's (pageable) array -> device staging.  One plain hipMemcpyAsync: the runtime stages pageable
 // memory through its own pinned buffers, and does it better than a hand-rolled version — copying 1-MiB slices into a pinned
 // buffer of the library's and queueing one DMA per slice (so that slice k's DMA overlaps slice k+1's memcpy) made the 2^20-env
-// CartPole step 130 us SLOWER (1054 vs 917 us, profiles/r03g_upload_ab.txt); narrowing int64 discrete actions to one byte each on
+// CartPole step 130 us SLOWER (1054 vs 917 us, profiles/r2/r03g_upload_ab.txt); narrowing int64 discrete actions to one byte each on
 // the host (AVX-512 vpmovqb loop with the range check folded in) so that 1 MB instead of 8 crosses the link lost as well, 1006 vs
 // 940 us: one core reading the caller's 8 MB takes longer than the DMA time it saves.
 int upload_actions(mxv_handle *h, const void *actions_host) {

@@ -290,7 +290,7 @@ __device__ __forceinline__ double div_par(double x, double c) {
 // instructions per env-step).  The three-address form reads the coefficient where it is.  Same operation, same bits.
 // It pays where the coefficients stay in registers across the loop (Pendulum, MountainCarContinuous: -7 % / -9 % instructions in the
 // K-step loop); the kernels at their 128-VGPR budget (CartPole and MountainCar at two envs per lane, Acrobot) re-materialise or spill
-// instead, so the form is chosen per env kind: bit `env id` of MXV_FMA3_ENVS (A/B hook; profiles/r3p_fma3_ab.jsonl).
+// instead, so the form is chosen per env kind: bit `env id` of MXV_FMA3_ENVS (A/B hook; profiles/r3/r3p_fma3_ab.jsonl).
 #ifndef MXV_FMA3_ENVS
 #define MXV_FMA3_ENVS ((1 << MXV_PENDULUM) | (1 << MXV_MOUNTAINCAR_CONT))
 #endif
@@ -356,7 +356,7 @@ __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) 
 // General-range sin/cos.  ocml's sincos costs ~80 VALU instructions per call on gfx950 (a 3-term Cody-Waite reduction kept in
 // double-double, ~20 v_mov to materialise polynomial coefficients next to v_fmac, a Payne-Hanek branch for |x| >= 2^30) and
 // Acrobot calls it eight times per step — two thirds of the most VALU-bound kernel of the engine (917 VALU instructions per
-// env-step at 82 % of the VALU issue rate, profiles/r02e_rooflines.jsonl).  mx_sincos is the medium-range version the dynamics
+// env-step at 82 % of the VALU issue rate, profiles/r2/r02e_rooflines.jsonl).  mx_sincos is the medium-range version the dynamics
 // need: k = rint(x * 2/pi); r = x - k*pi/2 with pi/2 split 33 + 33 + 53 bits (k * P1 and, once r is small, k * P2 are exact, so
 // cancellation near multiples of pi/2 costs no accuracy: three FMAs); the fdlibm kernel polynomials of sincos_kernel on
 // |r| <= pi/4; quadrant swap and signs from k.  Error <= 1.5 ulp over |x| <= 40 including 3e6 arguments within 5e-7 of a

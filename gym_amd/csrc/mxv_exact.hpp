@@ -5,7 +5,7 @@
 // post-step angles and its height agree with the reference's to a few fp64 ulps — not to the bit, so a height within a few ulps of 1.0
 // could land on the other side of the threshold (measured on tests/golden/Acrobot_p1_threshold.npz, 4096 states bisected onto the
 // threshold: 37 masks differ, 32 of them because of the terminal cosines, 5 because the post-step ANGLES differ in the last bit;
-// profiles/r4a_acrobot_threshold_flip_split.json).  The reference's own libm (glibc 2.35 / NumPy's scalar loops) returns the correctly
+// profiles/r4/r4a_acrobot_threshold_flip_split.jsonl).  The reference's own libm (glibc 2.35 / NumPy's scalar loops) returns the correctly
 // rounded value for all but ~1 in 10^3..10^4 arguments, so: whenever the hot path's height lies within 2^-40 of the threshold — a band
 // ~4000x wider than anything the hot path's error can bridge, hit by ~1 step in 10^12 — the WHOLE step is evaluated again here the way
 // the reference writes it (every cosine taken directly of the reference's own rounded argument, no angle addition, IEEE `/`), with

@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_obs_at(char *base, uint32_t byte_off, cons
 // its own L2.  Handing out tiles in id order makes every XCD write 4-8 KiB crumbs interleaved with the other seven
 // all over each output row; giving XCD x the x-th contiguous eighth of the tiles instead lets each L2 stream long
 // contiguous runs to its memory channels.  Measured on the rollout's store pattern with the physics removed
-// (profiles/r01_wbench.txt; the probe lives on as mxv_write_probe): 4.7 -> 5.7 TB/s.  Works for any tile count (remainder tiles go to the
+// (profiles/r1/r01_wbench.txt; the probe lives on as mxv_write_probe): 4.7 -> 5.7 TB/s.  Works for any tile count (remainder tiles go to the
 // low XCDs, matching how many ids of each residue exist).
 constexpr unsigned kXcds = 8;
 __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned ntiles) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned n
 //                   lane-private (no LDS, no barrier) and the flag bytes of a lane are contiguous.
 //   CLOCK = true  : the launch advances the device clock itself (single steps with default parameters of a handle in device-clock mode,
 //                   small grids).  An instantiation of its own: as a run-time branch at the exit of the one kernel it cost every
-//                   launch 1.1 us per 2^20-env step (18.6 -> 19.8, profiles/r4q_step_clock_tail_ab.txt).
+//                   launch 1.1 us per 2^20-env step (18.6 -> 19.8, profiles/r4/r4q_step_clock_tail_ab.txt).
 template <int ENV, int DEF, int E, bool CONSEC, bool MULTI, bool CLOCK = false>
 __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepArgs a) {
     using EV = Env<ENV>;
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
             // terminated.  Done BEHIND the step's stores, as a correction of the reward just written (same lane, same address: the later
             // store stands): a wave-uniform test of the pointer keeps every other launch off this code, and no block boundary cuts
             // through the step's arithmetic.  (In the middle of the dynamics loop the same lines cost step(actions) 22.1 -> 23.3 us
-            // per 2^20-env step although they never ran: profiles/r4d_step_path_ab.log.)
+            // per 2^20-env step although they never ran: profiles/r4/r4d_step_path_ab.json.)
             if (MXV_CARTPOLE_BEYOND && a.beyond != nullptr) {
 #pragma unroll
                 for (int j = 0; j < E; ++j)
@@ -959,7 +959,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
 // ... and the waves per SIMD it may NOT exceed.  The default-parameter kernels are pinned to exactly 4: a shard of 2^19 / 2^20
 // envs is a whole number of 4-wave rounds (8192 or 16384 single-wave workgroups on 1024 SIMDs), and a kernel that fits 5 waves
 // (Pendulum: 87 VGPRs) runs 3.2 rounds' worth of work in 4 rounds, the last one a fifth full: measured 6.4 instead of 5.9 us per
-// 2^20-env Pendulum step when the medium-range sincos shrank the kernel to 5 waves (profiles/r02f_fast_trig_ab.jsonl).
+// 2^20-env Pendulum step when the medium-range sincos shrank the kernel to 5 waves (profiles/r2/r02f_fast_trig_ab.jsonl).
 template <int ENV, bool DEF, bool SAFE>
 constexpr int rollout_max_waves() {
     return rollout_min_waves<ENV, DEF, SAFE>() == 1 ? 8 : rollout_min_waves<ENV, DEF, SAFE>();
@@ -994,7 +994,7 @@ union MixedLds {
 
 // Block -> segment: segment i owns the contiguous block range [first_block[i], first_block[i+1]).  (An interleaved table — chunks of
 // 8 blocks dealt round-robin to the segments, order rotated per round — was measured too: 4.52 us per mixed step against 3.27 us
-// for the contiguous ranges, profiles/r02e_mixed_dispatch_interleaved.jsonl.  The hardware deals consecutive workgroups over the
+// for the contiguous ranges, profiles/r2/r02e_mixed_dispatch_interleaved.jsonl.  The hardware deals consecutive workgroups over the
 // SIMDs, so what matters is WHICH two waves end up sharing a SIMD: the interleaving paired Acrobot waves with each other.)
 __global__ void __launch_bounds__(kWave) mixed_rollout_kernel(const MixedArgs m) {
     __shared__ MixedLds lds;
@@ -1078,7 +1078,7 @@ __global__ void add_word_kernel(uint64_t *dst, uint64_t delta) { *dst += delta; 
 // every step, pack (env index, row) pairs of the finished envs IN ASCENDING ENV ORDER (= np.flatnonzero(terminated | truncated)):
 // two small kernels over chunks of kCompactChunk envs — count per chunk, then every chunk's workgroup sums the counts of the
 // chunks before it and writes its pairs at the right offset.  No atomics: a first version took one returning atomicAdd per wave on
-// a single counter, 16 384 same-address atomics at 2^20 envs = 163 us for a 5-us job (profiles/r03d_numpy_loop_trace.md).
+// a single counter, 16 384 same-address atomics at 2^20 envs = 163 us for a 5-us job (profiles/r2/r03d_numpy_loop_trace.md).
 constexpr int kCompactChunk = 4096, kCompactIters = kCompactChunk / kBlock, kCompactWaves = kBlock / kWave;
 
 __device__ __forceinline__ bool compact_done(const CompactArgs &a, int64_t e) {
@@ -1229,8 +1229,8 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
         };
         // Two envs per lane (the tuned choice of the light envs: two independent chains of ILP) only pay when the shard fills
         // the chip: below one E = 2 wave per SIMD (1024 SIMDs x 128 envs) the work is latency-bound and one env per lane
-        // puts twice as many waves on it (profiles/r02a_shard_sweep.jsonl: 0.76 vs 1.05 us per step at 2^16 CartPole envs;
-        // at 2^17 itself, one E = 2 wave per SIMD: 0.92 vs 1.01, profiles/r3k_small_shard_e1_ab.jsonl) — the shard sizes of an 8-GPU
+        // puts twice as many waves on it (profiles/r2/r02a_shard_sweep.jsonl: 0.76 vs 1.05 us per step at 2^16 CartPole envs;
+        // at 2^17 itself, one E = 2 wave per SIMD: 0.92 vs 1.01, profiles/r3/r3k_small_shard_e1_ab.jsonl) — the shard sizes of an 8-GPU
         // strong-scaling or mixed-batch job.
         constexpr int ER = rollout_envs_per_lane(ENV);
         if (ER > 1 && a.n < (int64_t)kSimds * ER * kWave * MXV_ROLLOUT_E1_FACTOR + MXV_ROLLOUT_E1_INCLUSIVE && MXV_ROLLOUT_SMALL_E1)

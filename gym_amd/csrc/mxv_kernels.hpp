@@ -105,7 +105,7 @@ struct SampleArgs {
 };
 
 // Envs per lane of the step kernel (tile = E * 256 envs per workgroup), chosen per env kind from the sweep in
-// profiles/r01_variant_sweep.md: two interleaved chains for the light envs (ILP without register spills; four
+// profiles/r1/r01_variant_sweep.md: two interleaved chains for the light envs (ILP without register spills; four
 // chains spill SGPRs/VGPRs inside the fused loop), one chain for Pendulum and for Acrobot's RK4 (~60 live fp64).
 #ifndef MXV_ENVS_PER_LANE
 #define MXV_ENVS_PER_LANE 2
@@ -158,7 +158,7 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #endif
 // the shard size below which a two-envs-per-lane kind runs one env per lane: FACTOR x (one E = 2 wave per SIMD); INCLUSIVE = 1 includes
 // the boundary itself, i.e. the 2^17-env shard of an 8-GPU strong-scaling job (round 3: 1.01 -> 0.92 us per CartPole step, MountainCar
-// 0.85 -> 0.75, MountainCarContinuous 0.99 -> 0.79; at 2^18 two envs per lane win, 1.43 vs 1.53, at 2^19 the two are equal.  profiles/r3k_small_shard_e1_ab.jsonl, r3s_e1_factor_ab.jsonl)
+// 0.85 -> 0.75, MountainCarContinuous 0.99 -> 0.79; at 2^18 two envs per lane win, 1.43 vs 1.53, at 2^19 the two are equal.  profiles/r3/r3k_small_shard_e1_ab.jsonl, r3s_e1_factor_ab.jsonl)
 #ifndef MXV_ROLLOUT_E1_FACTOR
 #define MXV_ROLLOUT_E1_FACTOR 1
 #endif

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(kThreads) obs_sums_kernel(const float *__restr
 #pragma unroll
     for (int j = 0; j < O; ++j) s[j] = q[j] = 0.0;
     // a lane's rows are tid, tid+256, ...: every wave load is a dense burst (64 rows x 4*O bytes)
-#pragma unroll 4   // (8 or 16 rows in flight per lane measured the same: profiles/r4n_normalize_variants.txt)
+#pragma unroll 4   // (8 or 16 rows in flight per lane measured the same: profiles/r4/r4n_normalize_variants.txt)
     for (int r = tid; r < rows; r += kThreads) {
         float f[O];
         load_row<O>(base + (int64_t)r * O, f);

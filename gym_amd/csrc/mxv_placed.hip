@@ -4,8 +4,8 @@
 // step, rewards 8 B, actions 8 B, two flag bytes).  On the MI355X a 16-B/lane stream and an 8-B/lane stream written concurrently run
 // 10-12 % slower when the PHYSICAL memory behind them belongs to the same CLASS of HBM regions, and the whole trajectory launch runs
 // 5.4 / 5.7 / 6.4 us per 2^20-env step when none / one / both of {rewards, actions} share the observations' class
-// (profiles/r3a_*; the probes were removed in round 4, tools/README.md).  The classes are three contiguous thirds of the physical address space —
-// 3 x 96 GB, what the three ranks of a 12-high HBM3E stack would give — (tools/vmm_classmap.hip, profiles/r3c_hbm_class_map_whole_device.jsonl):
+// (profiles/r3/r3a_*; the probes were removed in round 4, tools/README.md).  The classes are three contiguous thirds of the physical address space —
+// 3 x 96 GB, what the three ranks of a 12-high HBM3E stack would give — (tools/vmm_classmap.hip, profiles/r3/r3c_hbm_class_map_whole_device.jsonl):
 // a fresh process is handed the first third for its first ~90 GiB, so ordinary allocations all share a class ("slow box") unless
 // earlier activity has scrambled the driver's free lists ("fast placement").  That is the placement lottery of DESIGN.md §6.  Nothing in
 // software sees the class of a page — but HIP's virtual-memory API decides which physical memory backs which virtual range, and the class
@@ -18,7 +18,7 @@
 // another class appears.  Spacers and surplus chunks are released before the call returns; every tensor then gets a fresh virtual
 // range with chunks of its group's class(es) mapped into it.
 //
-// Runtime facts this code is written around (ROCm 7.0 / this driver; profiles/r3a_* hold the test runs):
+// Runtime facts this code is written around (ROCm 7.0 / this driver; profiles/r3/r3a_* hold the test runs):
 //   * a virtual address that has been mapped once keeps translating to the FIRST physical memory it saw, even after hipMemUnmap and
 //     hipMemMap of another handle -> every mapping here uses a fresh address, and no reservation is ever given back
 //     (hipMemAddressFree) so the runtime cannot hand a used address out again; freeing leaks virtual address space only;

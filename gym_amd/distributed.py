@@ -29,7 +29,7 @@ import torch.distributed as dist
 def prefer_high_priority_collectives() -> bool:
     """RCCL's kernels on a high-priority stream: a chunk's all-gather then gets CUs as soon as rollout waves retire instead of queueing
     behind the next chunk's long, chip-filling launch.  Measured with the real RCCL call at world size 1 on a 2^17-env shard: +3.4 % per
-    chunk with it, +21 % without (profiles/r3k_chunk_overhead_priority.jsonl).  torch reads TORCH_NCCL_HIGH_PRIORITY when it creates a
+    chunk with it, +21 % without (profiles/r3/r3k_chunk_overhead_priority.jsonl).  torch reads TORCH_NCCL_HIGH_PRIORITY when it creates a
     process group, and the variable is PROCESS-WIDE — it changes every NCCL group of the process, a learner's included — so nothing sets
     it behind the caller's back (round 3 did, at import): call this before torch.distributed.init_process_group if you want it (bench.py
     does), or export the variable yourself.  An explicit setting of the user's wins.  Returns whether the variable is now "1".

@@ -12,7 +12,7 @@ Dispatch: one engine (= one C-ABI handle, one HIP stream) per segment per GPU.  
   * `single_launch=True`: ONE kernel for all segments (`mxv_rollout_mixed`, include/mxv.h): a block -> segment table sends every
     workgroup (= one wave) to the rollout body of its segment's env kind, so waves stay homogeneous (no per-lane switch that
     would serialise the code paths).  Measured SLOWER on the MI355X: 3.27 us with contiguous block ranges, 4.52 us with the
-    ranges interleaved (profiles/r02d_mixed_dispatch_contiguous.jsonl, r02e_mixed_dispatch_interleaved.jsonl): inside one grid the
+    ranges interleaved (profiles/r2/r02d_mixed_dispatch_contiguous.jsonl, r02e_mixed_dispatch_interleaved.jsonl): inside one grid the
     hardware deals consecutive workgroups over the SIMDs, which pairs waves of the same segment — two VALU-bound Acrobot waves —
     on one SIMD, while separate grids interleave kinds.  Kept as an option (one launch instead of four matters when launches
     are the bottleneck: short chunks, many small segments).

@@ -4,7 +4,7 @@ The MI355X's HBM address space consists of three contiguous classes of 96 GB (wh
 Long store streams written concurrently interfere when the physical memory behind them shares a class: the fused CartPole rollout
 (observations 16 B per env-step | rewards 8 + actions 8) runs 5.4 / 5.7 / 6.4 us per 2^20-env step with none / one / both of {rewards,
 actions} in the observations' class, the tabular rollout (four 8-B streams) 5.7 / 6.1 / 7.1 us split 2 + 2 / 1 + 3 / 4 + 0
-(profiles/r3a_*, r3g_tab_class_ab.jsonl).  The rule: split the streams into two groups of about equal bytes per env-step and keep the
+(profiles/r3/r3a_*, r3g_tab_class_ab.jsonl).  The rule: split the streams into two groups of about equal bytes per env-step and keep the
 groups on different classes.  A fresh process is handed ONE class for its first ~90 GiB, so back-to-back allocations do the opposite.
 
 `sorted_tensors` gets there with ordinary (torch / hipMalloc) allocations: the first group-0 tensor is the anchor; every other grouped

@@ -210,7 +210,7 @@ class DeviceRollout:
         at irregular offsets (pseudo-random gaps of up to ~60 % of the tensors' size in total, 4-KiB aligned, fixed by `seed`):
         on the boxes where placement matters the speed mode of the write-bound rollout is a function of the ADDRESSES — packed
         back to back (which is also what consecutive separate allocations are) can hit the slow mode, eight of eight such
-        irregular layouts measured fast (profiles/r02q_placement_scan_one_allocation.jsonl)."""
+        irregular layouts measured fast (profiles/r2/r02q_placement_scan_one_allocation.jsonl)."""
         if obs_partials or ret_partials:
             # + "obs_partials" [K, leaves, 2 O] float64: rollout_per_step then also leaves every step's column sums / sums of squares
             # of the observations per tile of envs (mxv_set_obs_partials) — RunningNormalizer.normalize_obs(x, partials=...) folds them
@@ -295,7 +295,7 @@ class DeviceRollout:
         WHERE its five output tensors sit physically relative to each other — a stable property of a set of allocations
         (same virtual addresses re-allocated can land in another mode; swapping single tensors between sets shows it is
         the combination, not any one tensor): 5.9 / 6.7 / 7.1 us per 2^20-env CartPole step for identical code
-        (profiles/r01h_placement_probe.txt).  This allocates `candidates` sets side by side, times `launches` fused
+        (profiles/r1/r01h_placement_probe.txt).  This allocates `candidates` sets side by side, times `launches` fused
         launches on each after a warm-up, then `mixes` (default 2 x candidates) random recombinations of their tensors —
         new combinations at no extra memory — keeps the fastest combination and frees every tensor it does not use.  The env
         state, TimeLimit counters, RNG counters and running episode returns are restored afterwards, so tuning does not change

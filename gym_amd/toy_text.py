@@ -495,7 +495,7 @@ class TabularRollout:
     def trajectory_buffers(self, K: int, layout: str = "auto"):
         """[K, N] output tensors of rollout_per_step.  Sets of 2 GiB and more ("auto") are sorted by HBM class (gym_amd/placement.py):
         the launch writes four 8-byte streams, and it runs 5.7 / 6.1 / 7.1 us per 2^20-env step with them split 2 + 2 / 1 + 3 / 4 + 0
-        over two classes (profiles/r3g_tab_class_ab.jsonl) — obs + reward on one, actions + prob on another.  layout="separate":
+        over two classes (profiles/r3/r3g_tab_class_ab.jsonl) — obs + reward on one, actions + prob on another.  layout="separate":
         ordinary allocations.  The report is left in self.last_placement."""
         t, n, dev = self._torch, self.num_envs, self.device
         it, rt = self.int_dtype, self.real_dtype

@@ -71,3 +71,53 @@ def test_self_launch_fails_fast_and_readably_when_a_rank_cannot_start():
     assert p.returncode != 0 and time.time() - t0 < 120
     assert "rank" in p.stderr and ("HIP device" in p.stderr or "exited with code" in p.stderr)
     assert not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+def _full_record():
+    """A long-form record as bench.py builds it: round 4's committed driver-argument run (24.9 KB as ONE line then: the driver's 8-KB
+    record lost the headline), plus the fields round 5 added."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4", "r4w_bench_driver_args_final_tree.json")))
+    full["cpu_baseline"]["sample_short"] = "C port (gcc -O2): 1 thread 2^20 envs x 100 steps 3.1 s; 64 threads x 16384 envs x 3000 steps 2.2 s"
+    full["details"] = {"variants": "gpurun_out/bench_variants.json", "headline": "gpurun_out/bench_headline.json"}
+    full["config"].update(gather_us=None, cadence_ab=None)
+    return full
+
+
+def test_compact_line_fits_the_drivers_record_and_keeps_the_contract():
+    full = _full_record()
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    s = json.dumps(line)
+    assert len(s) < bench.LINE_LIMIT == 4096 and json.loads(s) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k] or line[k] == __import__("pytest").approx(full[k], rel=1e-7), k
+    assert line["value"] == full["value"]                                    # the headline figure is never rounded
+    roof = line["roofline"]
+    assert (roof["bound"], roof["peak"], roof["unit"]) == ("hbm", 8000.0, "GB/s") and roof["frac"] == __import__("pytest").approx(full["roofline"]["frac"], rel=1e-7)
+    assert roof["env_steps_per_launch"] == 1 << 28 and roof["kernel_over_probe"] > 1.0       # whole numbers stay exact
+    assert line["config"]["work_check"]["checksum"] == full["config"]["work_check"]["checksum"] and "what" not in line["config"]["work_check"]
+    assert line["config"]["launch_info"] == full["config"]["launch_info"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["reference_python"]["value"] > 1e4
+    assert set(line["variants"]) == set(full["variants"]) and all(v == "error" or len(v) == 2 for v in line["variants"].values())
+    assert line["variants"]["step_loop"][1] == __import__("pytest").approx(full["variants"]["step_loop"]["one_engine"]["roofline"]["frac"], rel=1e-3)
+
+
+def test_compact_line_of_an_eight_rank_run():
+    import copy
+
+    f8 = copy.deepcopy(_full_record())
+    f8.pop("variants"), f8.pop("cpu_baseline")
+    f8["n_gpus"] = 8
+    r0 = f8["config"]["per_rank"][0]
+    f8["config"]["per_rank"] = [dict(r0, rank=i, device=i, kernel_us_per_step=0.78 + 0.0123456789 * i) for i in range(8)]
+    f8["config"]["gather_us"] = {"measured_blocking": 312.123456789, "predicted": [180.123456, 320.987654], "bytes_received_per_rank": 24117248,
+                                 "steps_of_this_shard_it_equals": 400.123456}
+    f8["config"]["cadence_ab"] = {"gather_every": 256, "steps": 2560, "ms_per_step": 0.00112345678}
+    f8["config"]["comm"] = {"backend": "nccl", "ranks_seen": 8, "transport": "torch", "launcher": "bench.py", "rccl_version": "2.26.6"}
+    line = bench.compact_line(f8)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert [r[0] for r in line["config"]["per_rank"]] == list(range(8)) and line["config"]["per_rank"][3][4] == "sorted"
+    assert line["config"]["gather_us"]["bytes_received_per_rank"] == 24117248 and line["config"]["cadence_ab"]["gather_every"] == 256
+    # a pathological record (a placement error message on every rank ...) sheds its optional parts instead of outgrowing the limit
+    f8["config"]["outputs"] = "x" * 3000
+    assert len(json.dumps(bench.compact_line(f8))) < bench.LINE_LIMIT

@@ -16,14 +16,52 @@ sys.path.insert(0, ROOT)
 
 
 @pytest.fixture(scope="module")
-def line():
+def run(tmp_path_factory):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5`, the driver's command (plus a short CPU sample and side files in a temporary
+    directory): (the stdout line parsed, the raw stdout, the full variant records from the side file, stderr)."""
+    d = tmp_path_factory.mktemp("bench")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-sample-steps", "4"], cwd=ROOT,
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-sample-steps", "4",
+                        "--variants-file", str(d / "variants.json"), "--headline-file", str(d / "headline.json")], cwd=ROOT,
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    return lines[0]
+    return json.loads(p.stdout), p.stdout, json.load(open(d / "variants.json")), json.load(open(d / "headline.json")), p.stderr
+
+
+@pytest.fixture(scope="module")
+def line(run):
+    return run[0]
+
+
+def test_stdout_is_one_line_the_driver_can_keep(run):
+    """VERDICT r4, Next #1: the driver's record keeps the last 8 KB of stdout and round 4's 24.9-KB line fell out of it.  stdout is ONE
+    JSON line under 4 KB that parses alone and carries the contract fields, roofline and cpu_baseline; everything else is beside it."""
+    import bench
+
+    line, raw, variants, headline, err = run
+    assert raw.endswith("\n") and len(raw.strip().splitlines()) == 1 and len(raw.encode()) < bench.LINE_LIMIT, len(raw)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "variants"):
+        assert k in line, k
+    assert (line["steps"], line["warmup"], line["n_gpus"], line["unit"], line["dtype"]) == (20, 5, 1, "env-steps/s", "f64")
+    assert line["value"] == pytest.approx((1 << 20) / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_env_step", "avg_launch_us",
+              "kernel_over_probe"):
+        assert k in line["roofline"], k
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] >= cb["single_core_value"] > 1e6 and cb["reference_python"]["value"] > 1e4
+    # one [us_per_step, roofline_frac] pair per secondary measurement; the full records are in the side file and on stderr
+    assert set(line["variants"]) == set(variants) and len(variants) >= 20
+    assert line["variants"]["compact_cartpole"][0] == pytest.approx(variants["compact_cartpole"]["us_per_step"], rel=1e-3)
+    assert line["variants"]["blackjack"][1] == pytest.approx(variants["blackjack"]["roofline"]["frac"], rel=1e-3)
+    assert err.count("[bench variant] ") == len(variants) and "[bench per-rank] " in err
+    for l in err.splitlines():
+        if l.startswith("[bench variant] "):
+            assert len(l) < bench.LINE_LIMIT + 16, (len(l), l[:80])
+            json.loads(l[len("[bench variant] "):])
+    # the long-form copy holds what the line dropped (prose, placement reports) and the same numbers
+    assert headline["value"] == line["value"] and "what" in headline["config"]["work_check"] and headline["variants"] == variants
+    assert headline["roofline"]["frac"] == pytest.approx(line["roofline"]["frac"], rel=1e-6)
 
 
 def test_work_check_is_reproduced_by_the_oracle(line):
@@ -55,15 +93,15 @@ def test_work_check_is_reproduced_by_the_oracle(line):
     assert 0.035 < wc["autoresets_per_env_step"] < 0.055                           # random-policy CartPole: ~ 1 / 22 steps
 
 
-def test_line_carries_what_the_review_asked_for(line):
+def test_line_carries_what_the_review_asked_for(run):
+    line, _, v, headline, _ = run
     assert line["n_gpus"] == 1 and line["config"]["ranks_seen"] == 1 and line["dtype"] == "f64"
     roof, cfg = line["roofline"], line["config"]
     assert roof["frac"] == pytest.approx(roof["achieved"] / 8000.0) and 0.3 < roof["frac"] < 0.9
     assert cfg["placement"]["kind"].startswith("sorted") and cfg["placement"]["balanced"] is True
     assert cfg["placement"]["parked_GiB"] <= 112
-    ref = line["cpu_baseline"]["reference_python"]
+    ref = headline["cpu_baseline"]["reference_python"]
     assert ref["source"].startswith("profiles/reference_cpu_baseline.json") and ref["value"] > 1e4
-    v = line["variants"]
     assert not [k for k, x in v.items() if isinstance(x, dict) and "error" in x], v
     for key in ("configs2_pendulum", "configs2_mountaincar_continuous", "mountaincar", "configs3_acrobot_shard", "compact_cartpole",
                 "compact_pendulum", "compact_mountaincar_continuous", "compact_mountaincar", "compact_acrobot"):

@@ -86,7 +86,11 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     out = lines[0]
     cfg = out["config"]
     assert out["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["comm"]["launcher"] == "bench.py" and cfg["comm"]["backend"] == "gloo"
-    assert [r["rank"] for r in cfg["per_rank"]] == [0, 1]
-    assert all(r["kernel_us_per_step"] > 0 and "placement" in r for r in cfg["per_rank"])
+    assert cfg["per_rank_fields"] == ["rank", "device", "kernel_us_per_step", "write_probe_us_per_step", "placement"]
+    assert [r[0] for r in cfg["per_rank"]] == [0, 1] and all(r[2] > 0 and isinstance(r[4], str) for r in cfg["per_rank"])
+    assert p.stderr.count("[bench per-rank] ") == 2 and len(p.stdout.encode()) < 4096
+    # the older cadence (one gather per launch, rounds 1-3) beside the default one, and the gather by itself
+    assert cfg["cadence_ab"]["gather_every"] == 256 and cfg["cadence_ab"]["ms_per_step"] > 0
+    assert cfg["gather_us"]["measured_blocking"] > 0 and cfg["gather_us"]["predicted"][0] < cfg["gather_us"]["predicted"][1]
     assert cfg["num_envs_per_gpu"] == 1 << 19 and cfg["repeats"] >= 100
     assert "cpu_baseline" not in out and "variants" not in out          # N = 1 only

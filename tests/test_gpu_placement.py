@@ -2,7 +2,7 @@
 default, DeviceRollout.trajectory_buffers(layout="sorted") (ordinary allocations classified with mxv_hbm_pair_probe).  What is pinned
 here: the memory is real and private (torch sees it, values survive, freeing returns it), results do not depend on where the tensors
 live (bit for bit), the reports say what happened.  That the placement makes the rollout FAST is a measurement, not a test:
-profiles/r3b_*, r3d_* and the bench line's roofline.write_probe."""
+profiles/r3/r3b_*, r3d_* and the bench line's roofline.write_probe."""
 import numpy as np
 import pytest
 import torch

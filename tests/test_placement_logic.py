@@ -1,6 +1,6 @@
 """gym_amd.placement.sorted_tensors — the search logic on a SIMULATED device (no GPU): allocations walk through an address space made of
 class regions, the pair probe answers "slow" for two addresses of one class and "fast" otherwise, exactly what mxv_hbm_pair_probe
-measures on the MI355X (profiles/r3a_vmm_probe7_chunk_matrix_and_prediction.jsonl).  Every branch is driven: nothing to do, a fresh
+measures on the MI355X (profiles/r3/r3a_vmm_probe7_chunk_matrix_and_prediction.jsonl).  Every branch is driven: nothing to do, a fresh
 device (everything in one class for 90 GiB), a boundary inside the anchor, a boundary inside group 0 (restart), the budget running out
 (best effort, balanced = False), scrambled free lists."""
 import bisect

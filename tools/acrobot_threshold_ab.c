@@ -20,7 +20,7 @@ static void kern(double x, double *sn, double *cs) {
     c = fma(z, c, 2.48015872894767294178e-05);
     c = fma(z, c, -1.38888888888741095749e-03);
     c = fma(z, c, 4.16666666666666019037e-02);
-#ifdef FDLIBM_COS   /* the cosine of the build profiles/r4a_acrobot_threshold_flip_split.jsonl was recorded with (MXV_FDLIBM_COS = 1) */
+#ifdef FDLIBM_COS   /* the cosine of the build profiles/r4/r4a_acrobot_threshold_flip_split.jsonl was recorded with (MXV_FDLIBM_COS = 1) */
     const double hz = 0.5 * z;
     const double t = 1.0 - hz;
     *cs = t + fma(z, z * c, (1.0 - t) - hz);

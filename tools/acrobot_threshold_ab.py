@@ -8,7 +8,7 @@ reference's (glibc) and from the reference on a correctly rounded libm (Acrobot_
     python tools/acrobot_threshold_ab.py --cpu                      # host emulation of the hot path (tools/acrobot_threshold_ab.c) + the exact path
     python tools/acrobot_threshold_ab.py --gpu name=lib.so [...]    # the device itself, one libmxv build variant per entry
 
-One JSON line per variant.  Committed result: profiles/r4a_acrobot_threshold_flip_split.jsonl."""
+One JSON line per variant.  Committed result: profiles/r4/r4a_acrobot_threshold_flip_split.jsonl."""
 import ctypes
 import json
 import os
