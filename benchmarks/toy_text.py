@@ -27,20 +27,22 @@ def measure_tabular(torch, gid, envs, chunk, reps=6, compact=False, general_kern
     return res
 
 
-def measure_blackjack(torch, envs, chunk, reps=6):
+def measure_blackjack(torch, envs, chunk, reps=6, compact=False):
     """Blackjack-v1 (gym/envs/toy_text/blackjack.py:108-160): fused K-step rollouts, observation = three int64 columns, reward float64,
-    flags, sampled actions int64 -> 42 B stored per env-step; contract bytes (4-byte scalars): 3 x 4 + 4 + 4 + 2 = 22."""
+    flags, sampled actions int64 -> 42 B stored per env-step; contract bytes (4-byte scalars): 3 x 4 + 4 + 4 + 2 = 22, which is what
+    compact=True (mxv_bj_rollout_compact: int32 / float32) stores."""
     from gym_amd import _native
 
     dev = torch.device("cuda", torch.cuda.current_device())
+    it, ft = (torch.int32, torch.float32) if compact else (torch.int64, torch.float64)
     h = _native.Blackjack(envs, seed=0, action_seed=1)
-    obs = torch.empty((chunk, 3, envs), dtype=torch.int64, device=dev)
-    rew = torch.empty((chunk, envs), dtype=torch.float64, device=dev)
+    obs = torch.empty((chunk, 3, envs), dtype=it, device=dev)
+    rew = torch.empty((chunk, envs), dtype=ft, device=dev)
     term, trunc = (torch.empty((chunk, envs), dtype=torch.uint8, device=dev) for _ in range(2))
-    act = torch.empty((chunk, envs), dtype=torch.int64, device=dev)
+    act = torch.empty((chunk, envs), dtype=it, device=dev)
     torch.cuda.synchronize()
     h.reset()
-    run = lambda: h.rollout(chunk, obs, rew, term, trunc, None, actions_out_dev=act, per_step=True)   # noqa: E731
+    run = lambda: h.rollout(chunk, obs, rew, term, trunc, None, actions_out_dev=act, per_step=True, compact=compact)   # noqa: E731
     for _ in range(2):
         run()
     h.sync()
@@ -49,8 +51,11 @@ def measure_blackjack(torch, envs, chunk, reps=6):
         run()
     h.sync()
     us = (time.perf_counter() - t0) / reps / chunk * 1e6
-    res = _hbm(us, envs, 22, workload=f"Blackjack-v1, num_envs={envs}, fused {chunk}-step launches, the reference's dtypes (42 B stored per env-step)",
-               stored_GBs=envs * 42 / us / 1e3, episodes_ended_per_env_step=float(((term | trunc) != 0).float().mean().item()))
+    stored = 22 if compact else 42
+    res = _hbm(us, envs, 22, workload=f"Blackjack-v1, num_envs={envs}, fused {chunk}-step launches, "
+                                      + ("int32 observations / actions + float32 rewards" if compact else "the reference's dtypes") + f" ({stored} B stored per env-step)",
+               stored_GBs=envs * stored / us / 1e3, episodes_ended_per_env_step=float(((term | trunc) != 0).float().mean().item()),
+               kernel="bj_kernel (one draw-stream Philox call per step, straight-line)")
     h.close()
     del obs, rew, term, trunc, act
     torch.cuda.empty_cache()

@@ -31,6 +31,7 @@ def groups(torch, chunk):
         ("compact_frozenlake8x8", lambda: measure_tabular(torch, "FrozenLake8x8-v1", ENVS_TOTAL, 128, compact=True)),
         ("compact_taxi", lambda: measure_tabular(torch, "Taxi-v3", ENVS_TOTAL, 128, compact=True)),
         ("blackjack", lambda: measure_blackjack(torch, ENVS_TOTAL, 128)),
+        ("compact_blackjack", lambda: measure_blackjack(torch, ENVS_TOTAL, 128, compact=True)),
         ("configs4_mixed_share", lambda: measure_mixed(torch, 1 << 15, chunk)),
         ("strong_scaling_share_of_8", f(ENV_ID, ENVS_TOTAL // 8)),
         ("step_loop", lambda: {

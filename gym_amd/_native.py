@@ -50,7 +50,7 @@ EXPORTS = (
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_device_clock", "mxv_bj_set_device_clock", "mxv_tab_set_stream",
-    "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout",
+    "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout", "mxv_bj_rollout_compact",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
     "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error", "mxv_hbm_pair_probe",
 )
@@ -280,6 +280,7 @@ def _load():
         "mxv_bj_reset": ([vp, vp, vp, vp], C.c_int),
         "mxv_bj_step": ([vp] * 8, C.c_int),
         "mxv_bj_rollout": ([vp, i32, i32] + [vp] * 7, C.c_int),
+        "mxv_bj_rollout_compact": ([vp, i32, i32] + [vp] * 7, C.c_int),
         "mxv_bj_reset_host": ([vp, vp, vp], C.c_int),
         "mxv_bj_step_host": ([vp] * 8, C.c_int),
         "mxv_bj_get_state": ([vp, vp, vp], C.c_int),
@@ -1310,10 +1311,12 @@ class Blackjack:
                                     _ptr(terminated_dev), _ptr(truncated_dev), _ptr(final_obs_dev)))
 
     def rollout(self, K, obs_dev, reward_dev=None, terminated_dev=None, truncated_dev=None, final_obs_dev=None,
-                actions_out_dev=None, actions_tape_dev=None, per_step=False):
-        self._check(lib.mxv_bj_rollout(self._h, int(K), int(per_step), _ptr(actions_tape_dev), _ptr(actions_out_dev),
-                                       _ptr(obs_dev), _ptr(reward_dev), _ptr(terminated_dev), _ptr(truncated_dev),
-                                       _ptr(final_obs_dev)))
+                actions_out_dev=None, actions_tape_dev=None, per_step=False, compact=False):
+        """compact: int32 observations / actions_out / final_obs and float32 rewards (mxv_bj_rollout_compact) instead of the
+        reference's int64 / float64."""
+        fn = lib.mxv_bj_rollout_compact if compact else lib.mxv_bj_rollout
+        self._check(fn(self._h, int(K), int(per_step), _ptr(actions_tape_dev), _ptr(actions_out_dev), _ptr(obs_dev), _ptr(reward_dev),
+                       _ptr(terminated_dev), _ptr(truncated_dev), _ptr(final_obs_dev)))
 
     def reset_host(self, cards=None) -> np.ndarray:
         """-> obs int64 [3][N].  cards: None or int8 [N][4] (dealer's two cards, then the player's)."""

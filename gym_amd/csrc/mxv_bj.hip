@@ -10,11 +10,11 @@
 // the two initial cards (is_natural: sorted(hand) == [1, 10], :44-45) — one packed int32 per env:
 //   bits 0-5 player sum | 6 player ace | 7 player has two cards | 8-11 dealer's first card | 12-17 dealer sum | 18 dealer ace |
 //   19 dealer has two cards.
-// Cards: card = deck[(word * 13) >> 32] from the engine's Philox streams — per step the draw stream (key = env seed,
-// ctr = (t_lo, t_hi, call, 5 << 28), four cards per call, consumed in the reference's order: the hit card or the dealer's
-// cards, then on termination the new dealer hand and player hand) — or, for bit-exact replays of the reference, injected
-// (`cards_dev`: int8 [N][MXV_BJ_MAX_DRAWS] in consumption order).  Explicit reset: the reset stream (words x,y = dealer,
-// z,w = player).  One env per lane; per env-step 3 int64 observations + reward + 2 flags + action = 42 B: HBM-bound.
+// Cards: from the engine's Philox draw stream (draw_call below: one call per step, eight cards with fixed roles) — or, for bit-exact
+// replays of the reference, injected (`cards_dev`: int8 [N][MXV_BJ_MAX_DRAWS] in the reference's consumption order: the hit card or
+// the dealer's cards, then on termination the new dealer hand and player hand).  Explicit reset: the reset stream (words x,y =
+// dealer, z,w = player).  One env per lane; per env-step 3 int64 observations + reward + 2 flags + action = 42 B stored in the
+// reference's dtypes (22 B with the contract's 4-byte scalars: mxv_bj_rollout_compact).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -29,18 +29,6 @@ using namespace mxv;
 
 namespace {
 
-#ifndef MXV_BJ_QUAD_ACTIONS
-#define MXV_BJ_QUAD_ACTIONS 1   // 1: the lanes of a quad share one action-word Philox call per four steps; 0: one call per lane per step (A/B hook)
-#endif
-#ifndef MXV_BJ_DPP_TRANSPOSE
-#define MXV_BJ_DPP_TRANSPOSE 1   // 1: the quad's action words change lanes by quad_transpose (DPP); 0: three shuffles and select chains (A/B hook)
-#endif
-#ifndef MXV_BJ_PACKED_DRAWS
-#define MXV_BJ_PACKED_DRAWS 1   // 1: the step's first eight cards evaluated up front (CardSource); 0: a Philox call at every draw (A/B hook)
-#endif
-#ifndef MXV_BJ_NEXT4
-#define MXV_BJ_NEXT4 1          // 1: a reset's four cards in one go, the third call decided once per wave (A/B hook)
-#endif
 constexpr int kBjBlock = 256;
 constexpr uint32_t kStreamDraw = 5u;
 
@@ -51,92 +39,37 @@ struct Hand {
     __device__ __forceinline__ int score() const { return total() > 21 ? 0 : total(); } // :36-41
     __device__ __forceinline__ bool natural() const { return two && ace && sum == 11; } // :44-45
     __device__ __forceinline__ void add(int c) { sum += c; ace |= (c == 1); }
+    // add(c) where `on`, nothing otherwise — without a branch
+    __device__ __forceinline__ void add_if(bool on, int c) { sum += on ? c : 0; ace |= (int)(on & (c == 1)); two &= (int)!on; }
 };
 
-__device__ __forceinline__ int card_of(uint32_t w) {
-    const int i = (int)(((uint64_t)w * 13u) >> 32);  // index into deck (:15)
-    return i < 9 ? i + 1 : 10;
+__device__ __forceinline__ int total_of(int sum, int ace) { return sum + ((ace && sum <= 11) ? 10 : 0); }   // sum_hand (:30-33)
+__device__ __forceinline__ int card_of_index(uint32_t i) { return (int)(i < 9u ? i + 1u : 10u); }   // deck[i], deck = [1..10, 10, 10, 10] (:15)
+__device__ __forceinline__ int card_of(uint32_t w) { return card_of_index((uint32_t)(((uint64_t)w * 13u) >> 32)); }   // one card per word (explicit resets)
+// Two cards per word: the word as a base-13 fraction, its first two digits (d0 = floor(13 x), d1 = floor(13 frac(13 x))).  Jointly
+// uniform over the 169 pairs up to 169 / 2^32 = 4e-8 relative (the one-card map is uniform up to 13 / 2^32), rejection-free.
+__device__ __forceinline__ void cards_of(uint32_t w, int &c0, int &c1) {
+    const uint64_t p = (uint64_t)w * 13u;
+    c0 = card_of_index((uint32_t)(p >> 32));
+    c1 = card_of_index((uint32_t)(((uint64_t)(uint32_t)p * 13u) >> 32));
 }
 
 struct BjArgs {
     int32_t *state, *elapsed;
     const uint64_t *seeds;
     const int64_t *actions;   // [N] / tape [K][N] or nullptr -> sampled
-    int64_t *actions_out;
+    void *actions_out;        // int64 (OUT = 1) / int32 (OUT = 2)
     const int8_t *cards;      // injected draws [N][MXV_BJ_MAX_DRAWS] or nullptr -> Philox
-    int64_t *obs;             // [3][N] (or [K][3][N]): player total, dealer's first card, usable ace
-    double *reward;
+    void *obs;                // [3][N] (or [K][3][N]): player total, dealer's first card, usable ace; int64 / int32
+    void *reward;             // float64 / float32
     uint8_t *terminated, *truncated;
-    int64_t *final_obs;       // [3][N] / [K][3][N], columns of finished envs only
+    void *final_obs;          // [3][N] / [K][3][N], columns of finished envs only
     int32_t *err;
     int64_t n;
     uint64_t env0, base_seed, action_seed, t;
     const uint64_t *t_dev;    // device clock (mxv_bj_set_device_clock): the step index = t + *t_dev; nullptr: t
     int32_t max_steps, K, natural, sab;
     int64_t slice, act_slice;
-};
-
-// The step's cards.  Philox draws: a step consumes 1 card (a hit that does not bust) to 4 + the dealer's draws + 4 (a stick, then the next
-// episode's hands), lane by lane, and a lane-by-lane "refill when the cursor crosses a call boundary" makes the WAVE run a Philox call
-// at nearly every draw (some lane always crosses).  Instead the first two calls of the step's draw stream are evaluated once, up front,
-// and their eight cards packed four bits each into one register: a draw is a shift and a mask.  Draws past the eighth (a dealer hand
-// of five and more cards) evaluate their call on the spot — except the four cards of the next episode's hands, which are taken in one go
-// (next4): whether ANY lane of the wave reaches into cards 8..11 is decided once (in a wave of 64 tables some dealer has drawn five
-// cards in about every second step) and the third call is then evaluated once, not at each of the four draws.
-struct CardSource {
-    const int8_t *inj;
-    uint64_t seed, t;
-    int cursor;
-    uint32_t pk;   // cards 0..7 of the step's draw stream, 4 bits each
-    uint32_t pk2;  // cards 8..11 (valid inside next4 only)
-    __device__ __forceinline__ U4 call(uint32_t i) const {
-        U4 ctr;
-        ctr.x = (uint32_t)t; ctr.y = (uint32_t)(t >> 32); ctr.z = i; ctr.w = (kStreamDraw << 28);
-        return philox4x32_10_vkey(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-    }
-    __device__ __forceinline__ void begin() {
-        if (inj) return;
-#if MXV_BJ_PACKED_DRAWS
-        const U4 w0 = call(0), w1 = call(1);
-        pk = (uint32_t)card_of(w0.x) | ((uint32_t)card_of(w0.y) << 4) | ((uint32_t)card_of(w0.z) << 8) | ((uint32_t)card_of(w0.w) << 12) |
-             ((uint32_t)card_of(w1.x) << 16) | ((uint32_t)card_of(w1.y) << 20) | ((uint32_t)card_of(w1.z) << 24) | ((uint32_t)card_of(w1.w) << 28);
-#endif
-    }
-    static __device__ __forceinline__ uint32_t pack4(const U4 &w) {
-        return (uint32_t)card_of(w.x) | ((uint32_t)card_of(w.y) << 4) | ((uint32_t)card_of(w.z) << 8) | ((uint32_t)card_of(w.w) << 12);
-    }
-    // the next four cards (a reset: dealer's two, player's two)
-    __device__ __forceinline__ void next4(int c[4]) {
-#if MXV_BJ_PACKED_DRAWS && MXV_BJ_NEXT4
-        if (!inj) {
-            const bool fast = cursor <= 8;                 // all four inside cards 0..11
-            if (__any(fast && cursor > 4)) pk2 = pack4(call(2));   // somebody's four reach past card 7: one call for the wave
-            if (fast) {
-                const uint64_t both = (uint64_t)pk | ((uint64_t)pk2 << 32);
-                const uint32_t four = (uint32_t)(both >> (4 * cursor)) & 0xffffu;
-                c[0] = (int)(four & 15u); c[1] = (int)((four >> 4) & 15u); c[2] = (int)((four >> 8) & 15u); c[3] = (int)(four >> 12);
-                cursor += 4;
-                return;
-            }
-        }
-#endif
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) c[i] = next();
-    }
-    __device__ __forceinline__ int next() {
-        int c;
-        if (inj) {
-            c = inj[cursor < MXV_BJ_MAX_DRAWS ? cursor : MXV_BJ_MAX_DRAWS - 1];
-        } else if (MXV_BJ_PACKED_DRAWS && cursor < 8) {
-            c = (int)((pk >> (4 * cursor)) & 15u);
-        } else {
-            const U4 w = call((uint32_t)(cursor >> 2));
-            const int q = cursor & 3;
-            c = card_of(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-        }
-        ++cursor;
-        return c;
-    }
 };
 
 __device__ __forceinline__ void unpack(int32_t s, Hand &p, Hand &d, int &dfirst) {
@@ -151,119 +84,146 @@ __device__ __forceinline__ void deal(int c1, int c2, Hand &h) {
     h.sum = c1 + c2; h.ace = (c1 == 1) | (c2 == 1); h.two = 1;
 }
 
-#ifndef MXV_BJ_WAVES
-#define MXV_BJ_WAVES 0   // 0: the register allocator's choice (89 VGPRs: 5 waves per SIMD); 6 / 8: a budget of 80 / 64 VGPRs (A/B hook)
-#endif
-__global__ void __launch_bounds__(kBjBlock)
-#if MXV_BJ_WAVES > 0
-    __attribute__((amdgpu_waves_per_eu(MXV_BJ_WAVES, MXV_BJ_WAVES)))
-#endif
-    bj_step_kernel(BjArgs a) {
-    const int64_t e = (int64_t)blockIdx.x * kBjBlock + threadIdx.x;
-    const bool valid = e < a.n;  // sampled actions: lanes past the end stay in the loop, their quad partners need their action words
-    if (!valid && a.actions) return;
+// The draw stream of one env at vector step t (round 5; rounds 2-4 drew one card per word, consumed in the reference's order, which cost
+// two to three Philox calls in every step of every wave).  ONE call per step, ctr = (t_lo, t_hi, 0, 5 << 28) under the env's seed, yields
+// eight cards, two per word (cards_of), with FIXED roles:
+//     words x, y -> cards 0..3 : the hit card (card 0) or the dealer's first four draws of a stick;
+//     word  z    -> cards 4, 5 : the next episode's dealer hand;      word w -> cards 6, 7 : the next episode's player hand.
+// A dealer that draws a fifth card and more (a hand of seven cards: ~1 stick in 400) continues with call index 1, 2, ...: draw j >= 4 is
+// card (j + 4) & 7 of call (j + 4) >> 3.  Every card is used at most once and all are independent uniform deck draws, so an episode is
+// distributed exactly as the reference's (up to the 4e-8 of cards_of); a step is straight-line code: no cursor, no packing, no second call.
+__device__ __forceinline__ U4 draw_call(uint64_t seed, uint64_t t, uint32_t i) {
+    U4 ctr;
+    ctr.x = (uint32_t)t; ctr.y = (uint32_t)(t >> 32); ctr.z = i; ctr.w = (kStreamDraw << 28);
+    return philox4x32_10_vkey(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __noinline__ int late_draw(uint64_t seed, uint64_t t, int j) {   // the dealer's draw j >= 4 (rare; kept out of line)
+    const int g = j + 4;
+    const U4 w = draw_call(seed, t, (uint32_t)(g >> 3));
+    const int q = (g >> 1) & 3;
+    int c0, c1;
+    cards_of(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)), c0, c1);
+    return (g & 1) ? c1 : c0;
+}
+
+template <int OUT> struct BjOut;
+template <> struct BjOut<1> { using I = int64_t; using R = double; };   // the reference's dtypes
+template <> struct BjOut<2> { using I = int32_t; using R = float; };    // the contract's 4-byte scalars
+
+// One vector step of Blackjack-v1 for K steps, one table per lane, the hands in registers.
+//   INJ     : cards come from `a.cards` in the reference's consumption order (bit-exact replays; K = 1) instead of the draw stream.
+//   SAMPLED : actions from the engine's Discrete(2) stream (one random bit per step: include/mxv.h, RNG contract) instead of a.actions.
+//   OUT     : output dtypes.
+// Both arms of `if action:` (:123-146) are evaluated for every lane and selected — under random or learned policies every wave holds
+// hitters and stickers, so a branch would run both anyway, plus its bookkeeping.
+template <bool INJ, bool SAMPLED, int OUT>
+__global__ void __launch_bounds__(kBjBlock) bj_kernel(BjArgs a) {
+    using I = typename BjOut<OUT>::I;
+    using R = typename BjOut<OUT>::R;
+    const uint32_t e = blockIdx.x * kBjBlock + threadIdx.x;    // num_envs <= 2^28 (mxv_bj_create): byte offsets of a row fit 32 bits
+    if ((int64_t)e >= a.n) return;
     const uint64_t ge = a.env0 + (uint64_t)e;
-    const uint64_t seed = (a.seeds && valid) ? a.seeds[e] : a.base_seed + ge;
+    const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + ge;
     Hand p, d;
     int dfirst;
-    unpack(valid ? a.state[e] : 0, p, d, dfirst);
-    int32_t el = valid ? a.elapsed[e] : 0;
-    // Action words: one Philox call yields the words of the 4 envs of group g = env >> 2 at ONE step.  The four lanes of a quad (= one
-    // group) each evaluate a different step of the aligned block 4 * (t >> 2) .. + 3 and trade words through quad_transpose (two DPP butterfly stages): one call per
-    // lane per four steps instead of one per step (the same stream, the same words: mxv_tab.hip's scheme).
-    const uint32_t q = (uint32_t)(ge & 3);
+    unpack(a.state[e], p, d, dfirst);
+    int32_t el = a.elapsed[e];
+    const int8_t *inj = INJ ? a.cards + (size_t)e * MXV_BJ_MAX_DRAWS : nullptr;
     uint64_t act_block = ~0ull;
-    uint32_t act_word[4] = {0, 0, 0, 0};
+    uint32_t act_bits = 0;
     const uint64_t t_base = a.t + (a.t_dev ? *a.t_dev : 0);
+    const int64_t col = a.slice ? a.slice : a.n;      // distance between the three observation columns
     mxv::settle_entry_loads();
     for (int k = 0; k < a.K; ++k) {
         const uint64_t t = t_base + (uint64_t)k;
-        const int64_t o = (int64_t)k * a.slice * 3 + e;   // observation columns: o, o + slice', ...
-        const int64_t o1 = (int64_t)k * a.slice + e;
-        const int64_t col = a.slice ? a.slice : a.n;      // distance between the three observation columns
-        int64_t act;
-        if (a.actions) {
-            act = a.actions[(int64_t)k * a.act_slice + e];
-            if (act < 0 || act > 1) {  // `assert self.action_space.contains(action)` (:122)
+        // rows of this step (wave-uniform bases: scalar registers; the lane adds its 32-bit index)
+        I *const obs_row = reinterpret_cast<I *>(a.obs) + (int64_t)k * a.slice * 3;
+        const int64_t row1 = (int64_t)k * a.slice;
+        int act;
+        if constexpr (SAMPLED) {
+            if ((t >> 5) != act_block) {    // uniform across the launch: one Philox call per 32 steps
+                act_block = t >> 5;
+                const U4 w = env_action_words<MXV_CARTPOLE>(a.action_seed, t, ge >> 2);   // the Discrete(2) bit stream (kStreamActionBits)
+                const uint32_t q = (uint32_t)(ge & 3);
+                act_bits = q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w));
+            }
+            act = (int)((act_bits >> ((uint32_t)t & 31u)) & 1u);
+            if (a.actions_out) reinterpret_cast<I *>(a.actions_out)[row1 + e] = (I)act;
+        } else {
+            const int64_t av = a.actions[(int64_t)k * a.act_slice + e];
+            if (av < 0 || av > 1) {  // `assert self.action_space.contains(action)` (:122)
                 *reinterpret_cast<volatile int32_t *>(a.err) = 1;  // single-bit code: a plain store (the word may live in pinned host memory)
                 continue;
             }
-        } else {
-#if !MXV_BJ_QUAD_ACTIONS
-            {   // A/B hook: round 2's one call per lane per step
-                const U4 w1 = action_words(a.action_seed, t, ge >> 2);
-                act_word[t & 3] = q == 0 ? w1.x : (q == 1 ? w1.y : (q == 2 ? w1.z : w1.w));
-            }
-#endif
-            if (MXV_BJ_QUAD_ACTIONS && (t >> 2) != act_block) {  // uniform across the launch: every lane refills its cache at the same step
-                act_block = t >> 2;
-                const U4 w = action_words(a.action_seed, (act_block << 2) + q, ge >> 2);
-#if MXV_BJ_DPP_TRANSPOSE
-                act_word[0] = w.x; act_word[1] = w.y; act_word[2] = w.z; act_word[3] = w.w;
-                quad_transpose(act_word, q);   // lane q evaluated step q of the block for the quad's four envs -> its own env's words for steps 0..3
-#else
-                const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+            act = (int)av;
+        }
+        int c[8];
+        if constexpr (INJ) {
 #pragma unroll
-                for (uint32_t r = 0; r < 4; ++r) {
-                    const uint32_t i = q ^ r;
-                    const uint32_t send = i == 0 ? wv[0] : (i == 1 ? wv[1] : (i == 2 ? wv[2] : wv[3]));
-                    const uint32_t recv = r == 0 ? send : (uint32_t)__shfl_xor((int)send, (int)r, 64);
-                    act_word[0] = i == 0 ? recv : act_word[0];
-                    act_word[1] = i == 1 ? recv : act_word[1];
-                    act_word[2] = i == 2 ? recv : act_word[2];
-                    act_word[3] = i == 3 ? recv : act_word[3];
-                }
-#endif
-            }
-            const uint32_t j = (uint32_t)(t & 3);
-            const uint32_t word = j == 0 ? act_word[0] : (j == 1 ? act_word[1] : (j == 2 ? act_word[2] : act_word[3]));
-            act = (int64_t)(((uint64_t)word * 2u) >> 32);
-            if (!valid) continue;
-            if (a.actions_out) a.actions_out[o1] = act;
+            for (int j = 0; j < 4; ++j) c[j] = inj[j];
+        } else {
+            const U4 w = draw_call(seed, t, 0);
+            cards_of(w.x, c[0], c[1]);
+            cards_of(w.y, c[2], c[3]);
+            cards_of(w.z, c[4], c[5]);
+            cards_of(w.w, c[6], c[7]);
         }
-        CardSource src{a.cards ? a.cards + e * MXV_BJ_MAX_DRAWS : nullptr, seed, t, 0, 0u, 0u};
-        src.begin();
-        bool term;
-        double rew;
-        if (act) {                                             // hit (:123-130)
-            p.add(src.next());
-            p.two = 0;
-            term = p.total() > 21;
-            rew = term ? -1.0 : 0.0;
-        } else {                                               // stick (:131-146)
-            term = true;
-            while (d.total() < 17) {
-                d.add(src.next());
-                d.two = 0;
-            }
-            const int ps = p.score(), ds = d.score();
-            rew = (double)(ps > ds) - (double)(ps < ds);       // cmp (:10-11)
-            if (a.sab && p.natural() && !d.natural()) rew = 1.0;
-            else if (!a.sab && a.natural && p.natural() && rew == 1.0) rew = 1.5;
+        // (plain ints and selects from here on: struct-valued ?: made the compiler keep the hands in scratch memory)
+        // hit (:123-130): the player draws card 0
+        const int hsum = p.sum + c[0], hace = p.ace | (int)(c[0] == 1);
+        const bool bust = total_of(hsum, hace) > 21;
+        // stick (:131-146): the dealer draws until its total reaches 17
+        int ssum = d.sum, sace = d.ace, stwo = d.two, n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool need = total_of(ssum, sace) < 17;
+            ssum += need ? c[j] : 0;
+            sace |= (int)(need & (c[j] == 1));
+            stwo = need ? 0 : stwo;
+            n += need ? 1 : 0;
         }
+        if (__builtin_expect(__any(!act && total_of(ssum, sace) < 17), 0)) {
+            while (!act && total_of(ssum, sace) < 17) {
+                const int cj = INJ ? (int)inj[n < MXV_BJ_MAX_DRAWS ? n : MXV_BJ_MAX_DRAWS - 1] : late_draw(seed, t, n);
+                ssum += cj; sace |= (int)(cj == 1); stwo = 0;
+                ++n;
+            }
+        }
+        const int pt = p.total(), st = total_of(ssum, sace);
+        const int ps = pt > 21 ? 0 : pt, ds = st > 21 ? 0 : st;    // score (:36-41)
+        const bool pnat = p.natural(), snat = stwo && sace && ssum == 11;
+        int r2 = 2 * ((int)(ps > ds) - (int)(ps < ds));             // twice the reward: cmp (:10-11)
+        if (a.sab) r2 = (pnat && !snat) ? 2 : r2;                    // :143-145
+        else if (a.natural) r2 = (pnat && r2 == 2) ? 3 : r2;         // a winning natural pays 1.5 (:146-148)
+        r2 = act ? (bust ? -2 : 0) : r2;
+        const bool term = act ? bust : true;
+        p.sum = act ? hsum : p.sum; p.ace = act ? hace : p.ace; p.two = act ? 0 : p.two;
+        d.sum = act ? d.sum : ssum; d.ace = act ? d.ace : sace; d.two = act ? d.two : stwo;
         el += 1;
         const bool trunc = a.max_steps > 0 && el >= a.max_steps;
-        if (term || trunc) {                                   // sync_vector_env.py:152-156
-            if (a.final_obs) {
-                a.final_obs[o] = p.total();
-                a.final_obs[o + col] = dfirst;
-                a.final_obs[o + 2 * col] = p.usable() ? 1 : 0;
-            }
-            int c4[4];
-            src.next4(c4);                                     // reset (:157-158): the dealer's hand first
-            deal(c4[0], c4[1], d);
-            dfirst = c4[0];
-            deal(c4[2], c4[3], p);
-            el = 0;
+        const bool done = term || trunc;
+        if (a.final_obs && done) {                             // sync_vector_env.py:152-156
+            I *const f = reinterpret_cast<I *>(a.final_obs) + (int64_t)k * a.slice * 3;
+            f[e] = (I)p.total();
+            f[col + e] = (I)dfirst;
+            f[2 * col + e] = (I)(p.usable() ? 1 : 0);
         }
-        a.obs[o] = p.total();
-        a.obs[o + col] = dfirst;
-        a.obs[o + 2 * col] = p.usable() ? 1 : 0;
-        if (a.reward) a.reward[o1] = rew;
-        if (a.terminated) a.terminated[o1] = term ? 1 : 0;
-        if (a.truncated) a.truncated[o1] = trunc ? 1 : 0;
+        if constexpr (INJ) {                                   // reset (:157-158): the four cards after the step's draws, the dealer's hand first
+            const int cur = act ? 1 : n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[4 + j] = inj[cur + j < MXV_BJ_MAX_DRAWS ? cur + j : MXV_BJ_MAX_DRAWS - 1];
+        }
+        d.sum = done ? c[4] + c[5] : d.sum; d.ace = done ? (int)((c[4] == 1) | (c[5] == 1)) : d.ace; d.two = done ? 1 : d.two;
+        dfirst = done ? c[4] : dfirst;
+        p.sum = done ? c[6] + c[7] : p.sum; p.ace = done ? (int)((c[6] == 1) | (c[7] == 1)) : p.ace; p.two = done ? 1 : p.two;
+        el = done ? 0 : el;
+        obs_row[e] = (I)p.total();
+        obs_row[col + e] = (I)dfirst;
+        obs_row[2 * col + e] = (I)(p.usable() ? 1 : 0);
+        if (a.reward) reinterpret_cast<R *>(a.reward)[row1 + e] = (R)(0.5f * (float)r2);    // -1, 0, 1, 1.5: exact
+        if (a.terminated) a.terminated[row1 + e] = term ? 1 : 0;
+        if (a.truncated) a.truncated[row1 + e] = trunc ? 1 : 0;
     }
-    if (!valid) return;
     a.state[e] = pack(p, d, dfirst);
     a.elapsed[e] = el;
 }
@@ -390,12 +350,13 @@ int bj_clock_set(mxv_bj *h) {
     return MXV_OK;
 }
 
-int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t act_slice, int64_t *actions_out,
-              const int8_t *cards, int64_t *obs, double *reward, uint8_t *term, uint8_t *trunc, int64_t *final_obs) {
+int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t act_slice, void *actions_out,
+              const int8_t *cards, void *obs, void *reward, uint8_t *term, uint8_t *trunc, void *final_obs, int out_mode = 1) {
     if (!h->was_reset) return bfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
     if (!obs) return bfail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
     if (K <= 0) return bfail(h, MXV_ERR_INVALID_ARG, "K must be positive");
     if (cards && K != 1) return bfail(h, MXV_ERR_INVALID_ARG, "injected cards are per step: K must be 1");
+    if (cards && (!actions || out_mode != 1)) return bfail(h, MXV_ERR_INVALID_ARG, "injected cards need given actions and the reference's dtypes");
     BJ_HIP(h, hipSetDevice(h->cfg.device));
     BjArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.actions = actions; a.actions_out = actions_out;
@@ -404,8 +365,12 @@ int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t a
     a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr;
     a.max_steps = h->cfg.max_episode_steps; a.K = K;
     a.natural = h->cfg.natural; a.sab = h->cfg.sab; a.slice = slice; a.act_slice = act_slice;
-    const unsigned blocks = (unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock);
-    hipLaunchKernelGGL(bj_step_kernel, dim3(blocks), dim3(kBjBlock), 0, h->stream, a);
+    const dim3 grid((unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock)), block(kBjBlock);
+    if (cards) hipLaunchKernelGGL((bj_kernel<true, false, 1>), grid, block, 0, h->stream, a);
+    else if (out_mode == 1 && actions) hipLaunchKernelGGL((bj_kernel<false, false, 1>), grid, block, 0, h->stream, a);
+    else if (out_mode == 1) hipLaunchKernelGGL((bj_kernel<false, true, 1>), grid, block, 0, h->stream, a);
+    else if (actions) hipLaunchKernelGGL((bj_kernel<false, false, 2>), grid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL((bj_kernel<false, true, 2>), grid, block, 0, h->stream, a);
     BJ_HIP(h, hipGetLastError());
     return bj_clock_add(h, K);
 }
@@ -462,7 +427,8 @@ extern "C" {
 int mxv_bj_create(const mxv_bj_config *cfg, mxv_bj **out) {
     if (!cfg || !out) return bfail(nullptr, MXV_ERR_INVALID_ARG, "NULL config or output pointer");
     *out = nullptr;
-    if (cfg->num_envs <= 0) return bfail(nullptr, MXV_ERR_INVALID_ARG, "num_envs must be positive");
+    if (cfg->num_envs <= 0 || cfg->num_envs > ((int64_t)1 << 28))
+        return bfail(nullptr, MXV_ERR_INVALID_ARG, "num_envs must be in [1, 2^28] (one handle; shard larger batches over handles: env_offset)");
     if (cfg->env_offset < 0 || cfg->env_offset % MXV_ENV_ALIGN != 0)
         return bfail(nullptr, MXV_ERR_INVALID_ARG, "env_offset must be a non-negative multiple of %d", MXV_ENV_ALIGN);
     int ndev = 0;
@@ -557,6 +523,14 @@ int mxv_bj_rollout(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *action
     return bj_launch(h, K, per_step ? h->cfg.num_envs : 0, actions_tape_dev, actions_tape_dev ? h->cfg.num_envs : 0,
                      actions_tape_dev ? nullptr : actions_out_dev, nullptr, obs_dev, reward_dev, terminated_dev, truncated_dev,
                      final_obs_dev);
+}
+
+int mxv_bj_rollout_compact(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int32_t *actions_out_dev,
+                           int32_t *obs_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, int32_t *final_obs_dev) {
+    BJ_CHECK(h);
+    return bj_launch(h, K, per_step ? h->cfg.num_envs : 0, actions_tape_dev, actions_tape_dev ? h->cfg.num_envs : 0,
+                     actions_tape_dev ? nullptr : actions_out_dev, nullptr, obs_dev, reward_dev, terminated_dev, truncated_dev,
+                     final_obs_dev, 2);
 }
 
 int mxv_bj_reset_host(mxv_bj *h, const int8_t *cards_host, int64_t *obs_host) {

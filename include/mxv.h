@@ -478,12 +478,16 @@ int mxv_tab_set_stream(mxv_tab *h, void *stream);
 /* -- Blackjack-v1 (gym/envs/toy_text/blackjack.py:48-160), the toy_text env that is not a P table ------------
  *    Observation = (player total, dealer's first card, usable ace) as three int64 columns obs[3][N] (Tuple(Discrete(32),
  *    Discrete(11), Discrete(2)) batched: three MultiDiscrete arrays); actions int64 {0 stick, 1 hit}; reward float64.
- *    Cards: card = deck[(word * 13) >> 32], deck = [1..10, 10, 10, 10] (:14-19), words from the Philox draw stream (key = env
- *    seed, ctr = (t_lo, t_hi, call, 5 << 28), four cards per call, consumed in the reference's order: the hit card or the
- *    dealer's cards, then on termination the new dealer hand, then the new player hand); explicit reset: key = env
- *    seed, ctr = (t_lo, t_hi, r, 2 << 28), r = ordinal of the reset call (words x, y dealer; z, w player); actions: the
- *    word-per-step action stream (stream id 1).  cards_*: optional injected draws, int8 [N][MXV_BJ_MAX_DRAWS] per step (resp. [N][4]
- *    for a reset) in consumption order — the values np_random.choice(deck) returned, for bit-exact replays. ------------------ */
+ *    Cards, deck = [1..10, 10, 10, 10] (:14-19), from the Philox draw stream (round-5 contract): key = env seed, ctr = (t_lo, t_hi,
+ *    call, 5 << 28); every word yields TWO cards, the first two base-13 digits of word / 2^32 (d0 = (word * 13) >> 32, d1 = ((word * 13
+ *    mod 2^32) * 13) >> 32, card = deck[d]: jointly uniform up to 169 / 2^32 = 4e-8).  The eight cards of call 0 have fixed roles —
+ *    cards 0..3 (words x, y): the hit card resp. the dealer's first four draws of a stick; cards 4, 5 (word z): the next episode's dealer
+ *    hand; cards 6, 7 (word w): the next player hand — and the dealer's draw j >= 4 is card (j + 4) & 7 of call (j + 4) >> 3: one Philox
+ *    call per step, straight-line code.  Explicit reset: key = env seed, ctr = (t_lo, t_hi, r, 2 << 28), r = ordinal of the reset call,
+ *    one card per word, deck[(word * 13) >> 32] (words x, y dealer; z, w player).  Sampled actions: the Discrete(2) bit stream of the
+ *    RNG contract above (stream id 6).  cards_*: optional injected draws, int8 [N][MXV_BJ_MAX_DRAWS] per step (resp. [N][4] for a
+ *    reset) in the reference's consumption order (the hit card or the dealer's cards, then on termination the new dealer hand, then the
+ *    new player hand) — the values np_random.choice(deck) returned, for bit-exact replays. ----------------------------------------- */
 #define MXV_BJ_MAX_DRAWS 24
 typedef struct mxv_bj mxv_bj;
 typedef struct mxv_bj_config {
@@ -507,6 +511,10 @@ int mxv_bj_step(mxv_bj *h, const int64_t *actions_dev, const int8_t *cards_dev, 
  * per_step != 0: outputs are [K][...] trajectories (obs [K][3][N]). */
 int mxv_bj_rollout(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *actions_out_dev,
                    int64_t *obs_dev, double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, int64_t *final_obs_dev);
+/* The same with the contract's 4-byte scalars: int32 observations / actions, float32 rewards — 22 B stored per
+ * env-step instead of 42. */
+int mxv_bj_rollout_compact(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int32_t *actions_out_dev,
+                           int32_t *obs_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, int32_t *final_obs_dev);
 int mxv_bj_reset_host(mxv_bj *h, const int8_t *cards_host, int64_t *obs_host);
 int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards_host, int64_t *obs_host, double *reward_host,
                      uint8_t *terminated_host, uint8_t *truncated_host, int64_t *final_obs_host);

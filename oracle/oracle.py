@@ -62,6 +62,7 @@ def lib():
         L.orc_bj_step.argtypes = [i64, u64, vp, u64, u64, u64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp,
                                   vp, vp, vp, vp, vp]
         L.orc_bj_step.restype = i64
+        L.orc_bj_stream_cards.argtypes = [i64, u64, u64, C.c_int, vp]
         L.orc_norm_obs_sums.argtypes = [vp, i64, i64, C.c_int, vp]
         L.orc_norm_obs_apply.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, vp, C.c_int, i64, vp]
         L.orc_norm_reward_sums.argtypes = [vp, vp, vp, vp, i64, i64, C.c_double, vp]

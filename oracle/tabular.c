@@ -114,8 +114,13 @@ int64_t orc_tab_step(int S, int A, int M, const double *cum, const double *prob,
 
 /* ------------------------------------------------------------------------------------------------------------------------
  * Blackjack-v1 — gym/envs/toy_text/blackjack.py.  Hands are kept as card lists exactly like the reference (:17-45); the
- * cards come either from the caller (the values np_random.choice(deck) returned, :18) or from the engine's Philox draw
- * stream (include/mxv.h: key = env seed, ctr = (t, call, 5 << 28), card = deck[(word * 13) >> 32]).
+ * cards come either from the caller (the values np_random.choice(deck) returned, :18, in the reference's consumption order) or
+ * from the engine's Philox draw stream (include/mxv.h, round-5 contract): key = env seed, ctr = (t_lo, t_hi, call, 5 << 28); every
+ * word yields TWO cards, the first two base-13 digits of word / 2^32 (d0 = (word * 13) >> 32, d1 = ((word * 13 mod 2^32) * 13) >> 32,
+ * card = deck[d]); the eight cards of call 0 have fixed roles — cards 0..3 (words x, y): the hit card resp. the dealer's first four
+ * draws; cards 4, 5 (word z): the next episode's dealer hand; cards 6, 7 (word w): the next player hand — and the dealer's draw
+ * j >= 4 is card (j + 4) & 7 of call (j + 4) >> 3.  Sampled actions: the engine's Discrete(2) bit stream (stream 6: one call per
+ * 32 steps, action = bit t & 31 of the env's word), as for CartPole.
  * ---------------------------------------------------------------------------------------------------------------------- */
 #define BJ_MAX_HAND 32
 typedef struct { int c[BJ_MAX_HAND]; int n; } bj_hand;
@@ -129,17 +134,41 @@ static int bj_natural(const bj_hand *h) {                                       
 }
 static const int BJ_DECK[13] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10};
 
-typedef struct { const int8_t *inj; uint64_t seed, t; int cursor; uint32_t w[4]; } bj_src;
-static int bj_next(bj_src *s) {
-    int c;
-    if (s->inj) {
-        c = s->inj[s->cursor];
-    } else {
-        if ((s->cursor & 3) == 0) tab_stream_words(s->seed, s->t, (uint32_t)(s->cursor >> 2), 5u, s->w);
-        c = BJ_DECK[(int)(((uint64_t)s->w[s->cursor & 3] * 13u) >> 32)];
-    }
-    s->cursor++;
-    return c;
+/* card g (0, 1, 2, ...) of the step's draw stream: digit g & 1 of word (g >> 1) & 3 of call g >> 3 */
+static int bj_stream_card(uint64_t seed, uint64_t t, int g) {
+    uint32_t w[4];
+    tab_stream_words(seed, t, (uint32_t)(g >> 3), 5u, w);
+    const uint64_t p = (uint64_t)w[(g >> 1) & 3] * 13u;
+    const uint32_t d0 = (uint32_t)(p >> 32), d1 = (uint32_t)(((uint64_t)(uint32_t)p * 13u) >> 32);
+    return BJ_DECK[(g & 1) ? d1 : d0];
+}
+typedef struct { const int8_t *inj; uint64_t seed, t; int cursor, draws; } bj_src;
+/* the step's next draw (the hit card / a dealer card) */
+static int bj_draw(bj_src *s) {
+    const int j = s->draws++;
+    if (s->inj) return s->inj[s->cursor++];
+    return bj_stream_card(s->seed, s->t, j < 4 ? j : j + 4);
+}
+/* card k (0..3) of the hands dealt after the step: dealer's two, then the player's two */
+static int bj_deal(bj_src *s, int k) {
+    if (s->inj) return s->inj[s->cursor++];
+    return bj_stream_card(s->seed, s->t, 4 + k);
+}
+static uint32_t tab_action_bits_word(uint64_t action_seed, uint64_t t, uint64_t env) {
+    uint32_t ctr[4], key[2], out[4];
+    const uint64_t g = env >> 2, b = t >> 5;
+    ctr[0] = (uint32_t)g; ctr[1] = (uint32_t)(g >> 32);
+    ctr[2] = (uint32_t)b; ctr[3] = ((uint32_t)(b >> 32) & 0x0fffffffu) | (6u << 28);
+    key[0] = (uint32_t)action_seed; key[1] = (uint32_t)(action_seed >> 32);
+    orc_philox4x32_10(ctr, key, out);
+    return out[env & 3];
+}
+
+/* test hook (tests/test_blackjack_oracle.py: the distribution of the card map): the first `count` cards of the draw stream of n envs
+ * (seeds base_seed + i) at step t, int8 out[n][count] */
+void orc_bj_stream_cards(int64_t n, uint64_t base_seed, uint64_t t, int count, int8_t *out) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int g = 0; g < count; ++g) out[i * count + g] = (int8_t)bj_stream_card(base_seed + (uint64_t)i, t, g);
 }
 
 /* state per env: dealer and player card lists (caller-owned arrays of bj_hand-compatible layout: int[33] each = 32 cards + n) */
@@ -175,19 +204,19 @@ int64_t orc_bj_step(int64_t n, uint64_t env0, const uint64_t *seeds, uint64_t ba
             a = actions[i];
             if (a < 0 || a > 1) { bad++; continue; }
         } else {
-            a = (int64_t)(((uint64_t)tab_action_word(action_seed, t, ge) * 2u) >> 32);
+            a = (int64_t)((tab_action_bits_word(action_seed, t, ge) >> (uint32_t)(t & 31u)) & 1u);
         }
         if (actions_out) actions_out[i] = a;
-        bj_src src = {cards ? cards + i * max_draws : 0, seeds ? seeds[i] : base_seed + ge, t, 0, {0, 0, 0, 0}};
+        bj_src src = {cards ? cards + i * max_draws : 0, seeds ? seeds[i] : base_seed + ge, t, 0, 0};
         int te;
         double r;
         if (a) {                                                   /* hit :123-130 */
-            p->c[p->n++] = bj_next(&src);
+            p->c[p->n++] = bj_draw(&src);
             te = bj_total(p) > 21;
             r = te ? -1.0 : 0.0;
         } else {                                                   /* stick :131-146 */
             te = 1;
-            while (bj_total(d) < 17) d->c[d->n++] = bj_next(&src);
+            while (bj_total(d) < 17) d->c[d->n++] = bj_draw(&src);
             const int ps = bj_score(p), ds = bj_score(d);
             r = (double)(ps > ds) - (double)(ps < ds);
             if (sab && bj_natural(p) && !bj_natural(d)) r = 1.0;
@@ -199,8 +228,8 @@ int64_t orc_bj_step(int64_t n, uint64_t env0, const uint64_t *seeds, uint64_t ba
         if (te || tr) {
             final_obs[i] = bj_total(p); final_obs[n + i] = d->c[0]; final_obs[2 * n + i] = bj_usable(p);
             final_mask[i] = 1;
-            d->c[0] = bj_next(&src); d->c[1] = bj_next(&src); d->n = 2;
-            p->c[0] = bj_next(&src); p->c[1] = bj_next(&src); p->n = 2;
+            d->c[0] = bj_deal(&src, 0); d->c[1] = bj_deal(&src, 1); d->n = 2;
+            p->c[0] = bj_deal(&src, 2); p->c[1] = bj_deal(&src, 3); p->n = 2;
             elapsed[i] = 0;
         }
         obs[i] = bj_total(p); obs[n + i] = d->c[0]; obs[2 * n + i] = bj_usable(p);

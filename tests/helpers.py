@@ -336,3 +336,35 @@ def run_cartpole_beyond(engine_cls, strict):
     obs, rew, term, trunc, fin = eng.step(g["action"][0])
     assert np.array_equal(rew, g["reward"][0]) and np.all(rew == 1.0)
     return zero
+
+
+# ---- Blackjack: exact probabilities of a deck of iid draws (deck = [1..10, 10, 10, 10], gym/envs/toy_text/blackjack.py:14-19) -------------
+DECK_P = np.array([1.0 / 13] * 9 + [4.0 / 13])       # P(card = 1..10)
+
+
+def chi2_ok(counts, probs, sigmas=5.0):
+    """Pearson chi-square of observed counts against probabilities, accepted within `sigmas` standard deviations of its mean (df)."""
+    counts, probs = np.asarray(counts, dtype=np.float64).ravel(), np.asarray(probs, dtype=np.float64).ravel()
+    exp = counts.sum() * probs
+    chi2 = float(((counts - exp) ** 2 / exp).sum())
+    df = counts.size - 1
+    return chi2 < df + sigmas * np.sqrt(2.0 * df), chi2
+
+
+def dealer_score_distribution(raw_sum, ace):
+    """P(final dealer score) for a dealer that starts at (raw sum with aces as 1, holds an ace) and draws iid deck cards until its total
+    (one ace as 11 when that does not bust, blackjack.py:26-33) reaches 17 (:132): dict score -> probability, score 0 = bust (:36-41)."""
+    from functools import lru_cache
+
+    @lru_cache(maxsize=None)
+    def go(s, a):
+        total = s + 10 if (a and s + 10 <= 21) else s
+        if total >= 17:
+            return ((0 if total > 21 else total, 1.0),)
+        out = {}
+        for c in range(1, 11):
+            for sc, pr in go(s + c, a or c == 1):
+                out[sc] = out.get(sc, 0.0) + pr * DECK_P[c - 1]
+        return tuple(sorted(out.items()))
+
+    return dict(go(int(raw_sum), bool(ace)))

@@ -173,3 +173,102 @@ def test_full_size_properties():
     assert -0.5 < r[te].mean() < -0.3                                    # a random policy loses about 0.4 per game
     a = act.cpu().numpy()
     assert np.all(te[a == 0])                                            # sticking always ends the game
+
+
+def _packed(p_sum, p_ace, p_two, dfirst, d_sum, d_ace, d_two):
+    """One table's state word (gym_amd/csrc/mxv_bj.hip: player sum | ace | two cards | dealer's first card | dealer sum | ace | two cards)."""
+    return p_sum | (p_ace << 6) | (p_two << 7) | (dfirst << 8) | (d_sum << 12) | (d_ace << 18) | (d_two << 19)
+
+
+def test_device_cards_are_deck_draws_in_every_role():
+    """The round-5 draw contract measured ON THE DEVICE, role by role, at 2^20 tables (not through the twin): from a hand that cannot bust
+    the hit card is the change of the player's raw sum (card 0); sticking on a hard 19 against a dealer that starts from a known hand is
+    won / drawn / lost with the probabilities of iid deck draws (cards 0..3 and the later calls: a dealer starting at 2 draws five cards
+    and more in several percent of the games); the hands dealt after those games (cards 4..7) show the dealer card, and the player
+    totals, of two deck cards each."""
+    import torch
+    from gym_amd import _native
+    from helpers import DECK_P, chi2_ok, dealer_score_distribution
+
+    n = 1 << 20
+    dev = torch.device("cuda")
+    h = _native.Blackjack(n, sab=False, seed=77, action_seed=78)
+    h.reset_host()
+    obs = torch.zeros((3, n), dtype=torch.int64, device=dev)
+    rew = torch.zeros(n, dtype=torch.float64, device=dev)
+    term = torch.zeros(n, dtype=torch.uint8, device=dev)
+    hit, stick = torch.ones(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    # card 0 as the hit card: player raw sum 2 without an ace (cannot bust), three cards on the table already
+    h.set_state(np.full(n, _packed(2, 0, 0, 10, 20, 0, 1), np.int32), np.zeros(n, np.int32), t=5, r=1)
+    h.step(hit, obs, rew, term)
+    h.sync()
+    st, _ = h.get_state()
+    assert not term.any().item() and not rew.any().item()
+    card = (st & 63) - 2
+    ok, chi2 = chi2_ok(np.bincount(card, minlength=11)[1:], DECK_P)
+    assert ok and card.min() == 1 and card.max() == 10, chi2
+    # the dealer's draws: exact win / draw / loss probabilities of a hard 19
+    for d_sum, d_ace in ((2, 0), (12, 0), (6, 1), (16, 0)):
+        h.set_state(np.full(n, _packed(19, 0, 0, 2, d_sum, d_ace, 1), np.int32), np.zeros(n, np.int32), t=100 + d_sum, r=1)
+        h.step(stick, obs, rew, term)
+        h.sync()
+        assert term.all().item()
+        dist = dealer_score_distribution(d_sum, bool(d_ace))
+        p_win, p_draw = sum(p for s, p in dist.items() if s < 19), dist.get(19, 0.0)
+        r = rew.cpu().numpy()
+        ok, chi2 = chi2_ok([(r == 1.0).sum(), (r == 0.0).sum(), (r == -1.0).sum()], [p_win, p_draw, 1.0 - p_win - p_draw])
+        assert ok, (d_sum, d_ace, chi2)
+        # ... and every table was dealt new hands from cards 4..7 of the same call
+        o = obs.cpu().numpy()
+        ok, chi2 = chi2_ok(np.bincount(o[1], minlength=11)[1:], DECK_P)                      # the dealer's first card = card 4
+        assert ok, ("dealer shows", d_sum, chi2)
+        totals = np.zeros(22)
+        for c1 in range(1, 11):
+            for c2 in range(1, 11):
+                s_, a_ = c1 + c2, c1 == 1 or c2 == 1
+                totals[s_ + 10 if a_ and s_ + 10 <= 21 else s_] += DECK_P[c1 - 1] * DECK_P[c2 - 1]
+        ok, chi2 = chi2_ok(np.bincount(o[0], minlength=22)[4:22], totals[4:22])             # the player's total = cards 6, 7
+        assert ok, ("player total", d_sum, chi2)
+        st, _ = h.get_state()
+        dsum = np.zeros(21)
+        for c1 in range(1, 11):
+            for c2 in range(1, 11):
+                dsum[c1 + c2] += DECK_P[c1 - 1] * DECK_P[c2 - 1]
+        ok, chi2 = chi2_ok(np.bincount((st >> 12) & 63, minlength=21)[2:21], dsum[2:21])    # the dealer's raw sum = cards 4 + 5
+        assert ok, ("dealer sum", d_sum, chi2)
+    h.close()
+
+
+@pytest.mark.parametrize("tape", [False, True])
+def test_compact_outputs_equal_the_reference_dtypes(tape):
+    """mxv_bj_rollout_compact (int32 observations / actions, float32 rewards: the contract's 4-byte scalars) == mxv_bj_rollout value for
+    value, sampled actions and an action tape, natural rule (1.5 is exact in float32), ragged size."""
+    import torch
+    from gym_amd import _native
+
+    n, K = 70_001, 48
+    dev = torch.device("cuda")
+    outs = []
+    for compact in (False, True):
+        it, ft = (torch.int32, torch.float32) if compact else (torch.int64, torch.float64)
+        h = _native.Blackjack(n, natural=True, sab=False, seed=8, action_seed=9, max_episode_steps=3)
+        h.reset_host()
+        b = dict(obs=torch.zeros((K, 3, n), dtype=it, device=dev), reward=torch.zeros((K, n), dtype=ft, device=dev),
+                 terminated=torch.zeros((K, n), dtype=torch.uint8, device=dev), truncated=torch.zeros((K, n), dtype=torch.uint8, device=dev),
+                 final_obs=torch.zeros((K, 3, n), dtype=it, device=dev), actions=torch.zeros((K, n), dtype=it, device=dev))
+        tape_dev = None
+        if tape:
+            g = torch.Generator().manual_seed(3)
+            tape_dev = torch.randint(0, 2, (K, n), generator=g, dtype=torch.int64).to(dev)
+        torch.cuda.synchronize()
+        h.rollout(K, b["obs"], b["reward"], b["terminated"], b["truncated"], b["final_obs"], None if tape else b["actions"],
+                  actions_tape_dev=tape_dev, per_step=True, compact=compact)
+        h.sync()
+        outs.append(({k: v.cpu().numpy() for k, v in b.items()}, h.get_state()))
+        h.close()
+    (a, sa), (c, sc) = outs
+    for k in a:
+        assert c[k].dtype.itemsize <= 4 and np.array_equal(a[k], c[k].astype(a[k].dtype)), k
+    assert np.array_equal(sa[0], sc[0]) and np.array_equal(sa[1], sc[1])
+    assert 1.5 in a["reward"] and a["truncated"].any() and a["terminated"].any()
