@@ -31,32 +31,26 @@ def measure_blackjack(torch, envs, chunk, reps=6, compact=False):
     """Blackjack-v1 (gym/envs/toy_text/blackjack.py:108-160): fused K-step rollouts, observation = three int64 columns, reward float64,
     flags, sampled actions int64 -> 42 B stored per env-step; contract bytes (4-byte scalars): 3 x 4 + 4 + 4 + 2 = 22, which is what
     compact=True (mxv_bj_rollout_compact: int32 / float32) stores."""
-    from gym_amd import _native
+    from gym_amd.toy_text import BlackjackRollout
 
-    dev = torch.device("cuda", torch.cuda.current_device())
-    it, ft = (torch.int32, torch.float32) if compact else (torch.int64, torch.float64)
-    h = _native.Blackjack(envs, seed=0, action_seed=1)
-    obs = torch.empty((chunk, 3, envs), dtype=it, device=dev)
-    rew = torch.empty((chunk, envs), dtype=ft, device=dev)
-    term, trunc = (torch.empty((chunk, envs), dtype=torch.uint8, device=dev) for _ in range(2))
-    act = torch.empty((chunk, envs), dtype=it, device=dev)
-    torch.cuda.synchronize()
-    h.reset()
-    run = lambda: h.rollout(chunk, obs, rew, term, trunc, None, actions_out_dev=act, per_step=True, compact=compact)   # noqa: E731
+    r = BlackjackRollout(envs, seed=0, action_seed=1, compact=compact)
+    r.reset(seed=0)
+    out = r.trajectory_buffers(chunk)              # sorted by HBM class, as a caller gets them by default
+    run = lambda: r.rollout_per_step(chunk, out=out)   # noqa: E731
     for _ in range(2):
         run()
-    h.sync()
+    r.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         run()
-    h.sync()
+    r.synchronize()
     us = (time.perf_counter() - t0) / reps / chunk * 1e6
     stored = 22 if compact else 42
     res = _hbm(us, envs, 22, workload=f"Blackjack-v1, num_envs={envs}, fused {chunk}-step launches, "
                                       + ("int32 observations / actions + float32 rewards" if compact else "the reference's dtypes") + f" ({stored} B stored per env-step)",
-               stored_GBs=envs * stored / us / 1e3, episodes_ended_per_env_step=float(((term | trunc) != 0).float().mean().item()),
-               kernel="bj_kernel (one draw-stream Philox call per step, straight-line)")
-    h.close()
-    del obs, rew, term, trunc, act
+               stored_GBs=envs * stored / us / 1e3, episodes_ended_per_env_step=float(((out["terminated"] | out["truncated"]) != 0).float().mean().item()),
+               placement=r.last_placement, kernel="bj_kernel (one draw-stream Philox call per step, straight-line)")
+    r.close()
+    del out
     torch.cuda.empty_cache()
     return res

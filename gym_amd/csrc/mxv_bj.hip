@@ -31,6 +31,19 @@ namespace {
 
 constexpr int kBjBlock = 256;
 constexpr uint32_t kStreamDraw = 5u;
+constexpr unsigned kBjXcds = 8;   // MI355X: consecutive workgroup ids go round the 8 XCDs
+#ifndef MXV_BJ_TILEMAP
+#define MXV_BJ_TILEMAP 1          // 1: XCD x steps (and stores) the x-th contiguous eighth of the tables; 0: tile = workgroup id (A/B hook)
+#endif
+__device__ __forceinline__ unsigned bj_tile(unsigned bid, unsigned ntiles) {
+#if MXV_BJ_TILEMAP
+    const unsigned x = bid % kBjXcds, idx = bid / kBjXcds;
+    const unsigned base = ntiles / kBjXcds, rem = ntiles % kBjXcds;
+    return x * base + (x < rem ? x : rem) + idx;
+#else
+    return bid;
+#endif
+}
 
 struct Hand {
     int sum, ace, two;
@@ -106,6 +119,11 @@ __device__ __noinline__ int late_draw(uint64_t seed, uint64_t t, int j) {   // t
     return (g & 1) ? c1 : c0;
 }
 
+__device__ __forceinline__ uint32_t bj_pin32(uint32_t v) {  // see pin32 in mxv_kernels.hip: keeps a store's saddr + 32-bit voffset form
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int OUT> struct BjOut;
 template <> struct BjOut<1> { using I = int64_t; using R = double; };   // the reference's dtypes
 template <> struct BjOut<2> { using I = int32_t; using R = float; };    // the contract's 4-byte scalars
@@ -116,12 +134,22 @@ template <> struct BjOut<2> { using I = int32_t; using R = float; };    // the c
 //   OUT     : output dtypes.
 // Both arms of `if action:` (:123-146) are evaluated for every lane and selected — under random or learned policies every wave holds
 // hitters and stickers, so a branch would run both anyway, plus its bookkeeping.
+#ifndef MXV_BJ_WAVES
+#define MXV_BJ_WAVES 8   // 8: 64 VGPRs and <= 96 SGPRs = two full rounds of the 16 waves per SIMD a 2^20-table launch needs (no spills); 0: the allocator's choice (63 VGPRs but 7 waves: SGPRs) (A/B hook)
+#endif
 template <bool INJ, bool SAMPLED, int OUT>
-__global__ void __launch_bounds__(kBjBlock) bj_kernel(BjArgs a) {
+__global__ void __launch_bounds__(kBjBlock)
+#if MXV_BJ_WAVES > 0
+    __attribute__((amdgpu_waves_per_eu(MXV_BJ_WAVES, MXV_BJ_WAVES)))
+#endif
+    bj_kernel(BjArgs a) {
     using I = typename BjOut<OUT>::I;
     using R = typename BjOut<OUT>::R;
-    const uint32_t e = blockIdx.x * kBjBlock + threadIdx.x;    // num_envs <= 2^28 (mxv_bj_create): byte offsets of a row fit 32 bits
-    if ((int64_t)e >= a.n) return;
+    constexpr uint32_t IB = sizeof(I), RB = sizeof(R);
+    const uint32_t tid = threadIdx.x;
+    const int64_t tile0 = (int64_t)bj_tile(blockIdx.x, gridDim.x) * kBjBlock;
+    const int64_t e = tile0 + tid;
+    if (e >= a.n) return;
     const uint64_t ge = a.env0 + (uint64_t)e;
     const uint64_t seed = a.seeds ? a.seeds[e] : a.base_seed + ge;
     Hand p, d;
@@ -132,13 +160,21 @@ __global__ void __launch_bounds__(kBjBlock) bj_kernel(BjArgs a) {
     uint64_t act_block = ~0ull;
     uint32_t act_bits = 0;
     const uint64_t t_base = a.t + (a.t_dev ? *a.t_dev : 0);
-    const int64_t col = a.slice ? a.slice : a.n;      // distance between the three observation columns
+    // Rows of the current step as wave-uniform byte pointers (scalar registers) that advance by one slice per step; the lane adds a small
+    // 32-bit offset (pin32: the stores keep the scalar-base + 32-bit-voffset form, no 64-bit address arithmetic in vector registers).
+    const int64_t col = (a.slice ? a.slice : a.n) * (int64_t)IB;      // distance between the three observation columns, bytes
+    char *p_o0 = static_cast<char *>(a.obs) + tile0 * IB, *p_o1 = p_o0 + col, *p_o2 = p_o1 + col;
+    char *p_f0 = a.final_obs ? static_cast<char *>(a.final_obs) + tile0 * IB : nullptr, *p_f1 = p_f0 + col, *p_f2 = p_f1 + col;
+    char *p_act = a.actions_out ? static_cast<char *>(a.actions_out) + tile0 * IB : nullptr;
+    char *p_rew = a.reward ? static_cast<char *>(a.reward) + tile0 * RB : nullptr;
+    uint8_t *p_term = a.terminated ? a.terminated + tile0 : nullptr, *p_trunc = a.truncated ? a.truncated + tile0 : nullptr;
+    const int64_t* p_in = SAMPLED ? nullptr : a.actions + tile0;
+    const int64_t step_o = a.slice * 3 * (int64_t)IB, step_i = a.slice * (int64_t)IB, step_r = a.slice * (int64_t)RB, step_b = a.slice;
+    const uint32_t off_i = tid * IB, off_r = tid * RB, off_b = tid;
     mxv::settle_entry_loads();
-    for (int k = 0; k < a.K; ++k) {
+    for (int k = 0; k < a.K; ++k, p_o0 += step_o, p_o1 += step_o, p_o2 += step_o, p_f0 += step_o, p_f1 += step_o, p_f2 += step_o,
+                                  p_act += step_i, p_rew += step_r, p_term += step_b, p_trunc += step_b, p_in += a.act_slice) {
         const uint64_t t = t_base + (uint64_t)k;
-        // rows of this step (wave-uniform bases: scalar registers; the lane adds its 32-bit index)
-        I *const obs_row = reinterpret_cast<I *>(a.obs) + (int64_t)k * a.slice * 3;
-        const int64_t row1 = (int64_t)k * a.slice;
         int act;
         if constexpr (SAMPLED) {
             if ((t >> 5) != act_block) {    // uniform across the launch: one Philox call per 32 steps
@@ -148,9 +184,9 @@ __global__ void __launch_bounds__(kBjBlock) bj_kernel(BjArgs a) {
                 act_bits = q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w));
             }
             act = (int)((act_bits >> ((uint32_t)t & 31u)) & 1u);
-            if (a.actions_out) reinterpret_cast<I *>(a.actions_out)[row1 + e] = (I)act;
+            if (a.actions_out) *reinterpret_cast<I *>(p_act + bj_pin32(off_i)) = (I)act;
         } else {
-            const int64_t av = a.actions[(int64_t)k * a.act_slice + e];
+            const int64_t av = p_in[tid];
             if (av < 0 || av > 1) {  // `assert self.action_space.contains(action)` (:122)
                 *reinterpret_cast<volatile int32_t *>(a.err) = 1;  // single-bit code: a plain store (the word may live in pinned host memory)
                 continue;
@@ -203,10 +239,9 @@ __global__ void __launch_bounds__(kBjBlock) bj_kernel(BjArgs a) {
         const bool trunc = a.max_steps > 0 && el >= a.max_steps;
         const bool done = term || trunc;
         if (a.final_obs && done) {                             // sync_vector_env.py:152-156
-            I *const f = reinterpret_cast<I *>(a.final_obs) + (int64_t)k * a.slice * 3;
-            f[e] = (I)p.total();
-            f[col + e] = (I)dfirst;
-            f[2 * col + e] = (I)(p.usable() ? 1 : 0);
+            *reinterpret_cast<I *>(p_f0 + bj_pin32(off_i)) = (I)p.total();
+            *reinterpret_cast<I *>(p_f1 + bj_pin32(off_i)) = (I)dfirst;
+            *reinterpret_cast<I *>(p_f2 + bj_pin32(off_i)) = (I)(p.usable() ? 1 : 0);
         }
         if constexpr (INJ) {                                   // reset (:157-158): the four cards after the step's draws, the dealer's hand first
             const int cur = act ? 1 : n;
@@ -217,12 +252,12 @@ __global__ void __launch_bounds__(kBjBlock) bj_kernel(BjArgs a) {
         dfirst = done ? c[4] : dfirst;
         p.sum = done ? c[6] + c[7] : p.sum; p.ace = done ? (int)((c[6] == 1) | (c[7] == 1)) : p.ace; p.two = done ? 1 : p.two;
         el = done ? 0 : el;
-        obs_row[e] = (I)p.total();
-        obs_row[col + e] = (I)dfirst;
-        obs_row[2 * col + e] = (I)(p.usable() ? 1 : 0);
-        if (a.reward) reinterpret_cast<R *>(a.reward)[row1 + e] = (R)(0.5f * (float)r2);    // -1, 0, 1, 1.5: exact
-        if (a.terminated) a.terminated[row1 + e] = term ? 1 : 0;
-        if (a.truncated) a.truncated[row1 + e] = trunc ? 1 : 0;
+        *reinterpret_cast<I *>(p_o0 + bj_pin32(off_i)) = (I)p.total();
+        *reinterpret_cast<I *>(p_o1 + bj_pin32(off_i)) = (I)dfirst;
+        *reinterpret_cast<I *>(p_o2 + bj_pin32(off_i)) = (I)(p.usable() ? 1 : 0);
+        if (a.reward) *reinterpret_cast<R *>(p_rew + bj_pin32(off_r)) = (R)(0.5f * (float)r2);    // -1, 0, 1, 1.5: exact
+        if (a.terminated) p_term[bj_pin32(off_b)] = term ? 1 : 0;
+        if (a.truncated) p_trunc[bj_pin32(off_b)] = trunc ? 1 : 0;
     }
     a.state[e] = pack(p, d, dfirst);
     a.elapsed[e] = el;

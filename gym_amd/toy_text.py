@@ -24,7 +24,7 @@ from .spaces import Discrete
 from .vector_env import LazyInfos, VectorEnv, _Pending
 
 __all__ = ["TabularMDP", "generate_random_map", "frozen_lake_mdp", "taxi_mdp", "cliff_walking_mdp", "HipTabularVectorEnv", "TabularRollout",
-           "HipBlackjackVectorEnv", "TOY_TEXT_REGISTRY", "taxi_encode", "taxi_decode"]
+           "HipBlackjackVectorEnv", "BlackjackRollout", "TOY_TEXT_REGISTRY", "taxi_encode", "taxi_decode"]
 
 
 @dataclass
@@ -574,6 +574,89 @@ class TabularRollout:
         self.handle.rollout_tape(K, actions, out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"],
                                  per_step=True)
         out["actions"] = actions
+        return out
+
+    def ready(self):
+        """The caller's current torch stream waits (on the GPU) for everything launched on the engine's stream."""
+        self._torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def synchronize(self):
+        self.handle.sync()
+
+    def close(self):
+        self.handle.close()
+
+
+class BlackjackRollout:
+    """Device-resident front-end of the Blackjack engine (mxv_bj_*): K sampled steps per launch into [K, ...] torch tensors — obs
+    [K, 3, N] (player total, dealer's first card, usable ace), actions [K, N], reward [K, N], terminated / truncated uint8 [K, N] — with
+    the hands resident on the device between calls.  compact=True: int32 observations / actions and float32 rewards (the contract dtypes
+    of SURVEY.md §8d: 22 instead of 42 bytes per env-step, same values)."""
+
+    def __init__(self, num_envs: int, *, device: int = 0, env_offset: int = 0, seed: int = 0, action_seed: int = 0, natural: bool = False,
+                 sab: bool = True, max_episode_steps: Optional[int] = None, compact: bool = False):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("BlackjackRollout needs a HIP device; gym_amd has no CPU fallback")
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", device)
+        self.compact = bool(compact)
+        self.int_dtype, self.real_dtype = (torch.int32, torch.float32) if compact else (torch.int64, torch.float64)
+        self.handle = _native.Blackjack(self.num_envs, natural=natural, sab=sab, device=device, env_offset=env_offset, seed=seed,
+                                        action_seed=action_seed, max_episode_steps=-1 if max_episode_steps is None else max_episode_steps)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.handle.set_stream(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.obs = torch.zeros((3, self.num_envs), dtype=torch.int64, device=self.device)
+        self.stream.synchronize()
+        self.last_placement = None
+
+    def reset(self, seed: Optional[int] = None):
+        if seed is not None:
+            self.handle.seed(seed, action_seed=self.handle._action_seed)
+        self.handle.reset(self.obs)
+        return self.obs
+
+    def trajectory_buffers(self, K: int, layout: str = "auto", want_final: bool = False):
+        """Output tensors of rollout_per_step.  Sets of 2 GiB and more ("auto") are sorted by HBM class (gym_amd/placement.py): the launch
+        writes five 8-byte (4-byte) streams — the three observation columns on one class, rewards + actions on another.  The report is left
+        in self.last_placement."""
+        t, n, dev = self._torch, self.num_envs, self.device
+        it, rt = self.int_dtype, self.real_dtype
+        specs = [("obs", (K, 3, n), it, False), ("reward", (K, n), rt, False), ("actions", (K, n), it, False),
+                 ("terminated", (K, n), t.uint8, False), ("truncated", (K, n), t.uint8, False)]
+        if want_final:
+            specs.append(("final_obs", (K, 3, n), it, True))
+        if layout == "auto":
+            from . import placement
+
+            layout = "sorted" if (22 if self.compact else 42) * K * n >= (2 << 30) and placement.enabled() else "separate"
+        if layout == "sorted":
+            from .placement import sorted_tensors
+
+            out, self.last_placement = sorted_tensors(specs, {"obs": 0, "reward": 1, "actions": 1}, dev, self.stream)
+            return out
+        if layout != "separate":
+            raise ValueError(f"layout must be 'auto', 'sorted' or 'separate', got {layout!r}")
+        with t.cuda.stream(self.stream):
+            return {name: (t.zeros if zero else t.empty)(shape, dtype=dt, device=dev) for name, shape, dt, zero in specs}
+
+    def rollout_per_step(self, K: int, out: Optional[dict] = None):
+        out = self.trajectory_buffers(K) if out is None else out
+        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
+                            actions_out_dev=out["actions"], per_step=True, compact=self.compact)
+        return out
+
+    def rollout_tape(self, actions, out: Optional[dict] = None):
+        """K = actions.shape[0] steps with the caller's actions (int64 [K, N] on the device)."""
+        K = actions.shape[0]
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == self._torch.int64
+        out = self.trajectory_buffers(K) if out is None else out
+        self.stream.wait_stream(self._torch.cuda.current_stream(self.device))   # the tape was produced on the caller's stream
+        self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
+                            actions_tape_dev=actions, per_step=True, compact=self.compact)
         return out
 
     def ready(self):
