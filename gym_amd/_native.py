@@ -50,6 +50,7 @@ EXPORTS = (
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_device_clock", "mxv_bj_set_device_clock", "mxv_tab_set_stream",
+    "mxv_get_beyond", "mxv_set_beyond",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout", "mxv_bj_rollout_compact",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
     "mxv_placed_alloc", "mxv_placed_free", "mxv_placed_info_get", "mxv_placed_last_error", "mxv_hbm_pair_probe",
@@ -223,6 +224,8 @@ def _load():
         "mxv_comm_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxv_get_episodes": ([vp, vp], C.c_int),
         "mxv_set_episodes": ([vp, vp], C.c_int),
+        "mxv_get_beyond": ([vp, vp], C.c_int),
+        "mxv_set_beyond": ([vp, vp], C.c_int),
         "mxv_get_params": ([vp, vp], C.c_int),
         "mxv_set_params": ([vp, vp], C.c_int),
         "mxv_set_params_per_env": ([vp, vp], C.c_int),
@@ -779,7 +782,7 @@ class Handle:
                     per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
                     action_seed=self._action_seed, state=state, elapsed=elapsed, t=t, r=r, episodes=self.get_episodes(),
                     params=self.get_params_per_env() if self._per_env_params else self.get_params(),
-                    per_env_params=self._per_env_params, stats_on=self._stats_on, running_returns=None)
+                    per_env_params=self._per_env_params, stats_on=self._stats_on, running_returns=None, beyond=self.get_beyond())
         if self._stats_on:
             snap["running_returns"] = self.episode_stats_host(want_running=True)[2]
         return snap
@@ -810,6 +813,18 @@ class Handle:
         self.set_state(snap["state"], snap["elapsed"])
         self.set_counters(snap["t"], snap["r"])
         self.set_episodes(snap["episodes"])
+        if snap.get("beyond") is not None:             # after set_state (which clears the marks: an injected state is a fresh one)
+            self.set_beyond(snap["beyond"])
+
+    def get_beyond(self) -> np.ndarray:
+        """CartPole's steps_beyond_terminated marks (uint8 [N]; all zero for handles that keep none: mxv_get_beyond)."""
+        b = np.zeros(self.num_envs, dtype=np.uint8)
+        self._check(lib.mxv_get_beyond(self._h, b.ctypes.data))
+        return b
+
+    def set_beyond(self, beyond):
+        b = np.ascontiguousarray(beyond, dtype=np.uint8).reshape(self.num_envs)
+        self._check(lib.mxv_set_beyond(self._h, b.ctypes.data))
 
     def set_episode_outputs(self, ep_return_dev=None, ep_length_dev=None):
         self._check(lib.mxv_set_episode_outputs(self._h, _ptr(ep_return_dev), _ptr(ep_length_dev)))

@@ -259,6 +259,19 @@ int no_partials_here(mxv_handle *h, const char *what) {
     return MXV_OK;
 }
 
+// A launch recorded into a caller's hipGraph with the step index as a by-value kernel argument would repeat that index — the same action
+// and noise draws — on every replay, silently.  With the device clock (mxv_set_device_clock) the index is read from device memory and
+// replays continue the streams; without it, recording is refused.  
+int no_capture_without_clock(mxv_handle *h) {
+    if (h->dev_clock) return MXV_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+        return fail(h, MXV_ERR_UNSUPPORTED,
+                    "the handle's stream is being captured into a hipGraph but the step index travels by value: replays would repeat the same "
+                    "draws — call mxv_set_device_clock(h, 1) before recording");
+    return MXV_OK;
+}
+
 int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, void *reward, uint8_t *term,
             uint8_t *trunc, float *final_obs) {
     if (!h->was_reset)
@@ -266,6 +279,7 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     if (int rc = no_partials_here(h, "a single step")) return rc;
     if (!obs) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
     if (int rc = use_device(h)) return rc;
+    if (int rc = no_capture_without_clock(h)) return rc;
     StepArgs a{};
     fill_step_args(h, a);
     a.actions = actions;
@@ -658,7 +672,8 @@ int rollout_checks(mxv_handle *h, int32_t K, const float *obs_dev) {
     if (!h->was_reset)
         return fail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
     if (!obs_dev) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
-    return use_device(h);
+    if (int rc = use_device(h)) return rc;
+    return no_capture_without_clock(h);
 }
 
 // Launch paths whose kernel does not write the snapshot itself: copy the last step's outputs (device to device, same stream).
@@ -1094,8 +1109,10 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
         const int S = h->S;
         for (int k = 0; k < S && in_range; ++k) {
             const double *row = state_soa_host + (size_t)k * n;
-            // (CartPole's other components only have to be finite: the unguarded path's quotients turn an infinite dividend into a NaN)
-            const double lim = (h->cfg.env_id == MXV_CARTPOLE) ? (k == 2 ? 0.78539816339744830962 : 1.7976931348623157e308) : 65536.0;
+            // (CartPole's other components must keep every intermediate finite — the unguarded path's quotients turn an infinite dividend
+            // into a NaN where IEEE division and the reference give +-Inf — and polemass_length * theta_dot^2 * sintheta overflows from
+            // |theta_dot| ~ 1.3e154 on: beyond 1e150 a state takes the guarded launch.  ADVICE r4.)
+            const double lim = (h->cfg.env_id == MXV_CARTPOLE) ? (k == 2 ? 0.78539816339744830962 : 1e150) : 65536.0;
             for (size_t i = 0; i < n; ++i)
                 if (!(std::fabs(row[i]) <= lim)) {
                     in_range = false;
@@ -1276,6 +1293,38 @@ int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host) {
     if (!episodes_host) return fail(h, MXV_ERR_INVALID_ARG, "episodes pointer is NULL");
     if (int rc = use_device(h)) return rc;
     MXV_HIP(h, hipMemcpyAsync(h->episodes, episodes_host, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+// steps_beyond_terminated marks (CartPole without autoreset): part of a checkpoint — a restored env that had terminated before must
+// keep paying 0.0, not 1.0 once more.  Handles that carry no marks (any other configuration): get fills zeros, set accepts
+// all-zero marks only.
+int mxv_get_beyond(mxv_handle *h, uint8_t *beyond_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!beyond_host) return fail(h, MXV_ERR_INVALID_ARG, "beyond pointer is NULL");
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (!h->beyond) {
+        std::memset(beyond_host, 0, n);
+        return MXV_OK;
+    }
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipMemcpyAsync(beyond_host, h->beyond, n, hipMemcpyDeviceToHost, h->stream));
+    MXV_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_set_beyond(mxv_handle *h, const uint8_t *beyond_host) {
+    MXV_CHECK_HANDLE(h);
+    if (!beyond_host) return fail(h, MXV_ERR_INVALID_ARG, "beyond pointer is NULL");
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (!h->beyond) {
+        for (size_t i = 0; i < n; ++i)
+            if (beyond_host[i]) return fail(h, MXV_ERR_UNSUPPORTED, "this handle keeps no steps_beyond_terminated marks (CartPole with MXV_FLAG_NO_AUTORESET does)");
+        return MXV_OK;
+    }
+    if (int rc = use_device(h)) return rc;
+    MXV_HIP(h, hipMemcpyAsync(h->beyond, beyond_host, n, hipMemcpyHostToDevice, h->stream));
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     return MXV_OK;
 }

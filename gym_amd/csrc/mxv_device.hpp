@@ -431,15 +431,16 @@ __device__ __forceinline__ void sincos_small_or_general(double x, double *sn, do
 // never zeros of opposite sign, the one other case where the forms differ); a NaN — which only a caller can bring in: a Box action of a
 // diverged policy, an injected state — passes through every one of the reference's forms unchanged (np.clip propagates it; Python's
 // `NaN > hi`, max(NaN, lo), min(NaN, hi) keep the first operand), whereas v_max / v_min return the OTHER operand.  So the pair is followed
-// by a NaN pass-through: float64 = one v_cmp_u_f64 + one v_cndmask_b32 on the high dword (a NaN is a NaN whatever its low dword);
+// by a NaN pass-through: float64 = one v_cmp_u_f64 + one v_cndmask_b32 per dword (both: a NaN whose payload sits in the low dword only
+// — 0x7FF00000:xxxxxxxx, which a caller can craft — would turn into an infinity on a bound's zero low dword otherwise);
 // float32 = nothing extra, gfx950 has the IEEE-754-2019 NaN-propagating v_maximum3_f32 / v_minimum3_f32.
 #ifndef MXV_MINMAX_CLAMPS
 #define MXV_MINMAX_CLAMPS 1   // A/B hook: 0 = compare + select
 #endif
 // np.clip(x, lo, hi) = minimum(maximum(x, lo), hi): the lower bound first (the order only shows when a caller sets lo > hi); NaN passes through
 __device__ __forceinline__ double nan_through(double x, double r) {
-    const int rh = (x != x) ? __double2hiint(x) : __double2hiint(r);
-    return __hiloint2double(rh, __double2loint(r));
+    const bool nan = x != x;
+    return __hiloint2double(nan ? __double2hiint(x) : __double2hiint(r), nan ? __double2loint(x) : __double2loint(r));
 }
 __device__ __forceinline__ double clamp_range(double x, double lo, double hi) {
 #if MXV_MINMAX_CLAMPS

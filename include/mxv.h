@@ -298,7 +298,10 @@ int mxv_set_counters(mxv_handle *h, uint64_t t, uint32_t r);
  * replayed graphs == the same calls made one by one, bit for bit, including Acrobot's step-indexed torque noise).  The host's copy of
  * the index is refreshed from the device by mxv_get_counters (which then synchronises the stream).  on = 0 reads the index back and
  * returns to argument passing.  Calls that synchronise or copy to the host (the *_host calls, mxv_sync, mxv_get_state) cannot be
- * captured, as with any stream. */
+ * captured, as with any stream.  WITHOUT the device clock a step / rollout call on a stream that is being captured returns
+ * MXV_ERR_UNSUPPORTED (its replays would repeat one step index, i.e. the same action and noise draws).  What a recording freezes
+ * besides the index: seeds, reset bounds, parameters and the kernel variant (guarded / unguarded) — re-record after mxv_seed*,
+ * reset(options) bounds, mxv_set_params* or an mxv_set_state outside the unguarded range. */
 int mxv_set_device_clock(mxv_handle *h, int32_t on);
 /* NormalizeObservation's batch moments, fused into the rollout (gym/wrappers/normalize.py:17-29: every step's batch mean / var are the
  * only cross-env reduction on the path).  With a buffer attached, every sampled trajectory launch (mxv_rollout, MXV_ROLLOUT_FUSED,
@@ -318,6 +321,11 @@ int mxv_set_return_partials(mxv_handle *h, double *returns_state_dev, double gam
 /* per-env reset ordinals (position of each env's reset stream, see RNG contract): uint32[N].  Synchronises. */
 int mxv_get_episodes(mxv_handle *h, uint32_t *episodes_host);
 int mxv_set_episodes(mxv_handle *h, const uint32_t *episodes_host);
+/* CartPole's steps_beyond_terminated marks (cartpole.py:169-184; kept only with MXV_FLAG_NO_AUTORESET): uint8[N], 1 = this env has
+ * terminated since its last reset and pays 0.0 from now on.  Part of a checkpoint: mxv_set_state clears the marks (a fresh state), so
+ * restore them AFTER it.  Handles without marks: get fills zeros, set accepts zeros only. */
+int mxv_get_beyond(mxv_handle *h, uint8_t *beyond_host);
+int mxv_set_beyond(mxv_handle *h, const uint8_t *beyond_host);
 
 /* -- physics parameters (VectorEnv.get_attr/set_attr/call, sync_vector_env.py:171-214) ----------- */
 /* One value per attribute for all sub-envs (set_attr with a scalar or a list of equal values).  Default values run

@@ -266,3 +266,36 @@ def test_the_graphed_policy_gradient_example_learns():
     e = mod.train(iterations=4, graphed=False, verbose=False)
     fast = min(x["us_per_step"] for x in h[2:])
     assert fast < 0.8 * min(x["us_per_step"] for x in e[1:]), (fast, [x["us_per_step"] for x in e])
+
+
+def test_recording_without_the_device_clock_is_refused():
+    """a step / rollout call on a stream that is being captured, with the step index still travelling by value, would replay
+    the same draws for ever; the C ABI returns MXV_ERR_UNSUPPORTED instead (and works again once the capture has ended)."""
+    import torch
+    from gym_amd import _native
+    from gym_amd.rollout import DeviceRollout
+
+    r = DeviceRollout("CartPole-v1", 2048, seed=1, action_seed=2)
+    r.reset(seed=1)
+    out = r.trajectory_buffers(4, layout="separate")
+    r.rollout_per_step(4, out=out)
+    r.synchronize()
+    codes = []
+    with torch.cuda.stream(r.stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=r.stream):
+            for call in (lambda: r.handle.step_sampled(r.obs, r.reward, r.terminated, r.truncated, None, r.actions),
+                         lambda: r.handle.rollout(4, out["obs"], out["reward"], out["terminated"], out["truncated"], None, out["actions"],
+                                                  per_step=True, mode=_native.ROLLOUT_FUSED)):
+                try:
+                    call()
+                    codes.append(None)
+                except _native.MxvError as e:
+                    codes.append(e.code)
+            r.obs.add_(0.0)              # (an empty capture is not worth instantiating)
+    assert codes == [_native.ERR_UNSUPPORTED, _native.ERR_UNSUPPORTED]
+    t0 = r.handle.get_counters()[0]
+    r.rollout_per_step(4, out=out)        # outside a capture: as before
+    r.synchronize()
+    assert r.handle.get_counters()[0] == t0 + 4 == 8
+    r.close()

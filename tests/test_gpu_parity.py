@@ -167,6 +167,99 @@ def test_non_finite_actions_inside_a_fused_rollout(name):
     r.close()
 
 
+def test_huge_cartpole_velocities_inside_a_fused_rollout():
+    """a FINITE injected theta_dot beyond ~1.3e154 overflows polemass_length * theta_dot^2 * sintheta; the unguarded fused
+    kernel's reciprocal-based division would turn the infinite dividend into NaN where IEEE division — the reference — gives +-Inf.
+    mxv_set_state sends such states (any CartPole velocity beyond 1e150) through the guarded launch: the final observations of the step
+    hold the oracle's infinities, not NaNs, and the launch after it is the unguarded one again."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+
+    n = 1024
+    r = DeviceRollout("CartPole-v1", n, seed=3, action_seed=4)
+    ref = OracleEngine("CartPole", n, 500, seed=3, action_seed=4).o
+    r.reset(seed=3), ref.reset(seed=3)
+    st, el = r.handle.get_state()
+    st = st.copy()
+    big = np.array([1.2e154, 1.4e154, 1e155, -1e160, 1e200, -1.7e308, 3e150, 1e151])
+    st[3, : 8 * 16] = np.repeat(big, 16)                         # theta_dot: the overflowing product
+    st[1, 200:264] = np.repeat(np.array([1e300, -1e300, 1e155, -2e200]), 16)      # x_dot: finite, beyond float32
+    r.handle.set_state(st, el)
+    ref.state[:] = st
+    ref.elapsed[:] = el
+    out = r.trajectory_buffers(2, layout="separate", want_final=True)
+    r.rollout_per_step(2, out=out)
+    r.synchronize()
+    assert r.handle.last_launch()["safe"] == 1                    # the guarded instantiation took the injected state
+    with np.errstate(all="ignore"):
+        for k in range(2):
+            a = ref.sample_actions()
+            assert np.array_equal(a, out["actions"][k].cpu().numpy())
+            o, rw, te, tr, fin, fm = ref.step(a)
+            got_f, got_o = out["final_obs"][k].cpu().numpy(), out["obs"][k].cpu().numpy()
+            assert np.array_equal(out["terminated"][k].cpu().numpy().astype(bool), te), k
+            assert np.array_equal(np.isnan(got_f[fm]), np.isnan(fin[fm])) and np.array_equal(np.isinf(got_f[fm]), np.isinf(fin[fm])), k
+            assert np.array_equal(got_f[fm][np.isinf(fin[fm])], fin[fm][np.isinf(fin[fm])])              # the sign of every infinity
+            ok = np.isfinite(fin) & fm[:, None]
+            assert (not ok.any() or ulps32(got_f[ok], fin[ok]).max() <= MAX_OBS_ULPS) and ulps32(got_o, o).max() <= MAX_OBS_ULPS
+            if k == 0:
+                assert np.isinf(fin[fm]).any() and te[:128].all()
+    r.rollout_per_step(2, out=out)
+    r.synchronize()
+    assert r.handle.last_launch()["safe"] == 0
+    r.close()
+
+
+def test_nan_with_a_low_dword_payload_passes_the_clamps():
+    """a NaN whose payload sits in the low dword only (0x7FF00000:00000001) is still a NaN after MountainCar's position and
+    velocity clamps (np.clip propagates it) — splicing only the high dword onto a bound with a zero low dword made it an infinity."""
+    from gym_amd import _native
+
+    n = 64
+    h = _native.Handle(ENV_IDS["MountainCar"], n, 200, seed=1, action_seed=2)
+    h.reset_host()
+    st, el = h.get_state()
+    st = st.copy()
+    weird = np.array([0x7FF0000000000001, 0xFFF0000000000001, 0x7FF00000FFFFFFFF], dtype=np.uint64).view(np.float64)
+    assert np.isnan(weird).all()
+    st[0, :3] = weird                       # position
+    st[1, 8:11] = weird                     # velocity
+    h.set_state(st, el)
+    obs, rew, term, trunc, fin = h.step_host(np.ones(n, dtype=np.int64), want_final=True)
+    after, _ = h.get_state()
+    assert np.isnan(obs[:3]).all() and np.isnan(obs[8:11]).any(axis=1).all() and not np.isinf(obs).any()
+    assert np.isnan(after[0, :3]).all() and np.isnan(after[1, 8:11]).all() and np.isfinite(after[:, 16:]).all()
+    h.close()
+
+
+def test_cartpole_beyond_marks_travel_with_a_snapshot():
+    """the steps_beyond_terminated marks are part of a checkpoint — a restored NO_AUTORESET CartPole handle that had terminated
+    keeps paying 0.0 (mxv_get_beyond / mxv_set_beyond; Handle.snapshot / restore), like the pickled reference env would."""
+    from gym_amd import _native
+
+    n = 256
+    h = _native.Handle(ENV_IDS["CartPole"], n, 500, seed=5, action_seed=6, flags=_native.FLAG_NO_AUTORESET)
+    h.reset_host()
+    ones = np.ones(n, dtype=np.int64)
+    for _ in range(40):                                            # always push right: every pole falls within ~10 steps
+        obs, rew, term, trunc, _ = h.step_host(ones, want_final=False)
+    assert term.all() and (rew == 0.0).all() and h.get_beyond().all()
+    snap = h.snapshot()
+    twin = _native.Handle(ENV_IDS["CartPole"], n, 500, seed=0, action_seed=0, flags=_native.FLAG_NO_AUTORESET)
+    twin.reset_host()
+    twin.restore(snap)
+    assert twin.get_beyond().all()
+    for _ in range(3):
+        a, b = h.step_host(ones, want_final=False), twin.step_host(ones, want_final=False)
+        assert (b[1] == 0.0).all() and all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a[:4], b[:4]))
+    plain = _native.Handle(ENV_IDS["CartPole"], n, 500, seed=5, action_seed=6)
+    assert not plain.get_beyond().any()
+    plain.set_beyond(np.zeros(n, np.uint8))
+    with pytest.raises(_native.MxvError):
+        plain.set_beyond(np.ones(n, np.uint8))
+    h.close(), twin.close(), plain.close()
+
+
 def test_cartpole_stepped_on_after_termination():
     """MXV_FLAG_NO_AUTORESET keeps the reference's steps_beyond_terminated bookkeeping (cartpole.py:169-184): the fall pays 1.0, every
     later step that is still terminated 0.0, a reset clears the mark."""
