@@ -251,7 +251,7 @@ def compact_line(full, limit=LINE_LIMIT):
     line["config"] = {
         "workload": cfg["workload"], "num_envs_per_gpu": cfg["num_envs_per_gpu"], "chunk": cfg["chunk"], "repeats": cfg["repeats"],
         "timed_steps": cfg["timed_steps"], "timed_region_ms": cfg["timed_region_ms"], "launch": cfg["launch"], "outputs": cfg["outputs"],
-        "placement": {k: pl[k] for k in ("kind", "balanced", "parked_GiB", "seconds", "error") if k in pl},
+        "placement": {k: pl[k] for k in ("kind", "mode", "balanced", "parked_GiB", "seconds", "error") if k in pl},
         "parallelism": cfg["parallelism"], "ranks_seen": cfg["ranks_seen"], "gathers_in_timed_region": cfg["gathers_in_timed_region"],
         "gather_every": cfg["gather_every"], "gather_transport": cfg["gather_transport"], "gather_us": cfg.get("gather_us"),
         "comm": cfg["comm"],

@@ -5,15 +5,27 @@ from .common import *  # noqa: F401,F403
 from .common import _event_us, _hbm, _spin
 
 
-def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin_ms=60.0, probe=True, valu=False):
+def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin_ms=60.0, probe=True, valu=False, placement_mode=None):
     """One env kind, fused trajectory launches on one GPU: us per step, env-steps/s, roofline on the algorithmic bytes, the
-    write probe of its own store pattern into the same tensors."""
+    write probe of its own store pattern into the same tensors.  placement_mode: MXV_PLACEMENT for the allocation of the trajectory
+    tensors ("search": the long walk of rounds 3-4; default: the process's setting, i.e. at most 8 GiB parked)."""
+    import os
+
     from gym_amd import _native
     from gym_amd.rollout import DeviceRollout
 
     r = DeviceRollout(env_id, envs, seed=0, action_seed=1, reward_f32=compact, action_i32=compact)
     r.reset(seed=0)
-    traj = r.trajectory_buffers(chunk)
+    saved = os.environ.get("MXV_PLACEMENT")
+    if placement_mode is not None and saved not in ("off", "0", "no", "false"):
+        os.environ["MXV_PLACEMENT"] = placement_mode
+    try:
+        traj = r.trajectory_buffers(chunk)
+    finally:
+        if saved is None:
+            os.environ.pop("MXV_PLACEMENT", None)
+        else:
+            os.environ["MXV_PLACEMENT"] = saved
     placement = getattr(r, "last_placement", None) if sum(t.numel() * t.element_size() for t in traj.values()) >= _native.SORTED_MIN_BYTES else None
     fn = lambda: r.rollout_per_step(chunk, out=traj)   # noqa: E731
     _spin(fn, r.stream.synchronize, spin_ms)

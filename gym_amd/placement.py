@@ -14,9 +14,16 @@ next to it, so no absolute threshold is involved) and, if it lies on the wrong s
 which lies further along in physical memory.  Parked tensors are released at the end.  Typical: a few GiB parked for 0.1 s; a fresh
 device: up to ~90 GiB for ~3 s.  Nothing here touches the results: only WHERE the tensors live.
 
-Safe beside a co-resident learner: what the search may park is capped (half of the memory that is free beyond the set itself, at most
-MXV_PLACEMENT_MAX_PARK_GIB, default 112), an out-of-memory error inside the search ends it with ordinary allocations instead of reaching
-the caller, and MXV_PLACEMENT=off (or layout="separate") switches it off altogether.
+Three modes (MXV_PLACEMENT):
+  on / unset ("cheap", the default)  the walk may park at most 8 GiB beside the set (and never more than half of the memory that is free
+        beyond the set): in a learner's process, whose allocator already holds blocks all over the device, that is enough to find the two
+        classes; in a FRESH process whose first ~90 GiB all lie in one class it is not — the set then comes back with balanced = False and
+        runs 4-18 % slower than a sorted one (bench.py: headline vs variants.placement_search).  A product default must not take a quarter
+        of the device for a second;
+  search  round 3-4's behaviour: up to 112 GiB parked transiently (~1-3 s on a fresh device) to leave the first class;
+  off     never sort — ordinary allocations, no probe launches, no synchronisation, nothing parked.
+MXV_PLACEMENT_MAX_PARK_GIB overrides the cap of either mode.  An out-of-memory error inside the walk ends it with ordinary allocations
+instead of reaching the caller.
 
 What was measured is remembered per device (`_ClassMemo`): torch's caching allocator hands a learner's loop the same blocks again and
 again (`out = r.rollout_per_step(K)` alternates between two sets), and a block keeps its physical memory for as long as its segment is
@@ -40,21 +47,32 @@ MiB = 1 << 20
 WIDE, NARROW = 256 * MiB, 128 * MiB     # what one probe window writes: 16 steps x 2^20 lanes x 16 B / 8 B
 SAME_RATIO = 0.955                      # a different-class pair runs at 0.89-0.91 of the same-class time
 MIN_SET_BYTES = _native.SORTED_MIN_BYTES
-DEFAULT_MAX_PARK_BYTES = 112 << 30      # the search never holds more than this beside the set itself (a fresh device needs ~90 GiB to leave its first class)
+CHEAP_MAX_PARK_BYTES = 8 << 30          # the default: never more than this parked beside the set itself
+SEARCH_MAX_PARK_BYTES = 112 << 30       # MXV_PLACEMENT=search (a fresh device needs ~90 GiB to leave its first class)
+DEFAULT_MAX_PARK_BYTES = CHEAP_MAX_PARK_BYTES
+
+
+def mode() -> str:
+    """"off" | "cheap" | "search" from MXV_PLACEMENT (unset / on / 1 / cheap -> "cheap")."""
+    v = os.environ.get("MXV_PLACEMENT", "on").strip().lower()
+    if v in ("off", "0", "no", "false"):
+        return "off"
+    return "search" if v == "search" else "cheap"
 
 
 def enabled() -> bool:
     """MXV_PLACEMENT=off (or 0 / no / false): trajectory_buffers(layout="auto") never sorts — ordinary allocations, no probe launches, no
-    device synchronisation, no memory parked.  For a process that shares its GPU with a learner that cannot spare the transient memory."""
-    return os.environ.get("MXV_PLACEMENT", "on").strip().lower() not in ("off", "0", "no", "false")
+    device synchronisation, no memory parked.  For a process that shares its GPU with a learner that cannot spare even 8 GiB transiently."""
+    return mode() != "off"
 
 
 def max_park_bytes() -> int:
-    """Upper bound of the memory the search may hold transiently: MXV_PLACEMENT_MAX_PARK_GIB (default 112)."""
+    """Upper bound of the memory the walk may hold transiently: MXV_PLACEMENT_MAX_PARK_GIB if set, else 8 GiB (default mode) or 112 GiB
+    (MXV_PLACEMENT=search)."""
     try:
         return max(0, int(float(os.environ["MXV_PLACEMENT_MAX_PARK_GIB"]) * (1 << 30)))
     except (KeyError, ValueError):
-        return DEFAULT_MAX_PARK_BYTES
+        return SEARCH_MAX_PARK_BYTES if mode() == "search" else CHEAP_MAX_PARK_BYTES
 
 
 def _is_oom(e: BaseException) -> bool:
@@ -169,7 +187,7 @@ def _sorted_locked(specs, groups, be, budget_bytes):
     nbytes = {n: _nbytes(spec[n][0], spec[n][1]) for n in names}
     g0 = [n for n in names if groups.get(n) == 0]
     g1 = [n for n in names if groups.get(n) == 1]
-    report = {"kind": "sorted", "balanced": False, "parked_GiB": 0.0, "candidates": 0, "remembered": 0,
+    report = {"kind": "sorted", "mode": mode(), "balanced": False, "parked_GiB": 0.0, "candidates": 0, "remembered": 0,
               "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
 
     dirty = [True]     # allocations (and their zero fills) issued since the last device synchronisation

@@ -138,13 +138,14 @@ def test_sorted_tensors_degrades_to_ordinary_allocations_when_there_is_nothing_t
     assert "nothing to keep apart" in rep["note"]
 
 
-def test_a_learners_loop_pays_for_the_placement_of_its_first_two_sets_only():
+def test_a_learners_loop_pays_for_the_placement_of_its_first_two_sets_only(monkeypatch):
     """`out = r.rollout_per_step(K)` without out=: the set of call i is released when call i + 1 has returned, so torch's caching allocator
     alternates between two sets of blocks; gym_amd.placement remembers what it measured about them (block address + size, valid until a
     segment goes back to the driver) and from the third call on launches no probe.  Also: the 2^17-env shard of an 8-GPU strong-scaling
     job (1.06 GiB of trajectory tensors) is sorted."""
     import time
 
+    monkeypatch.setenv("MXV_PLACEMENT", "search")      # (the memo is what is tested: let the first set walk as far as it needs to be balanced)
     torch.cuda.empty_cache()       # whatever earlier tests left in the allocator's cache would be split for these requests
     r = DeviceRollout("CartPole-v1", 1 << 17, seed=0, action_seed=1)
     r.reset(seed=0)

@@ -80,6 +80,14 @@ def _classes(dev, out, specs):
     return res
 
 
+@pytest.fixture(autouse=True)
+def _search_mode(monkeypatch):
+    """These tests drive the walk itself: MXV_PLACEMENT=search (up to 112 GiB parked).  The default mode — at most 8 GiB — has its own
+    tests at the end of the file."""
+    monkeypatch.setenv("MXV_PLACEMENT", "search")
+    monkeypatch.delenv("MXV_PLACEMENT_MAX_PARK_GIB", raising=False)
+
+
 def test_fresh_device_walks_to_the_next_class_and_releases_what_it_parked():
     dev = SimDevice([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")])
     out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=dev)
@@ -392,10 +400,35 @@ def test_a_set_of_remembered_blocks_costs_no_probe_and_no_synchronisation():
     assert dev.probes == probes and Recycling.syncs == syncs
 
 
+def test_the_default_mode_parks_at_most_eight_gib(monkeypatch):
+    """the product default must not take a quarter of the device.  On a fresh device (one class for the first 91 GiB)
+    the default walk gives up after 8 GiB and says so (balanced False, mode "cheap"); where the allocator's blocks are spread over the
+    classes — a learner's process — the same 8 GiB are plenty; MXV_PLACEMENT=search restores the long walk."""
+    from gym_amd import placement
+
+    monkeypatch.setenv("MXV_PLACEMENT", "on")
+    assert placement.mode() == "cheap" and placement.max_park_bytes() == 8 * GiB
+    fresh = SimDevice([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")])
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=fresh)
+    assert rep["mode"] == "cheap" and rep["balanced"] is False and rep["parked_GiB"] <= 8.0 and rep["budget_GiB"] == 8.0
+    assert fresh.peak <= 8.5 * GiB + 8 * GiB + 3 * GiB and fresh.live == sum(t.n for t in out.values())
+    regions, addr = [], 0
+    for i in range(200):                                         # runs of 6 GiB, alternating classes
+        addr += 6 * GiB
+        regions.append((addr, "AB"[i % 2]))
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=SimDevice(regions))
+    assert rep["balanced"] is True and rep["parked_GiB"] <= 8.0
+    monkeypatch.setenv("MXV_PLACEMENT", "search")
+    assert placement.mode() == "search" and placement.max_park_bytes() == 112 * GiB
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=SimDevice([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")]))
+    assert rep["mode"] == "search" and rep["balanced"] is True and rep["parked_GiB"] >= 80
+
+
 def test_environment_switch(monkeypatch):
     from gym_amd import placement
 
-    assert placement.enabled()
+    monkeypatch.delenv("MXV_PLACEMENT", raising=False)
+    assert placement.enabled() and placement.mode() == "cheap"
     for v in ("off", "0", "OFF", "no", "false"):
         monkeypatch.setenv("MXV_PLACEMENT", v)
         assert not placement.enabled()
