@@ -427,6 +427,10 @@ class HipTabularVectorEnv(VectorEnv):
         self._assert_is_running()
         if name == "s":
             return tuple(int(v) for v in self._handle.get_state()[0])
+        if name == "_max_episode_steps":               # TimeLimit's attributes (time_limit.py:43-44)
+            return (self._limit if self._limit and self._limit > 0 else None,) * self.num_envs
+        if name == "_elapsed_steps":
+            return tuple(int(v) for v in self._handle.get_state()[1])
         if name == "P":
             P = {s: {a: self.mdp.transitions(s, a) for a in range(self.mdp.num_actions)} for s in range(self.mdp.num_states)}
             return (P,) * self.num_envs

@@ -592,19 +592,92 @@ class HipVectorEnv(VectorEnv):
         return self._handle
 
 
+def _sub_env_wrappers(wrappers):
+    """gym.vector.make(..., wrappers=...) applies callables to every Python sub-env (gym/vector/__init__.py:56-65).  There are no Python
+    sub-envs here; the wrappers that are pure functions of what the engine already owns are recognised — passed as the class or as a
+    functools.partial of it, the reference's class or this package's — and mapped to the engine's equivalent with the SAME per-sub-env
+    semantics:
+        TimeLimit(max_episode_steps=k)        the engine's TimeLimit counter with min(k, the id's own limit)  (time_limit.py:50-53: the outer
+                                              wrapper truncates at k, the registered inner one at the spec's limit)
+        RecordEpisodeStatistics(deque_size=)  the fused episode accumulators, reported in infos["final_info"][i]["episode"]
+        OrderEnforcing, PassiveEnvChecker     what gym.make applies anyway: accepted, nothing to do
+    NormalizeObservation / NormalizeReward are NOT mapped: around a sub-env each keeps its own running statistics over that env's history
+    (a batch of one), which is a different normalisation from the vector-level wrappers' batch statistics — wrap the vector env
+    (gym_amd.NormalizeObservation(env)) if that is what is meant.  Anything else (lambdas, observation transforms, ...) cannot run
+    inside the device engine.  Returns (max_episode_steps or None, [post-construction vector wrappers])."""
+    import functools
+
+    if wrappers is None:
+        return None, []
+    if callable(wrappers):
+        wrappers = [wrappers]
+    try:
+        wrappers = list(wrappers)
+    except TypeError:
+        raise NotImplementedError("`wrappers` must be a callable or an iterable of callables (gym/vector/__init__.py:56-65)") from None
+    limit, post = None, []
+    for w in wrappers:
+        fn, args, kw = (w.func, w.args, dict(w.keywords)) if isinstance(w, functools.partial) else (w, (), {})
+        name = getattr(fn, "__name__", None) if isinstance(fn, type) else None
+        if name == "TimeLimit" and not args:
+            k = kw.pop("max_episode_steps", None)
+            if kw:
+                raise NotImplementedError(f"TimeLimit arguments {sorted(kw)} are not supported by the device engine")
+            if k is not None:
+                limit = int(k) if limit is None else min(limit, int(k))
+        elif name == "RecordEpisodeStatistics" and not args and set(kw) <= {"deque_size"}:
+            post.append(("episode_statistics", kw))
+        elif name in ("OrderEnforcing", "PassiveEnvChecker") and not args and not kw:
+            continue
+        elif name in ("NormalizeObservation", "NormalizeReward"):
+            raise NotImplementedError(
+                f"wrappers={name}: around each sub-env the reference keeps per-env running statistics (a batch of one per update), which the "
+                f"vector-level gym_amd.{name} (batch statistics over all sub-envs, fused into the engine) does not reproduce — wrap the "
+                f"vector env instead if shared statistics are what is meant: gym_amd.{name}(gym_amd.make(id, num_envs))")
+        else:
+            raise NotImplementedError(
+                f"per-sub-environment wrapper {w!r} cannot run inside the device engine (no Python sub-envs); recognised: TimeLimit, "
+                "RecordEpisodeStatistics, OrderEnforcing, PassiveEnvChecker as classes or functools.partial — otherwise wrap the vector env "
+                "(gym_amd.VectorEnvWrapper) or pass the env's own keyword arguments / max_episode_steps")
+    return limit, post
+
+
 def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> VectorEnv:
     """gym.vector.make (gym/vector/__init__.py:12-73) for the engine's ids.  `asynchronous` is accepted and
-    ignored: there are no sub-processes, all sub-envs step in one kernel launch."""
+    ignored: there are no sub-processes, all sub-envs step in one kernel launch.  `wrappers`: see _sub_env_wrappers."""
     kwargs.pop("disable_env_checker", None)
-    if kwargs.pop("wrappers", None) is not None:
-        # gym/vector/__init__.py:56-65 applies them to every Python sub-env; there are no Python sub-envs here
-        raise NotImplementedError("per-sub-environment `wrappers` cannot run inside the device engine; wrap the vector env "
-                                  "instead (gym_amd.VectorEnvWrapper, RecordEpisodeStatistics, NormalizeObservation/Reward) "
-                                  "or pass the env's own keyword arguments / max_episode_steps")
+    limit, post = _sub_env_wrappers(kwargs.pop("wrappers", None))
     from . import toy_text
 
     if id == "Blackjack-v1":
-        return toy_text.HipBlackjackVectorEnv(id, num_envs, **kwargs)
-    if id in toy_text.TOY_TEXT_REGISTRY:  # FrozenLake / Taxi / CliffWalking: the table-driven engine (SURVEY.md §8f-4)
-        return toy_text.HipTabularVectorEnv(id, num_envs, **kwargs)
-    return HipVectorEnv(id, num_envs, **kwargs)
+        cls = toy_text.HipBlackjackVectorEnv
+    elif id in toy_text.TOY_TEXT_REGISTRY:  # FrozenLake / Taxi / CliffWalking: the table-driven engine (SURVEY.md §8f-4)
+        cls = toy_text.HipTabularVectorEnv
+    else:
+        cls = HipVectorEnv
+    if limit is not None:
+        # the outer TimeLimit(k) over the id's own: whichever is shorter ends the episode (both restart at reset)
+        own = kwargs.get("max_episode_steps", _default_limit(id))
+        kwargs["max_episode_steps"] = limit if own is None or own <= 0 else min(limit, own)
+    env = cls(id, num_envs, **kwargs)
+    for what, kw in post:
+        if what == "episode_statistics":
+            if not isinstance(env, HipVectorEnv):
+                env.close()
+                raise NotImplementedError("wrappers=RecordEpisodeStatistics is mapped to the classic-control engine's fused accumulators; "
+                                          "the toy_text engines do not carry them")
+            from .wrappers import SubEnvEpisodeStatistics
+
+            env = SubEnvEpisodeStatistics(env, **kw)
+    return env
+
+
+def _default_limit(id: str):
+    """The TimeLimit an id is registered with (gym/envs/__init__.py), or None."""
+    from . import registration, toy_text
+
+    if id in toy_text.TOY_TEXT_REGISTRY:
+        return toy_text.TOY_TEXT_REGISTRY[id].max_episode_steps
+    if id == "Blackjack-v1":
+        return None
+    return registration.spec(id).max_episode_steps

@@ -20,7 +20,7 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward"]
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics"]
 
 
 class _VectorWrapper:
@@ -153,6 +153,37 @@ class RecordEpisodeStatistics(_VectorWrapper):
         self.return_queue.extend((r if keep is None else r[-keep:]).tolist())
         self.length_queue.extend((l if keep is None else l[-keep:]).tolist())
         self.episode_count += int(idx.size)
+
+
+class SubEnvEpisodeStatistics(_VectorWrapper):
+    """What `gym.vector.make(id, n, wrappers=RecordEpisodeStatistics)` yields in the reference (gym/vector/__init__.py:56-65: the wrapper
+    around EVERY sub-env): the sub-env whose episode ends reports `{"episode": {"r": float32, "l": int32, "t": float}}` in its own info
+    (record_episode_statistics.py:125-136, non-vector branch), and because SyncVectorEnv autoresets that env in the same step, the info
+    travels in `infos["final_info"][i]` (sync_vector_env.py:152-156).  Same numbers as the vector-level wrapper — the engine's fused
+    float32 accumulators and TimeLimit counters — delivered where the per-sub-env wrapper puts them."""
+
+    def __init__(self, env, deque_size: int = 100):
+        super().__init__(RecordEpisodeStatistics(env, deque_size))
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        if "_episode" not in infos:
+            return obs, rew, term, trunc, infos
+        ep, mask = infos.pop("episode"), infos.pop("_episode")
+        idx = np.flatnonzero(mask)
+        base = dict.__getitem__(infos, "final_info") if isinstance(infos, LazyInfos) else infos["final_info"]
+
+        def build():
+            arr = base.build() if isinstance(base, _Pending) else base
+            for i in idx:
+                arr[i] = {**(arr[i] or {}), "episode": {"r": np.float32(ep["r"][i]), "l": np.int32(ep["l"][i]), "t": float(ep["t"][i])}}
+            return arr
+
+        if isinstance(infos, LazyInfos):
+            dict.__setitem__(infos, "final_info", _Pending(build))
+        else:
+            infos["final_info"] = build()
+        return obs, rew, term, trunc, infos
 
 
 class VectorListInfo(_VectorWrapper):

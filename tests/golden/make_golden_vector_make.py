@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""vector_make_wrappers_CartPole.npz — `gym.vector.make("CartPole-v1", num_envs=8, asynchronous=False, wrappers=[functools.partial(
+TimeLimit, max_episode_steps=7), RecordEpisodeStatistics])` run by THE REFERENCE (gym/vector/__init__.py:56-65: both wrappers around
+every sub-env): per step the pre-step fp64 state and the elapsed counter of the OUTER TimeLimit of every sub-env, the actions, the
+step's masks and rewards, and what the per-sub-env RecordEpisodeStatistics reported — in infos["final_info"][i]["episode"] (the sub-env is
+autoreset in the same step, sync_vector_env.py:152-156): r (float32), l (int32).
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden_vector_make.py"""
+import functools
+import os
+import sys
+
+import numpy as np
+
+for _name, _val in (("bool8", np.bool_), ("float_", np.float64), ("alltrue", np.all)):
+    if not hasattr(np, _name):
+        setattr(np, _name, _val)
+
+sys.path.insert(0, "/root/reference")
+import gym  # noqa: E402
+import warnings  # noqa: E402
+from gym.wrappers import RecordEpisodeStatistics, TimeLimit  # noqa: E402
+
+warnings.filterwarnings("ignore")
+gym.logger.set_level(gym.logger.ERROR)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    N, T, K = 8, 90, 12
+    env = gym.vector.make("CartPole-v1", num_envs=N, asynchronous=False,
+                          wrappers=[functools.partial(TimeLimit, max_episode_steps=K), RecordEpisodeStatistics])
+    env.reset(seed=123)
+    rng = np.random.default_rng(7)
+    rec = {k: [] for k in ("state_pre", "elapsed_pre", "action", "obs", "reward", "terminated", "truncated", "ep_mask", "ep_r", "ep_l")}
+    for t in range(T):
+        subs = env.envs
+        rec["state_pre"].append(np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in subs]))
+        outer = [e.env for e in subs]                       # RecordEpisodeStatistics -> the outer TimeLimit
+        assert all(type(o).__name__ == "TimeLimit" and o._max_episode_steps == K for o in outer)
+        rec["elapsed_pre"].append(np.array([o._elapsed_steps for o in outer], dtype=np.int32))
+        a = (rng.random(N) < np.linspace(0.15, 0.85, N)).astype(np.int64)      # biased pushes: some poles fall before the limit
+        obs, rew, term, trunc, infos = env.step(a)
+        rec["action"].append(a), rec["obs"].append(obs), rec["reward"].append(rew), rec["terminated"].append(term), rec["truncated"].append(trunc)
+        mask, er, el = np.zeros(N, bool), np.zeros(N, np.float32), np.zeros(N, np.int32)
+        assert "episode" not in infos                        # nothing at the vector level: the wrapper sits around the sub-envs
+        if "final_info" in infos:
+            for i, fi in enumerate(infos["final_info"]):
+                if fi is not None:
+                    assert set(fi) == {"episode"} or set(fi) == {"episode", "TimeLimit.truncated"}, fi
+                    ep = fi["episode"]
+                    assert isinstance(ep["r"], np.float32) and isinstance(ep["l"], np.int32) and isinstance(ep["t"], float), ep
+                    mask[i], er[i], el[i] = True, ep["r"], ep["l"]
+        assert np.array_equal(mask, term | trunc)
+        rec["ep_mask"].append(mask), rec["ep_r"].append(er), rec["ep_l"].append(el)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["max_episode_steps"] = np.int64(K)
+    assert out["truncated"].any() and out["terminated"].any()
+    np.savez_compressed(os.path.join(HERE, "vector_make_wrappers_CartPole.npz"), **out)
+    print("episodes:", int(out["ep_mask"].sum()), "truncated:", int(out["truncated"].sum()), "terminated:", int(out["terminated"].sum()))
+
+
+if __name__ == "__main__":
+    main()

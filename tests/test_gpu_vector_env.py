@@ -666,3 +666,59 @@ def test_snapshots_carry_a_format_version_and_old_ones_are_refused_with_a_reason
     h.restore(keyless)
     assert np.array_equal(h.get_state()[0], snap["state"]) and np.array_equal(h.get_episodes(), snap["episodes"])
     h.close()
+
+
+def test_vector_make_with_recognised_sub_env_wrappers_against_the_reference():
+    """gym.vector.make(id, n, wrappers=[partial(TimeLimit, max_episode_steps=12), RecordEpisodeStatistics]) (gym/vector/__init__.py:56-65;
+    the reference's tests/vector/test_vector_make.py applies a wrapper to every sub-env the same way): the two wrappers the engine owns an
+    equivalent of are mapped onto it — the TimeLimit counter with min(12, 500), the fused episode accumulators — and what a caller sees is
+    what the reference's per-sub-env wrappers produce (tests/golden/vector_make_wrappers_CartPole.npz, made by running the reference):
+    masks exactly, and `infos["final_info"][i]["episode"]` = {"r": float32, "l": int32, "t": float} for the sub-envs whose episode ended,
+    nothing at the vector level."""
+    import functools
+    import os
+
+    import gym_amd
+    from gym_amd.wrappers import RecordEpisodeStatistics, SubEnvEpisodeStatistics
+
+    class TimeLimit:            # recognised by name: the reference's gym.wrappers.TimeLimit is not importable on the GPU box
+        pass
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vector_make_wrappers_CartPole.npz"))
+    T, N = g["action"].shape
+    env = gym_amd.make("CartPole-v1", num_envs=N, wrappers=[functools.partial(TimeLimit, max_episode_steps=int(g["max_episode_steps"])),
+                                                             RecordEpisodeStatistics])
+    assert isinstance(env, SubEnvEpisodeStatistics) and env.get_attr("_max_episode_steps") == (12,) * N
+    env.reset(seed=1)
+    handle = env.unwrapped.handle
+    episodes = 0
+    for t in range(T):
+        handle.set_state(np.ascontiguousarray(g["state_pre"][t].T), g["elapsed_pre"][t])
+        obs, rew, term, trunc, infos = env.step(g["action"][t])
+        assert np.array_equal(term, g["terminated"][t]) and np.array_equal(trunc, g["truncated"][t]), t
+        assert np.array_equal(rew, g["reward"][t]) and "episode" not in infos and "_episode" not in infos
+        done = g["ep_mask"][t]
+        nd = ~done
+        assert ulps32(obs[nd], g["obs"][t][nd]).max() <= MAX_OBS_ULPS if nd.any() else True
+        if done.any():
+            assert np.array_equal(infos["_final_info"], done)
+            for i in np.flatnonzero(done):
+                ep = infos["final_info"][i]["episode"]
+                assert isinstance(ep["r"], np.float32) and isinstance(ep["l"], np.int32) and isinstance(ep["t"], float)
+                assert ep["r"] == g["ep_r"][t][i] and ep["l"] == g["ep_l"][t][i], (t, i, ep)
+                episodes += 1
+            assert all(infos["final_info"][i] is None for i in np.flatnonzero(nd))
+        else:
+            assert "final_info" not in infos
+    assert episodes == int(g["ep_mask"].sum()) == 59
+    env.close()
+    # a bare TimeLimit class (max_episode_steps=None -> the spec's own limit, time_limit.py:40-43) changes nothing
+    plain = gym_amd.make("CartPole-v1", num_envs=4, wrappers=TimeLimit)
+    assert plain.get_attr("_max_episode_steps") == (500,) * 4
+    plain.close()
+    shorter = gym_amd.make("CartPole-v1", num_envs=4, max_episode_steps=5, wrappers=[functools.partial(TimeLimit, max_episode_steps=9)])
+    assert shorter.get_attr("_max_episode_steps") == (5,) * 4             # whichever TimeLimit is shorter ends the episode
+    shorter.close()
+    lake = gym_amd.make("FrozenLake-v1", num_envs=4, wrappers=functools.partial(TimeLimit, max_episode_steps=6))
+    assert lake.get_attr("_max_episode_steps") == (6,) * 4
+    lake.close()

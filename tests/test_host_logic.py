@@ -733,3 +733,43 @@ def test_normaliser_folds_partials_instead_of_reading_the_batch_again():
                    ("ret_partials", K, leaves), ("reward_apply", (1, K, 2)), "reward_sums", ("reward_apply", (1, K, 2))]
     with pytest.raises(AssertionError):
         nz.normalize_obs(x, partials=torch.zeros((K, leaves, 2 * O + 1), dtype=torch.float64))
+
+
+def test_vector_make_recognises_the_sub_env_wrappers_it_can_map():
+    """gym.vector.make(..., wrappers=...) (gym/vector/__init__.py:56-65): TimeLimit / RecordEpisodeStatistics / OrderEnforcing /
+    PassiveEnvChecker as classes or functools.partial — the reference's classes where the reference is importable, this package's, or any
+    class of that name — are mapped; Normalize* (per-sub-env statistics are a different normalisation) and everything else say why not."""
+    import functools
+
+    from gym_amd.vector_env import _sub_env_wrappers
+    from gym_amd.wrappers import NormalizeObservation, RecordEpisodeStatistics
+
+    class TimeLimit:
+        pass
+
+    class OrderEnforcing:
+        pass
+
+    assert _sub_env_wrappers(None) == (None, [])
+    assert _sub_env_wrappers(TimeLimit) == (None, [])                                      # max_episode_steps=None: the spec's own limit
+    assert _sub_env_wrappers(functools.partial(TimeLimit, max_episode_steps=25)) == (25, [])
+    assert _sub_env_wrappers([functools.partial(TimeLimit, max_episode_steps=25), OrderEnforcing,
+                              functools.partial(TimeLimit, max_episode_steps=9)]) == (9, [])
+    assert _sub_env_wrappers((RecordEpisodeStatistics,)) == (None, [("episode_statistics", {})])
+    assert _sub_env_wrappers([functools.partial(RecordEpisodeStatistics, deque_size=5)]) == (None, [("episode_statistics", {"deque_size": 5})])
+    for bad, needle in ((lambda e: e, "cannot run inside the device engine"), (NormalizeObservation, "per-env running statistics"),
+                        (functools.partial(TimeLimit, new_step_api=True), "not supported"), (functools.partial(TimeLimit, 5), "cannot run"),
+                        ([3], "cannot run"), (7, "callable or an iterable")):
+        with pytest.raises(NotImplementedError) as e:
+            _sub_env_wrappers(bad)
+        assert needle in str(e.value), (bad, str(e.value))
+    try:                                                                                   # the reference's own classes, where it is importable
+        import sys
+        sys.path.insert(0, "/root/reference")
+        for name, val in (("bool8", np.bool_), ("float_", np.float64)):
+            if not hasattr(np, name):
+                setattr(np, name, val)
+        from gym.wrappers import RecordEpisodeStatistics as RefStats, TimeLimit as RefLimit
+    except Exception:  # noqa: BLE001
+        return
+    assert _sub_env_wrappers([functools.partial(RefLimit, max_episode_steps=30), RefStats]) == (30, [("episode_statistics", {})])
