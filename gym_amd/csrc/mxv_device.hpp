@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/mxv.h"
+#include "../../include/mxv_diag.h"
 
 #define MXV_XFN __device__ inline
 #define MXV_XCONST __device__ const

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/mxv.h"
+#include "../../include/mxv_diag.h"
 
 namespace {
 

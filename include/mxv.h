@@ -57,6 +57,16 @@
 #ifndef MXV_H
 #define MXV_H
 
+/* API levels — additive: a consumer written against level n keeps working.  MXV_API_LEVEL is the level of this header.
+ *   1  (round 1)  static information, lifetime, seeding, reset, step, rollout, host-buffer convenience, state access, physics parameters,
+ *                 stream / sync: the ~25 entry points SURVEY.md §8(b) sketches — all a drop-in VectorEnv needs
+ *   2  (round 2)  episode statistics, mapped / packed / block host I/O, action tapes, mixed-batch launch; mxv_norm.h, mxv_toytext.h
+ *   3  (round 3)  collectives (mxv_comm.h), per-env parameters, final-tensor snapshots, mxv_wait_stream
+ *   4  (round 4)  device clock (hipGraph capture), fused moments (mxv_set_obs_partials / mxv_set_return_partials); mxv_diag.h
+ *   5  (round 5)  mxv_get_beyond / mxv_set_beyond, mxv_bj_rollout_compact, Blackjack's one-call draw contract
+ * Every section below says the level it appeared at. */
+#define MXV_API_LEVEL 5
+
 #include <stddef.h>
 #include <stdint.h>
 
@@ -208,23 +218,6 @@ typedef struct mxv_step_outputs {
 int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int32_t K, int32_t per_step, const mxv_step_outputs *outs);
 /* action_space.sample() for the NEXT step index without stepping. */
 int mxv_sample_actions(mxv_handle *h, void *actions_out_dev);
-/* Which kernel instantiation the handle's LAST step / rollout launch took — the library picks among ~150 (one launch per step or K
- * fused steps, envs per lane by shard size, guarded or unguarded trigonometry, folded or runtime physics parameters, the output-dtype
- * specialisations of the trajectory launch).  Lets a test or a benchmark state which code it measured (tests/test_gpu_soak.py,
- * bench.py config.launch_info).  kernel = -1 before the first launch; mxv_rollout_mixed does not update it. */
-typedef struct mxv_launch_info {
-    int32_t kernel;        /* 0 = step_kernel (one launch per step; also EAGER / GRAPH rollouts), 1 = rollout_kernel_v3 (FUSED) */
-    int32_t env_id;
-    int32_t param_mode;    /* 1 = default attributes folded into the code, 0 = common runtime values, 2 = per-env values */
-    int32_t envs_per_lane;
-    int32_t safe;          /* 1 = guarded sin / cos (state injected, unusual reset bounds, non-default attributes) */
-    int32_t out_mode;      /* rollout_kernel_v3: 1 = trajectory outputs float64 rewards + int64 actions, 2 = float32 + int32, 0 = generic */
-    int32_t tape;          /* actions supplied by the caller */
-    int32_t steps;         /* K of the launch */
-    uint32_t grid, block;
-} mxv_launch_info;
-int mxv_last_launch(mxv_handle *h, mxv_launch_info *out);
-
 /* -- host-buffer convenience (what a NumPy-returning gym.vector.VectorEnv adapter calls) -------- */
 /* Copies through library-owned staging buffers and synchronises.  final_obs_host may be NULL. */
 int mxv_reset_host(mxv_handle *h, const uint8_t *mask_host, const double *bounds2_host, float *obs_host);
@@ -358,278 +351,6 @@ int mxv_episode_stats_host(mxv_handle *h, float *ep_return_host, int32_t *ep_len
  * (the reference's envs are restored by pickling: tests/envs/test_envs.py:192-200). */
 int mxv_set_running_returns(mxv_handle *h, const float *running_return_host);
 
-/* -- running normalisation: gym.wrappers.NormalizeObservation / NormalizeReward (gym/wrappers/normalize.py:8-144), SURVEY.md
- *    §8f-2.  One mxv_norm = one RunningMeanStd (normalize.py:8-29: fp64 mean[dim], var[dim], count = 1e-4 at creation)
- *    plus, for rewards, the wrapper's per-env discounted-return accumulator (:123), device resident.  It works on the
- *    tensors the step calls produce, K consecutive batches per call ([K][num_envs][dim]; K = 1 for a single step()):
- *    for k: rms.update(batch_k) then the affine map with the UPDATED statistics, exactly the wrappers' order.  Batch
- *    moments are formed in the reference's dtypes (float32 for observations, float64 for returns) from exact-order fp64
- *    sums (fixed binary trees: bit-reproducible, and invariant under power-of-two sharding of the env axis).
- *    dim must be one of 1, 2, 3, 4, 6.  Calls are asynchronous on `stream` (a hipStream_t; NULL = null stream). -------- */
-typedef struct mxv_norm mxv_norm;
-int mxv_norm_create(int32_t device, int32_t dim, int64_t num_envs, void *stream, mxv_norm **out);
-int mxv_norm_destroy(mxv_norm *nm);
-const char *mxv_norm_last_error(const mxv_norm *nm); /* nm may be NULL: last failed mxv_norm_create on this thread */
-int mxv_norm_set_stream(mxv_norm *nm, void *stream);
-/* obs_rms.mean / .var / .count (and NormalizeReward.returns, double[num_envs]); any pointer may be NULL.  Synchronises. */
-int mxv_norm_get_state(mxv_norm *nm, double *mean_host, double *var_host, double *count_host, double *returns_host);
-int mxv_norm_set_state(mxv_norm *nm, const double *mean_host, const double *var_host, double count, const double *returns_host);
-/* NormalizeObservation.normalize (:90-93): y[k] = (x[k] - mean) / sqrt(var + epsilon) after rms.update(x[k]).
- * x_dev float32 [K][num_envs][dim]; y_dev float64 (the reference's result dtype: float32 - float64) or float32 when
- * out_f32 != 0; y_dev may alias x_dev only when out_f32 != 0. */
-int mxv_norm_observations(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon);
-/* NormalizeReward.step (:127-145): returns = returns*gamma + rews; return_rms.update(returns); out = rews / sqrt(var +
- * epsilon); returns[terminated | truncated] = 0.  reward/out are float64 [K][num_envs] (float32 when reward_f32 != 0);
- * out_dev may alias reward_dev.  Needs dim == 1. */
-int mxv_norm_rewards(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,
-                     const uint8_t *truncated_dev, void *out_dev, double gamma, double epsilon);
-/* Split form for a vector env sharded over `world` handles / GPUs (the batch of the reference is ALL num_envs rows):
- * *_sums writes this shard's per-step (sum_0..sum_{dim-1}, sumsq_0..sumsq_{dim-1}) to sums_dev[K][2*dim] (and, for
- * rewards, advances this shard's return accumulators); the caller concatenates the shards' sums in rank order
- * (all-gather) into all_sums_dev[world][K][2*dim]; *_apply merges them (binary tree over the rank index), runs the
- * running update with batch_count = total_rows and applies the map to this shard's rows.  world <= 64.
- * The one-call forms above are *_sums + *_apply with world = 1. */
-int mxv_norm_obs_sums(mxv_norm *nm, int32_t K, const float *x_dev, double *sums_dev);
-/* the same sums from partials a rollout left behind (mxv_set_obs_partials): [K][leaves][2 dim] -> sums_dev [K][2 dim] */
-int mxv_norm_obs_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev);
-int mxv_norm_reward_sums_partials(mxv_norm *nm, int32_t K, const double *partials_dev, int64_t leaves, double *sums_dev);
-/* device address of the running discounted returns [N] (float64) this object keeps for NormalizeReward */
-int mxv_norm_returns_ptr(mxv_norm *nm, double **returns_dev);
-int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon,
-                       const double *all_sums_dev, int32_t world, int64_t total_rows);
-int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,
-                         const uint8_t *truncated_dev, double gamma, double *sums_dev);
-int mxv_norm_reward_apply(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, void *out_dev, double epsilon,
-                          const double *all_sums_dev, int32_t world, int64_t total_rows);
-
-/* -- tabular toy_text environments: FrozenLake-v1 / FrozenLake8x8-v1 / Taxi-v3 / CliffWalking-v0 ---------
- *    One table-driven engine for the reference classes whose step() is `i = categorical_sample(P[s][a] probabilities);
- *    p, s, r, t = P[s][a][i]` and whose reset() is `categorical_sample(initial_state_distrib)` (gym/envs/toy_text/
- *    frozen_lake.py:247-270, taxi.py:254-278, cliffwalking.py:148-166, utils.py:4-8), with TimeLimit and SyncVectorEnv's
- *    autoreset fused as above.  The caller supplies the MDP as dense host tables [S][A][M] (M = longest transition list):
- *    cum_prob = np.cumsum of the list's probabilities, padded with -1; prob / next_state / reward / terminated per
- *    transition (padding ignored); initial_cum[S] = np.cumsum(initial_state_distrib).  Observations and actions are
- *    int64 [N] (MultiDiscrete, gym/vector/utils/spaces.py:53-68), rewards float64, info["prob"] float64.
- *    RNG: actions from the word-per-step Philox action stream above (ctr stream id 1, Discrete(A): (word*A)>>32); transitions from a Philox4x32-10 call keyed by the env's seed, ctr =
- *    (b_lo, b_hi, 0, 3 << 28), b = t >> 1: words (x, y) serve step 2b, (z, w) step 2b+1 — first the transition's uniform, then
- *    the uniform of an autoreset inside that step; explicit resets: key = env seed, ctr = (t_lo, t_hi, r, 2<<28), r = ordinal of the reset call (word x);
- *    uniform = (word + 0.5) * 2^-32. -------------------------------- */
-typedef struct mxv_tab mxv_tab;
-typedef struct mxv_tab_config {
-    int32_t device;
-    int32_t num_states;        /* S */
-    int32_t num_actions;       /* A */
-    int32_t max_transitions;   /* M */
-    int64_t num_envs;
-    int64_t env_offset;        /* global index of local env 0 (multiple of MXV_ENV_ALIGN) */
-    int32_t max_episode_steps; /* TimeLimit; <= 0 disables (CliffWalking-v0 has none) */
-    int32_t flags;             /* MXV_TAB_FLAG_* */
-    uint64_t seed;
-    uint64_t action_seed;
-} mxv_tab_config;
-/* MXV_TAB_FLAG_COMPACT: the trajectory calls (mxv_tab_rollout, mxv_tab_rollout_tape) take and produce the contract dtypes of SURVEY.md
- * §8(d) — int32 observations / actions (tape included), float32 rewards / probs: 18 B per env-step instead of 34 — on the device tensors;
- * every other call (mxv_tab_step, reset, the host calls) keeps the reference's int64 / float64.  Same values, narrower stores. */
-enum { MXV_TAB_FLAG_COMPACT = 1, MXV_TAB_FLAG_GENERAL_KERNEL = 2 };
-/* mxv_tab_rollout launches with every per-step output present (actions, obs, reward, both flags, prob; no final_* tensors) run a
- * kernel specialised for them (gym_amd/csrc/mxv_tab.hip: tab_traj_kernel — categorical_sample as integer compares against thresholds
- * packed at create time) whenever the MDP allows the packing: transition lists of length 1 or 3 whose cumulative probabilities end at
- * 1, float32-representable rewards, 64 KiB of table at most.  Same streams, same values, bit for bit.  MXV_TAB_FLAG_GENERAL_KERNEL
- * keeps such a handle on the general kernel (the tests' A/B switch); mxv_tab_last_kernel reports which one the last step / rollout
- * call launched. */
-enum { MXV_TAB_KERNEL_NONE = 0, MXV_TAB_KERNEL_GENERAL = 1, MXV_TAB_KERNEL_TRAJECTORY = 2 };
-int mxv_tab_create(const mxv_tab_config *cfg, const double *cum_prob_host, const double *prob_host,
-                   const int32_t *next_state_host, const double *reward_host, const uint8_t *terminated_host,
-                   const double *initial_cum_host, mxv_tab **out);
-int mxv_tab_destroy(mxv_tab *h);
-const char *mxv_tab_last_error(const mxv_tab *h);
-int mxv_tab_seed(mxv_tab *h, uint64_t base_seed, const uint64_t *per_env_seeds_host);
-int mxv_tab_seed_actions(mxv_tab *h, uint64_t action_seed);
-/* mask_dev NULL = all envs; obs_dev (may be NULL) receives the states as int64. */
-int mxv_tab_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev);
-/* One vector step.  uniforms_dev: NULL = Philox; else double[2][N] = (transition uniform, autoreset uniform) per env — the
- * values the reference's np_random.random() returned, for bit-exact replays.  On terminated | truncated: obs = the reset
- * state, prob = 1.0 (reset()'s info), final_obs / final_prob = the terminal state and its transition probability
- * (info["final_observation"], info["final_info"]["prob"]; rows of other envs untouched).  Any output but obs_dev may be NULL. */
-int mxv_tab_step(mxv_tab *h, const int64_t *actions_dev, const double *uniforms_dev, int64_t *obs_dev, double *reward_dev,
-                 uint8_t *terminated_dev, uint8_t *truncated_dev, double *prob_dev, int64_t *final_obs_dev,
-                 double *final_prob_dev);
-/* K steps in ONE launch (state + TimeLimit counter in registers), actions sampled on device (Discrete(A).sample()) or read
- * from a tape int64 [K][N]; per_step != 0: outputs are [K][N] trajectories, else overwritten K times.  Integer tensors are int64 and
- * real ones float64 — int32 / float32 with MXV_TAB_FLAG_COMPACT. */
-int mxv_tab_rollout(mxv_tab *h, int32_t K, int32_t per_step, void *actions_out_dev, void *obs_dev, void *reward_dev,
-                    uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev, void *final_obs_dev,
-                    void *final_prob_dev);
-int mxv_tab_rollout_tape(mxv_tab *h, int32_t K, int32_t per_step, const void *actions_tape_dev, void *obs_dev,
-                         void *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, void *prob_dev,
-                         void *final_obs_dev, void *final_prob_dev);
-/* host-buffer convenience (staged copies, synchronising) */
-int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host);
-int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uniforms_host, int64_t *obs_host,
-                      double *reward_host, uint8_t *terminated_host, uint8_t *truncated_host, double *prob_host,
-                      int64_t *final_obs_host, double *final_prob_host);
-/* env.unwrapped.s and TimeLimit._elapsed_steps: int32 [N] each (either may be NULL) */
-int mxv_tab_get_state(mxv_tab *h, int32_t *state_host, int32_t *elapsed_host);
-int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elapsed_host);
-int mxv_tab_get_counters(mxv_tab *h, uint64_t *t, uint32_t *r);
-int mxv_tab_set_counters(mxv_tab *h, uint64_t t, uint32_t r);
-int mxv_tab_sync(mxv_tab *h);
-/* the device clock of mxv_set_device_clock for this engine: mxv_tab_step / mxv_tab_rollout / mxv_tab_rollout_tape become recordable in a
- * caller's hipGraph (explicit resets are not: their ordinal travels by value) */
-int mxv_tab_set_device_clock(mxv_tab *h, int32_t on);
-int mxv_tab_last_kernel(const mxv_tab *h);
-/* The integer form of categorical_sample's comparison (host function, no device needed): T in [0, 2^32] with
- * cum_prob > (w + 0.5) * 2^-32  <=>  w < T  for every 32-bit word w. */
-uint64_t mxv_tab_word_threshold(double cum_prob);
-int mxv_tab_set_stream(mxv_tab *h, void *stream);
-
-/* -- Blackjack-v1 (gym/envs/toy_text/blackjack.py:48-160), the toy_text env that is not a P table ------------
- *    Observation = (player total, dealer's first card, usable ace) as three int64 columns obs[3][N] (Tuple(Discrete(32),
- *    Discrete(11), Discrete(2)) batched: three MultiDiscrete arrays); actions int64 {0 stick, 1 hit}; reward float64.
- *    Cards, deck = [1..10, 10, 10, 10] (:14-19), from the Philox draw stream (round-5 contract): key = env seed, ctr = (t_lo, t_hi,
- *    call, 5 << 28); every word yields TWO cards, the first two base-13 digits of word / 2^32 (d0 = (word * 13) >> 32, d1 = ((word * 13
- *    mod 2^32) * 13) >> 32, card = deck[d]: jointly uniform up to 169 / 2^32 = 4e-8).  The eight cards of call 0 have fixed roles —
- *    cards 0..3 (words x, y): the hit card resp. the dealer's first four draws of a stick; cards 4, 5 (word z): the next episode's dealer
- *    hand; cards 6, 7 (word w): the next player hand — and the dealer's draw j >= 4 is card (j + 4) & 7 of call (j + 4) >> 3: one Philox
- *    call per step, straight-line code.  Explicit reset: key = env seed, ctr = (t_lo, t_hi, r, 2 << 28), r = ordinal of the reset call,
- *    one card per word, deck[(word * 13) >> 32] (words x, y dealer; z, w player).  Sampled actions: the Discrete(2) bit stream of the
- *    RNG contract above (stream id 6).  cards_*: optional injected draws, int8 [N][MXV_BJ_MAX_DRAWS] per step (resp. [N][4] for a
- *    reset) in the reference's consumption order (the hit card or the dealer's cards, then on termination the new dealer hand, then the
- *    new player hand) — the values np_random.choice(deck) returned, for bit-exact replays. ----------------------------------------- */
-#define MXV_BJ_MAX_DRAWS 24
-typedef struct mxv_bj mxv_bj;
-typedef struct mxv_bj_config {
-    int32_t device;
-    int32_t natural;           /* BlackjackEnv(natural=...): a winning natural pays 1.5 (ignored when sab) */
-    int32_t sab;               /* BlackjackEnv(sab=...): Sutton & Barto rules (Blackjack-v1 registers sab=True) */
-    int32_t max_episode_steps; /* <= 0: none (Blackjack-v1 has no TimeLimit) */
-    int64_t num_envs;
-    int64_t env_offset;
-    uint64_t seed;
-    uint64_t action_seed;
-} mxv_bj_config;
-int mxv_bj_create(const mxv_bj_config *cfg, mxv_bj **out);
-int mxv_bj_destroy(mxv_bj *h);
-const char *mxv_bj_last_error(const mxv_bj *h);
-int mxv_bj_seed(mxv_bj *h, uint64_t base_seed, const uint64_t *per_env_seeds_host, uint64_t action_seed);
-int mxv_bj_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int64_t *obs_dev);
-int mxv_bj_step(mxv_bj *h, const int64_t *actions_dev, const int8_t *cards_dev, int64_t *obs_dev, double *reward_dev,
-                uint8_t *terminated_dev, uint8_t *truncated_dev, int64_t *final_obs_dev);
-/* K steps in one launch; actions from actions_tape_dev int64 [K][N], or sampled (NULL; recorded in actions_out_dev if given);
- * per_step != 0: outputs are [K][...] trajectories (obs [K][3][N]). */
-int mxv_bj_rollout(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int64_t *actions_out_dev,
-                   int64_t *obs_dev, double *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, int64_t *final_obs_dev);
-/* The same with the contract's 4-byte scalars: int32 observations / actions, float32 rewards — 22 B stored per
- * env-step instead of 42. */
-int mxv_bj_rollout_compact(mxv_bj *h, int32_t K, int32_t per_step, const int64_t *actions_tape_dev, int32_t *actions_out_dev,
-                           int32_t *obs_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, int32_t *final_obs_dev);
-int mxv_bj_reset_host(mxv_bj *h, const int8_t *cards_host, int64_t *obs_host);
-int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards_host, int64_t *obs_host, double *reward_host,
-                     uint8_t *terminated_host, uint8_t *truncated_host, int64_t *final_obs_host);
-/* packed hands (see mxv_bj.hip) + TimeLimit counters, int32 [N] each; set_state also restores the step index / reset ordinal */
-int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host);
-int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapsed_host, uint64_t t, uint32_t r);
-/* step index / reset ordinal of the draw streams (checkpointing: what mxv_bj_set_state takes back) */
-int mxv_bj_get_counters(mxv_bj *h, uint64_t *t, uint32_t *r);
-int mxv_bj_set_device_clock(mxv_bj *h, int32_t on);   /* as mxv_tab_set_device_clock: mxv_bj_step / mxv_bj_rollout recordable in a caller's hipGraph */
-int mxv_bj_sync(mxv_bj *h);
-int mxv_bj_set_stream(mxv_bj *h, void *stream);
-
-/* -- collectives of a sharded vector env ------------------------------------------------------------------
- *    One logical vector env of N_total envs = `world` handles, one per GPU / process, rank r holding the contiguous global
- *    index range [r * N, (r+1) * N) (mxv_config.env_offset = r * N).  Env instances never interact (gym/vector/vector_env.py:
- *    13-16), so stepping needs no collective; the one exchange is the concatenation np.stack performs in the reference
- *    (gym/vector/sync_vector_env.py:159-169; AsyncVectorEnv gathers its workers' results the same way, async_vector_env.py:
- *    319-346): an all-gather of the shards' step outputs in rank order, here over RCCL / xGMI (librccl.so is opened with
- *    dlopen at mxv_comm_init: libmxv.so has no link-time dependency on it).
- *    Bootstrap like NCCL: one rank calls mxv_comm_unique_id and ships the MXV_COMM_ID_BYTES bytes to the others by any means
- *    (MPI, a file, torch.distributed's store ...); then every rank calls mxv_comm_init on its handle. ----------------------- */
-#define MXV_COMM_ID_BYTES 128
-int mxv_comm_unique_id(void *id_out);
-int mxv_comm_init(mxv_handle *h, int32_t rank, int32_t world, const void *unique_id);
-int mxv_comm_destroy(mxv_handle *h);
-/* Asynchronous all-gather of this shard's outputs (obs float32 [N][O], reward in the handle's reward dtype [N], terminated /
- * truncated uint8 [N]; device pointers, e.g. the last slices of a rollout chunk's trajectory tensors) into [world][...]
- * device buffers = the full (N_total, ...) tensors in global env order.  The four gathers are issued as ONE grouped RCCL
- * launch on the communicator's own high-priority stream, ordered after everything launched so far on the handle's stream;
- * the call returns immediately and later launches on the handle's stream (the next rollout chunk) overlap it.  Any
- * send/receive pair may be NULL (skipped).  The send buffers must stay untouched until the gather has completed. */
-int mxv_allgather_outputs(mxv_handle *h, const float *obs_dev, const void *reward_dev, const uint8_t *terminated_dev,
-                          const uint8_t *truncated_dev, float *all_obs_dev, void *all_reward_dev, uint8_t *all_terminated_dev,
-                          uint8_t *all_truncated_dev);
-/* Wait for the last gather (age 0) or the one before it (age 1: what a caller that alternates between two snapshot buffers
- * needs before it lets a rollout overwrite the older one — the younger gather keeps overlapping).  host_sync == 0: the handle's
- * stream waits on the GPU, the host does not block; host_sync != 0: block the host until those gathered tensors are complete. */
-int mxv_allgather_wait(mxv_handle *h, int32_t age, int32_t host_sync);
-/* the hipStream_t the gathers run on (NULL before mxv_comm_init) */
-int mxv_comm_stream(mxv_handle *h, void **stream);
-
-/* -- diagnostics ------------------------------------------------------------------------------------------------------------------
- * What this GPU sustains for the store pattern of the fused CartPole rollout with the physics removed (one wave per workgroup, two
- * envs per lane, XCD-aware tiles; obs float32 [K][N][4], reward float64 [K][N], actions int64 [K][N], two flag bytes [K][N]: 34 B
- * per env-step): microseconds per vector step, averaged over `launches` K-step launches into the caller's [K][num_envs] buffers
- * (contents destroyed).  MI355X boxes differ by 20 % on this pattern; bench.py prints the figure next to the
- * kernel's own time so that a number can be read against the box it was taken on.  Synchronises. */
-int mxv_write_probe(int32_t device, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev, double *reward_dev, int64_t *actions_dev,
-                    uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step);
-
-/* The same for any env kind and output dtypes (flags: MXV_FLAG_REWARD_F32 | MXV_FLAG_ACTION_I32): observation rows of that kind's width,
- * envs per lane as its fused rollout runs them, Box actions float32.  mxv_write_probe_env(MXV_CARTPOLE, 0, ...) is mxv_write_probe. */
-int mxv_write_probe_env(int32_t device, int32_t env_id, int32_t flags, int64_t num_envs, int32_t K, int32_t launches, float *obs_dev,
-                        void *reward_dev, void *actions_dev, uint8_t *terminated_dev, uint8_t *truncated_dev, double *us_per_step);
-
-/* -- placed device memory for trajectory tensors ------------------------------------------------------------------------------------
- *    The fused rollout's outputs are a few long, parallel store streams.  On the MI355X a 16-byte-per-lane stream (observations) and
- *    an 8-byte-per-lane stream (rewards, actions) written concurrently run 10-12 % slower when the PHYSICAL memory behind them lies in
- *    the same CLASS of HBM regions — the classes are three contiguous thirds of the physical address space (3 x 96 GB: what the three
- *    ranks of a 12-high HBM3E stack would give; profiles/r3/r3c_hbm_class_map_whole_device.jsonl) —; a whole CartPole trajectory launch
- *    runs 5.4 / 5.7 / 6.4 us per 2^20-env step with none / one / both of {rewards, actions} in the observations' class (DESIGN.md §6,
- *    profiles/r3/r3a_*).  A fresh process is handed the first third for its first ~90 GiB, so hipMalloc'ed tensors all share a class unless
- *    earlier activity scrambled the driver's free lists — the "placement lottery" of rounds 1-2.  This call builds the tensors from
- *    256-MiB physical chunks (hipMemCreate) whose class it MEASURES (two concurrent streams against a reference chunk of each class
- *    seen so far) and maps chunks of one class under the tensors of one group and chunks of the other classes under the other group
- *    (group -1: whatever is left), each tensor contiguous in a fresh virtual range.
- *    Transient physical memory: chunks up to 2x the request; in addition, while only ONE class has been seen, unmapped spacer
- *    allocations (4 GiB each) that make the next chunk come from further along in physical memory — up to half of the device's free
- *    memory (at most 112 GiB; never into the last 16 GiB), released before the call returns; MXV_PLACED_NO_JUMP forbids the spacers
- *    (then a process that sits deep inside one class gets best effort: info.balanced = 0).  0.2-1.5 s.
- *    Sets below MXV_PLACED_MIN_BYTES (2 GiB: the real kernel runs 4-10 % slower on memory mapped through this API than on hipMalloc'ed
- *    memory, which the 8 % a 2^17-env shard of 1 GiB gains from separated classes does not win back — such sets are better served by
- *    ordinary allocations SORTED by class with mxv_hbm_pair_probe, what gym_amd/placement.py does from 1 GiB on), sets with an empty
- *    group and MXV_PLACED_PLAIN take ordinary hipMalloc allocations (info.placed = 0).
- *    bytes[i] > 0, group[i] in {-1, 0, 1}; ptrs_out[i] receives tensor i's device address (contents uninitialised).  mxv_placed_free
- *    releases the physical memory; the virtual ranges are NOT returned to the runtime (this runtime keeps stale translations for an
- *    address that is mapped a second time), i.e. every call consumes a little virtual address space for the life of the process. */
-typedef struct mxv_placed mxv_placed;
-#define MXV_PLACED_CHUNK_BYTES ((size_t)256 << 20)
-#define MXV_PLACED_MIN_BYTES ((size_t)2 << 30)
-enum { MXV_PLACED_PLAIN = 1, MXV_PLACED_NO_JUMP = 2 };
-typedef struct mxv_placed_info {
-    int32_t placed;            /* 1: chunks placed by class; 0: ordinary allocations */
-    int32_t balanced;          /* 1: the two groups share no class */
-    int32_t chunks_created;    /* physical chunks created (and classified) in total */
-    int32_t chunks_kept;
-    int32_t classes_seen;
-    int32_t class_chunks[4];   /* chunks held of each class when the search ended (class 0 = the class of the first chunk) */
-    int32_t solo_group;        /* the group that sits alone on class solo_class; the other group takes the other classes */
-    int32_t solo_class;
-    int32_t stop_reason;       /* why the search ended: 0 balanced, 1 chunk cap, 2 jump budget, 3 spacer allocation failed, 4 chunk allocation failed */
-    double same_class_us;      /* the two-stream probe window, us per 2^20-lane step, both streams in one class ... */
-    double different_class_us; /* ... and in different classes (0 if never seen) */
-    double seconds;            /* wall time of the call */
-    size_t requested_bytes, held_bytes, peak_bytes, jumped_bytes; /* peak: chunks + spacers at the worst moment; jumped: spacers */
-} mxv_placed_info;
-/* The measurement underneath: one 16-step window of two concurrent store streams of the rollout's launch shape (2^20 lanes), a 16-B/lane
- * stream over the 256 MiB at wide_dev and an 8-B/lane stream over the 128 MiB at narrow_dev (contents destroyed), us per step, best of
- * three timings of `launches` launches.  The same-class time of a box is ~4.2-4.4 us, a different-class pair runs at 0.89-0.91 of it:
- * compare against a pair known to share a class (two halves of one allocation), timed next to it. */
-int mxv_hbm_pair_probe(int32_t device, void *wide_dev, void *narrow_dev, int32_t launches, double *us_per_step);
-int mxv_placed_alloc(int32_t device, int32_t count, const size_t *bytes, const int32_t *group, int32_t flags, void **ptrs_out,
-                     mxv_placed **out);
-int mxv_placed_free(mxv_placed *p);
-int mxv_placed_info_get(const mxv_placed *p, mxv_placed_info *out);
-const char *mxv_placed_last_error(const mxv_placed *p); /* p may be NULL: last failed mxv_placed_alloc on this thread */
-
 /* -- stream / sync -------------------------------------------------------------------------------- */
 /* Waits for the handle's stream; returns MXV_ERR_INVALID_ACTION if a step since the last
  * sync saw an out-of-range action (and clears the latch). */
@@ -645,4 +366,15 @@ int mxv_wait_stream(mxv_handle *h, void *other_stream);
 #ifdef __cplusplus
 }
 #endif
+
+/* The rest of the ABI lives in per-subsystem headers, included here so that `#include "mxv.h"` declares the whole product surface:
+ *   mxv_norm.h     NormalizeObservation / NormalizeReward kernels (mxv_norm_*)
+ *   mxv_toytext.h  tabular toy_text engine (mxv_tab_*) and Blackjack (mxv_bj_*)
+ *   mxv_comm.h     RCCL collectives of a sharded vector env (mxv_comm_*, mxv_allgather_*)
+ * and, NOT included here (optional; include it yourself):
+ *   mxv_diag.h     diagnostics: mxv_last_launch, write / HBM-class probes, placed memory */
+#include "mxv_norm.h"
+#include "mxv_toytext.h"
+#include "mxv_comm.h"
+
 #endif /* MXV_H */

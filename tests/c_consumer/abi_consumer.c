@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "mxv.h"
+#include "mxv_diag.h"   /* optional diagnostics: the consumer prints the layout of mxv_placed_info and mxv_launch_info too */
 
 #define FN(name) static __typeof__(name) *p_##name
 FN(mxv_version);
