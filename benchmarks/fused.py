@@ -8,7 +8,8 @@ from .common import _event_us, _hbm, _spin
 def measure_fused(torch, env_id, envs, chunk, *, compact=False, launches=8, spin_ms=60.0, probe=True, valu=False, placement_mode=None):
     """One env kind, fused trajectory launches on one GPU: us per step, env-steps/s, roofline on the algorithmic bytes, the
     write probe of its own store pattern into the same tensors.  placement_mode: MXV_PLACEMENT for the allocation of the trajectory
-    tensors ("search": the long walk of rounds 3-4; default: the process's setting, i.e. at most 8 GiB parked)."""
+    tensors ("cheap": at most 8 GiB parked; "search": the long walk; default: the process's setting — auto: the long walk only on an
+    otherwise empty device)."""
     import os
 
     from gym_amd import _native

@@ -14,13 +14,16 @@ next to it, so no absolute threshold is involved) and, if it lies on the wrong s
 which lies further along in physical memory.  Parked tensors are released at the end.  Typical: a few GiB parked for 0.1 s; a fresh
 device: up to ~90 GiB for ~3 s.  Nothing here touches the results: only WHERE the tensors live.
 
-Three modes (MXV_PLACEMENT):
-  on / unset ("cheap", the default)  the walk may park at most 8 GiB beside the set (and never more than half of the memory that is free
-        beyond the set): in a learner's process, whose allocator already holds blocks all over the device, that is enough to find the two
-        classes; in a FRESH process whose first ~90 GiB all lie in one class it is not — the set then comes back with balanced = False and
-        runs 4-18 % slower than a sorted one (bench.py: headline vs variants.placement_search).  A product default must not take a quarter
-        of the device for a second;
-  search  round 3-4's behaviour: up to 112 GiB parked transiently (~1-3 s on a fresh device) to leave the first class;
+Modes (MXV_PLACEMENT):
+  auto / on / unset (the default)  "cheap" whenever anybody holds device memory — this process's learner, another process, another rank:
+        less than 90 % of the device free beyond the set —, "search" only on an otherwise EMPTY device, where parked memory disturbs
+        nobody and is released before the call returns (a dedicated rollout or benchmark process).  The report says which it was;
+  cheap   the walk may park at most 8 GiB beside the set (and never more than half of the memory that is free beyond the set): in a
+        learner's process, whose allocator already holds blocks all over the device, that is enough to find the two classes; in a fresh
+        process whose first ~90 GiB all lie in one class it is not — the set then comes back with balanced = False and runs 5-17 % slower
+        than a sorted one (bench.py: variants.placement_cheap against the headline).  A product default must not take a quarter of the
+        device beside a learner;
+  search  up to 112 GiB parked transiently (~1-3 s on a fresh device) to leave the first class, whoever else is there;
   off     never sort — ordinary allocations, no probe launches, no synchronisation, nothing parked.
 MXV_PLACEMENT_MAX_PARK_GIB overrides the cap of either mode.  An out-of-memory error inside the walk ends it with ordinary allocations
 instead of reaching the caller.
@@ -52,12 +55,25 @@ SEARCH_MAX_PARK_BYTES = 112 << 30       # MXV_PLACEMENT=search (a fresh device n
 DEFAULT_MAX_PARK_BYTES = CHEAP_MAX_PARK_BYTES
 
 
+EMPTY_DEVICE_FRACTION = 0.90            # auto: the long walk only when at least this much of the device is free (nobody to disturb)
+
+
 def mode() -> str:
-    """"off" | "cheap" | "search" from MXV_PLACEMENT (unset / on / 1 / cheap -> "cheap")."""
-    v = os.environ.get("MXV_PLACEMENT", "on").strip().lower()
+    """"off" | "auto" | "cheap" | "search" from MXV_PLACEMENT (unset / on / 1 / auto -> "auto")."""
+    v = os.environ.get("MXV_PLACEMENT", "auto").strip().lower()
     if v in ("off", "0", "no", "false"):
         return "off"
-    return "search" if v == "search" else "cheap"
+    return v if v in ("search", "cheap") else "auto"
+
+
+def resolve_mode(free_bytes: Optional[int] = None, total_bytes: Optional[int] = None) -> str:
+    """"cheap" or "search" for this call: an explicit MXV_PLACEMENT wins; "auto" walks far only on an otherwise empty device."""
+    m = mode()
+    if m != "auto":
+        return m
+    if free_bytes is None or not total_bytes:
+        return "cheap"
+    return "search" if free_bytes >= EMPTY_DEVICE_FRACTION * total_bytes else "cheap"
 
 
 def enabled() -> bool:
@@ -66,13 +82,13 @@ def enabled() -> bool:
     return mode() != "off"
 
 
-def max_park_bytes() -> int:
-    """Upper bound of the memory the walk may hold transiently: MXV_PLACEMENT_MAX_PARK_GIB if set, else 8 GiB (default mode) or 112 GiB
-    (MXV_PLACEMENT=search)."""
+def max_park_bytes(resolved: Optional[str] = None) -> int:
+    """Upper bound of the memory the walk may hold transiently: MXV_PLACEMENT_MAX_PARK_GIB if set, else 112 GiB for a "search" walk and
+    8 GiB otherwise (`resolved`: what resolve_mode() returned for this call; default: the environment's explicit mode)."""
     try:
         return max(0, int(float(os.environ["MXV_PLACEMENT_MAX_PARK_GIB"]) * (1 << 30)))
     except (KeyError, ValueError):
-        return SEARCH_MAX_PARK_BYTES if mode() == "search" else CHEAP_MAX_PARK_BYTES
+        return SEARCH_MAX_PARK_BYTES if (resolved or mode()) == "search" else CHEAP_MAX_PARK_BYTES
 
 
 def _is_oom(e: BaseException) -> bool:
@@ -105,6 +121,9 @@ class _Device:
 
     def free_bytes(self) -> int:
         return torch.cuda.mem_get_info(self.dev)[0]
+
+    def total_bytes(self) -> int:
+        return torch.cuda.mem_get_info(self.dev)[1]
 
     def probe(self, wide_ptr: int, narrow_ptr: int) -> float:
         return _native.hbm_pair_probe(self.dev.index, wide_ptr, narrow_ptr, 4)
@@ -187,8 +206,10 @@ def _sorted_locked(specs, groups, be, budget_bytes):
     nbytes = {n: _nbytes(spec[n][0], spec[n][1]) for n in names}
     g0 = [n for n in names if groups.get(n) == 0]
     g1 = [n for n in names if groups.get(n) == 1]
-    report = {"kind": "sorted", "mode": mode(), "balanced": False, "parked_GiB": 0.0, "candidates": 0, "remembered": 0,
-              "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
+    free_now = be.free_bytes()
+    resolved = resolve_mode(free_now, getattr(be, "total_bytes", lambda: None)())
+    report = {"kind": "sorted", "mode": resolved if mode() != "auto" else f"auto->{resolved}", "balanced": False, "parked_GiB": 0.0,
+              "candidates": 0, "remembered": 0, "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
 
     dirty = [True]     # allocations (and their zero fills) issued since the last device synchronisation
 
@@ -206,7 +227,7 @@ def _sorted_locked(specs, groups, be, budget_bytes):
     if nbytes[anchor_name] < WIDE + NARROW or any(nbytes[n] < NARROW for n in g0 + g1):
         return plain("tensors too small to classify: ordinary allocations")
     # what may be parked beside the set: half of what is free once the set itself is counted, never more than the cap
-    budget = (min(max(be.free_bytes() - sum(nbytes.values()), 0) // 2, max_park_bytes()) if budget_bytes is None else int(budget_bytes))
+    budget = (min(max(free_now - sum(nbytes.values()), 0) // 2, max_park_bytes(resolved)) if budget_bytes is None else int(budget_bytes))
     report["budget_GiB"] = round(budget / 2**30, 2)
     parked, parked_bytes = [], 0
     warmed = [False]

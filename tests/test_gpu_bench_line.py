@@ -98,14 +98,14 @@ def test_line_carries_what_the_review_asked_for(run):
     assert line["n_gpus"] == 1 and line["config"]["ranks_seen"] == 1 and line["dtype"] == "f64"
     roof, cfg = line["roofline"], line["config"]
     assert roof["frac"] == pytest.approx(roof["achieved"] / 8000.0) and 0.3 < roof["frac"] < 0.9
-    # the product default: at most 8 GiB parked — balanced or not depends on where this process's memory starts;
-    # what the cap costs on this box is the headline against the same configuration placed with the long walk (MXV_PLACEMENT=search)
-    assert cfg["placement"]["kind"].startswith("sorted") and cfg["placement"]["mode"] == "cheap" and cfg["placement"]["parked_GiB"] <= 8.0
-    ps = v["placement_search"]
-    assert ps["placement"]["mode"] == "search" and ps["placement"]["balanced"] is True and ps["placement"]["parked_GiB"] <= 112
-    assert ps["us_per_step"] <= 1.03 * line["ms_per_step"] * 1e3 and line["ms_per_step"] * 1e3 <= 1.25 * ps["us_per_step"]
-    if cfg["placement"]["balanced"]:
-        assert line["ms_per_step"] * 1e3 <= 1.05 * ps["us_per_step"]
+    # the product default (MXV_PLACEMENT unset = auto): this benchmark process has the device to itself, so the placement walks as far as it
+    # must and releases what it parked; beside anybody else's memory it would stop at 8 GiB — what that cap costs on
+    # this box is variants.placement_cheap against the headline
+    assert cfg["placement"]["kind"].startswith("sorted") and cfg["placement"]["mode"] == "auto->search"
+    assert cfg["placement"]["balanced"] is True and cfg["placement"]["parked_GiB"] <= 112
+    pc = v["placement_cheap"]
+    assert pc["placement"]["mode"] == "cheap" and pc["placement"]["parked_GiB"] <= 8.0
+    assert 0.97 * line["ms_per_step"] * 1e3 <= pc["us_per_step"] <= 1.30 * line["ms_per_step"] * 1e3
     ref = headline["cpu_baseline"]["reference_python"]
     assert ref["source"].startswith("profiles/reference_cpu_baseline.json") and ref["value"] > 1e4
     assert not [k for k, x in v.items() if isinstance(x, dict) and "error" in x], v
@@ -122,7 +122,7 @@ def test_line_carries_what_the_review_asked_for(run):
         both_balanced = all((v[k].get("placement") or {}).get("balanced") for k in (key, ref_key))
         # fewer bytes per env-step cannot be slower — where both sets ended up sorted by HBM class (one that did not runs 10-20 % slower)
         assert v[key]["value"] >= (0.95 if both_balanced else 0.75) * v[ref_key]["value"], (key, v[key].get("placement"), v[ref_key].get("placement"))
-    assert v["compact_cartpole"]["roofline"]["stored_bytes_per_env_step"] == 26 and v["compact_cartpole"]["value"] >= 0.9 * line["value"]     # (0.9: either set may have ended up unsorted under the 8-GiB cap)
+    assert v["compact_cartpole"]["roofline"]["stored_bytes_per_env_step"] == 26 and v["compact_cartpole"]["value"] >= line["value"]
     rv = v["configs3_acrobot_shard"]["roofline_valu"]
     assert rv["source"].startswith("profiles/valu_") and rv["frac"] > 0.5 and 500 < rv["valu_instructions_per_env_step"] < 900
     for key in ("compact_frozenlake8x8", "compact_taxi"):                # the table engine with the contract dtypes: 18 B stored
@@ -141,7 +141,7 @@ def test_line_carries_what_the_review_asked_for(run):
     assert nl["num_envs_2^20"]["value"] > 2e8 and nl["configs0_num_envs_8"]["value"] > 5e4 and nl["num_envs_2^20"]["episodes_ended"] > 0
     assert v["configs4_mixed_share"]["value"] > 1e10
     share = v["strong_scaling_share_of_8"]                    # 2^17 envs: what each GPU of an 8-GPU strong-scaling job steps
-    assert share["placement"]["mode"] == "cheap" and share["us_per_step"] * 8 < 1.45 * line["ms_per_step"] * 1e3
+    assert share["placement"]["balanced"] is True and share["us_per_step"] * 8 < 1.35 * line["ms_per_step"] * 1e3
     sl = v["step_loop"]
     assert sl["one_engine"]["roofline"]["algorithmic_bytes_per_env_step"] == 66
     assert sl["one_engine"]["roofline"]["frac"] > 0.38        # round 2's loop: 0.34 (a cross-stream wait per step), kernel 0.44

@@ -127,6 +127,8 @@ def test_placement_beside_a_process_that_holds_most_of_the_device():
             rep = j["placement"]
             assert rep["kind"] == "sorted" and rep["parked_GiB"] <= rep.get("budget_GiB", 0) + 0.01, rep
             assert rep.get("budget_GiB", 0) <= (j["free0_GiB"] - 8.5) / 2 + 0.5
+            if not extra:       # the default beside somebody who holds most of the device: the 8-GiB cap, not the long walk
+                assert rep["mode"] == "auto->cheap" and rep["parked_GiB"] <= 8.0 and rep["budget_GiB"] <= 8.0, rep
             if "MXV_PLACEMENT_MAX_PARK_GIB" in extra:
                 assert rep["budget_GiB"] <= 2.0 and rep["parked_GiB"] <= 2.0
     finally:

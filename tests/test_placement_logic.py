@@ -406,7 +406,7 @@ def test_the_default_mode_parks_at_most_eight_gib(monkeypatch):
     classes — a learner's process — the same 8 GiB are plenty; MXV_PLACEMENT=search restores the long walk."""
     from gym_amd import placement
 
-    monkeypatch.setenv("MXV_PLACEMENT", "on")
+    monkeypatch.setenv("MXV_PLACEMENT", "cheap")
     assert placement.mode() == "cheap" and placement.max_park_bytes() == 8 * GiB
     fresh = SimDevice([(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")])
     out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=fresh)
@@ -424,11 +424,38 @@ def test_the_default_mode_parks_at_most_eight_gib(monkeypatch):
     assert rep["mode"] == "search" and rep["balanced"] is True and rep["parked_GiB"] >= 80
 
 
+def test_auto_walks_far_only_on_an_otherwise_empty_device(monkeypatch):
+    """The default (MXV_PLACEMENT unset = auto): the long walk when at least 90 % of the device is free — a dedicated rollout / benchmark
+    process: the parked memory disturbs nobody and is released before the call returns —, the 8-GiB cap as soon as anybody (this process's
+    learner, another process, another rank) holds memory."""
+    from gym_amd import placement
+
+    monkeypatch.delenv("MXV_PLACEMENT", raising=False)
+    assert placement.mode() == "auto"
+    regions = [(91 * GiB, "A"), (187 * GiB, "B"), (288 * GiB, "C")]
+
+    class WithTotal(SimDevice):
+        def total_bytes(self):
+            return 288 * GiB
+
+    empty = WithTotal(regions, free=286 * GiB)
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=empty)
+    assert rep["mode"] == "auto->search" and rep["balanced"] is True and rep["parked_GiB"] >= 80 and empty.live == sum(t.n for t in out.values())
+    shared = WithTotal(regions, free=200 * GiB)                    # somebody holds 88 GiB
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=shared)
+    assert rep["mode"] == "auto->cheap" and rep["balanced"] is False and rep["parked_GiB"] <= 8.0 and rep["budget_GiB"] == 8.0
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, None, _backend=SimDevice(regions))      # a backend that cannot say: the cap
+    assert rep["mode"] == "auto->cheap" and rep["parked_GiB"] <= 8.0
+    assert placement.resolve_mode(280 * GiB, 288 * GiB) == "search" and placement.resolve_mode(250 * GiB, 288 * GiB) == "cheap"
+    monkeypatch.setenv("MXV_PLACEMENT", "cheap")
+    assert placement.resolve_mode(288 * GiB, 288 * GiB) == "cheap"
+
+
 def test_environment_switch(monkeypatch):
     from gym_amd import placement
 
     monkeypatch.delenv("MXV_PLACEMENT", raising=False)
-    assert placement.enabled() and placement.mode() == "cheap"
+    assert placement.enabled() and placement.mode() == "auto"
     for v in ("off", "0", "OFF", "no", "false"):
         monkeypatch.setenv("MXV_PLACEMENT", v)
         assert not placement.enabled()
