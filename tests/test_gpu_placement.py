@@ -18,6 +18,11 @@ SPECS = [("obs", (K, N, 4), "<f4", 0), ("reward", (K, N), "<f8", 1), ("actions",
 
 
 def test_placed_memory_is_real_private_and_returned():
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()            # (whatever earlier tests left in the caching allocator must not be released between the two readings)
+    torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info(0)
     mem = _native.PlacedMemory(0, SPECS)
     info = mem.info

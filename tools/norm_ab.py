@@ -9,8 +9,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+from benchmarks.normalize import measure_normalize  # noqa: E402
 
 for rep in range(3):
-    r = bench.measure_normalize(torch, 1 << 20, 128)
+    r = measure_normalize(torch, 1 << 20, 128)
     print(json.dumps({k: {"us_per_step": round(r[k]["us_per_step"], 3), "frac": round(r[k]["roofline"]["frac"], 3)} for k in ("normalize_obs", "normalize_reward")}), flush=True)

@@ -45,7 +45,7 @@ def main():
         g = load_golden(name, "p1")
         n = len(g["action"])
         eng = HipEngine(name, n, 0, autoreset=False)
-        eng.set_state(g["state0"].T, np.zeros(n, np.int32))
+        eng.set_state(g["state0"].T, np.where(g["fresh"] == 1, 0, 5).astype(np.int32))     # (MountainCarContinuous: float32 state after any step)
         obs, rew, term, trunc, _ = eng.step(g["action"])
         st, _ = eng.get_state()
         every = np.ones(n, bool)
