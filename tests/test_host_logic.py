@@ -773,3 +773,43 @@ def test_vector_make_recognises_the_sub_env_wrappers_it_can_map():
     except Exception:  # noqa: BLE001
         return
     assert _sub_env_wrappers([functools.partial(RefLimit, max_episode_steps=30), RefStats]) == (30, [("episode_statistics", {})])
+
+
+def test_vector_make_wrappers_replay_the_reference_on_the_host_adapter(monkeypatch):
+    """The host side of make(wrappers=[partial(TimeLimit, max_episode_steps=12), RecordEpisodeStatistics]) without a device: the adapter over
+    an oracle-backed handle (tests/oracle_engine.py) replays tests/golden/vector_make_wrappers_CartPole.npz — what the REFERENCE's
+    per-sub-env wrappers produced — mask for mask, with `final_info[i]["episode"]` where the reference puts it (the GPU twin of this
+    test, through the HIP engine: tests/test_gpu_vector_env.py)."""
+    import functools
+
+    import gym_amd
+    from gym_amd import _native
+    from gym_amd.wrappers import RecordEpisodeStatistics, SubEnvEpisodeStatistics
+    from oracle_engine import PackedFakeHandle
+
+    class TimeLimit:
+        pass
+
+    monkeypatch.setattr(_native, "Handle", PackedFakeHandle)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vector_make_wrappers_CartPole.npz"))
+    T, N = g["action"].shape
+    env = gym_amd.make("CartPole-v1", num_envs=N, wrappers=[functools.partial(TimeLimit, max_episode_steps=int(g["max_episode_steps"])),
+                                                             functools.partial(RecordEpisodeStatistics, deque_size=7)])
+    assert isinstance(env, SubEnvEpisodeStatistics) and env.return_queue.maxlen == 7
+    env.reset(seed=1)
+    handle = env.unwrapped.handle
+    episodes = 0
+    for t in range(T):
+        handle.set_state(np.ascontiguousarray(g["state_pre"][t].T), g["elapsed_pre"][t])
+        obs, rew, term, trunc, infos = env.step(g["action"][t])
+        assert np.array_equal(term, g["terminated"][t]) and np.array_equal(trunc, g["truncated"][t]) and np.array_equal(rew, g["reward"][t]), t
+        assert "episode" not in infos and "_episode" not in infos
+        done = g["ep_mask"][t]
+        assert np.array_equal(obs[~done], g["obs"][t][~done])            # the oracle is bit-exact against the reference
+        for i in np.flatnonzero(done):
+            ep = infos["final_info"][i]["episode"]
+            assert isinstance(ep["r"], np.float32) and isinstance(ep["l"], np.int32) and isinstance(ep["t"], float)
+            assert ep["r"] == g["ep_r"][t][i] and ep["l"] == g["ep_l"][t][i], (t, i, ep)
+            episodes += 1
+    assert episodes == int(g["ep_mask"].sum()) and env.episode_count == episodes and len(env.return_queue) == 7
+    env.close()

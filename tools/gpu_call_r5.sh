@@ -18,5 +18,6 @@ cd $GRAFT_REPO_ROOT
 find $O/variants_trace $O/compact_pmc_FETCH_SIZE $O/compact_pmc_WRITE_SIZE -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete 2>/dev/null
 ( time timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --variants-file $O/bench_driver_args_variants.json --headline-file $O/bench_driver_args_headline.json > $O/bench_driver_args.json 2> $O/bench_driver_args.err ) 2> $O/bench_driver_args.time
 timeout 400 python bench.py --variants-file $O/bench_default_variants.json --headline-file $O/bench_default_headline.json > $O/bench_default.json 2> $O/bench_default.err
-MXV_PLACEMENT=search timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-variants --no-cpu-baseline --headline-file "" > $O/bench_driver_args_placement_search.json 2> /dev/null
+python tools/parity_report.py > $O/parity_report.json 2> /dev/null
+bash tools/gpu_valu_bj.sh $R > $O/valu_bj.log 2>&1
 echo done > $O/finished
