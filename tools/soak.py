@@ -58,6 +58,39 @@ def main():
         hb.close()
         total += 4099 * 200
         print(f"ok Blackjack-v1 seed={seed}", flush=True)
+    # Blackjack, round-5 kernel and draw contract: fused sampled rollouts (both dtype sets, every rule set, TimeLimits, ragged sizes, shard
+    # offsets, random launch lengths) against the oracle twin stepping with its own sampled actions — every output of every step
+    from gym_amd.toy_text import BlackjackRollout
+
+    rng_b = np.random.default_rng(int(os.environ.get("SOAK_RANDOM_SEED", "20260924")))
+    for case in range(int(os.environ.get("SOAK_BLACKJACK_CASES", "24"))):
+        n = int(rng_b.choice([1, 63, 64, 65, 255, 256, 257, 4099, 70001]))
+        rules = [dict(sab=True), dict(natural=True, sab=False), dict(natural=False, sab=False)][case % 3]
+        limit = None if rng_b.random() < 0.5 else int(rng_b.integers(1, 6))
+        seed, aseed, off = int(rng_b.integers(1 << 40)), int(rng_b.integers(1 << 40)), int(rng_b.integers(0, 1 << 30)) * 4
+        compact = bool(case & 1)
+        r = BlackjackRollout(n, seed=seed, action_seed=aseed, env_offset=off, compact=compact, max_episode_steps=limit, **rules)
+        o = OracleBlackjack(n, seed=seed, action_seed=aseed, env_offset=off, max_episode_steps=limit, natural=rules.get("natural", False),
+                            sab=rules.get("sab", False))
+        assert np.array_equal(r.reset(seed=seed).cpu().numpy(), o.reset(seed=seed))
+        games = 0
+        for launch in range(3):
+            K = int(rng_b.integers(1, 70))
+            out = r.rollout_per_step(K, out=r.trajectory_buffers(K, layout="separate", want_final=True))
+            r.synchronize()
+            d = {k: v.cpu().numpy() for k, v in out.items()}
+            for k in range(K):
+                w = o.step()
+                assert np.array_equal(d["actions"][k], w["actions"]) and np.array_equal(d["obs"][k], w["obs"]), (case, launch, k)
+                assert np.array_equal(d["reward"][k].astype(np.float64), w["reward"]), (case, launch, k)
+                assert np.array_equal(d["terminated"][k].astype(bool), w["terminated"].astype(bool))
+                assert np.array_equal(d["truncated"][k].astype(bool), w["truncated"].astype(bool))
+                m = w["final_mask"].astype(bool)
+                assert np.array_equal(d["final_obs"][k][:, m], w["final_obs"][:, m])
+                games += int(m.sum())
+            total += n * K
+        r.close()
+        print(f"ok Blackjack fused vs twin case={case:<3d} n={n:<6d} {'compact' if compact else 'ref    '} rules={rules} limit={limit} games={games}", flush=True)
     # long horizons: the fused rollout (rollout_kernel_v3: K steps per launch, ready-made resets in LDS, look-ahead refills) against
     # one launch per step (step_kernel), bit for bit over thousands of steps — every output of every step, then state, elapsed
     # steps, reset ordinals and counters
