@@ -92,6 +92,7 @@ class DeviceRollout:
         if seed is not None:
             self.handle.seed(seed)
         self.handle.reset(self.obs, mask_dev=mask, bounds=bounds)
+        self.ready()        # resets are rare: the returned tensor is safe to read on the caller's current stream (GPU-side ordering, no host wait)
         return self.obs
 
     def step(self, actions: torch.Tensor, want_final: bool = True):

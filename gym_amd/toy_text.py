@@ -494,6 +494,7 @@ class TabularRollout:
         if seed is not None:
             self.handle.seed(seed)
         self.handle.reset(self.obs)
+        self.ready()        # the returned tensor is safe to read on the caller's current stream (GPU-side ordering, no host wait)
         return self.obs
 
     def trajectory_buffers(self, K: int, layout: str = "auto"):
@@ -621,6 +622,7 @@ class BlackjackRollout:
         if seed is not None:
             self.handle.seed(seed, action_seed=self.handle._action_seed)
         self.handle.reset(self.obs)
+        self.ready()        # the returned tensor is safe to read on the caller's current stream (GPU-side ordering, no host wait)
         return self.obs
 
     def trajectory_buffers(self, K: int, layout: str = "auto", want_final: bool = False):

@@ -722,3 +722,41 @@ def test_vector_make_with_recognised_sub_env_wrappers_against_the_reference():
     lake = gym_amd.make("FrozenLake-v1", num_envs=4, wrappers=functools.partial(TimeLimit, max_episode_steps=6))
     assert lake.get_attr("_max_episode_steps") == (6,) * 4
     lake.close()
+
+
+def test_reset_outputs_are_ordered_on_the_callers_stream():
+    """`obs = r.reset(seed=s)` of the device-resident front-ends returns a tensor the CALLER may read at once on its own stream: the engines
+    launch on a non-blocking stream of their own, so without an ordering the caller's `.cpu()` could run before the reset kernel — or, as
+    here, before the long rollout queued in front of it (round 5: tools/soak.py read a Blackjack reset before it had happened)."""
+    import torch
+    from gym_amd.rollout import DeviceRollout
+    from gym_amd.toy_text import BlackjackRollout, TabularRollout
+    from oracle.oracle import OracleBlackjack, OracleVecEnv
+
+    n = 1 << 18
+    r = DeviceRollout("CartPole-v1", n, seed=3, action_seed=4)
+    r.reset(seed=3)
+    out = r.trajectory_buffers(256, layout="separate")
+    o = OracleVecEnv(0, n, 500, seed=77, action_seed=4)
+    want = o.reset(seed=77)
+    for _ in range(3):
+        r.rollout_per_step(256, out=out)                     # ~0.4 ms of work queued on the engine's stream ...
+        got = r.reset(seed=77).cpu().numpy()                 # ... then the reset, read at once on the default stream
+        assert np.array_equal(got, want)
+        r.handle.seed(3)
+    r.close()
+    b = BlackjackRollout(n, seed=1, action_seed=2)
+    b.reset(seed=1)
+    traj = b.trajectory_buffers(128, layout="separate")
+    wantb = OracleBlackjack(n, seed=9, action_seed=2, sab=True).reset(seed=9)
+    for _ in range(3):
+        b.rollout_per_step(128, out=traj)
+        assert np.array_equal(b.reset(seed=9).cpu().numpy(), wantb)
+    b.close()
+    t = TabularRollout("FrozenLake8x8-v1", n, seed=1, action_seed=2)
+    first = t.reset(seed=5).cpu().numpy().copy()
+    tr = t.trajectory_buffers(128, layout="separate")
+    for _ in range(3):
+        t.rollout_per_step(128, out=tr)
+        assert np.array_equal(t.reset(seed=5).cpu().numpy(), first) and (first == 0).all()      # FrozenLake starts in state 0
+    t.close()
