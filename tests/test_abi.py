@@ -125,6 +125,21 @@ def test_product_code_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower().replace("# oracle-free", ""), f"{f} mentions the oracle"
                 assert "liborc" not in src
+    # the bench: only bench.py's cpu_baseline leg may load the oracle (as the host baseline); benchmarks/*.py and examples/ never import it
+    import ast
+
+    for d in ("benchmarks", "examples"):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(ROOT, d, f)).read())
+            mods = [n.module or "" for n in ast.walk(tree) if isinstance(n, ast.ImportFrom)] + \
+                   [a.name for n in ast.walk(tree) if isinstance(n, ast.Import) for a in n.names]
+            assert not [m for m in mods if m.split(".")[0] == "oracle"], f"{d}/{f} imports the oracle"
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    users = [fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef)
+             for n in ast.walk(fn) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
+    assert users == ["cpu_baseline"], users
 
 
 def _header_prototypes():
