@@ -601,6 +601,9 @@ def _sub_env_wrappers(wrappers):
                                               wrapper truncates at k, the registered inner one at the spec's limit)
         RecordEpisodeStatistics(deque_size=)  the fused episode accumulators, reported in infos["final_info"][i]["episode"]
         OrderEnforcing, PassiveEnvChecker     what gym.make applies anyway: accepted, nothing to do
+        ClipAction                            Box-action ids only (clip_action.py:28 asserts it): np.clip(action, low, high) before a step whose
+                                              first operation is the same clip (pendulum.py:126, continuous_mountain_car.py:148-149): a no-op
+        FlattenObservation                    classic-control observations are flat Box vectors already (flatten_observation.py:33-43): a no-op
     NormalizeObservation / NormalizeReward are NOT mapped: around a sub-env each keeps its own running statistics over that env's history
     (a batch of one), which is a different normalisation from the vector-level wrappers' batch statistics — wrap the vector env
     (gym_amd.NormalizeObservation(env)) if that is what is meant.  Anything else (lambdas, observation transforms, ...) cannot run
@@ -629,6 +632,8 @@ def _sub_env_wrappers(wrappers):
             post.append(("episode_statistics", kw))
         elif name in ("OrderEnforcing", "PassiveEnvChecker") and not args and not kw:
             continue
+        elif name in ("ClipAction", "FlattenObservation") and not args and not kw:
+            post.append(("identity_for_classic_control", {"wrapper": name}))
         elif name in ("NormalizeObservation", "NormalizeReward"):
             raise NotImplementedError(
                 f"wrappers={name}: around each sub-env the reference keeps per-env running statistics (a batch of one per update), which the "
@@ -661,6 +666,13 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
         kwargs["max_episode_steps"] = limit if own is None or own <= 0 else min(limit, own)
     env = cls(id, num_envs, **kwargs)
     for what, kw in post:
+        if what == "identity_for_classic_control":
+            box_actions = type(env.single_action_space).__name__ == "Box"
+            if not isinstance(env, HipVectorEnv) or (kw["wrapper"] == "ClipAction" and not box_actions):
+                env.close()
+                raise NotImplementedError(f"wrappers={kw['wrapper']} is an identity only for the classic-control ids"
+                                          + (" with Box actions (clip_action.py:28 asserts a Box action space)" if kw["wrapper"] == "ClipAction" else ""))
+            continue
         if what == "episode_statistics":
             if not isinstance(env, HipVectorEnv):
                 env.close()

@@ -755,6 +755,10 @@ def test_vector_make_recognises_the_sub_env_wrappers_it_can_map():
     assert _sub_env_wrappers(functools.partial(TimeLimit, max_episode_steps=25)) == (25, [])
     assert _sub_env_wrappers([functools.partial(TimeLimit, max_episode_steps=25), OrderEnforcing,
                               functools.partial(TimeLimit, max_episode_steps=9)]) == (9, [])
+    class ClipAction:
+        pass
+
+    assert _sub_env_wrappers([ClipAction]) == (None, [("identity_for_classic_control", {"wrapper": "ClipAction"})])
     assert _sub_env_wrappers((RecordEpisodeStatistics,)) == (None, [("episode_statistics", {})])
     assert _sub_env_wrappers([functools.partial(RecordEpisodeStatistics, deque_size=5)]) == (None, [("episode_statistics", {"deque_size": 5})])
     for bad, needle in ((lambda e: e, "cannot run inside the device engine"), (NormalizeObservation, "per-env running statistics"),
@@ -813,3 +817,30 @@ def test_vector_make_wrappers_replay_the_reference_on_the_host_adapter(monkeypat
             episodes += 1
     assert episodes == int(g["ep_mask"].sum()) and env.episode_count == episodes and len(env.return_queue) == 7
     env.close()
+
+
+def test_vector_make_identity_wrappers(monkeypatch):
+    """ClipAction around a Box-action sub-env clips to the bounds the env's own step clips to first (pendulum.py:126,
+    continuous_mountain_car.py:148-149), FlattenObservation flattens what is flat: accepted as identities for the classic-control ids,
+    refused elsewhere (ClipAction asserts a Box action space, clip_action.py:28)."""
+    import gym_amd
+    from gym_amd import _native
+    from oracle_engine import FakeHandle
+
+    class ClipAction:
+        pass
+
+    class FlattenObservation:
+        pass
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    env = gym_amd.make("Pendulum-v1", num_envs=3, wrappers=[ClipAction, FlattenObservation])
+    plain = gym_amd.make("Pendulum-v1", num_envs=3)
+    env.reset(seed=4), plain.reset(seed=4)
+    a = np.array([[5.0], [-7.0], [0.3]], dtype=np.float32)                  # beyond the bounds: the env's own clip handles it
+    for x, y in zip(env.step(a)[:4], plain.step(a)[:4]):
+        assert np.array_equal(x, y)
+    env.close(), plain.close()
+    with pytest.raises(NotImplementedError):
+        gym_amd.make("CartPole-v1", num_envs=3, wrappers=ClipAction)
+    gym_amd.make("CartPole-v1", num_envs=3, wrappers=FlattenObservation).close()
