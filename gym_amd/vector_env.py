@@ -604,10 +604,13 @@ def _sub_env_wrappers(wrappers):
         ClipAction                            Box-action ids only (clip_action.py:28 asserts it): np.clip(action, low, high) before a step whose
                                               first operation is the same clip (pendulum.py:126, continuous_mountain_car.py:148-149): a no-op
         FlattenObservation                    classic-control observations are flat Box vectors already (flatten_observation.py:33-43): a no-op
-    NormalizeObservation / NormalizeReward are NOT mapped: around a sub-env each keeps its own running statistics over that env's history
-    (a batch of one), which is a different normalisation from the vector-level wrappers' batch statistics — wrap the vector env
-    (gym_amd.NormalizeObservation(env)) if that is what is meant.  Anything else (lambdas, observation transforms, ...) cannot run
-    inside the device engine.  Returns (max_episode_steps or None, [post-construction vector wrappers])."""
+        NormalizeObservation(epsilon=), NormalizeReward(gamma=, epsilon=)
+                                              per-sub-env running statistics (a batch of one per update) — a DIFFERENT normalisation from
+                                              the vector-level gym_amd.NormalizeObservation / NormalizeReward (batch statistics, device
+                                              kernels): mapped to SubEnvNormalizeObservation / SubEnvNormalizeReward, host-side NumPy
+                                              over the adapter's arrays, exact; for very large batches wrap the vector env instead
+    in the order given (innermost first, as the reference applies them).  Anything else (lambdas, observation transforms, ...) cannot
+    run inside the device engine.  Returns (max_episode_steps or None, [post-construction vector wrappers])."""
     import functools
 
     if wrappers is None:
@@ -634,11 +637,10 @@ def _sub_env_wrappers(wrappers):
             continue
         elif name in ("ClipAction", "FlattenObservation") and not args and not kw:
             post.append(("identity_for_classic_control", {"wrapper": name}))
-        elif name in ("NormalizeObservation", "NormalizeReward"):
-            raise NotImplementedError(
-                f"wrappers={name}: around each sub-env the reference keeps per-env running statistics (a batch of one per update), which the "
-                f"vector-level gym_amd.{name} (batch statistics over all sub-envs, fused into the engine) does not reproduce — wrap the "
-                f"vector env instead if shared statistics are what is meant: gym_amd.{name}(gym_amd.make(id, num_envs))")
+        elif name == "NormalizeObservation" and not args and set(kw) <= {"epsilon"}:
+            post.append(("normalize_observation", kw))
+        elif name == "NormalizeReward" and not args and set(kw) <= {"gamma", "epsilon"}:
+            post.append(("normalize_reward", kw))
         else:
             raise NotImplementedError(
                 f"per-sub-environment wrapper {w!r} cannot run inside the device engine (no Python sub-envs); recognised: TimeLimit, "
@@ -668,13 +670,22 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
     for what, kw in post:
         if what == "identity_for_classic_control":
             box_actions = type(env.single_action_space).__name__ == "Box"
-            if not isinstance(env, HipVectorEnv) or (kw["wrapper"] == "ClipAction" and not box_actions):
+            if not isinstance(getattr(env, "unwrapped", env), HipVectorEnv) or (kw["wrapper"] == "ClipAction" and not box_actions):
                 env.close()
                 raise NotImplementedError(f"wrappers={kw['wrapper']} is an identity only for the classic-control ids"
                                           + (" with Box actions (clip_action.py:28 asserts a Box action space)" if kw["wrapper"] == "ClipAction" else ""))
             continue
+        if what in ("normalize_observation", "normalize_reward"):
+            base = getattr(env, "unwrapped", env)
+            if not isinstance(base, HipVectorEnv):
+                env.close()
+                raise NotImplementedError("wrappers=NormalizeObservation / NormalizeReward are mapped for the classic-control ids (Box observations)")
+            from .wrappers import SubEnvNormalizeObservation, SubEnvNormalizeReward
+
+            env = (SubEnvNormalizeObservation if what == "normalize_observation" else SubEnvNormalizeReward)(env, **kw)
+            continue
         if what == "episode_statistics":
-            if not isinstance(env, HipVectorEnv):
+            if not isinstance(getattr(env, "unwrapped", env), HipVectorEnv):
                 env.close()
                 raise NotImplementedError("wrappers=RecordEpisodeStatistics is mapped to the classic-control engine's fused accumulators; "
                                           "the toy_text engines do not carry them")

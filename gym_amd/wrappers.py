@@ -20,7 +20,8 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics"]
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics",
+           "SubEnvNormalizeObservation", "SubEnvNormalizeReward"]
 
 
 class _VectorWrapper:
@@ -72,7 +73,7 @@ class RecordEpisodeStatistics(_VectorWrapper):
         # env's step() returns (record_episode_statistics.py:119-121), so with a NormalizeReward underneath the episode returns
         # are sums of NORMALISED rewards: in that stacking order the returns are accumulated here on the host from the wrapped
         # step's rewards (one vectorised float32 add per step, the reference's own arithmetic); lengths stay the TimeLimit counter.
-        self._host_returns = any(isinstance(w, NormalizeReward) for w in chain)
+        self._host_returns = any(isinstance(w, (NormalizeReward, SubEnvNormalizeReward)) for w in chain)
         self._acc = None
 
     # episode_returns / episode_lengths are None before the first reset (record_episode_statistics.py:89-90)
@@ -183,6 +184,92 @@ class SubEnvEpisodeStatistics(_VectorWrapper):
             dict.__setitem__(infos, "final_info", _Pending(build))
         else:
             infos["final_info"] = build()
+        return obs, rew, term, trunc, infos
+
+
+class _PerEnvMeanStd:
+    """N independent RunningMeanStd objects (gym/wrappers/normalize.py:8-48), one per sub-env, each updated with batches of ONE row — what
+    `NormalizeObservation(sub_env)` / `NormalizeReward(sub_env)` keep — as arrays over the env axis.  The update is the reference's
+    `update_mean_var_count_from_moments` with batch_mean = the row (the float32 / float64 mean of one element is the element), batch_var = 0,
+    batch_count = 1, operation for operation and in its order, so every env's statistics are bit-identical to its own wrapper's."""
+
+    def __init__(self, n: int, shape=()):
+        self.mean = np.zeros((n,) + tuple(shape), np.float64)
+        self.var = np.ones((n,) + tuple(shape), np.float64)
+        self.count = np.full(n, 1e-4, np.float64)
+        self._bc = (slice(None),) + (None,) * len(shape)
+
+    def update(self, rows, idx=slice(None)):
+        mean, var, count = self.mean[idx], self.var[idx], self.count[idx][self._bc]
+        delta = rows - mean                                           # :37
+        tot = count + 1                                               # :38
+        self.mean[idx] = mean + delta * 1 / tot                       # :40
+        m2 = var * count + np.float32(0.0) * 1 + np.square(delta) * count * 1 / tot      # :41-43 (m_b = batch_var * batch_count = 0)
+        self.var[idx] = m2 / tot                                      # :44
+        self.count[idx] = tot[(slice(None),) + (0,) * (tot.ndim - 1)]
+
+
+class SubEnvNormalizeObservation(_VectorWrapper):
+    """What `gym.vector.make(id, n, wrappers=NormalizeObservation)` yields in the reference (gym/vector/__init__.py:56-65 around
+    gym/wrappers/normalize.py:50-93): every sub-env normalises its observations with ITS OWN running statistics, updated with one row per
+    call — the terminal observation of an episode and the reset observation that follows it are two calls of that env's wrapper
+    (step, then the autoreset's reset: sync_vector_env.py:152-156), the batched observations are the float32 cast of the float64 results
+    (the vector env's observation space stays float32: numpy_utils.py:49-50 writes into it) and `final_observation` holds the float64
+    arrays.  A different normalisation from the vector-level `NormalizeObservation` (batch statistics over all sub-envs, device kernels):
+    this one is host-side NumPy over the arrays the adapter hands back, vectorised over the env axis — exact, and meant for the sizes the
+    reference itself handles; wrap the vector env instead for 2^20 envs."""
+
+    def __init__(self, env, epsilon: float = 1e-8):
+        super().__init__(env)
+        self.epsilon = epsilon
+        self.obs_rms = _PerEnvMeanStd(env.num_envs, env.single_observation_space.shape)
+
+    def _normalize(self, rows, idx=slice(None)):
+        self.obs_rms.update(rows, idx)
+        return (rows - self.obs_rms.mean[idx]) / np.sqrt(self.obs_rms.var[idx] + self.epsilon)       # :90-93
+
+    def reset(self, **kwargs):
+        obs, infos = self.env.reset(**kwargs)
+        return self._normalize(obs).astype(obs.dtype), infos
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        done = term | trunc
+        if not done.any():
+            return self._normalize(obs).astype(obs.dtype), rew, term, trunc, infos
+        idx = np.flatnonzero(done)
+        fin = infos["final_observation"]
+        first = obs.copy()                                            # what every sub-env's step() returned: terminal rows where it ended
+        first[idx] = np.stack([fin[i] for i in idx])
+        y = self._normalize(first)
+        new_fin = np.full(len(done), None, dtype=object)
+        for i in idx:
+            new_fin[i] = y[i].copy()                                  # float64, as the sub-env's wrapper returned it
+        y[idx] = self._normalize(obs[idx], idx)                       # ... then each finished sub-env's reset(): its second update
+        if isinstance(infos, LazyInfos):
+            dict.__setitem__(infos, "final_observation", new_fin)
+        else:
+            infos["final_observation"] = new_fin
+        return y.astype(obs.dtype), rew, term, trunc, infos
+
+
+class SubEnvNormalizeReward(_VectorWrapper):
+    """`wrappers=NormalizeReward` (gym/wrappers/normalize.py:96-145 around every sub-env): per-env discounted return, per-env running
+    variance of it (batches of one), reward / sqrt(var + epsilon), the return zeroed where the episode ended.  Host-side NumPy, exact, see
+    SubEnvNormalizeObservation."""
+
+    def __init__(self, env, gamma: float = 0.99, epsilon: float = 1e-8):
+        super().__init__(env)
+        self.gamma, self.epsilon = gamma, epsilon
+        self.return_rms = _PerEnvMeanStd(env.num_envs, ())
+        self.returns = np.zeros(env.num_envs)
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        self.returns = self.returns * self.gamma + rew                 # :132
+        self.return_rms.update(self.returns)                           # :144
+        rew = rew / np.sqrt(self.return_rms.var + self.epsilon)        # :145
+        self.returns[term | trunc] = 0.0                               # :134-135
         return obs, rew, term, trunc, infos
 
 

@@ -26,7 +26,58 @@ gym.logger.set_level(gym.logger.ERROR)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def normalize_case(gid, name, actions_of):
+    """wrappers=[TimeLimit(12), NormalizeObservation, NormalizeReward(gamma=0.97), RecordEpisodeStatistics] around every sub-env: the
+    per-sub-env running statistics (batches of one; terminal and reset observation of a finished env are two updates), float32 batched
+    observations, float64 final observations, normalised rewards, and episode returns that are sums of NORMALISED rewards."""
+    from gym.wrappers import NormalizeObservation, NormalizeReward
+
+    N, T, K = 8, 120, 12
+    env = gym.vector.make(gid, num_envs=N, asynchronous=False,
+                          wrappers=[functools.partial(TimeLimit, max_episode_steps=K), NormalizeObservation,
+                                    functools.partial(NormalizeReward, gamma=0.97), RecordEpisodeStatistics])
+    obs0, _ = env.reset(seed=321)
+    rng = np.random.default_rng(11)
+    rec = {k: [] for k in ("state_pre", "elapsed_pre", "action", "obs", "reward", "terminated", "truncated", "final_obs", "ep_r", "ep_l",
+                           "raw_obs_post")}
+
+    def raw_obs(e):      # the sub-env's un-normalised observation of its current state (what step / reset returned to the innermost wrapper)
+        u = e.unwrapped
+        return u._get_obs() if hasattr(u, "_get_obs") else np.array(u.state, dtype=np.float32)
+
+    reset_state = np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in env.envs])
+    raw_obs0 = np.stack([raw_obs(e) for e in env.envs])
+    for t in range(T):
+        subs = env.envs
+        rec["state_pre"].append(np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in subs]))
+        tl = [e.env.env.env for e in subs]                  # RecordEpisodeStatistics -> NormalizeReward -> NormalizeObservation -> TimeLimit
+        assert all(type(o).__name__ == "TimeLimit" and o._max_episode_steps == K for o in tl)
+        rec["elapsed_pre"].append(np.array([o._elapsed_steps for o in tl], dtype=np.int32))
+        a = actions_of(rng, N)
+        obs, rew, term, trunc, infos = env.step(a)
+        assert obs.dtype == np.float32 and rew.dtype == np.float64
+        O = obs.shape[1]
+        fo, er, el = np.full((N, O), np.nan), np.zeros(N, np.float32), np.zeros(N, np.int32)
+        if "final_info" in infos:
+            for i, fi in enumerate(infos["final_info"]):
+                if fi is not None:
+                    assert infos["final_observation"][i].dtype == np.float64
+                    fo[i], er[i], el[i] = infos["final_observation"][i], fi["episode"]["r"], fi["episode"]["l"]
+        for k, v in (("action", a), ("obs", obs), ("reward", rew), ("terminated", term), ("truncated", trunc), ("final_obs", fo), ("ep_r", er), ("ep_l", el),
+                     ("raw_obs_post", np.stack([raw_obs(e) for e in env.envs]))):
+            rec[k].append(v)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(max_episode_steps=np.int64(K), obs0=obs0, reset_state=reset_state, gamma=np.float64(0.97), raw_obs0=raw_obs0)
+    # every step's post-reset raw state of the finished envs (the PCG64 reset the reference drew): the replay injects it
+    out["state_post"] = np.concatenate([out["state_pre"][1:], np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in env.envs])[None]])
+    assert (out["truncated"] | out["terminated"]).sum() > 20
+    np.savez_compressed(os.path.join(HERE, f"vector_make_normalize_{name}.npz"), **out)
+    print(name, "episodes:", int((out["truncated"] | out["terminated"]).sum()))
+
+
 def main():
+    normalize_case("CartPole-v1", "CartPole", lambda rng, n: (rng.random(n) < np.linspace(0.15, 0.85, n)).astype(np.int64))
+    normalize_case("Pendulum-v1", "Pendulum", lambda rng, n: rng.uniform(-2, 2, (n, 1)).astype(np.float32))
     N, T, K = 8, 90, 12
     env = gym.vector.make("CartPole-v1", num_envs=N, asynchronous=False,
                           wrappers=[functools.partial(TimeLimit, max_episode_steps=K), RecordEpisodeStatistics])

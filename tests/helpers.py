@@ -368,3 +368,86 @@ def dealer_score_distribution(raw_sum, ace):
         return tuple(sorted(out.items()))
 
     return dict(go(int(raw_sum), bool(ace)))
+
+
+# ---- gym.vector.make(..., wrappers=[TimeLimit, NormalizeObservation, NormalizeReward, RecordEpisodeStatistics]) replays ---------------------
+def replay_vector_make_normalize(name, exact):
+    """tests/golden/vector_make_normalize_<name>.npz (made by tests/golden/make_golden_vector_make.py: THE REFERENCE with those four wrappers
+    around every sub-env) replayed through gym_amd's per-sub-env wrappers over whatever engine gym_amd.make builds (the HIP engine on the GPU
+    box, the oracle-backed handle in the CPU tests): teacher-forced pre-step states, the reference's own reset observations injected for
+    the finished sub-envs (its resets are PCG64 draws), then every output compared — batched float32 observations, float64 final
+    observations, normalised float64 rewards, episode returns of NORMALISED rewards.  exact: bit-equal (oracle) / engine tolerances."""
+    import functools
+
+    import gym_amd
+    from gym_amd.wrappers import (RecordEpisodeStatistics, SubEnvEpisodeStatistics, SubEnvNormalizeObservation, SubEnvNormalizeReward,
+                                  _VectorWrapper)
+
+    class TimeLimit:
+        pass
+
+    class NormalizeObservation:
+        pass
+
+    class NormalizeReward:
+        pass
+
+    g = np.load(os.path.join(GOLDEN, f"vector_make_normalize_{name}.npz"))
+    T, N = g["terminated"].shape
+    K, gamma = int(g["max_episode_steps"]), float(g["gamma"])
+    # (1) the mapping: the chain gym_amd.make builds from the reference-style wrappers list
+    built = gym_amd.make(GYM_IDS[name], num_envs=N, wrappers=[functools.partial(TimeLimit, max_episode_steps=K), NormalizeObservation,
+                                                              functools.partial(NormalizeReward, gamma=gamma), RecordEpisodeStatistics])
+    chain, e = [], built
+    while isinstance(e, _VectorWrapper):
+        chain.append(type(e).__name__)
+        e = e.env
+    assert chain == ["SubEnvEpisodeStatistics", "RecordEpisodeStatistics", "SubEnvNormalizeReward", "SubEnvNormalizeObservation"], chain
+    assert built.get_attr("_max_episode_steps") == (K,) * N and built.env.env.gamma == gamma
+    built.close()
+
+    # (2) the numbers: the same chain with a shim above the engine that hands the finished sub-envs the reference's reset observations
+    class ReferenceResets(_VectorWrapper):
+        t = 0
+
+        def reset(self, **kw):
+            obs, infos = self.env.reset(**kw)
+            return g["raw_obs0"].copy(), infos
+
+        def step(self, action):
+            obs, rew, term, trunc, infos = self.env.step(action)
+            done = term | trunc
+            obs = obs.copy()
+            obs[done] = g["raw_obs_post"][self.t][done]
+            return obs, rew, term, trunc, infos
+
+    base = gym_amd.make(GYM_IDS[name], num_envs=N, max_episode_steps=K)
+    shim = ReferenceResets(base)
+    env = SubEnvEpisodeStatistics(SubEnvNormalizeReward(SubEnvNormalizeObservation(shim), gamma=gamma))
+    obs0, _ = env.reset(seed=1)
+    assert obs0.dtype == np.float32 and np.array_equal(obs0, g["obs0"])
+    episodes = 0
+    for t in range(T):
+        shim.t = t
+        base.handle.set_state(np.ascontiguousarray(g["state_pre"][t].T), g["elapsed_pre"][t])
+        obs, rew, term, trunc, infos = env.step(g["action"][t])
+        done = g["terminated"][t] | g["truncated"][t]
+        assert np.array_equal(term, g["terminated"][t]) and np.array_equal(trunc, g["truncated"][t]), t
+        assert obs.dtype == np.float32 and rew.dtype == np.float64
+        if exact:
+            assert np.array_equal(obs, g["obs"][t]) and np.array_equal(rew, g["reward"][t]), t
+        else:
+            np.testing.assert_allclose(obs, g["obs"][t], rtol=2e-5, atol=2e-6, err_msg=f"obs t={t}")
+            np.testing.assert_allclose(rew, g["reward"][t], rtol=1e-6, atol=1e-8, err_msg=f"reward t={t}")
+        for i in np.flatnonzero(done):
+            fo, ep = infos["final_observation"][i], infos["final_info"][i]["episode"]
+            assert fo.dtype == np.float64 and isinstance(ep["r"], np.float32) and ep["l"] == g["ep_l"][t][i]
+            if exact:
+                assert np.array_equal(fo, g["final_obs"][t][i]) and ep["r"] == g["ep_r"][t][i], (t, i)
+            else:
+                np.testing.assert_allclose(fo, g["final_obs"][t][i], rtol=2e-5, atol=2e-6)
+                np.testing.assert_allclose(ep["r"], g["ep_r"][t][i], rtol=1e-5)
+            episodes += 1
+    assert episodes == int((g["terminated"] | g["truncated"]).sum()) > 50
+    env.close()
+    return episodes

@@ -760,3 +760,13 @@ def test_reset_outputs_are_ordered_on_the_callers_stream():
         t.rollout_per_step(128, out=tr)
         assert np.array_equal(t.reset(seed=5).cpu().numpy(), first) and (first == 0).all()      # FrozenLake starts in state 0
     t.close()
+
+
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum"])
+def test_vector_make_normalize_wrappers_against_the_reference(name):
+    """The GPU twin of tests/test_host_logic.py::test_vector_make_normalize_wrappers_replay_the_reference_bit_for_bit: the same golden (the
+    reference run with TimeLimit + NormalizeObservation + NormalizeReward + RecordEpisodeStatistics around every sub-env) through the HIP
+    engine — masks and episode lengths exact, normalised observations / rewards / episode returns within the engine's tolerances."""
+    from helpers import replay_vector_make_normalize
+
+    assert replay_vector_make_normalize(name, exact=False) > 50

@@ -761,7 +761,9 @@ def test_vector_make_recognises_the_sub_env_wrappers_it_can_map():
     assert _sub_env_wrappers([ClipAction]) == (None, [("identity_for_classic_control", {"wrapper": "ClipAction"})])
     assert _sub_env_wrappers((RecordEpisodeStatistics,)) == (None, [("episode_statistics", {})])
     assert _sub_env_wrappers([functools.partial(RecordEpisodeStatistics, deque_size=5)]) == (None, [("episode_statistics", {"deque_size": 5})])
-    for bad, needle in ((lambda e: e, "cannot run inside the device engine"), (NormalizeObservation, "per-env running statistics"),
+    assert _sub_env_wrappers([NormalizeObservation]) == (None, [("normalize_observation", {})])
+    assert _sub_env_wrappers([functools.partial(NormalizeObservation, epsilon=1e-6)]) == (None, [("normalize_observation", {"epsilon": 1e-6})])
+    for bad, needle in ((lambda e: e, "cannot run inside the device engine"), (functools.partial(NormalizeObservation, foo=1), "cannot run"),
                         (functools.partial(TimeLimit, new_step_api=True), "not supported"), (functools.partial(TimeLimit, 5), "cannot run"),
                         ([3], "cannot run"), (7, "callable or an iterable")):
         with pytest.raises(NotImplementedError) as e:
@@ -844,3 +846,17 @@ def test_vector_make_identity_wrappers(monkeypatch):
     with pytest.raises(NotImplementedError):
         gym_amd.make("CartPole-v1", num_envs=3, wrappers=ClipAction)
     gym_amd.make("CartPole-v1", num_envs=3, wrappers=FlattenObservation).close()
+
+
+@pytest.mark.parametrize("name", ["CartPole", "Pendulum"])
+def test_vector_make_normalize_wrappers_replay_the_reference_bit_for_bit(name, monkeypatch):
+    """wrappers=[TimeLimit, NormalizeObservation, NormalizeReward, RecordEpisodeStatistics] around every sub-env, as the reference runs them
+    (gym/vector/__init__.py:56-65 + gym/wrappers/normalize.py:50-145): per-sub-env running statistics with batches of one, the terminal and
+    the reset observation of a finished sub-env as two updates, float32 batched / float64 final observations, episode returns of normalised
+    rewards — gym_amd's per-sub-env wrappers over the oracle-backed handle reproduce the reference's own run BIT FOR BIT."""
+    from gym_amd import _native
+    from helpers import replay_vector_make_normalize
+    from oracle_engine import PackedFakeHandle
+
+    monkeypatch.setattr(_native, "Handle", PackedFakeHandle)
+    assert replay_vector_make_normalize(name, exact=True) > 50
