@@ -105,7 +105,7 @@ def test_line_carries_what_the_review_asked_for(run):
     assert cfg["placement"]["balanced"] is True and cfg["placement"]["parked_GiB"] <= 112
     pc = v["placement_cheap"]
     assert pc["placement"]["mode"] == "cheap" and pc["placement"]["parked_GiB"] <= 8.0
-    assert 0.97 * line["ms_per_step"] * 1e3 <= pc["us_per_step"] <= 1.30 * line["ms_per_step"] * 1e3
+    assert 0.93 * line["ms_per_step"] * 1e3 <= pc["us_per_step"] <= 1.35 * line["ms_per_step"] * 1e3      # (balanced by luck: equal; all in one class: +17 %)
     ref = headline["cpu_baseline"]["reference_python"]
     assert ref["source"].startswith("profiles/reference_cpu_baseline.json") and ref["value"] > 1e4
     assert not [k for k, x in v.items() if isinstance(x, dict) and "error" in x], v
