@@ -151,13 +151,12 @@ def parse_args():
     ap.add_argument("--compact-outputs", action="store_true",
                     help="float32 rewards + int32 actions (MXV_FLAG_REWARD_F32|ACTION_I32: 26 real bytes per env-step "
                          "instead of 34); off by default: the headline keeps the reference's float64 / int64 dtypes")
-    ap.add_argument("--placement", default="sorted", choices=["sorted", "placed", "tuned", "first", "off"],
+    ap.add_argument("--placement", default="sorted", choices=["sorted", "placed", "first", "off"],
                     help="trajectory tensors: sorted = ordinary allocations sorted by measured HBM class (the product default, "
                          "DeviceRollout.trajectory_buffers); placed = 256-MiB physical chunks of measured class mapped through the HIP "
-                         "virtual-memory API (mxv_placed_alloc); tuned = round 2's timing of --placement-candidates ordinary sets; "
+                         "virtual-memory API (mxv_placed_alloc); "
                          "first = the first ordinary allocation; off = first, and MXV_PLACEMENT=off for every measurement of the run "
                          "(no probe launch, no memory parked anywhere: the setting that cannot fail)")
-    ap.add_argument("--placement-candidates", type=int, default=8, help="candidate sets of --placement tuned")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (N=1 only)")

@@ -222,14 +222,7 @@ def run(args, bench_file, cpu_baseline=None):
     sr.reset(seed=0)
     # [chunk][N] obs / reward / flags / actions, reused every chunk
     placement = None
-    if mode == "fused" and args.placement == "tuned" and args.placement_candidates > 1:
-        try:
-            traj, placement = eng.tuned_trajectory_buffers(args.chunk, candidates=args.placement_candidates)
-            placement["kind"] = "tuned (timing of candidate sets)"
-        except (RuntimeError, MemoryError) as e:   # e.g. out of device memory: measure on the first allocation instead
-            torch.cuda.empty_cache()
-            traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"error": f"placement tuning failed: {e}"[:300]}
-    elif args.placement in ("first", "tuned", "off") or mode != "fused":   # (tuned with < 2 candidates, or a one-launch-per-step mode: nothing to place)
+    if args.placement in ("first", "off") or mode != "fused":   # (a one-launch-per-step mode: nothing to place)
         traj, placement = eng.trajectory_buffers(args.chunk, layout="separate"), {"kind": "first ordinary allocation"}
     else:
         from gym_amd import _native

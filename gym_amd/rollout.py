@@ -193,7 +193,7 @@ class DeviceRollout:
                 self.handle.set_episode_outputs(*tgt)
                 self._ep_attached = tgt[0]
 
-    def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "auto", seed: int = 0,
+    def trajectory_buffers(self, K: int, want_final: bool = False, layout: str = "auto",
                            max_park_bytes: Optional[int] = None, obs_partials: bool = False, ret_partials: bool = False):
         """[K, N, ...] output tensors for rollout_per_step (allocate once, reuse every chunk).  want_final adds
         `final_obs` [K, N, O]: info["final_observation"] of every step — rows are written only where terminated | truncated
@@ -207,17 +207,14 @@ class DeviceRollout:
         on its own account (out of memory inside the search -> ordinary allocations), and MXV_PLACEMENT=off makes "auto" mean
         "separate" for the whole process (gym_amd/placement.py).  layout="placed": the same goal through HIP's virtual-memory API (mxv_placed_alloc, include/mxv.h:
         256-MiB physical chunks of measured class mapped under the tensors) — less transient memory when the classes are interleaved,
-        but the real kernel runs 4-10 % slower on memory mapped that way.  layout="separate": one torch allocation per tensor.  layout="spread": all tensors carved out of ONE allocation in shuffled order
-        at irregular offsets (pseudo-random gaps of up to ~60 % of the tensors' size in total, 4-KiB aligned, fixed by `seed`):
-        on the boxes where placement matters the speed mode of the write-bound rollout is a function of the ADDRESSES — packed
-        back to back (which is also what consecutive separate allocations are) can hit the slow mode, eight of eight such
-        irregular layouts measured fast (profiles/r2/r02q_placement_scan_one_allocation.jsonl)."""
+        but the real kernel runs 4-10 % slower on memory mapped that way.  layout="separate": one torch allocation per tensor.  (Rounds 1-2's "spread" layout and timing-based
+        `tuned_trajectory_buffers` were removed in round 5: sorting by measured HBM class replaced both; profiles/HISTORY.md.)"""
         if obs_partials or ret_partials:
             # + "obs_partials" [K, leaves, 2 O] float64: rollout_per_step then also leaves every step's column sums / sums of squares
             # of the observations per tile of envs (mxv_set_obs_partials) — RunningNormalizer.normalize_obs(x, partials=...) folds them
             # instead of reading the observations a second time;  + "ret_partials" [K, leaves, 2]: the same for NormalizeReward's
             # discounted returns, which the rollout then advances itself (after fuse_reward_normalizer(normalizer))
-            out = self.trajectory_buffers(K, want_final, layout, seed, max_park_bytes)
+            out = self.trajectory_buffers(K, want_final, layout, max_park_bytes)
             leaves, _, vals = self.handle.obs_partials_layout()
             with torch.cuda.stream(self.stream):
                 if obs_partials:
@@ -255,31 +252,7 @@ class DeviceRollout:
         with torch.cuda.stream(self.stream):
             if layout == "separate":
                 return {name: (torch.zeros if zero else torch.empty)(shape, dtype=dt, device=dev) for name, shape, dt, zero in specs}
-            if layout != "spread":
-                raise ValueError(f"layout must be 'auto', 'sorted', 'placed', 'separate' or 'spread', got {layout!r}")
-            import random
-
-            rng = random.Random(0x5EED + 7919 * seed)
-            order = list(range(len(specs)))
-            rng.shuffle(order)
-            nbytes = [math.prod(shape) * torch.empty((), dtype=dt).element_size() for _, shape, dt, _ in specs]
-            total = sum(nbytes)
-            cuts = sorted(rng.uniform(0.0, 0.6) * total for _ in order)
-            gaps = [cuts[0]] + [b - a for a, b in zip(cuts, cuts[1:])]
-            offs, off = {}, 0
-            for i, g in zip(order, gaps):
-                off = (int(off + g) + 4095) // 4096 * 4096
-                offs[i] = off
-                off += nbytes[i]
-            block = torch.empty(off + 4096, dtype=torch.uint8, device=dev)
-            base = (-block.data_ptr()) % 4096
-            out = {}
-            for i, (name, shape, dt, zero) in enumerate(specs):
-                t = block[base + offs[i]: base + offs[i] + nbytes[i]].view(dt).view(shape)
-                if zero:
-                    t.zero_()
-                out[name] = t
-            return out
+            raise ValueError(f"layout must be 'auto', 'sorted', 'placed' or 'separate', got {layout!r}")
 
     def _sorted_buffers(self, specs, budget_bytes: Optional[int] = None):
         """Ordinary (torch / hipMalloc) tensors, SORTED by HBM class (gym_amd/placement.py): observations on one class, rewards +
@@ -290,102 +263,6 @@ class DeviceRollout:
         self.last_placement = report
         return out
 
-    def tuned_trajectory_buffers(self, K: int, candidates: int = 8, launches: int = 6, want_final: bool = False,
-                                 mixes: Optional[int] = None, max_candidates: Optional[int] = None):
-        """trajectory_buffers(K) chosen by measurement.  On the MI355X the speed of the write-bound fused rollout depends on
-        WHERE its five output tensors sit physically relative to each other — a stable property of a set of allocations
-        (same virtual addresses re-allocated can land in another mode; swapping single tensors between sets shows it is
-        the combination, not any one tensor): 5.9 / 6.7 / 7.1 us per 2^20-env CartPole step for identical code
-        (profiles/r1/r01h_placement_probe.txt).  This allocates `candidates` sets side by side, times `launches` fused
-        launches on each after a warm-up, then `mixes` (default 2 x candidates) random recombinations of their tensors —
-        new combinations at no extra memory — keeps the fastest combination and frees every tensor it does not use.  The env
-        state, TimeLimit counters, RNG counters and running episode returns are restored afterwards, so tuning does not change
-        any result.  Returns (buffers, report).
-
-        The mode belongs to the PHYSICAL pages behind an allocation (the same virtual addresses re-allocated run in
-        either mode; roughly one allocation in four or five is fast, fewer on some boxes), so when none of the first `candidates`
-        sets stands out (all within 7 % of each other: only one mode seen) further sets are allocated and timed one at a time, up to
-        `max_candidates` (default 2 x candidates) or until one does."""
-        import random
-
-        st, el = self.handle.get_state()
-        t, r = self.handle.get_counters()
-        episodes = self.handle.get_episodes()
-        running = self.handle.episode_stats_host(want_running=True)[2] if self.handle._stats_on else None
-        per_step = self.num_envs * (4 * self.O * (2 if want_final else 1) + self.reward.element_size()
-                                    + self.actions.element_size() + 2)
-        free, _ = torch.cuda.mem_get_info(self.device)
-        fit = int(0.8 * free) // max(1, int(1.3 * K * per_step))    # never tune the device out of memory
-        candidates = max(1, min(int(candidates), fit))
-        max_candidates = max(candidates, min(2 * candidates if max_candidates is None else int(max_candidates), fit))
-        # the last quarter of the first batch are single-allocation "spread" layouts (see trajectory_buffers)
-        n_spread = candidates // 4
-        kinds = ["separate"] * (candidates - n_spread) + ["spread"] * n_spread
-        sets = [self.trajectory_buffers(K, want_final=want_final, layout=kind, seed=i) for i, kind in enumerate(kinds)]
-
-        def timed(traj, warm):
-            for _ in range(warm):
-                self.rollout_per_step(K, out=traj)
-            self.stream.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(self.stream)
-            for _ in range(launches):
-                self.rollout_per_step(K, out=traj)
-            e1.record(self.stream)
-            self.stream.synchronize()
-            return e0.elapsed_time(e1) / launches / K * 1e3
-
-        import time as _time
-
-        t_spin = _time.perf_counter()   # clock ramp first: a cold device would make the first candidates look slow
-        while (_time.perf_counter() - t_spin) < 0.15:
-            self.rollout_per_step(K, out=sets[0])
-            self.stream.synchronize()
-        best, best_us, times = None, float("inf"), []
-        for traj in sets:
-            us = timed(traj, 2)  # warm-up = first touch: page mapping, TLB
-            times.append(us)
-            if us < best_us:
-                best, best_us = traj, us
-
-        def stands_out():   # both modes seen: some set is clearly faster than some other
-            return len(times) > 1 and best_us <= 0.93 * max(times)
-
-        big = K * per_step >= (1 << 30)   # the modes were only ever seen on sets of a GiB and more
-        while big and len(sets) < max_candidates and not stands_out():   # nothing fast yet: new physical pages, one set at a time
-            traj = self.trajectory_buffers(K, want_final=want_final, layout="separate", seed=len(sets))
-            sets.append(traj)
-            kinds.append("separate")
-            us = timed(traj, 2)
-            times.append(us)
-            if us < best_us:
-                best, best_us = traj, us
-        rng = random.Random(len(sets) * 7919 + K)
-        mix_times = []
-        for _ in range(2 * len(sets) if mixes is None else mixes):
-            if len(sets) < 2:
-                break
-            donors = [t for t, kind in zip(sets, kinds) if kind == "separate"]   # a tensor of a "spread" set pins that set's whole block
-            if len(donors) < 2:
-                break
-            mix = {k: donors[rng.randrange(len(donors))][k] for k in sets[0]}
-            us = timed(mix, 1)
-            mix_times.append(us)
-            if us < best_us:
-                best, best_us = mix, us
-        best = dict(best)
-        best_us = timed(best, 0)   # confirm: the report carries the re-measured figure
-        del sets, traj
-        self.handle.set_state(st, el)
-        self.handle.set_counters(t, r)
-        self.handle.set_episodes(episodes)
-        if running is not None:
-            self.handle.set_running_returns(running)
-        torch.cuda.empty_cache()
-        return best, {"candidates": len(times), "kinds": kinds, "us_per_step": [round(x, 3) for x in times],
-                      "mixes_us_per_step": [round(x, 3) for x in mix_times], "chosen_us_per_step": round(best_us, 3)}
-
-    # -- checkpoint / resume -------------------------------------------------------------------------
     def state_dict(self) -> dict:
         """Snapshot (NumPy arrays and ints, picklable) from which load_state_dict() continues bit-identically: env state,
         TimeLimit counters, RNG seeds + counters, physics parameters, running episode returns.  Output tensors are not part

@@ -521,50 +521,6 @@ class TabularRollout:
         with t.cuda.stream(self.stream):
             return {name: t.empty(shape, dtype=dt, device=dev) for name, shape, dt, _ in specs}
 
-    def tuned_trajectory_buffers(self, K: int, candidates: int = 6, launches: int = 6):
-        """trajectory_buffers(K) with the placement of the output tensors chosen by measurement (see
-        DeviceRollout.tuned_trajectory_buffers: the write-bound kernels run in one of a few speed modes depending on where
-        their output tensors sit physically relative to each other).  State and RNG counters are restored."""
-        import random
-        import time as _time
-
-        t = self._torch
-        st, el = self.handle.get_state()
-        ct, cr = self.handle.get_counters()
-        free, _ = t.cuda.mem_get_info(self.device)
-        candidates = max(1, min(int(candidates), int(0.8 * free) // (K * self.num_envs * 34)))
-        sets = [self.trajectory_buffers(K, layout="separate") for _ in range(candidates)]
-
-        def timed(traj, warm):
-            for _ in range(warm):
-                self.rollout_per_step(K, out=traj)
-            self.stream.synchronize()
-            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-            e0.record(self.stream)
-            for _ in range(launches):
-                self.rollout_per_step(K, out=traj)
-            e1.record(self.stream)
-            self.stream.synchronize()
-            return e0.elapsed_time(e1) / launches / K * 1e3
-
-        t0 = _time.perf_counter()
-        while _time.perf_counter() - t0 < 0.15:
-            self.rollout_per_step(K, out=sets[0])
-            self.stream.synchronize()
-        results = [(timed(s, 2), s) for s in sets]
-        rng = random.Random(len(sets) * 7919 + K)
-        for _ in range(2 * len(sets) if len(sets) > 1 else 0):
-            mix = {k: sets[rng.randrange(len(sets))][k] for k in sets[0]}
-            results.append((timed(mix, 1), mix))
-        best_us, best = min(results, key=lambda x: x[0])
-        best = dict(best)
-        report = {"candidates": len(sets), "us_per_step": [round(u, 3) for u, _ in results], "chosen_us_per_step": round(timed(best, 0), 3)}
-        del sets, results
-        self.handle.set_state(st, el)
-        self.handle.set_counters(ct, cr)
-        t.cuda.empty_cache()
-        return best, report
-
     def rollout_per_step(self, K: int, out: Optional[dict] = None):
         out = self.trajectory_buffers(K) if out is None else out
         self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"],

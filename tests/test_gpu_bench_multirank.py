@@ -31,8 +31,7 @@ def _torchrun(script_args, env=None, timeout=240):
 
 def test_bench_two_ranks_strong_scaling_is_the_default():
     """BASELINE.json's metric: 2^20 logical envs in total, partitioned over the ranks (gather included in the timed region)."""
-    lines = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "512", "--warmup", "256", "--no-cpu-baseline",
-                       "--placement-candidates", "2"])
+    lines = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "512", "--warmup", "256", "--no-cpu-baseline"])
     assert len(lines) == 1          # rank 0 prints the one line
     out = lines[0]
     assert out["n_gpus"] == 2 and out["steps"] == 512 and out["scaling"] == "strong"
@@ -50,7 +49,7 @@ def test_bench_two_ranks_weak_scaling_and_the_drivers_short_run():
     """--scaling weak keeps 2^20 envs per GPU; `--steps 20 --warmup 5` (what the driver passes) must repeat the 0.1-ms region
     inside one bracket instead of timing a single launch, with the byte accounting of the launches that really ran."""
     lines = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--scaling", "weak", "--steps", "20", "--warmup", "5",
-                       "--no-cpu-baseline", "--placement-candidates", "1"])
+                       "--no-cpu-baseline"])
     out = lines[0]
     assert out["scaling"] == "weak" and out["config"]["num_envs_per_gpu"] == 1 << 20 and out["steps"] == 20
     cfg, roof = out["config"], out["roofline"]

@@ -679,64 +679,6 @@ def test_trajectory_final_observations(name):
 GYM_IDS_LOCAL = {"CartPole": "CartPole-v1", "Pendulum": "Pendulum-v1"}
 
 
-def test_tuned_trajectory_buffers_leave_results_unchanged():
-    """DeviceRollout.tuned_trajectory_buffers times the fused rollout on several candidate buffer sets and keeps the fastest;
-    env state, TimeLimit and RNG counters are restored, so the trajectory that follows is bit-identical to an untuned run."""
-    from gym_amd.rollout import DeviceRollout
-
-    n, K = 1 << 16, 32
-    outs = []
-    for tune in (False, True):
-        r = DeviceRollout("CartPole-v1", n, seed=13, action_seed=14)
-        r.reset(seed=13)
-        if tune:
-            traj, report = r.tuned_trajectory_buffers(K, candidates=3, launches=2)
-            nc = report["candidates"]           # 3, or up to 6 when none of the first three stood out (adaptive second batch)
-            assert 3 <= nc <= 6 and len(report["us_per_step"]) == nc == len(report["kinds"]) and len(report["mixes_us_per_step"]) == 2 * nc
-            assert report["chosen_us_per_step"] > 0
-        else:
-            traj = r.trajectory_buffers(K)
-        r.rollout_per_step(K, out=traj)
-        r.synchronize()
-        outs.append({k: v.cpu().numpy() for k, v in traj.items()})
-        r.close()
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
-
-
-def test_spread_layout_buffers_give_identical_trajectories():
-    """trajectory_buffers(layout="spread"): all output tensors carved out of ONE allocation at irregular offsets (the placement
-    experiment's fast family) — a placement choice only: same shapes, dtypes and bits as separate allocations,
-    non-overlapping, also with final observations and episode statistics; the tuner reports which kind each candidate was."""
-    import torch
-    from gym_amd.rollout import DeviceRollout
-
-    n, K = 1 << 14, 24
-    outs = []
-    for layout in ("separate", "spread"):
-        r = DeviceRollout("CartPole-v1", n, seed=3, action_seed=4)
-        r.enable_episode_stats()
-        r.reset(seed=3)
-        traj = r.trajectory_buffers(K, want_final=True, layout=layout, seed=5)
-        if layout == "spread":
-            spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in traj.values())
-            assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and all(s[0] % 4096 == 0 for s in spans)
-            assert len({t.untyped_storage().data_ptr() for t in traj.values()}) == 1
-        r.rollout_per_step(K, out=traj)
-        r.synchronize()
-        outs.append({k: v.cpu().numpy().copy() for k, v in traj.items()})
-        r.close()
-    assert set(outs[0]) == set(outs[1]) == {"obs", "reward", "terminated", "truncated", "actions", "final_obs", "ep_return", "ep_length"}
-    for k in outs[0]:
-        assert outs[0][k].dtype == outs[1][k].dtype and np.array_equal(outs[0][k], outs[1][k]), k
-    r = DeviceRollout("CartPole-v1", 1 << 16, seed=1, action_seed=2)
-    r.reset(seed=1)
-    traj, report = r.tuned_trajectory_buffers(16, candidates=8, launches=2)
-    assert report["kinds"][:8] == ["separate"] * 6 + ["spread"] * 2 and 8 <= len(report["us_per_step"]) <= 16
-    assert all(k == "separate" for k in report["kinds"][8:])
-    r.close()
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("name", ENV_NAMES)

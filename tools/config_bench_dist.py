@@ -78,9 +78,10 @@ def main():
 
     sr = ShardedRollout("Acrobot-v1", (1 << 19) * world, rank=rank, world_size=world, device=local, seed=0, action_seed=1)
     sr.reset(seed=0)
-    traj, rep = sr.engine.tuned_trajectory_buffers(chunk, candidates=4)
+    traj = sr.engine.trajectory_buffers(chunk)
+    rep = getattr(sr.engine, "last_placement", None) or {}
     timed(sr, traj, (1 << 19) * world, "config4: Acrobot-v1, 2^19 envs per GPU, all-gather of final tensors per chunk",
-          {"placement_us_per_step": rep["chosen_us_per_step"]})
+          {"placement": {k: rep.get(k) for k in ("mode", "balanced", "parked_GiB")}})
     sr.close()
     del traj
 

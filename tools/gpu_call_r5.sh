@@ -10,7 +10,7 @@ bash tools/gpu_profile.sh $R fused 256 > $O/profile.log 2>&1
 cd /tmp
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/variants_trace -o bench -- $B > $O/variants_trace.log 2>&1
-C="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --compact-outputs --placement-candidates 1 --steps 1024 --warmup 256"
+C="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --compact-outputs --steps 1024 --warmup 256"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/compact_pmc_$c -o bench -- $C > $O/compact_pmc_$c.log 2>&1
 done

@@ -8,7 +8,7 @@ rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 [ -x $GRAFT_REPO_ROOT/tools/calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $GRAFT_REPO_ROOT/tools/calib $GRAFT_REPO_ROOT/tools/calib.hip
 cd /tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --placement-candidates ${PLACE:-1} --mode $MODE --chunk $CHUNK"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --mode $MODE --chunk $CHUNK"
 if [ "$MODE" = fused ]; then TS=$((CHUNK*8)); TW=$CHUNK; PS=$((CHUNK*4)); PW=$CHUNK; else TS=1000; TW=100; PS=40; PW=10; fi
 echo "$MODE $CHUNK trace:$TS/$TW pmc:$PS/$PW" > $out/meta.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- $B --steps $TS --warmup $TW > $out/trace.log 2>&1
