@@ -23,6 +23,8 @@ _LAZY = {
     "RunningNormalizer": ("gym_amd.normalize", "RunningNormalizer"),
     "HipTabularVectorEnv": ("gym_amd.toy_text", "HipTabularVectorEnv"),
     "TabularRollout": ("gym_amd.toy_text", "TabularRollout"),
+    "HipBlackjackVectorEnv": ("gym_amd.toy_text", "HipBlackjackVectorEnv"),
+    "BlackjackRollout": ("gym_amd.toy_text", "BlackjackRollout"),
 }
 
 
