@@ -71,7 +71,8 @@ struct mxv_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double *state = nullptr;
-    int32_t *elapsed = nullptr;
+    void *elapsed = nullptr;    // uint16 [N] when elapsed16, else int32 [N] (always n * 4 bytes allocated)
+    bool elapsed16 = false;     // 0 < max_episode_steps <= 65535: the step kernels move 2 instead of 4 bytes each way
     uint32_t *episodes = nullptr;  // [N] resets of each env since seeding = index of its next draw from the reset stream
     uint64_t *seeds = nullptr;  // optional per-env seeds
     uint64_t *t_dev = nullptr;  // device-resident step index for graph replay
@@ -218,6 +219,7 @@ int clock_add(mxv_handle *h, int64_t delta) {
 void fill_step_args(mxv_handle *h, StepArgs &a) {
     a.state = h->state;
     a.elapsed = h->elapsed;
+    a.elapsed16 = h->elapsed16 ? 1 : 0;
     a.episodes = h->episodes;
     a.seeds = h->seeds;
     a.t_dev = nullptr;
@@ -326,6 +328,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     ResetArgs a{};
     a.state = h->state;
     a.elapsed = h->elapsed;
+    a.elapsed16 = h->elapsed16 ? 1 : 0;
     a.episodes = h->episodes;
     a.obs = obs_dev;
     a.mask = mask_dev;
@@ -571,6 +574,7 @@ int mxv_create(const mxv_config *cfg, mxv_handle **out) {
     MXV_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
     MXV_CREATE_HIP(hipMalloc((void **)&h->state, n * h->S * sizeof(double)));
+    h->elapsed16 = cfg->max_episode_steps > 0 && cfg->max_episode_steps <= 65535 && !getenv("MXV_ELAPSED32");   // (A/B hook)
     MXV_CREATE_HIP(hipMalloc((void **)&h->elapsed, n * sizeof(int32_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->episodes, n * sizeof(uint32_t)));
     MXV_CREATE_HIP(hipMalloc((void **)&h->t_dev, sizeof(uint64_t)));
@@ -1081,9 +1085,17 @@ int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host) 
     const size_t n = (size_t)h->cfg.num_envs;
     if (state_soa_host)
         MXV_HIP(h, hipMemcpyAsync(state_soa_host, h->state, n * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (elapsed_host)
-        MXV_HIP(h, hipMemcpyAsync(elapsed_host, h->elapsed, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint16_t> narrow;
+    if (elapsed_host) {
+        if (h->elapsed16) {
+            narrow.resize(n);
+            MXV_HIP(h, hipMemcpyAsync(narrow.data(), h->elapsed, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+        } else {
+            MXV_HIP(h, hipMemcpyAsync(elapsed_host, h->elapsed, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        }
+    }
     MXV_HIP(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < narrow.size(); ++i) elapsed_host[i] = narrow[i];
     return MXV_OK;
 }
 
@@ -1093,8 +1105,19 @@ int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *el
     const size_t n = (size_t)h->cfg.num_envs;
     if (state_soa_host)
         MXV_HIP(h, hipMemcpyAsync(h->state, state_soa_host, n * h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (elapsed_host)
-        MXV_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    std::vector<uint16_t> narrow;
+    if (elapsed_host) {
+        if (h->elapsed16) {
+            narrow.resize(n);
+            for (size_t i = 0; i < n; ++i) {
+                if (elapsed_host[i] < 0) return fail(h, MXV_ERR_INVALID_ARG, "elapsed[%zu] = %d is negative", i, elapsed_host[i]);
+                narrow[i] = (uint16_t)(elapsed_host[i] > 65535 ? 65535 : elapsed_host[i]);
+            }
+            MXV_HIP(h, hipMemcpyAsync(h->elapsed, narrow.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+        } else {
+            MXV_HIP(h, hipMemcpyAsync(h->elapsed, elapsed_host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        }
+    }
     if (state_soa_host && h->beyond) MXV_HIP(h, hipMemsetAsync(h->beyond, 0, n, h->stream));  // a fresh state: steps_beyond_terminated = None
     MXV_HIP(h, hipStreamSynchronize(h->stream));
     h->was_reset = true;  // an injected state stands in for reset() (parity harness, checkpoint restore)

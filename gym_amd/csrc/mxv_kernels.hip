@@ -25,6 +25,19 @@ namespace {
 // word lives in pinned host memory (host steps of small envs, mxv_api.cpp: ErrInBlock), where a PCIe atomic might not.
 __device__ __forceinline__ void raise_error(int32_t *err, int32_t bit) { *reinterpret_cast<volatile int32_t *>(err) = bit; }
 
+// elapsed[] is stored in 16 bits whenever the handle's TimeLimit fits (mxv_api.cpp: elapsed16): step(actions) reads and writes it every
+// launch, 2 + 2 instead of 4 + 4 bytes per env-step.  The counter saturates at 65535 (only reachable without autoreset, far beyond the limit:
+// `truncated` stays set, `elapsed == 0` stays false).  A wave-uniform branch on a kernel argument at entry and exit, nothing in the loops.
+__device__ __forceinline__ int32_t load_elapsed(const void *p, int32_t el16, int64_t e) {
+    return el16 ? (int32_t) static_cast<const uint16_t *>(p)[e] : static_cast<const int32_t *>(p)[e];
+}
+__device__ __forceinline__ void store_elapsed(void *p, int32_t el16, int64_t e, int32_t v) {
+    if (el16)
+        static_cast<uint16_t *>(p)[e] = (uint16_t)(v > 65535 ? 65535 : v);
+    else
+        static_cast<int32_t *>(p)[e] = v;
+}
+
 template <int O>
 __device__ __forceinline__ void store_obs(float *base, int64_t e, const float *o) {
     if constexpr (O == 4) {
@@ -138,7 +151,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         const int64_t ec = valid[j] ? e : 0;
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + ec];
-        el[j] = a.elapsed[ec];
+        el[j] = load_elapsed(a.elapsed, a.elapsed16, ec);
         EV::prime(s[j], aux[j]);
     }
     float er[E];  // running episode return (RecordEpisodeStatistics.episode_returns)
@@ -351,7 +364,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         const int64_t e = env_of(j);
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + e] = s[j][k];
-        a.elapsed[e] = el[j];
+        store_elapsed(a.elapsed, a.elapsed16, e, el[j]);
         if (ep[j] != ep_in[j]) a.episodes[e] = ep[j];
         if (a.ep_acc) a.ep_acc[e] = er[j];
     }
@@ -533,7 +546,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         le[j] = (uint32_t)(valid[j] ? e : 0);
 #pragma unroll
         for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + le[j]];
-        el[j] = a.elapsed[le[j]];
+        el[j] = load_elapsed(a.elapsed, a.elapsed16, le[j]);
         ep[j] = a.episodes[le[j]];
         EV::template prime<SAFE>(s[j], aux[j]);
     }
@@ -948,7 +961,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
         if (!valid[j] || bad[j]) continue;
 #pragma unroll
         for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + le[j]] = s[j][k];
-        a.elapsed[le[j]] = el[j];
+        store_elapsed(a.elapsed, a.elapsed16, le[j], el[j]);
         a.episodes[le[j]] = ep[j];
         if (ep_on) a.ep_acc[le[j]] = er[j];
         if constexpr ((STATS & 2) != 0) a.ret_state[le[j]] = ret[j];
@@ -1031,7 +1044,7 @@ __global__ void __launch_bounds__(kBlock) reset_kernel(const ResetArgs a) {
     EV::reset(w, a.b0, a.b1, s);
 #pragma unroll
     for (int k = 0; k < S; ++k) a.state[(int64_t)k * a.n + e] = s[k];
-    a.elapsed[e] = 0;  // time_limit.py:67
+    store_elapsed(a.elapsed, a.elapsed16, e, 0);  // time_limit.py:67
     if (a.ep_acc != nullptr) a.ep_acc[e] = 0.0f;  // record_episode_statistics.py:91-94
     if (a.beyond != nullptr) a.beyond[e] = 0;     // steps_beyond_terminated = None (cartpole.py:205)
     if (a.obs != nullptr) {

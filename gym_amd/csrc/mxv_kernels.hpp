@@ -10,7 +10,7 @@ namespace mxv {
 
 struct StepArgs {
     double *state;         // [S][N] fp64, struct-of-arrays
-    int32_t *elapsed;      // [N] TimeLimit counters
+    void *elapsed;         // [N] TimeLimit counters: uint16 when elapsed16 (every handle whose limit fits: 2 B instead of 4 each way per step), else int32
     uint32_t *episodes;    // [N] resets each env has had since seeding = index of its next draw from the reset stream
     const void *actions;   // int64/int32/float32 [N]; nullptr -> draw from the Philox action stream
     void *actions_out;     // optional record of the sampled actions
@@ -38,6 +38,7 @@ struct StepArgs {
     int32_t flags;         // MXV_FLAG_*
     int32_t K;             // vector steps fused into this launch (>= 1)
     int32_t state_injected; // mxv_set_state() ran since the last launch: no invariant on the state may be assumed
+    int32_t elapsed16;      // storage type of elapsed[] (see above)
     int32_t step_noise;     // Acrobot torque_noise_max > 0 somewhere: draw the step-noise word (step_kernel launches only)
     int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
     int64_t act_slice;     // action tape advance per step (envs) or 0
@@ -65,7 +66,8 @@ struct MixedArgs {
 
 struct ResetArgs {
     double *state;
-    int32_t *elapsed;
+    void *elapsed;         // as in StepArgs
+    int32_t elapsed16;
     uint32_t *episodes;    // [N] reset ordinals (read: index of this draw; written back + 1)
     float *obs;            // may be nullptr
     const uint8_t *mask;   // may be nullptr (all)
