@@ -87,3 +87,57 @@ def measure_normalize(torch, envs, chunk, reps=6):
     del tr, y32, o64
     torch.cuda.empty_cache()
     return out
+
+
+def measure_subenv_normalize(torch, envs, chunk=64, reps=6):
+    """The PER-SUB-ENV NormalizeObservation / NormalizeReward of `make(wrappers=[...])` (gym/vector/__init__.py:56-65 around
+    gym/wrappers/normalize.py:50-145: every sub-env its own RunningMeanStd, batches of one) at `envs` sub-envs, three ways:
+    the mxv_subnorm_* kernels on a [K][N] trajectory (statistics in registers across the K steps: 8 O + 2 algorithmic bytes per
+    env-step for the observations, 8 + 8 + 2 for the rewards), the same kernels called once per step (K = 1: + 16 (2 O + 1) bytes of
+    statistics each way), and the host-side NumPy statistics the wrappers used before round 6 (and still use below 4096 sub-envs)."""
+    import time
+
+    import numpy as np
+
+    from gym_amd.rollout import DeviceRollout
+    from gym_amd.wrappers import _PerEnvMeanStd
+
+    dr = DeviceRollout(ENV_ID, envs, seed=0, action_seed=1)
+    obs0 = dr.reset(seed=0)
+    tr = dr.rollout_per_step(chunk, out=dr.trajectory_buffers(chunk, want_final=True, layout="separate"))
+    dr.synchronize()
+    s, O = dr.stream, dr.O
+    nz = dr.make_subenv_normalizer()
+    with torch.cuda.stream(s):
+        nz.normalize_reset_obs(obs0)
+        y = torch.empty((chunk, envs, O), dtype=torch.float32, device=dr.device)
+        yf = torch.empty((chunk, envs, O), dtype=torch.float64, device=dr.device)
+        ro = torch.empty_like(tr["reward"])
+    args = (tr["obs"], tr["final_obs"], tr["terminated"], tr["truncated"])
+    obs_k = _event_us(torch, s, lambda: nz.normalize_obs(*args, out=y, final_out=yf), reps, chunk)
+    rew_k = _event_us(torch, s, lambda: nz.normalize_rewards(tr["reward"], tr["terminated"], tr["truncated"], out=ro), reps, chunk)
+    one = lambda k: nz.normalize_obs(tr["obs"][k], tr["final_obs"][k], tr["terminated"][k], tr["truncated"][k], out=y[k], final_out=yf[k])  # noqa: E731
+    obs_1 = _event_us(torch, s, lambda: [one(k) for k in range(chunk)], reps, chunk)
+    rew_1 = _event_us(torch, s, lambda: [nz.normalize_rewards(tr["reward"][k], tr["terminated"][k], tr["truncated"][k], out=ro[k]) for k in range(chunk)],
+                      reps, chunk)
+    # the host statistics on the same step (NumPy over [N][O] float64 arrays; inputs already on the host: PCIe not counted)
+    x = tr["obs"][0].cpu().numpy()
+    h = _PerEnvMeanStd(envs, (O,))
+    h.update(x)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        h.update(x)
+        _ = ((x - h.mean) / np.sqrt(h.var + 1e-8)).astype(np.float32)
+    host_us = (time.perf_counter() - t0) / 3 * 1e6
+    out = {"workload": f"{ENV_ID}, num_envs={envs}: per-sub-env running statistics (batches of one row), K = {chunk} trajectory steps per call "
+                       "vs one call per step vs the host NumPy statistics",
+           "normalize_obs": _hbm(obs_k, envs, 8 * O + 2, kernels="mxv_subnorm.hip: subnorm_obs_kernel (read 4 O + 2 flag bytes, write 4 O float32; "
+                                                                    "terminal rows of finished sub-envs: + 4 O read, 8 O written, ~5 % of rows)"),
+           "normalize_reward": _hbm(rew_k, envs, 18, kernels="mxv_subnorm.hip: subnorm_rew_kernel (read 8 + 2, write 8)"),
+           "normalize_obs_one_call_per_step": _hbm(obs_1, envs, 8 * O + 2 + 16 * (2 * O + 1), kernels="the same kernel, K = 1: the statistics make the round trip"),
+           "normalize_reward_one_call_per_step": _hbm(rew_1, envs, 18 + 16 * 4, kernels="K = 1"),
+           "host_numpy_obs_us_per_step": host_us, "device_over_host": host_us / obs_1}
+    nz.close(), dr.close()
+    del tr, y, yf, ro
+    torch.cuda.empty_cache()
+    return out

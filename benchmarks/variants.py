@@ -4,7 +4,7 @@ learner-in-the-loop paths).  They are reported BESIDE the headline and never ins
 from .common import ENV_ID, ENVS_TOTAL
 from .fused import measure_fused, measure_mixed
 from .loops import measure_numpy_loop, measure_policy_loop, measure_step_kernel, measure_step_loop
-from .normalize import measure_normalize
+from .normalize import measure_normalize, measure_subenv_normalize
 from .toy_text import measure_blackjack, measure_tabular
 
 
@@ -26,6 +26,7 @@ def groups(torch, chunk):
         ("compact_acrobot", f("Acrobot-v1", half, compact=True)),
         # the wrappers and toy_text engines behind the same library
         ("normalize", lambda: measure_normalize(torch, ENVS_TOTAL, 128)),
+        ("subenv_normalize", lambda: measure_subenv_normalize(torch, ENVS_TOTAL)),
         ("frozenlake8x8", lambda: measure_tabular(torch, "FrozenLake8x8-v1", ENVS_TOTAL, 128)),
         ("taxi", lambda: measure_tabular(torch, "Taxi-v3", ENVS_TOTAL, 128)),
         ("compact_frozenlake8x8", lambda: measure_tabular(torch, "FrozenLake8x8-v1", ENVS_TOTAL, 128, compact=True)),
@@ -65,7 +66,7 @@ def run_all(torch, chunk, emit=None):
     return out
 
 
-_HEADLINE_OF = {"normalize": "normalize_obs", "step_loop": "one_engine", "numpy_loop": "num_envs_2^20", "policy_loop_4096_envs": "recorded_in_a_hipgraph"}
+_HEADLINE_OF = {"normalize": "normalize_obs", "subenv_normalize": "normalize_obs", "step_loop": "one_engine", "numpy_loop": "num_envs_2^20", "policy_loop_4096_envs": "recorded_in_a_hipgraph"}
 
 
 def summary(v):

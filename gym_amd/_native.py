@@ -47,6 +47,8 @@ EXPORTS = (
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_sums_partials", "mxv_norm_reward_sums_partials", "mxv_norm_returns_ptr", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
+    "mxv_subnorm_create", "mxv_subnorm_destroy", "mxv_subnorm_last_error", "mxv_subnorm_set_stream", "mxv_subnorm_get_state",
+    "mxv_subnorm_set_state", "mxv_subnorm_observations", "mxv_subnorm_rewards",
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
     "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_device_clock", "mxv_bj_set_device_clock", "mxv_tab_set_stream",
@@ -255,6 +257,14 @@ def _load():
         "mxv_norm_obs_apply": ([vp, i32, vp, vp, i32, C.c_double, vp, i32, i64], C.c_int),
         "mxv_norm_reward_sums": ([vp, i32, vp, i32, vp, vp, C.c_double, vp], C.c_int),
         "mxv_norm_reward_apply": ([vp, i32, vp, i32, vp, C.c_double, vp, i32, i64], C.c_int),
+        "mxv_subnorm_create": ([i32, i32, i64, vp, C.POINTER(vp)], C.c_int),
+        "mxv_subnorm_destroy": ([vp], C.c_int),
+        "mxv_subnorm_last_error": ([vp], C.c_char_p),
+        "mxv_subnorm_set_stream": ([vp, vp], C.c_int),
+        "mxv_subnorm_get_state": ([vp, vp, vp, vp, vp], C.c_int),
+        "mxv_subnorm_set_state": ([vp, vp, vp, vp, vp], C.c_int),
+        "mxv_subnorm_observations": ([vp, i32, vp, vp, vp, vp, vp, i32, vp, C.c_double], C.c_int),
+        "mxv_subnorm_rewards": ([vp, i32, vp, i32, vp, vp, vp, C.c_double, C.c_double], C.c_int),
         "mxv_tab_create": ([C.POINTER(MxvTabConfig), vp, vp, vp, vp, vp, vp, C.POINTER(vp)], C.c_int),
         "mxv_tab_destroy": ([vp], C.c_int),
         "mxv_tab_last_error": ([vp], C.c_char_p),
@@ -658,6 +668,18 @@ class Handle:
         p = [C.c_void_p() for _ in range(4)]
         self._check(lib.mxv_staging_view(self._h, *[C.byref(x) for x in p]))
         return tuple(x.value for x in p)
+
+    def staging_final(self) -> int:
+        """Device address of the dense terminal-observation rows [N][O] float32 of the last host step (valid where that step's
+        terminated | truncated; the host steps always leave them there, packed transfer or not): the block's layout applied to
+        staging_view()'s observation address."""
+        lay = getattr(self, "_block_layout", None)
+        if lay is None:
+            v = [C.c_size_t() for _ in range(6)]
+            self._check(lib.mxv_host_block_layout(self._h, *[C.byref(x) for x in v]))
+            lay = self._block_layout = tuple(x.value for x in v)
+            self._block_pool = _BlockPool(lay[0])
+        return self.staging_view()[0] - lay[2] + lay[1]
 
     def final_packed_stats(self):
         """(indices, episode returns float32, episode lengths int32) of the envs that finished the LAST host step — copies.
@@ -1091,6 +1113,64 @@ class Norm:
     def reward_apply(self, K, reward_dev, reward_f32: bool, out_dev, epsilon: float, all_sums_dev, world: int, total_rows: int):
         self._check(lib.mxv_norm_reward_apply(self._h, int(K), _ptr(reward_dev), int(reward_f32), _ptr(out_dev),
                                               float(epsilon), _ptr(all_sums_dev), int(world), int(total_rows)))
+
+
+class SubNorm:
+    """One mxv_subnorm = num_envs device-resident RunningMeanStd objects of shape (dim,), each fed with batches of one row (+ every
+    sub-env's discounted return): the per-sub-env NormalizeObservation / NormalizeReward of `make(wrappers=[...])`; see
+    include/mxv_norm.h."""
+
+    def __init__(self, dim: int, num_envs: int, *, device: int = 0, stream: int = 0):
+        self.dim, self.num_envs, self.device = int(dim), int(num_envs), int(device)
+        h = C.c_void_p()
+        rc = lib.mxv_subnorm_create(self.device, self.dim, self.num_envs, C.c_void_p(stream or None), C.byref(h))
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_subnorm_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MxvError(rc, (lib.mxv_subnorm_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.mxv_subnorm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        self._check(lib.mxv_subnorm_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def get_state(self):
+        """(mean[num_envs][dim], var[num_envs][dim], count[num_envs], returns[num_envs]) as float64 host arrays."""
+        mean = np.zeros((self.num_envs, self.dim), np.float64)
+        var = np.zeros((self.num_envs, self.dim), np.float64)
+        count = np.zeros(self.num_envs, np.float64)
+        ret = np.zeros(self.num_envs, np.float64)
+        self._check(lib.mxv_subnorm_get_state(self._h, mean.ctypes.data, var.ctypes.data, count.ctypes.data, ret.ctypes.data))
+        return mean, var, count, ret
+
+    def set_state(self, mean, var, count, returns=None):
+        m = np.ascontiguousarray(mean, dtype=np.float64).reshape(self.num_envs, self.dim)
+        v = np.ascontiguousarray(var, dtype=np.float64).reshape(self.num_envs, self.dim)
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(count, dtype=np.float64), (self.num_envs,)))
+        r = None if returns is None else np.ascontiguousarray(returns, dtype=np.float64).reshape(self.num_envs)
+        self._check(lib.mxv_subnorm_set_state(self._h, m.ctypes.data, v.ctypes.data, c.ctypes.data, _ptr(r)))
+
+    def observations(self, K, x_dev, final_dev, terminated_dev, truncated_dev, y_dev, out_f32: bool, final_y_dev, epsilon: float):
+        self._check(lib.mxv_subnorm_observations(self._h, int(K), _ptr(x_dev), _ptr(final_dev), _ptr(terminated_dev), _ptr(truncated_dev),
+                                                 _ptr(y_dev), int(out_f32), _ptr(final_y_dev), float(epsilon)))
+        return y_dev
+
+    def rewards(self, K, reward_dev, reward_f32: bool, terminated_dev, truncated_dev, out_dev, gamma: float, epsilon: float):
+        self._check(lib.mxv_subnorm_rewards(self._h, int(K), _ptr(reward_dev), int(reward_f32), _ptr(terminated_dev), _ptr(truncated_dev),
+                                            _ptr(out_dev), float(gamma), float(epsilon)))
+        return out_dev
 
 
 class Tab:

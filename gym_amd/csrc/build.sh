@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result ${MXV_EXTRA_FLAGS:-})
 # stale objects must never survive a failed compile: remove them first, then wait for every compile BY PID
 # (a bare `wait` returns 0 even when a background job failed, so `set -e` would not fire).
-srcs=(mxv_kernels.hip mxv_api.cpp mxv_norm.hip mxv_tab.hip mxv_bj.hip mxv_placed.hip)
+srcs=(mxv_kernels.hip mxv_api.cpp mxv_norm.hip mxv_subnorm.hip mxv_tab.hip mxv_bj.hip mxv_placed.hip)
 objs=()
 pids=()
 for s in "${srcs[@]}"; do

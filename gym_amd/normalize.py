@@ -17,7 +17,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ["RunningNormalizer", "HipNormBackend"]
+__all__ = ["RunningNormalizer", "HipNormBackend", "SubEnvNormalizer"]
 
 
 class HipNormBackend:
@@ -215,3 +215,100 @@ class RunningNormalizer:
 
     def close(self):
         self.backend.close()
+
+
+class SubEnvNormalizer:
+    """The PER-SUB-ENV NormalizeObservation / NormalizeReward of `gym.vector.make(id, n, wrappers=[...])` (gym/vector/__init__.py:56-65
+    around gym/wrappers/normalize.py:50-145) on device tensors: every sub-env owns its running statistics and folds ONE row per call
+    into them — the terminal observation of an episode that ends and the reset observation that follows are two calls.  Backed by the
+    mxv_subnorm_* kernels (one lane per sub-env, statistics in registers across the K steps of a trajectory tensor, no cross-env
+    reduction: a sharded vector env needs no collective for it).
+
+    normalize_obs(x, final_obs, terminated, truncated)   x float32 [K, N, O] (or [N, O]) -> same shape float32 (the dtype of the
+                                                         reference's batched observations; out_dtype=torch.float64 for the unrounded
+                                                         results); `final` = the float64 normalised terminal rows (finished sub-envs only)
+    normalize_reset_obs(x)                               reset(): one update per sub-env, nobody has finished
+    normalize_rewards(r, terminated, truncated)          float64 / float32 [K, N] (or [N]) -> same shape and dtype
+    obs_rms / return_rms / returns                       host copies of every sub-env's statistics ([N, O] / [N])"""
+
+    def __init__(self, num_envs: int, obs_dim: int, *, device: int = 0, stream=None, gamma: float = 0.99, obs_epsilon: float = 1e-8,
+                 reward_epsilon: float = 1e-8, backend=None):
+        self.num_envs, self.obs_dim = int(num_envs), int(obs_dim)
+        self.gamma, self.obs_epsilon, self.reward_epsilon = float(gamma), float(obs_epsilon), float(reward_epsilon)
+        self.stream = stream
+        if backend is None:
+            from . import _native
+
+            if not torch.cuda.is_available():
+                raise RuntimeError("SubEnvNormalizer needs a HIP device; gym_amd has no CPU fallback")
+            sp = stream.cuda_stream if stream is not None else 0
+            backend = SimpleNamespace(obs=_native.SubNorm(obs_dim, num_envs, device=device, stream=sp),
+                                      rew=_native.SubNorm(1, num_envs, device=device, stream=sp))
+        self.backend = backend
+
+    def _ctx(self):
+        from contextlib import nullcontext
+
+        return torch.cuda.stream(self.stream) if self.stream is not None else nullcontext()
+
+    def normalize_obs(self, x, final_obs=None, terminated=None, truncated=None, *, out=None, out_dtype=torch.float32, final_out=None):
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        K = x.shape[0] if x.dim() == 3 else 1
+        assert x.numel() == K * self.num_envs * self.obs_dim, (tuple(x.shape), self.num_envs, self.obs_dim)
+        for t_ in (final_obs, terminated, truncated):
+            assert t_ is None or t_.is_contiguous()
+        if terminated is not None:
+            assert truncated is not None and terminated.numel() == K * self.num_envs == truncated.numel()
+            assert terminated.element_size() == 1 and truncated.element_size() == 1
+        if final_obs is not None:
+            assert final_obs.dtype == torch.float32 and final_obs.numel() == x.numel() and terminated is not None
+        with self._ctx():
+            if out is None:
+                out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+            assert out.is_contiguous() and out.shape == x.shape and out.dtype in (torch.float32, torch.float64)
+            if final_out is None and final_obs is not None:
+                final_out = torch.zeros(x.shape, dtype=torch.float64, device=x.device)
+            self.backend.obs.observations(K, x, final_obs, terminated, truncated, out, out.dtype == torch.float32, final_out, self.obs_epsilon)
+        return (out, final_out) if final_obs is not None else out
+
+    def normalize_reset_obs(self, x, *, out=None, out_dtype=torch.float32):
+        return self.normalize_obs(x, out=out, out_dtype=out_dtype)
+
+    def normalize_rewards(self, reward, terminated, truncated, *, out=None):
+        assert reward.dtype in (torch.float64, torch.float32) and reward.is_contiguous()
+        K = reward.shape[0] if reward.dim() == 2 else 1
+        assert reward.numel() == K * self.num_envs == terminated.numel() == truncated.numel()
+        assert terminated.is_contiguous() and truncated.is_contiguous() and terminated.element_size() == 1 == truncated.element_size()
+        with self._ctx():
+            if out is None:
+                out = torch.empty_like(reward)
+            assert out.is_contiguous() and out.shape == reward.shape and out.dtype == reward.dtype
+            self.backend.rew.rewards(K, reward, reward.dtype == torch.float32, terminated, truncated, out, self.gamma, self.reward_epsilon)
+        return out
+
+    @property
+    def obs_rms(self):
+        mean, var, count, _ = self.backend.obs.get_state()
+        return SimpleNamespace(mean=mean, var=var, count=count)
+
+    @property
+    def return_rms(self):
+        mean, var, count, _ = self.backend.rew.get_state()
+        return SimpleNamespace(mean=mean[:, 0], var=var[:, 0], count=count)
+
+    @property
+    def returns(self):
+        return self.backend.rew.get_state()[3]
+
+    def state_dict(self):
+        om, ov, oc, _ = self.backend.obs.get_state()
+        rm, rv, rc, ret = self.backend.rew.get_state()
+        return dict(obs_mean=om, obs_var=ov, obs_count=oc, ret_mean=rm, ret_var=rv, ret_count=rc, returns=ret)
+
+    def load_state_dict(self, sd):
+        self.backend.obs.set_state(sd["obs_mean"], sd["obs_var"], sd["obs_count"])
+        self.backend.rew.set_state(sd["ret_mean"], sd["ret_var"], sd["ret_count"], sd.get("returns"))
+
+    def close(self):
+        self.backend.obs.close()
+        self.backend.rew.close()

@@ -332,6 +332,14 @@ class DeviceRollout:
 
         return RunningNormalizer(self.num_envs, self.O, device=self.device.index, stream=self.stream, **kw)
 
+    def make_subenv_normalizer(self, **kw):
+        """SubEnvNormalizer: the PER-SUB-ENV NormalizeObservation / NormalizeReward of `make(wrappers=[...])` (every sub-env its own running
+        statistics, batches of one) on this engine's device tensors and stream; feed it step() outputs or [K, N, ...] trajectory tensors
+        (with their "final_obs")."""
+        from .normalize import SubEnvNormalizer
+
+        return SubEnvNormalizer(self.num_envs, self.O, device=self.device.index, stream=self.stream, **kw)
+
     def final_tensors(self):
         """(obs, reward, terminated, truncated) of the most recent vector step (views, valid until the next call)."""
         return self._last

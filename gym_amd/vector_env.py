@@ -601,8 +601,10 @@ def _sub_env_wrappers(wrappers):
                                               wrapper truncates at k, the registered inner one at the spec's limit)
         RecordEpisodeStatistics(deque_size=)  the fused episode accumulators, reported in infos["final_info"][i]["episode"]
         OrderEnforcing, PassiveEnvChecker     what gym.make applies anyway: accepted, nothing to do
-        ClipAction                            Box-action ids only (clip_action.py:28 asserts it): np.clip(action, low, high) before a step whose
-                                              first operation is the same clip (pendulum.py:126, continuous_mountain_car.py:148-149): a no-op
+        ClipAction                            Box-action ids only (clip_action.py:28 asserts it): np.clip(action, low, high).  Pendulum-v1: the
+                                              step's first operation is the same clip and nothing else sees the action (pendulum.py:126-129):
+                                              a no-op.  MountainCarContinuous-v0: the reward uses the action AS GIVEN
+                                              (continuous_mountain_car.py:169), so the clip is applied for real (SubEnvClipAction)
         FlattenObservation                    classic-control observations are flat Box vectors already (flatten_observation.py:33-43): a no-op
         NormalizeObservation(epsilon=), NormalizeReward(gamma=, epsilon=)
                                               per-sub-env running statistics (a batch of one per update) — a DIFFERENT normalisation from
@@ -624,7 +626,10 @@ def _sub_env_wrappers(wrappers):
     limit, post = None, []
     for w in wrappers:
         fn, args, kw = (w.func, w.args, dict(w.keywords)) if isinstance(w, functools.partial) else (w, (), {})
-        name = getattr(fn, "__name__", None) if isinstance(fn, type) else None
+        # recognised by class name AND home (the reference's gym.wrappers.* or this package's): a user class that merely shares a name
+        # keeps its own semantics and must reach the error below
+        home = (getattr(fn, "__module__", "") or "").split(".")
+        name = getattr(fn, "__name__", None) if isinstance(fn, type) and (home[:2] == ["gym", "wrappers"] or home[0] == "gym_amd") else None
         if name == "TimeLimit" and not args:
             k = kw.pop("max_episode_steps", None)
             if kw:
@@ -674,6 +679,10 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
                 env.close()
                 raise NotImplementedError(f"wrappers={kw['wrapper']} is an identity only for the classic-control ids"
                                           + (" with Box actions (clip_action.py:28 asserts a Box action space)" if kw["wrapper"] == "ClipAction" else ""))
+            if kw["wrapper"] == "ClipAction" and id.split("/")[-1].startswith("MountainCarContinuous"):
+                from .wrappers import SubEnvClipAction
+
+                env = SubEnvClipAction(env)      # the reward's action penalty sees the clipped action (continuous_mountain_car.py:169)
             continue
         if what in ("normalize_observation", "normalize_reward"):
             base = getattr(env, "unwrapped", env)

@@ -20,7 +20,7 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics",
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics", "SubEnvClipAction",
            "SubEnvNormalizeObservation", "SubEnvNormalizeReward"]
 
 
@@ -187,6 +187,17 @@ class SubEnvEpisodeStatistics(_VectorWrapper):
         return obs, rew, term, trunc, infos
 
 
+class SubEnvClipAction(_VectorWrapper):
+    """`wrappers=ClipAction` (gym/wrappers/clip_action.py:33-43 around every sub-env) where it is NOT an identity:
+    MountainCarContinuous-v0 charges `action[0] ** 2 * 0.1` on the action as given (continuous_mountain_car.py:169), so an out-of-range
+    action must reach the engine clipped to the action space's bounds."""
+
+    def step(self, actions):
+        sp = self.env.single_action_space
+        a = np.asarray(actions, dtype=sp.dtype).reshape((self.env.num_envs,) + sp.shape)
+        return self.env.step(np.clip(a, sp.low, sp.high))
+
+
 class _PerEnvMeanStd:
     """N independent RunningMeanStd objects (gym/wrappers/normalize.py:8-48), one per sub-env, each updated with batches of ONE row — what
     `NormalizeObservation(sub_env)` / `NormalizeReward(sub_env)` keep — as arrays over the env axis.  The update is the reference's
@@ -207,70 +218,6 @@ class _PerEnvMeanStd:
         m2 = var * count + np.float32(0.0) * 1 + np.square(delta) * count * 1 / tot      # :41-43 (m_b = batch_var * batch_count = 0)
         self.var[idx] = m2 / tot                                      # :44
         self.count[idx] = tot[(slice(None),) + (0,) * (tot.ndim - 1)]
-
-
-class SubEnvNormalizeObservation(_VectorWrapper):
-    """What `gym.vector.make(id, n, wrappers=NormalizeObservation)` yields in the reference (gym/vector/__init__.py:56-65 around
-    gym/wrappers/normalize.py:50-93): every sub-env normalises its observations with ITS OWN running statistics, updated with one row per
-    call — the terminal observation of an episode and the reset observation that follows it are two calls of that env's wrapper
-    (step, then the autoreset's reset: sync_vector_env.py:152-156), the batched observations are the float32 cast of the float64 results
-    (the vector env's observation space stays float32: numpy_utils.py:49-50 writes into it) and `final_observation` holds the float64
-    arrays.  A different normalisation from the vector-level `NormalizeObservation` (batch statistics over all sub-envs, device kernels):
-    this one is host-side NumPy over the arrays the adapter hands back, vectorised over the env axis — exact, and meant for the sizes the
-    reference itself handles; wrap the vector env instead for 2^20 envs."""
-
-    def __init__(self, env, epsilon: float = 1e-8):
-        super().__init__(env)
-        self.epsilon = epsilon
-        self.obs_rms = _PerEnvMeanStd(env.num_envs, env.single_observation_space.shape)
-
-    def _normalize(self, rows, idx=slice(None)):
-        self.obs_rms.update(rows, idx)
-        return (rows - self.obs_rms.mean[idx]) / np.sqrt(self.obs_rms.var[idx] + self.epsilon)       # :90-93
-
-    def reset(self, **kwargs):
-        obs, infos = self.env.reset(**kwargs)
-        return self._normalize(obs).astype(obs.dtype), infos
-
-    def step(self, action):
-        obs, rew, term, trunc, infos = self.env.step(action)
-        done = term | trunc
-        if not done.any():
-            return self._normalize(obs).astype(obs.dtype), rew, term, trunc, infos
-        idx = np.flatnonzero(done)
-        fin = infos["final_observation"]
-        first = obs.copy()                                            # what every sub-env's step() returned: terminal rows where it ended
-        first[idx] = np.stack([fin[i] for i in idx])
-        y = self._normalize(first)
-        new_fin = np.full(len(done), None, dtype=object)
-        for i in idx:
-            new_fin[i] = y[i].copy()                                  # float64, as the sub-env's wrapper returned it
-        y[idx] = self._normalize(obs[idx], idx)                       # ... then each finished sub-env's reset(): its second update
-        if isinstance(infos, LazyInfos):
-            dict.__setitem__(infos, "final_observation", new_fin)
-        else:
-            infos["final_observation"] = new_fin
-        return y.astype(obs.dtype), rew, term, trunc, infos
-
-
-class SubEnvNormalizeReward(_VectorWrapper):
-    """`wrappers=NormalizeReward` (gym/wrappers/normalize.py:96-145 around every sub-env): per-env discounted return, per-env running
-    variance of it (batches of one), reward / sqrt(var + epsilon), the return zeroed where the episode ended.  Host-side NumPy, exact, see
-    SubEnvNormalizeObservation."""
-
-    def __init__(self, env, gamma: float = 0.99, epsilon: float = 1e-8):
-        super().__init__(env)
-        self.gamma, self.epsilon = gamma, epsilon
-        self.return_rms = _PerEnvMeanStd(env.num_envs, ())
-        self.returns = np.zeros(env.num_envs)
-
-    def step(self, action):
-        obs, rew, term, trunc, infos = self.env.step(action)
-        self.returns = self.returns * self.gamma + rew                 # :132
-        self.return_rms.update(self.returns)                           # :144
-        rew = rew / np.sqrt(self.return_rms.var + self.epsilon)        # :145
-        self.returns[term | trunc] = 0.0                               # :134-135
-        return obs, rew, term, trunc, infos
 
 
 class VectorListInfo(_VectorWrapper):
@@ -356,6 +303,209 @@ class _StagedIO:
         self.__dict__.update(d)
         self._torch = torch
         self._pools = {}
+
+
+# Per-sub-env Normalize* (what `make(wrappers=[NormalizeObservation, NormalizeReward])` maps to): from this many sub-envs on, every
+# sub-env's running statistics live on the device and are advanced by the mxv_subnorm_* kernels (one lane per sub-env); below it
+# they are NumPy arrays on the host — the same arithmetic in the same order, bit for bit (tests/test_gpu_subnorm.py).
+SUBENV_DEVICE_MIN = 4096
+
+
+class _SubEnvDevice(_StagedIO):
+    """Device side of SubEnvNormalizeObservation / SubEnvNormalizeReward: one _native.SubNorm, the staged outputs of the host step as
+    its inputs (no second upload), pooled pinned arrays for its results."""
+
+    def _device_setup(self, env, dim, inner_ok, device):
+        base = getattr(env, "unwrapped", env)
+        on = device if device is not None else (isinstance(base, HipVectorEnv) and env.num_envs >= SUBENV_DEVICE_MIN)
+        self._sub = None
+        if not on:
+            return False
+        import torch
+
+        from . import _native
+
+        if not isinstance(base, HipVectorEnv):
+            raise TypeError("the device form of the per-sub-env Normalize* wrappers needs a HipVectorEnv underneath")
+        self._torch = torch
+        self._dev = torch.device("cuda", base.handle.device)
+        self._sub = _native.SubNorm(dim, env.num_envs, device=base.handle.device)
+        self._staged_setup(base, inner_ok)
+        self._staged = self._staged and hasattr(base.handle, "staging_final")
+        return True
+
+    def _dev_buf(self, name, shape, dtype):
+        b = self.__dict__.get(name)
+        if b is None:
+            b = self.__dict__[name] = self._torch.empty(shape, dtype=dtype, device=self._dev)
+        return b
+
+    def _up(self, a, dtype):
+        return self._torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self._dev)
+
+    def __getstate__(self):
+        d = _StagedIO.__getstate__(self)
+        sub = d.pop("_sub", None)
+        for k in [k for k in d if k.startswith("_buf_")]:
+            d.pop(k)
+        d["_sub_state"] = None if sub is None else (sub.dim, sub.get_state())
+        return d
+
+    def __setstate__(self, d):
+        st = d.pop("_sub_state", None)
+        _StagedIO.__setstate__(self, d)
+        self._sub = None
+        if st is not None:
+            from . import _native
+
+            base = getattr(self.env, "unwrapped", self.env)
+            self._dev = self._torch.device("cuda", base.handle.device)
+            self._sub = _native.SubNorm(st[0], self.env.num_envs, device=base.handle.device)
+            self._sub.set_state(*st[1])
+
+    def close(self):
+        if self._sub is not None:
+            self._sub.close()
+        return self.env.close()
+
+
+class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
+    """What `gym.vector.make(id, n, wrappers=NormalizeObservation)` yields in the reference (gym/vector/__init__.py:56-65 around
+    gym/wrappers/normalize.py:50-93): every sub-env normalises its observations with ITS OWN running statistics, updated with one row per
+    call — the terminal observation of an episode and the reset observation that follows it are two calls of that env's wrapper
+    (step, then the autoreset's reset: sync_vector_env.py:152-156), the batched observations are the float32 cast of the float64 results
+    (the vector env's observation space stays float32: numpy_utils.py:49-50 writes into it) and `final_observation` holds the float64
+    arrays.  A different normalisation from the vector-level `NormalizeObservation` (batch statistics over all sub-envs).  From
+    SUBENV_DEVICE_MIN sub-envs on the statistics live on the device (mxv_subnorm_observations reads the step's outputs where the host
+    step left them and one DMA brings the result back); below, host-side NumPy over the arrays the adapter hands back.  Both are the
+    reference's arithmetic in its order: bit-identical to each other and to the reference on the same inputs.  `device=True / False`
+    forces either."""
+
+    def __init__(self, env, epsilon: float = 1e-8, device=None):
+        super().__init__(env)
+        self.epsilon = epsilon
+        shape = env.single_observation_space.shape
+        if not self._device_setup(env, int(shape[0]), (RecordEpisodeStatistics, SubEnvEpisodeStatistics, SubEnvNormalizeReward), device):
+            self.obs_rms = _PerEnvMeanStd(env.num_envs, shape)
+
+    def __getattr__(self, name):
+        if name == "obs_rms" and self.__dict__.get("_sub") is not None:      # host copies of every sub-env's statistics, like the wrappers' attribute
+            from types import SimpleNamespace
+
+            mean, var, count, _ = self._sub.get_state()
+            return SimpleNamespace(mean=mean, var=var, count=count)
+        return _VectorWrapper.__getattr__(self, name)
+
+    def _normalize(self, rows, idx=slice(None)):
+        self.obs_rms.update(rows, idx)
+        return (rows - self.obs_rms.mean[idx]) / np.sqrt(self.obs_rms.var[idx] + self.epsilon)       # :90-93
+
+    def reset(self, **kwargs):
+        obs, infos = self.env.reset(**kwargs)
+        if self._sub is None:
+            return self._normalize(obs).astype(obs.dtype), infos
+        t = self._torch
+        y = self._dev_buf("_buf_y", obs.shape, t.float32)
+        x = self._base.handle.staging_view()[0] if self._staged else self._up(obs, np.float32)
+        self._sub.observations(1, x, None, None, None, y, True, None, self.epsilon)
+        return self._to_host(y, obs.shape, np.float32), infos
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        done = term | trunc
+        if self._sub is not None:
+            return self._step_device(obs, rew, term, trunc, infos, done)
+        if not done.any():
+            return self._normalize(obs).astype(obs.dtype), rew, term, trunc, infos
+        idx = np.flatnonzero(done)
+        fin = infos["final_observation"]
+        first = obs.copy()                                            # what every sub-env's step() returned: terminal rows where it ended
+        first[idx] = np.stack([fin[i] for i in idx])
+        y = self._normalize(first)
+        new_fin = np.full(len(done), None, dtype=object)
+        for i in idx:
+            new_fin[i] = y[i].copy()                                  # float64, as the sub-env's wrapper returned it
+        y[idx] = self._normalize(obs[idx], idx)                       # ... then each finished sub-env's reset(): its second update
+        self._set_final(infos, new_fin)
+        return y.astype(obs.dtype), rew, term, trunc, infos
+
+    @staticmethod
+    def _set_final(infos, new_fin):
+        if isinstance(infos, LazyInfos):
+            dict.__setitem__(infos, "final_observation", new_fin)
+        else:
+            infos["final_observation"] = new_fin
+
+    def _step_device(self, obs, rew, term, trunc, infos, done):
+        t = self._torch
+        idx = np.flatnonzero(done)
+        y = self._dev_buf("_buf_y", obs.shape, t.float32)
+        yfin = self._dev_buf("_buf_yfin", obs.shape, t.float64)
+        if self._staged:
+            h = self._base.handle
+            x, _, te, tr = h.staging_view()
+            fin = h.staging_final()
+        else:                                                         # an inner wrapper altered the arrays: normalise what step() returned
+            x, te, tr = self._up(obs, np.float32), self._up(term, np.uint8), self._up(trunc, np.uint8)
+            dense = np.zeros(obs.shape, np.float32)
+            if idx.size:
+                f = infos["final_observation"]
+                dense[idx] = np.stack([f[i] for i in idx])
+            fin = self._up(dense, np.float32)
+        self._sub.observations(1, x, fin, te, tr, y, True, yfin, self.epsilon)
+        if idx.size:
+            rows = yfin[t.from_numpy(idx).to(self._dev)].cpu().numpy()       # the float64 rows of the finished sub-envs only
+            n = len(done)
+
+            def build():
+                arr = np.full(n, None, dtype=object)
+                for j, i in enumerate(idx):
+                    arr[i] = rows[j]
+                return arr
+
+            if isinstance(infos, LazyInfos):
+                dict.__setitem__(infos, "final_observation", _Pending(build))
+            else:
+                infos["final_observation"] = build()
+        return self._to_host(y, obs.shape, np.float32), rew, term, trunc, infos
+
+
+class SubEnvNormalizeReward(_SubEnvDevice, _VectorWrapper):
+    """`wrappers=NormalizeReward` (gym/wrappers/normalize.py:96-145 around every sub-env): per-env discounted return, per-env running
+    variance of it (batches of one), reward / sqrt(var + epsilon), the return zeroed where the episode ended.  On the device from
+    SUBENV_DEVICE_MIN sub-envs on (mxv_subnorm_rewards), host-side NumPy below; exact either way, see SubEnvNormalizeObservation."""
+
+    def __init__(self, env, gamma: float = 0.99, epsilon: float = 1e-8, device=None):
+        super().__init__(env)
+        self.gamma, self.epsilon = gamma, epsilon
+        if not self._device_setup(env, 1, (RecordEpisodeStatistics, SubEnvEpisodeStatistics, SubEnvNormalizeObservation), device):
+            self.return_rms = _PerEnvMeanStd(env.num_envs, ())
+            self.returns = np.zeros(env.num_envs)
+
+    def __getattr__(self, name):
+        if name in ("return_rms", "returns") and self.__dict__.get("_sub") is not None:
+            from types import SimpleNamespace
+
+            mean, var, count, ret = self._sub.get_state()
+            return ret if name == "returns" else SimpleNamespace(mean=mean[:, 0], var=var[:, 0], count=count)
+        return _VectorWrapper.__getattr__(self, name)
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        if self._sub is not None:
+            t = self._torch
+            out = self._dev_buf("_buf_r", rew.shape, t.float64)
+            if self._staged and rew.dtype == np.float64:
+                _, r, te, tr = self._base.handle.staging_view()
+            else:
+                r, te, tr = self._up(rew, np.float64), self._up(term, np.uint8), self._up(trunc, np.uint8)
+            self._sub.rewards(1, r, False, te, tr, out, self.gamma, self.epsilon)
+            return obs, self._to_host(out, rew.shape, np.float64), term, trunc, infos
+        self.returns = self.returns * self.gamma + rew                 # :132
+        self.return_rms.update(self.returns)                           # :144
+        rew = rew / np.sqrt(self.return_rms.var + self.epsilon)        # :145
+        self.returns[term | trunc] = 0.0                               # :134-135
+        return obs, rew, term, trunc, infos
 
 
 class NormalizeObservation(_StagedIO, _VectorWrapper):

@@ -63,9 +63,11 @@
  *   2  (round 2)  episode statistics, mapped / packed / block host I/O, action tapes, mixed-batch launch; mxv_norm.h, mxv_toytext.h
  *   3  (round 3)  collectives (mxv_comm.h), per-env parameters, final-tensor snapshots, mxv_wait_stream
  *   4  (round 4)  device clock (hipGraph capture), fused moments (mxv_set_obs_partials / mxv_set_return_partials); mxv_diag.h
- *   5  (round 5)  mxv_get_beyond / mxv_set_beyond, mxv_bj_rollout_compact, Blackjack's one-call draw contract
+ *   5  (round 5)  mxv_get_beyond / mxv_set_beyond, mxv_bj_rollout_compact; Blackjack's one-call draw contract — NOT additive: the card and
+ *                 Discrete(2) action streams of a Blackjack handle changed, so its snapshots carry the contract number (mxv_toytext.h)
+ *   6  (round 6)  mxv_subnorm_* (per-sub-env Normalize*, mxv_norm.h); elapsed[] stored in 16 bits where the TimeLimit fits (no ABI change)
  * Every section below says the level it appeared at. */
-#define MXV_API_LEVEL 5
+#define MXV_API_LEVEL 6
 
 #include <stddef.h>
 #include <stdint.h>

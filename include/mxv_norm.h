@@ -54,6 +54,39 @@ int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_
 int mxv_norm_reward_apply(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, void *out_dev, double epsilon,
                           const double *all_sums_dev, int32_t world, int64_t total_rows);
 
+/* -- the PER-SUB-ENV form (API level 6): `gym.vector.make(id, n, wrappers=[NormalizeObservation, NormalizeReward])` puts the wrappers
+ *    around EVERY sub-env (gym/vector/__init__.py:56-65), so each sub-env owns a RunningMeanStd updated with batches of ONE row
+ *    (normalize.py:17-47 with batch_mean = the row, batch_var = 0, batch_count = 1) — a different normalisation from the vector-level
+ *    wrappers above, with no cross-env reduction.  One mxv_subnorm = num_envs RunningMeanStd objects of shape (dim,) (fp64 mean / var /
+ *    count per sub-env, device resident) plus, for rewards (dim == 1), every sub-env's discounted return.  Works on K consecutive
+ *    batches per call like mxv_norm ([K][num_envs][dim]; K = 1 for a single step()); the statistics stay in registers across the K
+ *    steps.  Arithmetic and order are the reference's; results are bit-identical to the NumPy wrappers' on the same inputs.
+ *    dim in {1, 2, 3, 4, 6}.  Asynchronous on `stream`. ------------------------------------------------------------------------- */
+typedef struct mxv_subnorm mxv_subnorm;
+int mxv_subnorm_create(int32_t device, int32_t dim, int64_t num_envs, void *stream, mxv_subnorm **out);
+int mxv_subnorm_destroy(mxv_subnorm *nm);
+const char *mxv_subnorm_last_error(const mxv_subnorm *nm); /* nm may be NULL: last failed mxv_subnorm_create on this thread */
+int mxv_subnorm_set_stream(mxv_subnorm *nm, void *stream);
+/* every sub-env's obs_rms.mean / .var (double[num_envs][dim]), .count (double[num_envs]) and NormalizeReward.returns
+ * (double[num_envs]); any pointer may be NULL (set_state: mean, var and count are required).  Synchronises. */
+int mxv_subnorm_get_state(mxv_subnorm *nm, double *mean_host, double *var_host, double *count_host, double *returns_host);
+int mxv_subnorm_set_state(mxv_subnorm *nm, const double *mean_host, const double *var_host, const double *count_host,
+                          const double *returns_host);
+/* NormalizeObservation around every sub-env (normalize.py:72-93 under sync_vector_env.py:142-156).  x_dev float32 [K][num_envs][dim]:
+ * the batched observations of K steps (the post-autoreset row where an episode ended); final_dev float32 [K][num_envs][dim]: the
+ * terminal observations (rows valid where terminated | truncated), terminated_dev / truncated_dev uint8 [K][num_envs].  Per sub-env and
+ * step: where the episode ended the terminal row is folded in and normalised first (-> final_y_dev float64 [K][num_envs][dim], rows of
+ * finished sub-envs only; may be NULL), then the batched row (-> y_dev, float32 when out_f32 != 0 — the dtype of the reference's
+ * batched observations — else float64; y_dev may alias x_dev only when out_f32 != 0).  reset(): final_dev = terminated_dev =
+ * truncated_dev = NULL, K = 1. */
+int mxv_subnorm_observations(mxv_subnorm *nm, int32_t K, const float *x_dev, const float *final_dev, const uint8_t *terminated_dev,
+                             const uint8_t *truncated_dev, void *y_dev, int32_t out_f32, double *final_y_dev, double epsilon);
+/* NormalizeReward around every sub-env (normalize.py:127-145): returns = returns * gamma + reward; return_rms.update(returns);
+ * out = reward / sqrt(var + epsilon); returns = 0 where terminated | truncated.  reward / out float64 [K][num_envs] (float32 when
+ * reward_f32 != 0); out_dev may alias reward_dev.  Needs dim == 1. */
+int mxv_subnorm_rewards(mxv_subnorm *nm, int32_t K, const void *reward_dev, int32_t reward_f32, const uint8_t *terminated_dev,
+                        const uint8_t *truncated_dev, void *out_dev, double gamma, double epsilon);
+
 #ifdef __cplusplus
 }
 #endif

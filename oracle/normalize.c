@@ -219,3 +219,67 @@ void orc_norm_reward_steps(double *returns, double *mean, double *var, double *c
     }
     free(tmp);
 }
+
+/* ---- the PER-SUB-ENV wrappers: gym.vector.make(id, n, wrappers=[NormalizeObservation, NormalizeReward]) -----------------------
+ * gym/vector/__init__.py:56-65 wraps EVERY sub-env, so each sub-env owns a RunningMeanStd that RunningMeanStd.update (:17-22) feeds
+ * with a batch of ONE row: np.array([obs]) (:78, :88): batch_mean = np.mean(x, axis=0) = the row itself (float32 for observations:
+ * the sum of one float32 over a count of 1), batch_var = np.var(x, axis=0) = float32 0, batch_count = 1.
+ * update_mean_var_count_from_moments (:32-47) then runs in float64 in source order; m_b = float32(0) * 1 adds an exact zero.
+ * Checked bit for bit against the reference's own run: tests/golden/vector_make_normalize_*.npz through
+ * tests/test_normalize_oracle.py::test_subnorm_oracle_replays_the_reference. */
+static void sub_update(double *mean, double *var, double *count, double x) {
+    const double delta = x - *mean;                                         /* :36 */
+    const double tot = *count + 1.0;                                        /* :37 */
+    const double new_mean = *mean + delta * 1.0 / tot;                      /* :39 */
+    const double m_a = *var * *count;                                       /* :40 */
+    const double m_b = (double)(0.0f * 1.0f);                               /* :41 */
+    const double M2 = m_a + m_b + delta * delta * *count * 1.0 / tot;       /* :42 */
+    *mean = new_mean;
+    *var = M2 / tot;                                                        /* :43 */
+    *count = tot;                                                           /* :44 */
+}
+
+/* NormalizeObservation around every sub-env under SyncVectorEnv's autoreset (sync_vector_env.py:142-156): where a sub-env's
+ * episode ended, its step() normalised the TERMINAL observation (fin; -> yfin, float64, info["final_observation"]), then its
+ * reset() normalised the reset observation (the row of the batch).  x, fin: float32 [K][n][O]; te, tr: uint8 [K][n] or NULL
+ * (reset()); mean, var: [n][O]; count: [n]; y: float64 [K][n][O]; yfin: float64 [K][n][O] (rows of finished sub-envs) or NULL. */
+void orc_subnorm_obs(double *mean, double *var, double *count, double epsilon, const float *x, const float *fin,
+                     const uint8_t *te, const uint8_t *tr, int64_t K, int64_t n, int O, double *y, double *yfin) {
+    for (int64_t k = 0; k < K; k++)
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t r = k * n + i;
+            const int done = te && (te[r] | tr[r]);
+            if (done && fin) {
+                double c = count[i];
+                for (int j = 0; j < O; j++) {
+                    c = count[i];
+                    sub_update(&mean[i * O + j], &var[i * O + j], &c, (double)fin[r * O + j]);
+                }
+                count[i] = c;
+                if (yfin)
+                    for (int j = 0; j < O; j++)
+                        yfin[r * O + j] = ((double)fin[r * O + j] - mean[i * O + j]) / sqrt(var[i * O + j] + epsilon); /* :93 */
+            }
+            double c = count[i];
+            for (int j = 0; j < O; j++) {
+                c = count[i];
+                sub_update(&mean[i * O + j], &var[i * O + j], &c, (double)x[r * O + j]);
+            }
+            count[i] = c;
+            for (int j = 0; j < O; j++) y[r * O + j] = ((double)x[r * O + j] - mean[i * O + j]) / sqrt(var[i * O + j] + epsilon);
+        }
+}
+
+/* NormalizeReward around every sub-env (:127-145): returns = returns * gamma + rews; return_rms.update(returns) with a batch of one;
+ * rews / sqrt(var + epsilon); returns = 0 where the episode ended.  All [n] / [K][n] float64. */
+void orc_subnorm_rew(double *returns, double *mean, double *var, double *count, double gamma, double epsilon, const double *rew,
+                     const uint8_t *te, const uint8_t *tr, int64_t K, int64_t n, double *out) {
+    for (int64_t k = 0; k < K; k++)
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t r = k * n + i;
+            returns[i] = returns[i] * gamma + rew[r];                       /* :132 */
+            sub_update(&mean[i], &var[i], &count[i], returns[i]);           /* :144 */
+            out[r] = rew[r] / sqrt(var[i] + epsilon);                       /* :145 */
+            if (te[r] | tr[r]) returns[i] = 0.0;                            /* :134-135 */
+        }
+}

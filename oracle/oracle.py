@@ -54,6 +54,8 @@ def lib():
                                   vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_norm_obs_batches.argtypes = [vp, vp, vp, C.c_double, vp, i64, i64, C.c_int, C.c_int, vp]
         L.orc_norm_reward_steps.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, i64, i64, C.c_int, vp]
+        L.orc_subnorm_obs.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, i64, i64, C.c_int, vp, vp]
+        L.orc_subnorm_rew.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, i64, i64, vp]
         L.orc_tab_reset.argtypes = [C.c_int, vp, i64, u64, vp, u64, u64, u32, vp, vp, vp, vp]
         L.orc_tab_step.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, u64, vp, u64, u64, u64, C.c_int,
                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -215,6 +217,60 @@ class EpisodeStats:
         self.returns[done] = 0                          # :142
         self.lengths[done] = 0                          # :143
         return r, l, done
+
+
+class SubEnvNorm:
+    """N independent RunningMeanStd objects fed with batches of one row: what `gym.vector.make(id, n, wrappers=[NormalizeObservation,
+    NormalizeReward])` keeps (oracle/normalize.c: orc_subnorm_*, following gym/wrappers/normalize.py:17-47,72-93,127-145 under
+    gym/vector/sync_vector_env.py:142-156).  The checker of the mxv_subnorm_* kernels; same call shapes as gym_amd._native.SubNorm
+    with NumPy arrays in place of device tensors."""
+
+    def __init__(self, dim: int, num_envs: int, **_):
+        self.dim, self.num_envs = int(dim), int(num_envs)
+        self.mean = np.zeros((self.num_envs, self.dim), np.float64)
+        self.var = np.ones((self.num_envs, self.dim), np.float64)
+        self.count = np.full(self.num_envs, 1e-4, np.float64)
+        self.returns = np.zeros(self.num_envs, np.float64)
+
+    def observations(self, K, x, fin, te, tr, y, out_f32, yfin, epsilon):
+        """x / fin float32 [K][n][dim], te / tr uint8 [K][n] or None; y float32 / float64 [K][n][dim] (written), yfin float64 or None."""
+        n, D = self.num_envs, self.dim
+        xs = np.ascontiguousarray(x, dtype=np.float32).reshape(K, n, D)
+        fs = None if fin is None else np.ascontiguousarray(fin, dtype=np.float32).reshape(K, n, D)
+        tes = None if te is None else np.ascontiguousarray(np.asarray(te).reshape(K, n), dtype=np.uint8)
+        trs = None if tr is None else np.ascontiguousarray(np.asarray(tr).reshape(K, n), dtype=np.uint8)
+        y64 = np.zeros((K, n, D), np.float64)
+        yf = None if yfin is None else np.zeros((K, n, D), np.float64)
+        lib().orc_subnorm_obs(_p(self.mean), _p(self.var), _p(self.count), float(epsilon), _p(xs), _p(fs), _p(tes), _p(trs), K, n, D,
+                              _p(y64), _p(yf))
+        np.copyto(np.asarray(y).reshape(K, n, D), y64, casting="same_kind")     # float64 -> float32 rounds once, like np.stack into the buffer
+        if yfin is not None:
+            np.asarray(yfin).reshape(K, n, D)[...] = yf
+        return y
+
+    def rewards(self, K, rew, reward_f32, te, tr, out, gamma, epsilon):
+        n = self.num_envs
+        rs = np.ascontiguousarray(rew, dtype=np.float64).reshape(K, n)
+        tes = np.ascontiguousarray(np.asarray(te).reshape(K, n), dtype=np.uint8)
+        trs = np.ascontiguousarray(np.asarray(tr).reshape(K, n), dtype=np.uint8)
+        o = np.zeros((K, n), np.float64)
+        lib().orc_subnorm_rew(_p(self.returns), _p(self.mean), _p(self.var), _p(self.count), float(gamma), float(epsilon), _p(rs), _p(tes),
+                              _p(trs), K, n, _p(o))
+        np.copyto(np.asarray(out).reshape(K, n), o, casting="same_kind")
+        return out
+
+    def get_state(self):
+        return self.mean.copy(), self.var.copy(), self.count.copy(), self.returns.copy()
+
+    def set_state(self, mean, var, count, returns=None):
+        self.mean[...] = np.asarray(mean).reshape(self.mean.shape)
+        self.var[...] = np.asarray(var).reshape(self.var.shape)
+        self.count[...] = count
+        if returns is not None:
+            self.returns[...] = returns
+
+    def close(self):
+        pass
 
 
 class RunningNorm:

@@ -75,6 +75,29 @@ def normalize_case(gid, name, actions_of):
     print(name, "episodes:", int((out["truncated"] | out["terminated"]).sum()))
 
 
+def clip_action_case():
+    """vector_make_clipaction_MountainCarContinuous.npz — `gym.vector.make("MountainCarContinuous-v0", 6, wrappers=ClipAction)` run by THE
+    REFERENCE with actions far outside [-1, 1]: the sub-env sees the CLIPPED action (gym/wrappers/clip_action.py:33-43), so the reward's
+    penalty `action[0] ** 2 * 0.1` (continuous_mountain_car.py:169) is at most 0.1 — ClipAction is not an identity for this id."""
+    from gym.wrappers import ClipAction
+
+    N, T = 6, 60
+    env = gym.vector.make("MountainCarContinuous-v0", num_envs=N, asynchronous=False, wrappers=ClipAction)
+    env.reset(seed=99)
+    rng = np.random.default_rng(3)
+    rec = {k: [] for k in ("state_pre", "action", "obs", "reward", "terminated", "truncated")}
+    for t in range(T):
+        rec["state_pre"].append(np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in env.envs]))
+        a = (rng.uniform(-6, 6, (N, 1)) * (rng.random((N, 1)) < 0.7) + rng.uniform(-1, 1, (N, 1)) * 0.3).astype(np.float32)
+        obs, rew, term, trunc, _ = env.step(a)
+        for k, v in (("action", a), ("obs", obs), ("reward", rew), ("terminated", term), ("truncated", trunc)):
+            rec[k].append(v)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    assert (np.abs(out["action"]) > 1).mean() > 0.4 and out["reward"].min() >= -0.1 - 1e-12
+    np.savez_compressed(os.path.join(HERE, "vector_make_clipaction_MountainCarContinuous.npz"), **out)
+    print("ClipAction: min reward", out["reward"].min(), "out-of-range actions", int((np.abs(out["action"]) > 1).sum()))
+
+
 def main():
     normalize_case("CartPole-v1", "CartPole", lambda rng, n: (rng.random(n) < np.linspace(0.15, 0.85, n)).astype(np.int64))
     normalize_case("Pendulum-v1", "Pendulum", lambda rng, n: rng.uniform(-2, 2, (n, 1)).astype(np.float32))
@@ -112,4 +135,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "clipaction":      # (added in round 6; the other files are not regenerated)
+        clip_action_case()
+    else:
+        main()
+        clip_action_case()

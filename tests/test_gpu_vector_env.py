@@ -5,6 +5,7 @@ tests/vector/test_vector_env.py:75-125), TimeLimit truncation (tests/wrappers/te
 under the same seed and actions (tests/envs/test_envs.py:63-115), reset bounds (tests/envs/test_env_implementation.py:
 150-215), error behaviour — plus numeric parity of every returned value against the oracle."""
 import numpy as np
+from helpers import reference_wrapper_stub
 import pytest
 
 from helpers import ENV_IDS, GYM_IDS, LIMITS, MAX_OBS_ULPS, ulps32
@@ -681,8 +682,7 @@ def test_vector_make_with_recognised_sub_env_wrappers_against_the_reference():
     import gym_amd
     from gym_amd.wrappers import RecordEpisodeStatistics, SubEnvEpisodeStatistics
 
-    class TimeLimit:            # recognised by name: the reference's gym.wrappers.TimeLimit is not importable on the GPU box
-        pass
+    TimeLimit = reference_wrapper_stub("TimeLimit")            # recognised by name: the reference's gym.wrappers.TimeLimit is not importable on the GPU box
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vector_make_wrappers_CartPole.npz"))
     T, N = g["action"].shape

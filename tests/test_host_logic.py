@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+from helpers import reference_wrapper_stub
 import pytest
 
 from gym_amd import error
@@ -744,19 +745,16 @@ def test_vector_make_recognises_the_sub_env_wrappers_it_can_map():
     from gym_amd.vector_env import _sub_env_wrappers
     from gym_amd.wrappers import NormalizeObservation, RecordEpisodeStatistics
 
-    class TimeLimit:
-        pass
+    TimeLimit = reference_wrapper_stub("TimeLimit")
 
-    class OrderEnforcing:
-        pass
+    OrderEnforcing = reference_wrapper_stub("OrderEnforcing")
 
     assert _sub_env_wrappers(None) == (None, [])
     assert _sub_env_wrappers(TimeLimit) == (None, [])                                      # max_episode_steps=None: the spec's own limit
     assert _sub_env_wrappers(functools.partial(TimeLimit, max_episode_steps=25)) == (25, [])
     assert _sub_env_wrappers([functools.partial(TimeLimit, max_episode_steps=25), OrderEnforcing,
                               functools.partial(TimeLimit, max_episode_steps=9)]) == (9, [])
-    class ClipAction:
-        pass
+    ClipAction = reference_wrapper_stub("ClipAction")
 
     assert _sub_env_wrappers([ClipAction]) == (None, [("identity_for_classic_control", {"wrapper": "ClipAction"})])
     assert _sub_env_wrappers((RecordEpisodeStatistics,)) == (None, [("episode_statistics", {})])
@@ -793,8 +791,7 @@ def test_vector_make_wrappers_replay_the_reference_on_the_host_adapter(monkeypat
     from gym_amd.wrappers import RecordEpisodeStatistics, SubEnvEpisodeStatistics
     from oracle_engine import PackedFakeHandle
 
-    class TimeLimit:
-        pass
+    TimeLimit = reference_wrapper_stub("TimeLimit")
 
     monkeypatch.setattr(_native, "Handle", PackedFakeHandle)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vector_make_wrappers_CartPole.npz"))
@@ -829,11 +826,9 @@ def test_vector_make_identity_wrappers(monkeypatch):
     from gym_amd import _native
     from oracle_engine import FakeHandle
 
-    class ClipAction:
-        pass
+    ClipAction = reference_wrapper_stub("ClipAction")
 
-    class FlattenObservation:
-        pass
+    FlattenObservation = reference_wrapper_stub("FlattenObservation")
 
     monkeypatch.setattr(_native, "Handle", FakeHandle)
     env = gym_amd.make("Pendulum-v1", num_envs=3, wrappers=[ClipAction, FlattenObservation])
@@ -846,6 +841,31 @@ def test_vector_make_identity_wrappers(monkeypatch):
     with pytest.raises(NotImplementedError):
         gym_amd.make("CartPole-v1", num_envs=3, wrappers=ClipAction)
     gym_amd.make("CartPole-v1", num_envs=3, wrappers=FlattenObservation).close()
+
+
+def test_vector_make_clipaction_is_applied_where_it_is_not_an_identity(monkeypatch):
+    """MountainCarContinuous-v0 charges its action penalty on the action AS GIVEN (continuous_mountain_car.py:169): under the reference's
+    per-sub-env ClipAction that is the clipped action.  The reference's own run (golden), bit for bit over the oracle-backed handle."""
+    from gym_amd import _native
+    from helpers import replay_vector_make_clipaction
+    from oracle_engine import FakeHandle
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    assert replay_vector_make_clipaction(exact=True) == 60
+
+
+def test_vector_make_recognises_wrappers_by_name_and_home(monkeypatch):
+    """A user class that merely shares a name with a known wrapper keeps its own semantics: it must reach the explicit error, not be
+    replaced by the engine's mapping."""
+    from gym_amd.vector_env import _sub_env_wrappers
+
+    class TimeLimit:                       # home module: this test file
+        def __init__(self, env, max_episode_steps=None):
+            self.env = env
+
+    with pytest.raises(NotImplementedError):
+        _sub_env_wrappers([TimeLimit])
+    assert _sub_env_wrappers([reference_wrapper_stub("TimeLimit")]) == (None, [])
 
 
 @pytest.mark.parametrize("name", ["CartPole", "Pendulum"])
