@@ -54,3 +54,34 @@ def measure_blackjack(torch, envs, chunk, reps=6, compact=False):
     del out
     torch.cuda.empty_cache()
     return res
+
+
+def measure_toytext_episode_stats(torch, envs, chunk, reps=6):
+    """What gym.wrappers.RecordEpisodeStatistics (record_episode_statistics.py:96-151) costs fused into the toy_text trajectory kernels
+    (round 6: a float32 add per step + two sparse stores where an episode ended): the same launches with the accumulators off and on,
+    both dtype sets.  Sparse output bytes: 8 per finished episode (Blackjack ~ 0.7 per env-step, Taxi ~ 0.005)."""
+    from gym_amd.toy_text import BlackjackRollout, TabularRollout
+
+    out = {"workload": f"num_envs={envs}, fused {chunk}-step launches, episode statistics off / on (us per vector step)"}
+    for name, make in (("blackjack", lambda c: BlackjackRollout(envs, seed=0, action_seed=1, compact=c)),
+                       ("taxi", lambda c: TabularRollout("Taxi-v3", envs, seed=0, action_seed=1, compact=c)),
+                       ("frozenlake8x8", lambda c: TabularRollout("FrozenLake8x8-v1", envs, seed=0, action_seed=1, compact=c))):
+        for compact in (False, True):
+            r = make(compact)
+            r.reset(seed=0)
+            bufs = r.trajectory_buffers(chunk)
+            off = _event_us(torch, r.stream, lambda: r.rollout_per_step(chunk, out=bufs), reps, chunk)
+            r.handle.episode_stats(True)
+            with torch.cuda.stream(r.stream):
+                epr = torch.zeros((chunk, envs), dtype=torch.float32, device=r.device)
+                epl = torch.zeros((chunk, envs), dtype=torch.int32, device=r.device)
+            r.handle.set_episode_outputs(epr, epl)
+            on = _event_us(torch, r.stream, lambda: r.rollout_per_step(chunk, out=bufs), reps, chunk)
+            ended = float(((bufs["terminated"] | bufs["truncated"]) != 0).float().mean().item())
+            out[f"{name}{'_compact' if compact else ''}"] = {"off_us_per_step": off, "on_us_per_step": on, "ratio": on / off, "episodes_ended_per_env_step": ended}
+            r.close()
+            del bufs, epr, epl
+            torch.cuda.empty_cache()
+    k = out["blackjack"]
+    out["us_per_step"] = k["on_us_per_step"]
+    return out

@@ -5,7 +5,7 @@ from .common import ENV_ID, ENVS_TOTAL
 from .fused import measure_fused, measure_mixed
 from .loops import measure_numpy_loop, measure_policy_loop, measure_step_kernel, measure_step_loop
 from .normalize import measure_normalize, measure_subenv_normalize
-from .toy_text import measure_blackjack, measure_tabular
+from .toy_text import measure_blackjack, measure_tabular, measure_toytext_episode_stats
 
 
 def groups(torch, chunk):
@@ -33,6 +33,7 @@ def groups(torch, chunk):
         ("compact_taxi", lambda: measure_tabular(torch, "Taxi-v3", ENVS_TOTAL, 128, compact=True)),
         ("blackjack", lambda: measure_blackjack(torch, ENVS_TOTAL, 128)),
         ("compact_blackjack", lambda: measure_blackjack(torch, ENVS_TOTAL, 128, compact=True)),
+        ("toytext_episode_stats", lambda: measure_toytext_episode_stats(torch, ENVS_TOTAL, 64)),
         # the headline configuration placed under the 8-GiB cap (MXV_PLACEMENT=cheap: what the default does as soon as anybody else holds
         # device memory; on the otherwise empty device of a benchmark the default walks as far as it must): what the cap costs on this box
         ("placement_cheap", f(ENV_ID, ENVS_TOTAL, placement_mode="cheap")),

@@ -51,7 +51,8 @@ EXPORTS = (
     "mxv_subnorm_set_state", "mxv_subnorm_observations", "mxv_subnorm_rewards",
     "mxv_tab_create", "mxv_tab_destroy", "mxv_tab_last_error", "mxv_tab_seed", "mxv_tab_seed_actions", "mxv_tab_reset",
     "mxv_tab_step", "mxv_tab_rollout", "mxv_tab_rollout_tape", "mxv_tab_reset_host", "mxv_tab_step_host", "mxv_tab_get_state",
-    "mxv_tab_set_state", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_device_clock", "mxv_bj_set_device_clock", "mxv_tab_set_stream",
+    "mxv_tab_set_state", "mxv_tab_episode_stats", "mxv_tab_set_episode_outputs", "mxv_tab_episode_stats_host",
+    "mxv_bj_episode_stats", "mxv_bj_set_episode_outputs", "mxv_bj_episode_stats_host", "mxv_tab_set_running_returns", "mxv_bj_set_running_returns", "mxv_tab_get_counters", "mxv_tab_set_counters", "mxv_tab_sync", "mxv_tab_last_kernel", "mxv_tab_word_threshold", "mxv_tab_set_device_clock", "mxv_bj_set_device_clock", "mxv_tab_set_stream",
     "mxv_get_beyond", "mxv_set_beyond",
     "mxv_bj_create", "mxv_bj_destroy", "mxv_bj_last_error", "mxv_bj_seed", "mxv_bj_reset", "mxv_bj_step", "mxv_bj_rollout", "mxv_bj_rollout_compact",
     "mxv_bj_reset_host", "mxv_bj_step_host", "mxv_bj_get_state", "mxv_bj_set_state", "mxv_bj_get_counters", "mxv_bj_sync", "mxv_bj_set_stream",
@@ -277,6 +278,14 @@ def _load():
         "mxv_tab_reset_host": ([vp, vp, vp], C.c_int),
         "mxv_tab_step_host": ([vp] * 10, C.c_int),
         "mxv_tab_get_state": ([vp, vp, vp], C.c_int),
+        "mxv_tab_episode_stats": ([vp, i32], C.c_int),
+        "mxv_tab_set_episode_outputs": ([vp, vp, vp], C.c_int),
+        "mxv_tab_episode_stats_host": ([vp, vp, vp, vp], C.c_int),
+        "mxv_bj_episode_stats": ([vp, i32], C.c_int),
+        "mxv_bj_set_episode_outputs": ([vp, vp, vp], C.c_int),
+        "mxv_bj_episode_stats_host": ([vp, vp, vp, vp], C.c_int),
+        "mxv_tab_set_running_returns": ([vp, vp], C.c_int),
+        "mxv_bj_set_running_returns": ([vp, vp], C.c_int),
         "mxv_tab_set_state": ([vp, vp, vp], C.c_int),
         "mxv_tab_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_tab_set_counters": ([vp, u64, u32], C.c_int),
@@ -1237,9 +1246,11 @@ class Tab:
         """State + TimeLimit counters + RNG seeds and counters (the table itself belongs to the caller's MDP)."""
         st, el = self.get_state()
         t, r = self.get_counters()
+        on = getattr(self, "_stats_on", False)
         return dict(num_envs=self.num_envs, state=st, elapsed=el, t=t, r=r, base_seed=self._base_seed,
                     per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
-                    action_seed=self._action_seed)
+                    action_seed=self._action_seed, stats_on=on,
+                    running_returns=self.episode_stats_host(want_running=True)[2] if on else None)
 
     def restore(self, snap: dict):
         if snap["num_envs"] != self.num_envs:
@@ -1248,6 +1259,9 @@ class Tab:
         self.seed_actions(snap["action_seed"])
         self.set_state(snap["state"], snap["elapsed"])
         self.set_counters(snap["t"], snap["r"])
+        if snap.get("stats_on"):
+            self.episode_stats(True)
+            self.set_running_returns(snap["running_returns"])
 
     def set_device_clock(self, on: bool = True):
         """The step index in device memory, advanced on the stream: step / rollout calls become recordable in a caller's hipGraph."""
@@ -1309,6 +1323,27 @@ class Tab:
                                           trunc.ctypes.data, prob.ctypes.data, fin.ctypes.data, fprob.ctypes.data))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), prob, fin, fprob
 
+    # -- episode statistics (gym.wrappers.RecordEpisodeStatistics fused into the kernels; include/mxv_toytext.h) --------------------------
+    def episode_stats(self, enable: bool = True):
+        self._check(lib.mxv_tab_episode_stats(self._h, 1 if enable else 0))
+        self._stats_on = bool(enable)
+
+    def set_episode_outputs(self, ep_return_dev=None, ep_length_dev=None):
+        """[N] / [K][N] device arrays (float32 returns, int32 lengths) the device-pointer calls fill where an episode ended; None detaches."""
+        self._check(lib.mxv_tab_set_episode_outputs(self._h, _ptr(ep_return_dev), _ptr(ep_length_dev)))
+
+    def episode_stats_host(self, want_running: bool = False):
+        """(returns, lengths[, running_returns]) of the last step_host call; valid where terminated | truncated."""
+        r = np.zeros(self.num_envs, dtype=np.float32)
+        l = np.zeros(self.num_envs, dtype=np.int32)
+        run = np.zeros(self.num_envs, dtype=np.float32) if want_running else None
+        self._check(lib.mxv_tab_episode_stats_host(self._h, r.ctypes.data, l.ctypes.data, _ptr(run)))
+        return (r, l, run) if want_running else (r, l)
+
+    def set_running_returns(self, running):
+        r = np.ascontiguousarray(running, dtype=np.float32).reshape(self.num_envs)
+        self._check(lib.mxv_tab_set_running_returns(self._h, r.ctypes.data))
+
     def get_state(self):
         st = np.empty(self.num_envs, dtype=np.int32)
         el = np.empty(self.num_envs, dtype=np.int32)
@@ -1333,6 +1368,11 @@ class Tab:
 
     def set_stream(self, stream_ptr: int):
         self._check(lib.mxv_tab_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+
+# Draw contract of the Blackjack engine's Philox streams (include/mxv.h RNG contract): 1 = rounds 2-4 (one card per word, consumed in the
+# reference's order; word-per-step actions), 2 = round 5 on (one call per step = eight cards with fixed roles; bit-stream actions).
+BJ_DRAW_CONTRACT = 2
 
 
 class Blackjack:
@@ -1388,15 +1428,26 @@ class Blackjack:
     def snapshot(self) -> dict:
         st, el = self.get_state()
         t, r = self.get_counters()
+        on = getattr(self, "_stats_on", False)
         return dict(num_envs=self.num_envs, state=st, elapsed=el, t=t, r=r, base_seed=self._base_seed,
                     per_env_seeds=None if self._per_env_seeds is None else self._per_env_seeds.copy(),
-                    action_seed=self._action_seed)
+                    action_seed=self._action_seed, draw_contract=BJ_DRAW_CONTRACT, stats_on=on,
+                    running_returns=self.episode_stats_host(want_running=True)[2] if on else None)
 
     def restore(self, snap: dict):
         if snap["num_envs"] != self.num_envs:
             raise ValueError(f"snapshot of {snap['num_envs']} envs does not fit this handle ({self.num_envs})")
+        if snap.get("draw_contract", 1) != BJ_DRAW_CONTRACT:
+            # API level 5 changed which cards and actions a (seed, step) pair yields: the hands in the snapshot are valid, the streams that
+            # continue them are not the ones the snapshot's run would have drawn (include/mxv.h, "API levels")
+            raise ValueError(f"Blackjack snapshot was taken under draw contract {snap.get('draw_contract', 1)} (gym_amd < 0.5); this library "
+                             f"draws under contract {BJ_DRAW_CONTRACT}: the run cannot be continued bit-identically — reset and reseed, "
+                             "or restore with the library version that took the snapshot")
         self.seed(snap["base_seed"], snap["per_env_seeds"], snap["action_seed"])
         self.set_state(snap["state"], snap["elapsed"], snap["t"], snap["r"])
+        if snap.get("stats_on"):
+            self.episode_stats(True)
+            self.set_running_returns(snap["running_returns"])
 
     def reset(self, obs_dev=None, mask_dev=None, cards_dev=None):
         self._check(lib.mxv_bj_reset(self._h, _ptr(mask_dev), _ptr(cards_dev), _ptr(obs_dev)))
@@ -1439,6 +1490,27 @@ class Blackjack:
         self._check(lib.mxv_bj_step_host(self._h, a.ctypes.data, _ptr(c), obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                          trunc.ctypes.data, fin.ctypes.data))
         return obs, rew, term.view(np.bool_), trunc.view(np.bool_), fin
+
+    # -- episode statistics (gym.wrappers.RecordEpisodeStatistics fused into the kernels; include/mxv_toytext.h) --------------------------
+    def episode_stats(self, enable: bool = True):
+        self._check(lib.mxv_bj_episode_stats(self._h, 1 if enable else 0))
+        self._stats_on = bool(enable)
+
+    def set_episode_outputs(self, ep_return_dev=None, ep_length_dev=None):
+        """[N] / [K][N] device arrays (float32 returns, int32 lengths) the device-pointer calls fill where an episode ended; None detaches."""
+        self._check(lib.mxv_bj_set_episode_outputs(self._h, _ptr(ep_return_dev), _ptr(ep_length_dev)))
+
+    def episode_stats_host(self, want_running: bool = False):
+        """(returns, lengths[, running_returns]) of the last step_host call; valid where terminated | truncated."""
+        r = np.zeros(self.num_envs, dtype=np.float32)
+        l = np.zeros(self.num_envs, dtype=np.int32)
+        run = np.zeros(self.num_envs, dtype=np.float32) if want_running else None
+        self._check(lib.mxv_bj_episode_stats_host(self._h, r.ctypes.data, l.ctypes.data, _ptr(run)))
+        return (r, l, run) if want_running else (r, l)
+
+    def set_running_returns(self, running):
+        r = np.ascontiguousarray(running, dtype=np.float32).reshape(self.num_envs)
+        self._check(lib.mxv_bj_set_running_returns(self._h, r.ctypes.data))
 
     def get_state(self):
         st = np.empty(self.num_envs, np.int32)

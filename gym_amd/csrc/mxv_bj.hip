@@ -83,6 +83,10 @@ struct BjArgs {
     const uint64_t *t_dev;    // device clock (mxv_bj_set_device_clock): the step index = t + *t_dev; nullptr: t
     int32_t max_steps, K, natural, sab;
     int64_t slice, act_slice;
+    // episode statistics (gym/wrappers/record_episode_statistics.py:96-151), all nullptr when disabled (mxv_bj_episode_stats)
+    float *ep_acc;           // [N] running episode return (float32, the reference's accumulator dtype)
+    float *ep_return_out;    // [N] / [K][N], written only where terminated | truncated
+    int32_t *ep_length_out;  // [N] / [K][N]
 };
 
 __device__ __forceinline__ void unpack(int32_t s, Hand &p, Hand &d, int &dfirst) {
@@ -137,10 +141,13 @@ template <> struct BjOut<2> { using I = int32_t; using R = float; };    // the c
 #ifndef MXV_BJ_WAVES
 #define MXV_BJ_WAVES 8   // 8: 64 VGPRs and <= 96 SGPRs = two full rounds of the 16 waves per SIMD a 2^20-table launch needs (no spills); 0: the allocator's choice (63 VGPRs but 7 waves: SGPRs) (A/B hook)
 #endif
-template <bool INJ, bool SAMPLED, int OUT>
+// STATS (round 6): the episode-statistics accumulators (mxv_bj_episode_stats) are an instantiation of their own — the kernel sits exactly
+// at the 64-VGPR budget of 8 waves per SIMD, and as a run-time branch the three extra live values put 32 bytes of every launch's lanes
+// into scratch, statistics or not.  The STATS = true twins may take 7 waves.
+template <bool INJ, bool SAMPLED, int OUT, bool STATS = false>
 __global__ void __launch_bounds__(kBjBlock)
 #if MXV_BJ_WAVES > 0
-    __attribute__((amdgpu_waves_per_eu(MXV_BJ_WAVES, MXV_BJ_WAVES)))
+    __attribute__((amdgpu_waves_per_eu(STATS ? 4 : MXV_BJ_WAVES, MXV_BJ_WAVES)))
 #endif
     bj_kernel(BjArgs a) {
     using I = typename BjOut<OUT>::I;
@@ -156,6 +163,8 @@ __global__ void __launch_bounds__(kBjBlock)
     int dfirst;
     unpack(a.state[e], p, d, dfirst);
     int32_t el = a.elapsed[e];
+    constexpr bool stats = STATS;
+    float er = stats ? a.ep_acc[e] : 0.0f;
     const int8_t *inj = INJ ? a.cards + (size_t)e * MXV_BJ_MAX_DRAWS : nullptr;
     uint64_t act_block = ~0ull;
     uint32_t act_bits = 0;
@@ -238,6 +247,15 @@ __global__ void __launch_bounds__(kBjBlock)
         el += 1;
         const bool trunc = a.max_steps > 0 && el >= a.max_steps;
         const bool done = term || trunc;
+        if constexpr (stats) {   // record_episode_statistics.py:119-143: float32 array += float64 reward (-1, 0, 1, 1.5: every partial sum is exact)
+            er = (float)((double)er + 0.5 * (double)r2);
+            if (__any(done)) {   // whole lines (zeros where no episode ended): 73 % of the tables finish per step, see mxv_tab.hip
+                const int64_t so = (int64_t)k * a.slice + e;     // (addresses formed here, from the argument segment: nothing extra lives across the loop)
+                if (a.ep_return_out) a.ep_return_out[so] = done ? er : 0.0f;
+                if (a.ep_length_out) a.ep_length_out[so] = done ? el : 0;
+            }
+            er = done ? 0.0f : er;
+        }
         if (a.final_obs && done) {                             // sync_vector_env.py:152-156
             *reinterpret_cast<I *>(p_f0 + bj_pin32(off_i)) = (I)p.total();
             *reinterpret_cast<I *>(p_f1 + bj_pin32(off_i)) = (I)dfirst;
@@ -261,6 +279,7 @@ __global__ void __launch_bounds__(kBjBlock)
     }
     a.state[e] = pack(p, d, dfirst);
     a.elapsed[e] = el;
+    if constexpr (stats) a.ep_acc[e] = er;
 }
 
 struct BjResetArgs {
@@ -273,6 +292,7 @@ struct BjResetArgs {
     uint64_t env0, base_seed, t;
     const uint64_t *t_dev;
     uint32_t r;
+    float *ep_acc;        // may be nullptr: zeroed for the envs being reset (record_episode_statistics.py:91-94)
 };
 
 __global__ void bj_set_word_kernel(uint64_t *dst, uint64_t v) { *dst = v; }
@@ -299,6 +319,7 @@ __global__ void __launch_bounds__(kBjBlock) bj_reset_kernel(BjResetArgs a) {
         deal(c[2], c[3], p);
         a.state[e] = pack(p, d, dfirst);
         a.elapsed[e] = 0;
+        if (a.ep_acc) a.ep_acc[e] = 0.0f;
     }
     if (a.obs) {
         a.obs[e] = p.total();
@@ -320,6 +341,10 @@ struct mxv_bj {
     bool dev_clock = false;
     uint32_t r = 0;
     bool was_reset = false;
+    // episode statistics (mxv_bj_episode_stats): running returns, the caller's trajectory outputs, dense staging of host steps
+    float *ep_acc = nullptr, *ep_return_out = nullptr, *st_ep_r = nullptr;
+    int32_t *ep_length_out = nullptr, *st_ep_l = nullptr;
+    bool ep_host_step = false;
     // staging of the *_host calls
     int64_t *st_actions = nullptr, *st_obs = nullptr, *st_final = nullptr;
     double *st_reward = nullptr;
@@ -400,8 +425,17 @@ int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t a
     a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr;
     a.max_steps = h->cfg.max_episode_steps; a.K = K;
     a.natural = h->cfg.natural; a.sab = h->cfg.sab; a.slice = slice; a.act_slice = act_slice;
+    a.ep_acc = h->ep_acc;
+    a.ep_return_out = h->ep_acc ? (h->ep_host_step ? h->st_ep_r : h->ep_return_out) : nullptr;
+    a.ep_length_out = h->ep_acc ? (h->ep_host_step ? h->st_ep_l : h->ep_length_out) : nullptr;
     const dim3 grid((unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock)), block(kBjBlock);
-    if (cards) hipLaunchKernelGGL((bj_kernel<true, false, 1>), grid, block, 0, h->stream, a);
+    if (a.ep_acc) {
+        if (cards) hipLaunchKernelGGL((bj_kernel<true, false, 1, true>), grid, block, 0, h->stream, a);
+        else if (out_mode == 1 && actions) hipLaunchKernelGGL((bj_kernel<false, false, 1, true>), grid, block, 0, h->stream, a);
+        else if (out_mode == 1) hipLaunchKernelGGL((bj_kernel<false, true, 1, true>), grid, block, 0, h->stream, a);
+        else if (actions) hipLaunchKernelGGL((bj_kernel<false, false, 2, true>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((bj_kernel<false, true, 2, true>), grid, block, 0, h->stream, a);
+    } else if (cards) hipLaunchKernelGGL((bj_kernel<true, false, 1>), grid, block, 0, h->stream, a);
     else if (out_mode == 1 && actions) hipLaunchKernelGGL((bj_kernel<false, false, 1>), grid, block, 0, h->stream, a);
     else if (out_mode == 1) hipLaunchKernelGGL((bj_kernel<false, true, 1>), grid, block, 0, h->stream, a);
     else if (actions) hipLaunchKernelGGL((bj_kernel<false, false, 2>), grid, block, 0, h->stream, a);
@@ -416,6 +450,7 @@ int bj_do_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int
     BjResetArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.mask = mask_dev; a.cards = cards_dev; a.obs = obs_dev;
     a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr; a.r = h->r;
+    a.ep_acc = h->ep_acc;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kBjBlock - 1) / kBjBlock);
     hipLaunchKernelGGL(bj_reset_kernel, dim3(blocks), dim3(kBjBlock), 0, h->stream, a);
     BJ_HIP(h, hipGetLastError());
@@ -503,7 +538,7 @@ int mxv_bj_destroy(mxv_bj *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->seeds, h->t_dev};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->seeds, h->t_dev, h->ep_acc, h->st_ep_r, h->st_ep_l};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->hostmap) {
@@ -598,9 +633,11 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
         std::memcpy(h->st_actions, actions_host, n * 8);
         if (cards_host) std::memcpy(h->st_cards, cards_host, n * MXV_BJ_MAX_DRAWS);
         h->err_in_block = true;
+        h->ep_host_step = true;
         const int lrc = bj_launch(h, 1, 0, h->st_actions, 0, nullptr, cards_host ? h->st_cards : nullptr, h->st_obs, h->st_reward,
                                   h->st_term, h->st_trunc, final_obs_host ? h->st_final : nullptr);
         h->err_in_block = false;
+        h->ep_host_step = false;
         if (lrc) return lrc;
         BJ_HIP(h, hipStreamSynchronize(h->stream));
         std::memcpy(obs_host, h->st_obs, 3 * n * 8);
@@ -617,9 +654,11 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
     }
     BJ_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * 8, hipMemcpyHostToDevice, h->stream));
     if (cards_host) BJ_HIP(h, hipMemcpyAsync(h->st_cards, cards_host, n * MXV_BJ_MAX_DRAWS, hipMemcpyHostToDevice, h->stream));
-    if (int rc = bj_launch(h, 1, 0, h->st_actions, 0, nullptr, cards_host ? h->st_cards : nullptr, h->st_obs, h->st_reward,
-                           h->st_term, h->st_trunc, final_obs_host ? h->st_final : nullptr))
-        return rc;
+    h->ep_host_step = true;
+    const int lrc = bj_launch(h, 1, 0, h->st_actions, 0, nullptr, cards_host ? h->st_cards : nullptr, h->st_obs, h->st_reward,
+                              h->st_term, h->st_trunc, final_obs_host ? h->st_final : nullptr);
+    h->ep_host_step = false;
+    if (lrc) return lrc;
     BJ_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, 3 * n * 8, hipMemcpyDeviceToHost, h->stream));
     if (reward_host) BJ_HIP(h, hipMemcpyAsync(reward_host, h->st_reward, n * 8, hipMemcpyDeviceToHost, h->stream));
     if (terminated_host) BJ_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
@@ -628,6 +667,61 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
     int rc = bj_latched(h);
     if (rc == MXV_ERR_INVALID_ACTION) (void)bj_clock_add(h, -1);
     return rc;
+}
+
+/* gym.wrappers.RecordEpisodeStatistics fused into the step (record_episode_statistics.py:96-151): see mxv_toytext.h */
+int mxv_bj_episode_stats(mxv_bj *h, int32_t enable) {
+    BJ_CHECK(h);
+    BJ_HIP(h, hipSetDevice(h->cfg.device));
+    BJ_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (enable && !h->ep_acc) {
+        BJ_HIP(h, hipMalloc((void **)&h->ep_acc, n * sizeof(float)));
+        BJ_HIP(h, hipMalloc((void **)&h->st_ep_r, n * sizeof(float)));
+        BJ_HIP(h, hipMalloc((void **)&h->st_ep_l, n * sizeof(int32_t)));
+        BJ_HIP(h, hipMemsetAsync(h->ep_acc, 0, n * sizeof(float), h->stream));
+        BJ_HIP(h, hipMemsetAsync(h->st_ep_r, 0, n * sizeof(float), h->stream));
+        BJ_HIP(h, hipMemsetAsync(h->st_ep_l, 0, n * sizeof(int32_t), h->stream));
+        BJ_HIP(h, hipStreamSynchronize(h->stream));
+    } else if (!enable && h->ep_acc) {
+        BJ_HIP(h, hipFree(h->ep_acc));
+        BJ_HIP(h, hipFree(h->st_ep_r));
+        BJ_HIP(h, hipFree(h->st_ep_l));
+        h->ep_acc = h->st_ep_r = nullptr;
+        h->st_ep_l = nullptr;
+    }
+    return MXV_OK;
+}
+
+int mxv_bj_set_episode_outputs(mxv_bj *h, float *ep_return_dev, int32_t *ep_length_dev) {
+    BJ_CHECK(h);
+    BJ_HIP(h, hipSetDevice(h->cfg.device));
+    BJ_HIP(h, hipStreamSynchronize(h->stream));
+    h->ep_return_out = ep_return_dev;
+    h->ep_length_out = ep_length_dev;
+    return MXV_OK;
+}
+
+int mxv_bj_episode_stats_host(mxv_bj *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host) {
+    BJ_CHECK(h);
+    if (!h->ep_acc) return bfail(h, MXV_ERR_INVALID_ARG, "episode statistics are not enabled (mxv_bj_episode_stats)");
+    BJ_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (ep_return_host) BJ_HIP(h, hipMemcpyAsync(ep_return_host, h->st_ep_r, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (ep_length_host) BJ_HIP(h, hipMemcpyAsync(ep_length_host, h->st_ep_l, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (running_return_host) BJ_HIP(h, hipMemcpyAsync(running_return_host, h->ep_acc, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    BJ_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_bj_set_running_returns(mxv_bj *h, const float *running_return_host) {
+    BJ_CHECK(h);
+    if (!h->ep_acc) return bfail(h, MXV_ERR_INVALID_ARG, "episode statistics are not enabled (mxv_bj_episode_stats)");
+    if (!running_return_host) return bfail(h, MXV_ERR_INVALID_ARG, "NULL pointer");
+    BJ_HIP(h, hipSetDevice(h->cfg.device));
+    BJ_HIP(h, hipMemcpyAsync(h->ep_acc, running_return_host, (size_t)h->cfg.num_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    BJ_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
 }
 
 int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host) {

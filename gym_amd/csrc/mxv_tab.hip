@@ -75,6 +75,10 @@ struct TabArgs {
     int32_t max_steps, K;
     int64_t slice;           // 0 or N (per-step trajectory outputs)
     int64_t act_slice;       // 0 or N (action tape)
+    // episode statistics (gym/wrappers/record_episode_statistics.py:96-151), all nullptr when disabled (mxv_tab_episode_stats)
+    float *ep_acc;           // [N] running episode return, float32 like the reference's accumulator
+    float *ep_return_out;    // [N] / [K][N]: episode return, written only where terminated | truncated
+    int32_t *ep_length_out;  // [N] / [K][N]: episode length (= the TimeLimit counter), written only where terminated | truncated
 };
 
 __device__ __forceinline__ unsigned tab_tile(unsigned bid, unsigned ntiles) {  // XCD x owns the x-th contiguous eighth
@@ -137,6 +141,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
     const uint64_t ge = a.env0 + (uint64_t)e;
     const uint64_t seed = (a.seeds && valid) ? a.seeds[e] : a.base_seed + ge;
     int32_t s = valid ? a.state[e] : 0, el = valid ? a.elapsed[e] : 0;
+    float er = (a.ep_acc && valid) ? a.ep_acc[e] : 0.0f;   // RecordEpisodeStatistics.episode_returns of this env
     // Philox caches.  Actions: one call yields the words of the 4 envs of group g = env >> 2 at ONE step, so the four
     // lanes of a quad (= one group) each evaluate a different step of the aligned block 4*(t >> 2) .. +3 and trade words
     // through a 4 x 4 transpose inside the quad (quad_transpose: two DPP butterfly stages): one call per lane per four steps.  Transitions: one call per two steps (see the contract).
@@ -204,6 +209,15 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
         el += 1;                                                   // TimeLimit.step, time_limit.py:50-53
         const bool trunc = a.max_steps > 0 && el >= a.max_steps;
         s = ns;
+        if (a.ep_acc) {  // record_episode_statistics.py:119-143: float32 array += float64 reward; lengths are the TimeLimit counter
+            er = (float)((double)er + rew);
+            const bool fin = term || trunc;
+            if (__any(fin)) {   // a wave with a finished episode stores its whole row segment (whole lines, zeros elsewhere): see tab_traj_kernel
+                if (a.ep_return_out) a.ep_return_out[o] = fin ? er : 0.0f;
+                if (a.ep_length_out) a.ep_length_out[o] = fin ? el : 0;
+            }
+            er = fin ? 0.0f : er;
+        }
         if (term || trunc) {  // sync_vector_env.py:152-156: the returned observation/info are the reset's
             if (a.final_obs) static_cast<IT *>(a.final_obs)[o] = (IT)ns;
             if (a.final_prob) static_cast<RT *>(a.final_prob)[o] = (RT)p;
@@ -220,6 +234,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_step_kernel(TabArgs a) {
     if (valid) {
         a.state[e] = s;
         a.elapsed[e] = el;
+        if (a.ep_acc) a.ep_acc[e] = er;
     }
 }
 
@@ -254,6 +269,10 @@ struct TabTrajArgs {
     const uint64_t *t_dev;
     int32_t max_steps, K;
     uint32_t tile_base;      // ALLV == false: the (one) ragged block's tile index
+    // episode statistics (mxv_tab_episode_stats), all nullptr when disabled: a wave-uniform test per step, one float32 add where enabled
+    float *ep_acc;           // [N]
+    float *ep_return_out;    // [K][N], written only where terminated | truncated
+    int32_t *ep_length_out;  // [K][N]
 };
 
 __device__ __forceinline__ uint32_t tab_pin32(uint32_t v) {  // see pin32 in mxv_kernels.hip: keeps the store's saddr + 32-bit voffset form
@@ -286,6 +305,10 @@ __global__ void __launch_bounds__(kTabBlock) tab_traj_kernel(TabTrajArgs a) {
         el = a.elapsed[e];
     }
     const uint32_t q = (uint32_t)(ge & 3);
+    const bool stats = a.ep_acc != nullptr;
+    float er = (stats && valid) ? a.ep_acc[e] : 0.0f;
+    float *p_epr = a.ep_return_out ? a.ep_return_out + tile0 : nullptr;
+    int32_t *p_epl = a.ep_length_out ? a.ep_length_out + tile0 : nullptr;
     const int32_t max_eff = a.max_steps > 0 ? a.max_steps : 0x7fffffff;
     char *p_act = a.actions + tile0 * IB, *p_obs = a.obs + tile0 * IB, *p_rew = a.reward + tile0 * IB, *p_prob = a.prob + tile0 * IB;
     uint8_t *p_term = a.terminated + tile0, *p_trunc = a.truncated + tile0;
@@ -348,6 +371,20 @@ __global__ void __launch_bounds__(kTabBlock) tab_traj_kernel(TabTrajArgs a) {
                 }
             }
             s = ns;
+            if (stats) {   // record_episode_statistics.py:119-143 (the table's rewards are float32 values: pack_fast_table)
+                er = (float)((double)er + (double)__uint_as_float(rew_bits));
+                // Stores by the few lanes whose episode ended are partial-line writes (read-modify-write at the memory side): with 3 % of
+                // the envs finishing per step (FrozenLake8x8) two such streams cost 3.4 us on a 5.6-us step.  A wave in which ANY episode
+                // ended therefore stores its 64 entries — the value where it ended, zero elsewhere — as two whole lines; waves without one
+                // store nothing (Taxi: 94 % of them).  Entries are MEANINGFUL only where terminated | truncated, as the header says.
+                if (__any(done) && (ALLV || valid)) {
+                    if (p_epr) p_epr[tid] = done ? er : 0.0f;
+                    if (p_epl) p_epl[tid] = done ? el : 0;
+                }
+                er = done ? 0.0f : er;
+                if (p_epr) p_epr += a.n;
+                if (p_epl) p_epl += a.n;
+            }
             el = done ? 0 : el;
             if (ALLV || valid) {
                 const float rew = __uint_as_float(rew_bits);
@@ -376,6 +413,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_traj_kernel(TabTrajArgs a) {
     if (valid) {
         a.state[e] = s;
         a.elapsed[e] = el;
+        if (stats) a.ep_acc[e] = er;
     }
 }
 
@@ -393,6 +431,7 @@ struct TabResetArgs {
     uint64_t env0, base_seed, t;
     const uint64_t *t_dev;
     uint32_t r;
+    float *ep_acc;           // may be nullptr: running episode returns, zeroed for the envs being reset (record_episode_statistics.py:91-94)
 };
 
 __global__ void __launch_bounds__(kTabBlock) tab_reset_kernel(TabResetArgs a) {
@@ -407,6 +446,7 @@ __global__ void __launch_bounds__(kTabBlock) tab_reset_kernel(TabResetArgs a) {
     const int32_t s = sample_initial(a.init_cum, a.S, a.log2S, u01(w.x));
     a.state[e] = s;
     a.elapsed[e] = 0;
+    if (a.ep_acc) a.ep_acc[e] = 0.0f;
     if (a.obs) a.obs[e] = (int64_t)s;
 }
 
@@ -432,6 +472,10 @@ struct mxv_tab {
     bool dev_clock = false;
     uint32_t r = 0;
     bool was_reset = false;
+    // episode statistics (mxv_tab_episode_stats): running returns, the caller's trajectory outputs, dense staging of host steps
+    float *ep_acc = nullptr, *ep_return_out = nullptr, *st_ep_r = nullptr;
+    int32_t *ep_length_out = nullptr, *st_ep_l = nullptr;
+    bool ep_host_step = false;   // the launch in flight is a host step: its statistics go to the staging arrays
     // staging for *_host calls
     int64_t *st_actions = nullptr, *st_obs = nullptr, *st_final = nullptr;
     double *st_reward = nullptr, *st_prob = nullptr, *st_fprob = nullptr, *st_uniforms = nullptr;
@@ -518,6 +562,9 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t ac
     a.err = h->err_in_block ? h->hm_err : h->err; a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset;
     a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr;
     a.max_steps = h->cfg.max_episode_steps; a.K = K; a.slice = slice; a.act_slice = act_slice;
+    a.ep_acc = h->ep_acc;
+    a.ep_return_out = h->ep_acc ? (h->ep_host_step ? h->st_ep_r : h->ep_return_out) : nullptr;
+    a.ep_length_out = h->ep_acc ? (h->ep_host_step ? h->st_ep_l : h->ep_length_out) : nullptr;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
     if (h->lds_table) {
         if (compact)
@@ -642,6 +689,9 @@ int tab_launch_traj(mxv_tab *h, int K, void *actions_out, void *obs, void *rewar
     a.n = h->cfg.num_envs; a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.action_seed = h->action_seed; a.t = h->dev_clock ? 0 : h->t;
     a.t_dev = h->dev_clock ? h->t_dev : nullptr;
     a.max_steps = h->cfg.max_episode_steps; a.K = K;
+    a.ep_acc = h->ep_acc;
+    a.ep_return_out = h->ep_acc ? h->ep_return_out : nullptr;
+    a.ep_length_out = h->ep_acc ? h->ep_length_out : nullptr;
     const bool single = h->single_start >= 0;
     const int sel = (h->fast_M == 3 ? 4 : 0) | (compact ? 2 : 0) | (single ? 1 : 0);
     switch (sel) {
@@ -666,6 +716,7 @@ int tab_do_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.mask = mask_dev; a.init_cum = h->init_cum;
     a.obs = obs_dev; a.S = h->cfg.num_states; a.log2S = h->log2S; a.n = h->cfg.num_envs;
     a.env0 = (uint64_t)h->cfg.env_offset; a.base_seed = h->base_seed; a.t = h->dev_clock ? 0 : h->t; a.t_dev = h->dev_clock ? h->t_dev : nullptr; a.r = h->r;
+    a.ep_acc = h->ep_acc;
     const unsigned blocks = (unsigned)((h->cfg.num_envs + kTabBlock - 1) / kTabBlock);
     hipLaunchKernelGGL(tab_reset_kernel, dim3(blocks), dim3(kTabBlock), 0, h->stream, a);
     TAB_HIP(h, hipGetLastError());
@@ -813,7 +864,8 @@ int mxv_tab_destroy(mxv_tab *h) {
     if (!h) return MXV_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->fast_tbl, h->t_dev};
+    void *bufs[] = {h->state, h->elapsed, h->err, h->nt, h->seeds, h->cum, h->prob, h->reward, h->init_cum, h->fast_tbl, h->t_dev,
+                    h->ep_acc, h->st_ep_r, h->st_ep_l};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->hostmap) {
@@ -924,11 +976,13 @@ int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uni
         std::memcpy(h->st_actions, actions_host, n * 8);
         if (uniforms_host) std::memcpy(h->st_uniforms, uniforms_host, 2 * n * 8);
         h->err_in_block = true;
+        h->ep_host_step = true;
         const int lrc = tab_launch(h, 1, 0, h->st_actions, 0, nullptr, uniforms_host ? h->st_uniforms : nullptr, h->st_obs,
                                    reward_host ? h->st_reward : nullptr, terminated_host ? h->st_term : nullptr,
                                    truncated_host ? h->st_trunc : nullptr, prob_host ? h->st_prob : nullptr,
                                    final_obs_host ? h->st_final : nullptr, final_prob_host ? h->st_fprob : nullptr);
         h->err_in_block = false;
+        h->ep_host_step = false;
         if (lrc) return lrc;
         TAB_HIP(h, hipStreamSynchronize(h->stream));
         std::memcpy(obs_host, h->st_obs, n * 8);
@@ -947,11 +1001,13 @@ int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uni
     }
     TAB_HIP(h, hipMemcpyAsync(h->st_actions, actions_host, n * 8, hipMemcpyHostToDevice, h->stream));
     if (uniforms_host) TAB_HIP(h, hipMemcpyAsync(h->st_uniforms, uniforms_host, 2 * n * 8, hipMemcpyHostToDevice, h->stream));
-    if (int rc = tab_launch(h, 1, 0, h->st_actions, 0, nullptr, uniforms_host ? h->st_uniforms : nullptr, h->st_obs,
-                            reward_host ? h->st_reward : nullptr, terminated_host ? h->st_term : nullptr,
-                            truncated_host ? h->st_trunc : nullptr, prob_host ? h->st_prob : nullptr,
-                            final_obs_host ? h->st_final : nullptr, final_prob_host ? h->st_fprob : nullptr))
-        return rc;
+    h->ep_host_step = true;
+    const int lrc = tab_launch(h, 1, 0, h->st_actions, 0, nullptr, uniforms_host ? h->st_uniforms : nullptr, h->st_obs,
+                               reward_host ? h->st_reward : nullptr, terminated_host ? h->st_term : nullptr,
+                               truncated_host ? h->st_trunc : nullptr, prob_host ? h->st_prob : nullptr,
+                               final_obs_host ? h->st_final : nullptr, final_prob_host ? h->st_fprob : nullptr);
+    h->ep_host_step = false;
+    if (lrc) return lrc;
     TAB_HIP(h, hipMemcpyAsync(obs_host, h->st_obs, n * 8, hipMemcpyDeviceToHost, h->stream));
     if (reward_host) TAB_HIP(h, hipMemcpyAsync(reward_host, h->st_reward, n * 8, hipMemcpyDeviceToHost, h->stream));
     if (terminated_host) TAB_HIP(h, hipMemcpyAsync(terminated_host, h->st_term, n, hipMemcpyDeviceToHost, h->stream));
@@ -962,6 +1018,61 @@ int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uni
     int rc = tab_check_latched(h);
     if (rc == MXV_ERR_INVALID_ACTION) (void)tab_clock_add(h, -1);
     return rc;
+}
+
+/* gym.wrappers.RecordEpisodeStatistics fused into the step (record_episode_statistics.py:96-151): see mxv_toytext.h */
+int mxv_tab_episode_stats(mxv_tab *h, int32_t enable) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (enable && !h->ep_acc) {
+        TAB_HIP(h, hipMalloc((void **)&h->ep_acc, n * sizeof(float)));
+        TAB_HIP(h, hipMalloc((void **)&h->st_ep_r, n * sizeof(float)));
+        TAB_HIP(h, hipMalloc((void **)&h->st_ep_l, n * sizeof(int32_t)));
+        TAB_HIP(h, hipMemsetAsync(h->ep_acc, 0, n * sizeof(float), h->stream));
+        TAB_HIP(h, hipMemsetAsync(h->st_ep_r, 0, n * sizeof(float), h->stream));
+        TAB_HIP(h, hipMemsetAsync(h->st_ep_l, 0, n * sizeof(int32_t), h->stream));
+        TAB_HIP(h, hipStreamSynchronize(h->stream));
+    } else if (!enable && h->ep_acc) {
+        TAB_HIP(h, hipFree(h->ep_acc));
+        TAB_HIP(h, hipFree(h->st_ep_r));
+        TAB_HIP(h, hipFree(h->st_ep_l));
+        h->ep_acc = h->st_ep_r = nullptr;
+        h->st_ep_l = nullptr;
+    }
+    return MXV_OK;
+}
+
+int mxv_tab_set_episode_outputs(mxv_tab *h, float *ep_return_dev, int32_t *ep_length_dev) {
+    TAB_CHECK(h);
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    h->ep_return_out = ep_return_dev;
+    h->ep_length_out = ep_length_dev;
+    return MXV_OK;
+}
+
+int mxv_tab_episode_stats_host(mxv_tab *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host) {
+    TAB_CHECK(h);
+    if (!h->ep_acc) return tfail(h, MXV_ERR_INVALID_ARG, "episode statistics are not enabled (mxv_tab_episode_stats)");
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (ep_return_host) TAB_HIP(h, hipMemcpyAsync(ep_return_host, h->st_ep_r, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (ep_length_host) TAB_HIP(h, hipMemcpyAsync(ep_length_host, h->st_ep_l, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (running_return_host) TAB_HIP(h, hipMemcpyAsync(running_return_host, h->ep_acc, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
+}
+
+int mxv_tab_set_running_returns(mxv_tab *h, const float *running_return_host) {
+    TAB_CHECK(h);
+    if (!h->ep_acc) return tfail(h, MXV_ERR_INVALID_ARG, "episode statistics are not enabled (mxv_tab_episode_stats)");
+    if (!running_return_host) return tfail(h, MXV_ERR_INVALID_ARG, "NULL pointer");
+    TAB_HIP(h, hipSetDevice(h->cfg.device));
+    TAB_HIP(h, hipMemcpyAsync(h->ep_acc, running_return_host, (size_t)h->cfg.num_envs * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    TAB_HIP(h, hipStreamSynchronize(h->stream));
+    return MXV_OK;
 }
 
 int mxv_tab_get_state(mxv_tab *h, int32_t *state_host, int32_t *elapsed_host) {

@@ -577,9 +577,9 @@ class BlackjackRollout:
     def reset(self, seed: Optional[int] = None):
         if seed is not None:
             self.handle.seed(seed, action_seed=self.handle._action_seed)
-        self.handle.reset(self.obs)
+        self.handle.reset(self.obs)     # (mxv_bj_reset writes int64: the reference's observation dtype)
         self.ready()        # the returned tensor is safe to read on the caller's current stream (GPU-side ordering, no host wait)
-        return self.obs
+        return self.obs.to(self.int_dtype) if self.compact else self.obs      # compact: the trajectories' dtype (int32), like every other tensor it hands out
 
     def trajectory_buffers(self, K: int, layout: str = "auto", want_final: bool = False):
         """Output tensors of rollout_per_step.  Sets of 2 GiB and more ("auto") are sorted by HBM class (gym_amd/placement.py): the launch
@@ -619,6 +619,8 @@ class BlackjackRollout:
         self.stream.wait_stream(self._torch.cuda.current_stream(self.device))   # the tape was produced on the caller's stream
         self.handle.rollout(K, out["obs"], out["reward"], out["terminated"], out["truncated"], out.get("final_obs"),
                             actions_tape_dev=actions, per_step=True, compact=self.compact)
+        with self._torch.cuda.stream(self.stream):
+            out["actions"][:K].copy_(actions)      # a tape-driven launch records no actions: the returned set still holds the ones that were played
         return out
 
     def ready(self):

@@ -693,11 +693,7 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
 
             env = (SubEnvNormalizeObservation if what == "normalize_observation" else SubEnvNormalizeReward)(env, **kw)
             continue
-        if what == "episode_statistics":
-            if not isinstance(getattr(env, "unwrapped", env), HipVectorEnv):
-                env.close()
-                raise NotImplementedError("wrappers=RecordEpisodeStatistics is mapped to the classic-control engine's fused accumulators; "
-                                          "the toy_text engines do not carry them")
+        if what == "episode_statistics":      # every engine carries the fused accumulators (the toy_text ones from round 6 on)
             from .wrappers import SubEnvEpisodeStatistics
 
             env = SubEnvEpisodeStatistics(env, **kw)

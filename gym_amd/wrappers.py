@@ -52,15 +52,24 @@ class _VectorWrapper:
         return f"<{type(self).__name__}{self.env}>"
 
 
+def _has_fused_statistics(env) -> bool:
+    """The engine's vector envs: the classic-control adapter and (round 6) the toy_text ones, whose kernels carry the same float32
+    return accumulator and report the TimeLimit counter as the episode length."""
+    from .toy_text import HipBlackjackVectorEnv, HipTabularVectorEnv
+
+    return isinstance(env, (HipVectorEnv, HipTabularVectorEnv, HipBlackjackVectorEnv))
+
+
 class RecordEpisodeStatistics(_VectorWrapper):
     def __init__(self, env: HipVectorEnv, deque_size: int = 100):
         chain, e = [], env
         while isinstance(e, _VectorWrapper):
             chain.append(e)
             e = e.env
-        if not isinstance(e, HipVectorEnv) or any(isinstance(w, VectorListInfo) for w in chain):
-            raise TypeError("gym_amd.wrappers.RecordEpisodeStatistics wraps a HipVectorEnv (the statistics are "
-                            "accumulated by its engine), possibly under Normalize* wrappers, and needs dict infos")
+        if not _has_fused_statistics(e) or any(isinstance(w, VectorListInfo) for w in chain):
+            raise TypeError("gym_amd.wrappers.RecordEpisodeStatistics wraps one of the engine's vector envs — HipVectorEnv, "
+                            "HipTabularVectorEnv, HipBlackjackVectorEnv: the statistics are accumulated by its kernels — possibly under "
+                            "Normalize* wrappers, and needs dict infos")
         super().__init__(env)
         self.num_envs = env.num_envs
         self.is_vector_env = True

@@ -76,6 +76,18 @@ int mxv_tab_reset_host(mxv_tab *h, const uint8_t *mask_host, int64_t *obs_host);
 int mxv_tab_step_host(mxv_tab *h, const int64_t *actions_host, const double *uniforms_host, int64_t *obs_host,
                       double *reward_host, uint8_t *terminated_host, uint8_t *truncated_host, double *prob_host,
                       int64_t *final_obs_host, double *final_prob_host);
+/* -- episode statistics (API level 6): gym.wrappers.RecordEpisodeStatistics (gym/wrappers/record_episode_statistics.py:96-151) fused into
+ * the step and trajectory kernels, as mxv_episode_stats does for the classic-control engine: enable -> a float32 running return per env
+ * (episode length is the TimeLimit counter), zeroed for every env an explicit reset covers.  set_episode_outputs: device arrays [N] /
+ * [K][N] for the device-pointer calls (entries are MEANINGFUL only where that step's terminated | truncated is set: a wave in which an
+ * episode ended stores its 64 entries as whole lines, zeros where none ended; other waves store nothing); episode_stats_host:
+ * the returns / lengths of the episodes that ended in the LAST host step (valid where its terminated | truncated is set) and the running
+ * returns of all envs; any pointer may be NULL. */
+int mxv_tab_episode_stats(mxv_tab *h, int32_t enable);
+int mxv_tab_set_episode_outputs(mxv_tab *h, float *ep_return_dev, int32_t *ep_length_dev);
+int mxv_tab_episode_stats_host(mxv_tab *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host);
+/* checkpoint restore of the running returns read with episode_stats_host(running_return_host): float32 [N] */
+int mxv_tab_set_running_returns(mxv_tab *h, const float *running_return_host);
 /* env.unwrapped.s and TimeLimit._elapsed_steps: int32 [N] each (either may be NULL) */
 int mxv_tab_get_state(mxv_tab *h, int32_t *state_host, int32_t *elapsed_host);
 int mxv_tab_set_state(mxv_tab *h, const int32_t *state_host, const int32_t *elapsed_host);
@@ -134,6 +146,11 @@ int mxv_bj_rollout_compact(mxv_bj *h, int32_t K, int32_t per_step, const int64_t
 int mxv_bj_reset_host(mxv_bj *h, const int8_t *cards_host, int64_t *obs_host);
 int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards_host, int64_t *obs_host, double *reward_host,
                      uint8_t *terminated_host, uint8_t *truncated_host, int64_t *final_obs_host);
+/* episode statistics of the Blackjack engine: as mxv_tab_episode_stats / _set_episode_outputs / _episode_stats_host above */
+int mxv_bj_episode_stats(mxv_bj *h, int32_t enable);
+int mxv_bj_set_episode_outputs(mxv_bj *h, float *ep_return_dev, int32_t *ep_length_dev);
+int mxv_bj_episode_stats_host(mxv_bj *h, float *ep_return_host, int32_t *ep_length_host, float *running_return_host);
+int mxv_bj_set_running_returns(mxv_bj *h, const float *running_return_host);
 /* packed hands (see mxv_bj.hip) + TimeLimit counters, int32 [N] each; set_state also restores the step index / reset ordinal */
 int mxv_bj_get_state(mxv_bj *h, int32_t *state_host, int32_t *elapsed_host);
 int mxv_bj_set_state(mxv_bj *h, const int32_t *state_host, const int32_t *elapsed_host, uint64_t t, uint32_t r);

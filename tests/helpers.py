@@ -544,3 +544,38 @@ def replay_vector_make_clipaction(exact):
             assert ulps32(obs, g["obs"][t]).max() <= MAX_OBS_ULPS, t
     env.close()
     return T
+
+
+# ---- episode statistics over the toy_text engines (tests/golden/toytext_stats_*.npz: the reference's RecordEpisodeStatistics) --------------
+TOYTEXT_STATS_CASES = ["FrozenLake-v1", "Taxi-v3", "Blackjack-v1"]
+
+
+def replay_toytext_stats(tag, make_engine):
+    """The reference's own run of RecordEpisodeStatistics over gym.vector.make(<tag>, 8) — vector-level wrapper and per-sub-env wrapper,
+    the same trajectory (tests/golden/make_golden_toytext_stats.py) — replayed with its recorded uniforms / cards:
+    make_engine(g, n) -> object with step(t) -> (reward, terminated, truncated, ep_return float32 [n], ep_length int32 [n]) where the last
+    two are valid where terminated | truncated.  Rewards, flags, episode returns and lengths must match bit for bit, in both of the
+    reference's dtypes (float64 arrays of the vector-level wrapper; float32 / int32 scalars of the per-sub-env one)."""
+    g = np.load(os.path.join(GOLDEN, f"toytext_stats_{tag}.npz"))
+    T, n = g["actions"].shape
+    eng = make_engine(g, n)
+    episodes = 0
+    for t in range(T):
+        rew, term, trunc, er, el = eng.step(t)
+        done = g["ep_mask"][t]
+        assert np.array_equal(rew, g["reward"][t]) and np.array_equal(term, g["terminated"][t]) and np.array_equal(trunc, g["truncated"][t]), t
+        assert er.dtype == np.float32 and el.dtype == np.int32
+        assert np.array_equal(er[done].astype(np.float64), g["ep_r"][t][done]) and np.array_equal(el[done].astype(np.float64), g["ep_l"][t][done]), t
+        assert np.array_equal(er[done], g["sub_ep_r"][t][done]) and np.array_equal(el[done], g["sub_ep_l"][t][done]), t
+        episodes += int(done.sum())
+    assert episodes == int(g["ep_mask"].sum()) > 10
+    return episodes, g
+
+
+def toytext_stats_start(g, mdp=None):
+    """What the recorded reset left the sub-envs in: tabular — categorical_sample(initial_state_distrib, u) (toy_text/utils.py:4-8) of the
+    recorded uniform; Blackjack — the four recorded cards (dealer's hand first, blackjack.py:157-158)."""
+    if mdp is None:
+        return g["first"].astype(np.int8)
+    u = g["first"][:, 0]
+    return np.array([int(np.argmax(mdp.initial_cum > x)) for x in u], dtype=np.int32)

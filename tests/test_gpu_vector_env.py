@@ -770,3 +770,11 @@ def test_vector_make_normalize_wrappers_against_the_reference(name):
     from helpers import replay_vector_make_normalize
 
     assert replay_vector_make_normalize(name, exact=False) > 50
+
+
+def test_vector_make_clipaction_charges_the_clipped_action_on_the_device():
+    """wrappers=ClipAction is not an identity for MountainCarContinuous-v0 — the reward's `action[0] ** 2 * 0.1`
+    (continuous_mountain_car.py:169) must see the clipped action.  The reference's own run with actions up to +-6 (golden), on the GPU."""
+    from helpers import replay_vector_make_clipaction
+
+    assert replay_vector_make_clipaction(exact=False) == 60

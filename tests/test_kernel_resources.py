@@ -106,7 +106,8 @@ def test_the_instantiations_with_fused_observation_moments_keep_four_waves(build
     remarks, asm = build
     res = _resources(remarks)
     stats_e = {0: 2, 1: 2, 2: 1, 3: 2, 4: 2}        # stats_envs_per_lane: Pendulum takes two envs per lane here (the tree's cost per env halves)
-    spill = {(0, 3): 8, (1, 2): 8, (1, 3): 10}                 # parked around the K-step loop, not inside it (checked below for CartPole)
+    spill = {(0, 3): 8, (1, 2): 8, (1, 3): 10, (2, 1): 2, (2, 2): 2, (2, 3): 4}      # parked around the K-step loop, not inside it (checked below for CartPole; Acrobot's two
+                                                               # arrived with the 16-bit elapsed[] branch at entry / exit, round 6: same 21 scratch ops in its loop as before)
     for env, (_, occ, _) in HOT.items():
         e = stats_e[env]
         for out, st in ((1, 1), (2, 1), (1, 2), (2, 2), (1, 3), (2, 3)):      # st: 1 observation moments, 2 discounted returns, 3 both
@@ -216,7 +217,9 @@ def test_tabular_trajectory_kernel_stays_lean():
         assert sum(1 for l in body.splitlines() if "_dpp" in l and "quad_perm" in l) >= 4, sym
         loops = [t for _, t in _inner_loops(body) if "global_store" in t]
         main = max(loops, key=lambda t: t.count("global_store"))
-        assert main.count("global_store") == 24, (sym, main.count("global_store"))                 # 6 outputs x 4 unrolled steps
+        # 6 outputs x 4 unrolled steps, + the two episode-statistics stores per step behind their wave-uniform branch (round 6: skipped when
+        # the accumulators are off, taken only by waves in which an episode ended when they are on)
+        assert main.count("global_store") == 32, (sym, main.count("global_store"))
         hot_reads = sum(1 for l in main.splitlines() if re.match(r"\s+ds_read", l))
         assert hot_reads >= lds_reads, (sym, hot_reads)
 
@@ -244,10 +247,13 @@ def test_blackjack_kernel_is_one_philox_call_of_straight_line_code_per_step():
     scalar-base + 32-bit-lane-offset form (no 64-bit address arithmetic in vector registers)."""
     remarks, asm = _compile("mxv_bj.hip")
     res = {k: v for k, v in _resources(remarks).items() if "bj_kernel" in k}
-    assert len(res) == 5, list(res)
+    assert len(res) == 10, list(res)
     for k, r in res.items():
-        assert r["ScratchSize"] == 0 and r["Occupancy"] == 8 and r["VGPRs"] <= 64, (k, r)
-    for sym in ("_ZN12_GLOBAL__N_19bj_kernelILb0ELb1ELi1EEEvNS_6BjArgsE", "_ZN12_GLOBAL__N_19bj_kernelILb0ELb1ELi2EEEvNS_6BjArgsE"):
+        if k.endswith("ELb1EEEvNS_6BjArgsE"):     # STATS = true (round 6: RecordEpisodeStatistics fused): an instantiation of its own, 7 waves allowed
+            assert r["ScratchSize"] == 0 and r["Occupancy"] >= 7 and r["VGPRs"] <= 72, (k, r)
+        else:                                     # the launches without statistics keep round 5's budget exactly
+            assert r["ScratchSize"] == 0 and r["Occupancy"] == 8 and r["VGPRs"] <= 64, (k, r)
+    for sym in ("_ZN12_GLOBAL__N_19bj_kernelILb0ELb1ELi1ELb0EEEvNS_6BjArgsE", "_ZN12_GLOBAL__N_19bj_kernelILb0ELb1ELi2ELb0EEEvNS_6BjArgsE"):
         body = _function_body(asm, sym)
         loops = [t for _, t in _inner_loops(body) if "global_store" in t]
         main = max(loops, key=lambda t: t.count("global_store"))

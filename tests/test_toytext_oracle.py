@@ -149,3 +149,42 @@ def test_generate_random_map_equals_reference_under_the_same_global_seed():
 
     np.random.seed(3)
     assert generate_random_map(6) == REF_MAP_SEED3_SIZE6
+
+
+# ---- episode statistics: the oracle engines + the oracle's RecordEpisodeStatistics restatement against the reference's own wrapper -------
+@pytest.mark.parametrize("tag", ["FrozenLake-v1", "Taxi-v3", "Blackjack-v1"])
+def test_oracle_episode_statistics_replay_the_reference_wrapper(tag):
+    """tests/golden/toytext_stats_<tag>.npz: gym.wrappers.RecordEpisodeStatistics run by the reference over the toy_text vector envs, both
+    ways it can be applied.  The oracle's tabular / Blackjack engines dealt the recorded draws, with oracle.EpisodeStats
+    (record_episode_statistics.py:119-143 restated) on top, reproduce returns and lengths bit for bit — which pins the checker the
+    device's fused accumulators are held against (tests/test_gpu_toytext_stats.py)."""
+    from helpers import replay_toytext_stats, toytext_stats_start
+    from oracle.oracle import EpisodeStats, OracleBlackjack, OracleTabEnv
+
+    class Eng:
+        def __init__(self, g, n):
+            self.g, self.stats = g, EpisodeStats(n)
+            if tag == "Blackjack-v1":
+                self.e = OracleBlackjack(n, natural=bool(g["natural"]), sab=bool(g["sab"]))
+                self.e.reset(cards=toytext_stats_start(g))
+            else:
+                from gym_amd import toy_text
+
+                mdp = toy_text.TOY_TEXT_REGISTRY[tag].build()
+                self.e = OracleTabEnv(mdp.cum_prob, mdp.prob, mdp.next_state, mdp.reward, mdp.terminated, mdp.initial_cum, n,
+                                      int(g["max_episode_steps"]))
+                self.e.reset()
+                self.e.state[:] = toytext_stats_start(g, mdp)
+                self.e.elapsed[:] = 0
+
+        def step(self, t):
+            g = self.g
+            if tag == "Blackjack-v1":
+                out = self.e.step(g["actions"][t], g["draws"][t].astype(np.int8))
+            else:
+                out = self.e.step(g["actions"][t], np.ascontiguousarray(g["draws"][t][:, :2].T))
+            r, l, _ = self.stats.step(out["reward"], out["terminated"], out["truncated"])
+            return out["reward"], out["terminated"].astype(bool), out["truncated"].astype(bool), r, l
+
+    episodes, g = replay_toytext_stats(tag, Eng)
+    assert episodes == int(g["ep_mask"].sum())
