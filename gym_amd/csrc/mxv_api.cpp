@@ -274,6 +274,31 @@ int no_capture_without_clock(mxv_handle *h) {
     return MXV_OK;
 }
 
+// Every caller-owned tensor a launch touches must sit on its element's natural boundary (observations: the row's vector width — the kernels
+// store them as float4 / float2).  An odd address would not fault on this device (unaligned global access is enabled) but tears every
+// coalesced burst, and it is a caller bug either way: refused up front with the name of the tensor (tests/c_consumer/abi_fuzz.c).
+int check_aligned(mxv_handle *h, const void *p, size_t bytes, const char *what) {
+    if (p && ((uintptr_t)p & (bytes - 1)) != 0)
+        return fail(h, MXV_ERR_INVALID_ARG, "%s pointer %p is not %zu-byte aligned", what, p, bytes);
+    return MXV_OK;
+}
+int check_step_buffers(mxv_handle *h, const StepArgs &a) {
+    const size_t obs_al = h->O == 4 ? 16 : ((h->O % 2 == 0) ? 8 : 4);
+    const size_t act_al = h->NA > 0 ? ((a.flags & MXV_FLAG_ACTION_I32) ? 4 : 8) : 4, rew_al = (a.flags & MXV_FLAG_REWARD_F32) ? 4 : 8;
+    if (int rc = check_aligned(h, a.obs, obs_al, "obs")) return rc;
+    if (int rc = check_aligned(h, a.final_obs, obs_al, "final_obs")) return rc;
+    if (int rc = check_aligned(h, a.snap_obs, obs_al, "snapshot obs")) return rc;
+    if (int rc = check_aligned(h, a.reward, rew_al, "reward")) return rc;
+    if (int rc = check_aligned(h, a.snap_reward, rew_al, "snapshot reward")) return rc;
+    if (int rc = check_aligned(h, a.actions, act_al, "actions")) return rc;
+    if (int rc = check_aligned(h, a.actions_out, act_al, "actions_out")) return rc;
+    if (int rc = check_aligned(h, a.ep_return_out, 4, "episode return")) return rc;
+    if (int rc = check_aligned(h, a.ep_length_out, 4, "episode length")) return rc;
+    if (int rc = check_aligned(h, a.obs_part, 8, "obs partials")) return rc;
+    if (int rc = check_aligned(h, a.ret_part, 8, "return partials")) return rc;
+    return check_aligned(h, a.ret_state, 8, "returns state");
+}
+
 int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, void *reward, uint8_t *term,
             uint8_t *trunc, float *final_obs) {
     if (!h->was_reset)
@@ -298,6 +323,7 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
         a.clock_out = h->t_dev;
         a.clock_ticket = h->clock_ticket;
     }
+    if (int rc = check_step_buffers(h, a)) return rc;
     MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
     h->state_injected = false;
     if (self_clock) {
@@ -340,6 +366,7 @@ int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float
     a.base_seed = h->base_seed;
     a.b0 = b[0];
     a.b1 = b[1];
+    if (int rc = check_aligned(h, a.obs, h->O == 4 ? 16 : ((h->O % 2 == 0) ? 8 : 4), "obs")) return rc;
     MXV_HIP(h, launch_reset(h->cfg.env_id, a, h->stream));
     h->was_reset = true;
     if (mask_dev == nullptr) h->state_out_of_range = false;  // every env re-drawn
@@ -727,6 +754,7 @@ int fused_launch(mxv_handle *h, int32_t K, int32_t per_step, const void *actions
         a.snap_terminated = h->snap_term;
         a.snap_truncated = h->snap_trunc;
     }
+    if (int rc = check_step_buffers(h, a)) return rc;
     MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
     h->state_injected = false;
     if (int rc = clock_add(h, K)) return rc;
@@ -752,6 +780,12 @@ int mxv_rollout(mxv_handle *h, int32_t K, int32_t per_step, int32_t mode, void *
         if (!p) return nullptr;
         return per_step ? (void *)((char *)p + (size_t)k * n * elem_bytes) : p;
     };
+    {
+        StepArgs a0{};
+        fill_step_args(h, a0);
+        a0.actions_out = actions_out_dev; a0.obs = obs_dev; a0.reward = reward_dev; a0.final_obs = final_obs_dev;
+        if (int rc = check_step_buffers(h, a0)) return rc;
+    }
     auto launch_k = [&](int k, const uint64_t *t_dev, uint64_t t) -> hipError_t {
         StepArgs a{};
         fill_step_args(h, a);
@@ -843,6 +877,7 @@ int mxv_sample_actions(mxv_handle *h, void *actions_out_dev) {
     a.flags = h->cfg.flags;
     a.params_pe = h->params_pe;
     a.P = h->P;
+    if (int rc = check_aligned(h, actions_out_dev, h->NA > 0 && !(h->cfg.flags & MXV_FLAG_ACTION_I32) ? 8 : 4, "actions_out")) return rc;
     MXV_HIP(h, launch_sample(h->cfg.env_id, h->param_mode(), a, h->stream));
     return MXV_OK;
 }
@@ -1559,6 +1594,10 @@ extern "C" int mxv_rollout_mixed(mxv_handle *const *handles, int32_t count, int3
         a.snap_reward = h->snap_reward;
         a.snap_terminated = h->snap_term;
         a.snap_truncated = h->snap_trunc;
+        if (int rc = check_step_buffers(h, a)) {
+            if (h != h0) h0->error = h->error;
+            return rc;
+        }
         m.kind[i] = h->cfg.env_id;
         m.first_block[i] = blocks;
         blocks += (uint32_t)((h->cfg.num_envs + 63) / 64);  // one env per lane, one wave per workgroup

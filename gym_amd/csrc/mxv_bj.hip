@@ -228,7 +228,9 @@ __global__ void __launch_bounds__(kBjBlock)
             n += need ? 1 : 0;
         }
         if (__builtin_expect(__any(!act && total_of(ssum, sace) < 17), 0)) {
-            while (!act && total_of(ssum, sace) < 17) {
+            // (injected cards come from the caller: a zero among them must not keep the dealer drawing forever — the loop is bounded by the deck's
+            // length; the engine's own draws are 1..10 and end within 17)
+            while (!act && total_of(ssum, sace) < 17 && (!INJ || n < MXV_BJ_MAX_DRAWS)) {
                 const int cj = INJ ? (int)inj[n < MXV_BJ_MAX_DRAWS ? n : MXV_BJ_MAX_DRAWS - 1] : late_draw(seed, t, n);
                 ssum += cj; sace |= (int)(cj == 1); stwo = 0;
                 ++n;
@@ -410,6 +412,11 @@ int bj_clock_set(mxv_bj *h) {
     return MXV_OK;
 }
 
+int bj_aligned(mxv_bj *h, const void *p, size_t bytes, const char *what) {   // see check_aligned in mxv_api.cpp
+    if (p && ((uintptr_t)p & (bytes - 1)) != 0) return bfail(h, MXV_ERR_INVALID_ARG, "%s pointer %p is not %zu-byte aligned", what, p, bytes);
+    return MXV_OK;
+}
+
 int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t act_slice, void *actions_out,
               const int8_t *cards, void *obs, void *reward, uint8_t *term, uint8_t *trunc, void *final_obs, int out_mode = 1) {
     if (!h->was_reset) return bfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
@@ -417,6 +424,14 @@ int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t a
     if (K <= 0) return bfail(h, MXV_ERR_INVALID_ARG, "K must be positive");
     if (cards && K != 1) return bfail(h, MXV_ERR_INVALID_ARG, "injected cards are per step: K must be 1");
     if (cards && (!actions || out_mode != 1)) return bfail(h, MXV_ERR_INVALID_ARG, "injected cards need given actions and the reference's dtypes");
+    {
+        const size_t w = out_mode == 1 ? 8 : 4;
+        const struct { const void *p; size_t b; const char *what; } t[] = {
+            {actions, 8, "actions"}, {actions_out, w, "actions_out"}, {obs, w, "obs"}, {reward, w, "reward"}, {final_obs, w, "final_obs"},
+            {h->ep_return_out, 4, "episode return"}, {h->ep_length_out, 4, "episode length"}};
+        for (const auto &e : t)
+            if (int rc = bj_aligned(h, e.p, e.b, e.what)) return rc;
+    }
     BJ_HIP(h, hipSetDevice(h->cfg.device));
     BjArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds; a.actions = actions; a.actions_out = actions_out;
@@ -445,6 +460,7 @@ int bj_launch(mxv_bj *h, int K, int64_t slice, const int64_t *actions, int64_t a
 }
 
 int bj_do_reset(mxv_bj *h, const uint8_t *mask_dev, const int8_t *cards_dev, int64_t *obs_dev) {
+    if (int rc = bj_aligned(h, obs_dev, 8, "obs")) return rc;
     BJ_HIP(h, hipSetDevice(h->cfg.device));
     h->r += 1;
     BjResetArgs a{};
@@ -626,6 +642,11 @@ int mxv_bj_step_host(mxv_bj *h, const int64_t *actions_host, const int8_t *cards
                      uint8_t *terminated_host, uint8_t *truncated_host, int64_t *final_obs_host) {
     BJ_CHECK(h);
     if (!actions_host || !obs_host) return bfail(h, MXV_ERR_INVALID_ARG, "actions/obs pointer is NULL");
+    if (cards_host)   // an injected deck: card values (1 = ace ... 10, blackjack.py:14), 0 = padding behind the draws a step consumes
+        for (size_t i = 0; i < (size_t)h->cfg.num_envs * MXV_BJ_MAX_DRAWS; ++i)
+            if (cards_host[i] < 0 || cards_host[i] > 10)
+                return bfail(h, MXV_ERR_INVALID_ARG, "injected card %d at [%zu][%zu] is no card value (1..10; 0 pads)", (int)cards_host[i],
+                             i / MXV_BJ_MAX_DRAWS, i % MXV_BJ_MAX_DRAWS);
     BJ_HIP(h, hipSetDevice(h->cfg.device));
     if (int rc = bj_staging(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;

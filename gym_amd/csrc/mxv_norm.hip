@@ -549,6 +549,13 @@ int checks(mxv_norm *nm, int K) {
     return MXV_OK;
 }
 
+// caller-owned tensors on their element's natural boundary (observation rows: the vector width the kernels load them with)
+int norm_aligned(mxv_norm *nm, const void *p, size_t bytes, const char *what) {
+    if (p && ((uintptr_t)p & (bytes - 1)) != 0) return nfail(nm, MXV_ERR_INVALID_ARG, "%s pointer %p is not %zu-byte aligned", what, p, bytes);
+    return MXV_OK;
+}
+size_t row_align(int dim, size_t elem) { return dim % 4 == 0 ? 4 * elem > 16 ? 16 : 4 * elem : (dim % 2 == 0 ? 2 * elem : elem); }
+
 int run_scan(mxv_norm *nm, int K, const double *all_sums, int world, int64_t total_rows, double epsilon, int obs) {
     if (world < 1 || world > kMaxWorld) return nfail(nm, MXV_ERR_INVALID_ARG, "world must be in [1, %d]", kMaxWorld);
     if (total_rows <= 0) return nfail(nm, MXV_ERR_INVALID_ARG, "total_rows must be positive");
@@ -653,6 +660,8 @@ int mxv_norm_set_state(mxv_norm *nm, const double *mean_host, const double *var_
 int mxv_norm_obs_sums(mxv_norm *nm, int32_t K, const float *x_dev, double *sums_dev) {
     if (int rc = checks(nm, K)) return rc;
     if (!x_dev || !sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "x/sums pointer is NULL");
+    if (int rc = norm_aligned(nm, x_dev, row_align(nm->dim, 4), "x")) return rc;
+    if (int rc = norm_aligned(nm, sums_dev, 8, "sums")) return rc;
     const int64_t leaves = ceil_div(nm->n, kObsLeafRows);
     if (int rc = ensure_capacity(nm, K, leaves, 2 * nm->dim)) return rc;
     if (int rc = dispatch_obs_sums(nm, K, x_dev, leaves)) return rc;
@@ -663,6 +672,8 @@ int mxv_norm_obs_sums_partials(mxv_norm *nm, int32_t K, const double *partials_d
     if (int rc = checks(nm, K)) return rc;
     if (!partials_dev || !sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "partials/sums pointer is NULL");
     if (leaves < 1) return nfail(nm, MXV_ERR_INVALID_ARG, "leaves must be positive");
+    if (int rc = norm_aligned(nm, partials_dev, 8, "partials")) return rc;
+    if (int rc = norm_aligned(nm, sums_dev, 8, "sums")) return rc;
     if (int rc = ensure_capacity(nm, K, ceil_div(leaves, kTreeFan), 2 * nm->dim)) return rc;
     return run_tree(nm, K, leaves, 2 * nm->dim, sums_dev, partials_dev);
 }
@@ -672,6 +683,8 @@ int mxv_norm_reward_sums_partials(mxv_norm *nm, int32_t K, const double *partial
     if (nm->dim != 1) return nfail(nm, MXV_ERR_INVALID_ARG, "reward sums need a 1-column mxv_norm");
     if (!partials_dev || !sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "partials/sums pointer is NULL");
     if (leaves < 1) return nfail(nm, MXV_ERR_INVALID_ARG, "leaves must be positive");
+    if (int rc = norm_aligned(nm, partials_dev, 8, "partials")) return rc;
+    if (int rc = norm_aligned(nm, sums_dev, 8, "sums")) return rc;
     if (int rc = ensure_capacity(nm, K, ceil_div(leaves, kTreeFan), 2)) return rc;
     return run_tree(nm, K, leaves, 2, sums_dev, partials_dev);
 }
@@ -686,6 +699,9 @@ int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev,
                        const double *all_sums_dev, int32_t world, int64_t total_rows) {
     if (int rc = checks(nm, K)) return rc;
     if (!x_dev || !y_dev || !all_sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "x/y/sums pointer is NULL");
+    if (int rc = norm_aligned(nm, x_dev, row_align(nm->dim, 4), "x")) return rc;
+    if (int rc = norm_aligned(nm, y_dev, row_align(nm->dim, out_f32 ? 4 : 8), "y")) return rc;
+    if (int rc = norm_aligned(nm, all_sums_dev, 8, "sums")) return rc;
     if (int rc = ensure_capacity(nm, K, 1, 2 * nm->dim)) return rc;
     if (int rc = run_scan(nm, K, all_sums_dev, world, total_rows, epsilon, 1)) return rc;
     return dispatch_obs_apply(nm, K, x_dev, y_dev, out_f32);
@@ -694,6 +710,8 @@ int mxv_norm_obs_apply(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev,
 int mxv_norm_observations(mxv_norm *nm, int32_t K, const float *x_dev, void *y_dev, int32_t out_f32, double epsilon) {
     if (int rc = checks(nm, K)) return rc;
     if (!x_dev || !y_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "x/y pointer is NULL");
+    if (int rc = norm_aligned(nm, x_dev, row_align(nm->dim, 4), "x")) return rc;
+    if (int rc = norm_aligned(nm, y_dev, row_align(nm->dim, out_f32 ? 4 : 8), "y")) return rc;
     const int64_t leaves = ceil_div(nm->n, kObsLeafRows);
     if (int rc = ensure_capacity(nm, K, leaves, 2 * nm->dim)) return rc;
     if (int rc = mxv_norm_obs_sums(nm, K, x_dev, nm->sums)) return rc;
@@ -706,6 +724,8 @@ int mxv_norm_reward_sums(mxv_norm *nm, int32_t K, const void *reward_dev, int32_
     if (nm->dim != 1) return nfail(nm, MXV_ERR_INVALID_ARG, "reward statistics need dim == 1 (RunningMeanStd(shape=()))");
     if (!reward_dev || !terminated_dev || !truncated_dev || !sums_dev)
         return nfail(nm, MXV_ERR_INVALID_ARG, "reward/terminated/truncated/sums pointer is NULL");
+    if (int rc = norm_aligned(nm, reward_dev, reward_f32 ? 4 : 8, "reward")) return rc;
+    if (int rc = norm_aligned(nm, sums_dev, 8, "sums")) return rc;
     const int64_t leaves = ceil_div(nm->n, kRewLeafEnvs);
     if (int rc = ensure_capacity(nm, K, leaves, 2)) return rc;
     // the vector loads (16 / 32 bytes of rewards, 4 of each flag array per lane) need tensors that start on those boundaries — true of
@@ -726,6 +746,9 @@ int mxv_norm_reward_apply(mxv_norm *nm, int32_t K, const void *reward_dev, int32
     if (int rc = checks(nm, K)) return rc;
     if (nm->dim != 1) return nfail(nm, MXV_ERR_INVALID_ARG, "reward statistics need dim == 1 (RunningMeanStd(shape=()))");
     if (!reward_dev || !out_dev || !all_sums_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "reward/out/sums pointer is NULL");
+    if (int rc = norm_aligned(nm, reward_dev, reward_f32 ? 4 : 8, "reward")) return rc;
+    if (int rc = norm_aligned(nm, out_dev, reward_f32 ? 4 : 8, "out")) return rc;
+    if (int rc = norm_aligned(nm, all_sums_dev, 8, "sums")) return rc;
     if (int rc = ensure_capacity(nm, K, 1, 2)) return rc;
     if (int rc = run_scan(nm, K, all_sums_dev, world, total_rows, epsilon, 0)) return rc;
     const int V = reward_f32 ? 4 : 2;
@@ -754,6 +777,7 @@ int mxv_norm_rewards(mxv_norm *nm, int32_t K, const void *reward_dev, int32_t re
                      const uint8_t *truncated_dev, void *out_dev, double gamma, double epsilon) {
     if (int rc = checks(nm, K)) return rc;
     if (!out_dev) return nfail(nm, MXV_ERR_INVALID_ARG, "out pointer is NULL");
+    if (int rc = norm_aligned(nm, out_dev, reward_f32 ? 4 : 8, "out")) return rc;
     const int64_t leaves = ceil_div(nm->n, kRewLeafEnvs);
     if (int rc = ensure_capacity(nm, K, leaves, 2)) return rc;
     if (int rc = mxv_norm_reward_sums(nm, K, reward_dev, reward_f32, terminated_dev, truncated_dev, gamma, nm->sums)) return rc;

@@ -203,6 +203,21 @@ int mxv_placed_free(mxv_placed *p) {
 int mxv_hbm_pair_probe(int32_t device, void *wide_dev, void *narrow_dev, int32_t launches, double *us_per_step) {
     if (!wide_dev || !narrow_dev || !us_per_step || launches < 1) return pfail(nullptr, MXV_ERR_INVALID_ARG, "mxv_hbm_pair_probe: NULL argument");
     if (hipSetDevice(device) != hipSuccess) return pfail(nullptr, MXV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    // the window writes 256 MiB behind wide_dev and 128 MiB behind narrow_dev: the sizes are part of the contract, so they are checked
+    // against the allocations the pointers belong to (a short buffer would be a device fault, i.e. the caller's process)
+    const struct { void *p; size_t need; const char *what; } spans[] = {{wide_dev, (size_t)256 << 20, "wide_dev"}, {narrow_dev, (size_t)128 << 20, "narrow_dev"}};
+    for (const auto &sp : spans) {
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, sp.p) != hipSuccess || !base) {
+            (void)hipGetLastError();
+            return pfail(nullptr, MXV_ERR_INVALID_ARG, "mxv_hbm_pair_probe: %s is not inside a device allocation", sp.what);
+        }
+        const size_t off = (size_t)((char *)sp.p - (char *)base);
+        if (((uintptr_t)sp.p & 15) != 0 || off > size || size - off < sp.need)
+            return pfail(nullptr, MXV_ERR_INVALID_ARG, "mxv_hbm_pair_probe: %s needs %zu MiB of 16-byte aligned device memory behind it (%zu bytes there)",
+                         sp.what, sp.need >> 20, off <= size ? size - off : (size_t)0);
+    }
     Prober pr;
     if (hipError_t e = pr.init(device); e != hipSuccess) return pfail(nullptr, MXV_ERR_HIP, "stream / events: %s", hipGetErrorString(e));
     Chunk w, n;

@@ -426,6 +426,14 @@ int mxv_subnorm_observations(mxv_subnorm *nm, int32_t K, const float *x_dev, con
     if (final_y_dev && !final_dev) return sfail(nm, MXV_ERR_INVALID_ARG, "final_y without the terminal observations");
     if (!out_f32 && (const void *)x_dev == (const void *)y_dev)
         return sfail(nm, MXV_ERR_INVALID_ARG, "float64 results cannot alias the float32 observations");
+    {   // rows on the boundary of the vector width the kernel moves them with
+        const int D = nm->dim;
+        const size_t a32 = D % 4 == 0 ? 16 : (D % 2 == 0 ? 8 : 4), a64 = D % 2 == 0 ? 16 : 8;
+        const struct { const void *p; size_t b; const char *what; } t[] = {{x_dev, a32, "x"}, {final_dev, a32, "final"}, {y_dev, out_f32 ? a32 : a64, "y"},
+                                                                           {final_y_dev, a64, "final_y"}};
+        for (const auto &e : t)
+            if (e.p && ((uintptr_t)e.p & (e.b - 1)) != 0) return sfail(nm, MXV_ERR_INVALID_ARG, "%s pointer %p is not %zu-byte aligned", e.what, e.p, e.b);
+    }
     SubObsArgs a{x_dev, final_dev, terminated_dev, truncated_dev, y_dev, final_y_dev, nm->stat, nm->n, K, epsilon};
     return out_f32 ? launch_obs<float>(nm, a) : launch_obs<double>(nm, a);
 }
@@ -435,6 +443,8 @@ int mxv_subnorm_rewards(mxv_subnorm *nm, int32_t K, const void *reward_dev, int3
     if (int rc = sub_checks(nm, K)) return rc;
     if (nm->dim != 1) return sfail(nm, MXV_ERR_INVALID_ARG, "reward statistics need dim == 1 (got %d)", nm->dim);
     if (!reward_dev || !terminated_dev || !truncated_dev || !out_dev) return sfail(nm, MXV_ERR_INVALID_ARG, "NULL device pointer");
+    if ((((uintptr_t)reward_dev | (uintptr_t)out_dev) & (reward_f32 ? 3u : 7u)) != 0)
+        return sfail(nm, MXV_ERR_INVALID_ARG, "reward / out pointer is not %d-byte aligned", reward_f32 ? 4 : 8);
     SubRewArgs a{reward_dev, terminated_dev, truncated_dev, out_dev, nm->stat, nm->returns, nm->n, K, gamma, epsilon};
     const dim3 grid((unsigned)((a.n + kThreads - 1) / kThreads)), block(kThreads);
     if (reward_f32)

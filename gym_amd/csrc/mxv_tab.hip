@@ -543,6 +543,23 @@ int tab_check_latched(mxv_tab *h) {
     return MXV_OK;
 }
 
+// caller-owned tensors on their element's natural boundary (see check_aligned in mxv_api.cpp): refused by name, not torn
+int tab_aligned(mxv_tab *h, const void *p, size_t bytes, const char *what) {
+    if (p && ((uintptr_t)p & (bytes - 1)) != 0) return tfail(h, MXV_ERR_INVALID_ARG, "%s pointer %p is not %zu-byte aligned", what, p, bytes);
+    return MXV_OK;
+}
+int tab_check_buffers(mxv_tab *h, bool compact, const void *actions, const void *actions_out, const void *uniforms, const void *obs,
+                      const void *reward, const void *prob, const void *final_obs, const void *final_prob) {
+    const size_t w = compact ? 4 : 8;
+    const struct { const void *p; size_t b; const char *what; } t[] = {
+        {actions, w, "actions"}, {actions_out, w, "actions_out"}, {uniforms, 8, "uniforms"}, {obs, w, "obs"}, {reward, w, "reward"},
+        {prob, w, "prob"}, {final_obs, w, "final_obs"}, {final_prob, w, "final_prob"}, {h->ep_return_out, 4, "episode return"},
+        {h->ep_length_out, 4, "episode length"}};
+    for (const auto &e : t)
+        if (int rc = tab_aligned(h, e.p, e.b, e.what)) return rc;
+    return MXV_OK;
+}
+
 int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t act_slice, void *actions_out,
                const double *uniforms, void *obs, void *reward, uint8_t *term, uint8_t *trunc, void *prob,
                void *final_obs, void *final_prob, bool compact = false) {
@@ -550,6 +567,7 @@ int tab_launch(mxv_tab *h, int K, int64_t slice, const void *actions, int64_t ac
         return tfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
     if (!obs) return tfail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
     if (K <= 0) return tfail(h, MXV_ERR_INVALID_ARG, "K must be positive");
+    if (int rc = tab_check_buffers(h, compact, actions, actions_out, uniforms, obs, reward, prob, final_obs, final_prob)) return rc;
     TAB_HIP(h, hipSetDevice(h->cfg.device));
     TabArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds;
@@ -679,6 +697,7 @@ void launch_traj(mxv_tab *h, const TabTrajArgs &a0) {
 int tab_launch_traj(mxv_tab *h, int K, void *actions_out, void *obs, void *reward, uint8_t *term, uint8_t *trunc, void *prob, bool compact) {
     if (!h->was_reset)
         return tfail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
+    if (int rc = tab_check_buffers(h, compact, nullptr, actions_out, nullptr, obs, reward, prob, nullptr, nullptr)) return rc;
     TAB_HIP(h, hipSetDevice(h->cfg.device));
     TabTrajArgs a{};
     a.state = h->state; a.elapsed = h->elapsed; a.seeds = h->seeds;
@@ -710,6 +729,7 @@ int tab_launch_traj(mxv_tab *h, int K, void *actions_out, void *obs, void *rewar
 }
 
 int tab_do_reset(mxv_tab *h, const uint8_t *mask_dev, int64_t *obs_dev) {
+    if (int rc = tab_aligned(h, obs_dev, 8, "obs")) return rc;
     TAB_HIP(h, hipSetDevice(h->cfg.device));
     h->r += 1;
     TabResetArgs a{};
