@@ -85,9 +85,9 @@ def compact_line(full, limit=LINE_LIMIT):
         "parallelism": cfg["parallelism"], "ranks_seen": cfg["ranks_seen"], "gathers_in_timed_region": cfg["gathers_in_timed_region"],
         "gather_every": cfg["gather_every"], "gather_transport": cfg["gather_transport"], "gather_us": cfg.get("gather_us"),
         "comm": cfg["comm"],
-        "per_rank_fields": ["rank", "device", "kernel_us_per_step", "write_probe_us_per_step", "placement"],
+        "per_rank_fields": ["rank", "device", "kernel_us_per_step", "write_probe_us_per_step", "placement", "placement_seconds"],
         "per_rank": [[r["rank"], r["device"], r["kernel_us_per_step"], r["write_probe_us_per_step"],
-                      (r.get("placement") or {}).get("kind", "").split(" ")[0]] for r in cfg["per_rank"]],
+                      (r.get("placement") or {}).get("kind", "").split(" ")[0], (r.get("placement") or {}).get("seconds")] for r in cfg["per_rank"]],
         "work_check": None if wc is None else {k: v for k, v in wc.items() if k != "what"},
         "launch_info": cfg["launch_info"],
     }
@@ -341,7 +341,7 @@ def run(args, bench_file, cpu_baseline=None):
     if gathering:
         sr._snapshots()
         shard_bytes = getattr(sr, "_shard_bytes", None) or sum(t.numel() * t.element_size() for t in eng.final_tensors())
-        reps_g = 4
+        reps_g = 1 if args.backend == "gloo" else 4      # (a gloo gather of ranks that share one GPU is a multi-second CPU affair: once is enough)
         fence()
         tg = time.perf_counter()
         for _ in range(reps_g):
@@ -380,7 +380,7 @@ def run(args, bench_file, cpu_baseline=None):
                  "timed_region_ms": elapsed_local * 1e3, "write_probe_us_per_step": probe_us,
                  "kernel_over_probe": (launch_ms * 1e3 / steps_per_launch / probe_us) if probe_us else None,
                  "placement": {k: placement.get(k) for k in ("kind", "balanced", "candidates", "parked_GiB", "chunks_created", "class_chunks",
-                                                             "seconds", "peak_GiB", "jumped_GiB", "chosen_us_per_step", "error") if k in placement}}]
+                                                             "seconds", "stopped_by", "mode", "peak_GiB", "jumped_GiB", "chosen_us_per_step", "error") if k in placement}}]
     if world > 1:
         if args.backend == "gloo":
             tc = t.cpu()
@@ -472,7 +472,9 @@ def run(args, bench_file, cpu_baseline=None):
         for r in per_rank:       # one line per rank on stderr: what every rank measured on ITS tensors
             print("[bench per-rank] " + json.dumps(_sig({"rank": r["rank"], "device": r["device"], "kernel_us_per_step": r["kernel_us_per_step"],
                                                          "write_probe_us_per_step": r["write_probe_us_per_step"],
-                                                         "placement.kind": (r.get("placement") or {}).get("kind")})), file=sys.stderr, flush=True)
+                                                         "placement.kind": (r.get("placement") or {}).get("kind"),
+                                                         "placement.seconds": (r.get("placement") or {}).get("seconds"),
+                                                         "placement.stopped_by": (r.get("placement") or {}).get("stopped_by")})), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and cpu_baseline is not None:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_steps)
         side = {}

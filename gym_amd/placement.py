@@ -26,7 +26,12 @@ Modes (MXV_PLACEMENT):
   search  up to 112 GiB parked transiently (~1-3 s on a fresh device) to leave the first class, whoever else is there;
   off     never sort — ordinary allocations, no probe launches, no synchronisation, nothing parked.
 MXV_PLACEMENT_MAX_PARK_GIB overrides the cap of either mode.  An out-of-memory error inside the walk ends it with ordinary allocations
-instead of reaching the caller.
+instead of reaching the caller.  Three more brakes (round 6): a process that is one of several ranks (WORLD_SIZE > 1) never takes the long
+walk on its own authority ("auto" resolves to "cheap": eight ranks starting together must not each hold ~90 GiB for seconds before their
+first barrier, and ranks that share a device would each see it as empty) and every walk there ends after MXV_PLACEMENT_MAX_SECONDS
+(default 0.5 s with WORLD_SIZE > 1, unbounded otherwise) with what it has; and every walk re-reads the device's free memory as it goes —
+if it shrank by more than the walk itself took (a learner or another process started allocating in the meantime) it stops parking at once.
+The report carries `seconds` and, when a brake ended the walk, `stopped_by`.
 
 What was measured is remembered per device (`_ClassMemo`): torch's caching allocator hands a learner's loop the same blocks again and
 again (`out = r.rollout_per_step(K)` alternates between two sets), and a block keeps its physical memory for as long as its segment is
@@ -66,14 +71,32 @@ def mode() -> str:
     return v if v in ("search", "cheap") else "auto"
 
 
+def world_size() -> int:
+    try:
+        return max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    except ValueError:
+        return 1
+
+
 def resolve_mode(free_bytes: Optional[int] = None, total_bytes: Optional[int] = None) -> str:
-    """"cheap" or "search" for this call: an explicit MXV_PLACEMENT wins; "auto" walks far only on an otherwise empty device."""
+    """"cheap" or "search" for this call: an explicit MXV_PLACEMENT wins; "auto" walks far only on an otherwise empty device, and only in
+    a process that is not one of several ranks."""
     m = mode()
     if m != "auto":
         return m
-    if free_bytes is None or not total_bytes:
+    if free_bytes is None or not total_bytes or world_size() > 1:
         return "cheap"
     return "search" if free_bytes >= EMPTY_DEVICE_FRACTION * total_bytes else "cheap"
+
+
+def max_seconds() -> Optional[float]:
+    """Wall-time bound of one walk: MXV_PLACEMENT_MAX_SECONDS if set (<= 0: none), else 0.5 s for a rank of a multi-process job, none
+    for a single process (whose walk is bounded by what it may park)."""
+    try:
+        v = float(os.environ["MXV_PLACEMENT_MAX_SECONDS"])
+        return v if v > 0 else None
+    except (KeyError, ValueError):
+        return 0.5 if world_size() > 1 else None
 
 
 def enabled() -> bool:
@@ -197,7 +220,9 @@ def sorted_tensors(specs: Sequence[Tuple[str, tuple, torch.dtype, bool]], groups
 
 
 def _sorted_locked(specs, groups, be, budget_bytes):
-    t_begin = time.perf_counter()
+    now = getattr(be, "now", time.perf_counter)
+    t_begin = now()
+    limit = max_seconds()
     memo = _MEMO.setdefault(be.key() if hasattr(be, "key") else id(be), _ClassMemo())
     frees_of = getattr(be, "segment_frees", lambda: None)
     memo.validate(frees_of())
@@ -212,9 +237,11 @@ def _sorted_locked(specs, groups, be, budget_bytes):
               "candidates": 0, "remembered": 0, "requested_GiB": round(sum(nbytes.values()) / 2**30, 3)}
 
     dirty = [True]     # allocations (and their zero fills) issued since the last device synchronisation
+    held = [0]         # bytes this call has allocated and not let go (the set + what is parked)
 
     def alloc(name):
         dirty[0] = True
+        held[0] += nbytes[name]
         return be.alloc(*spec[name])
 
     def plain(note):
@@ -231,6 +258,15 @@ def _sorted_locked(specs, groups, be, budget_bytes):
     report["budget_GiB"] = round(budget / 2**30, 2)
     parked, parked_bytes = [], 0
     warmed = [False]
+
+    def brake():
+        """Why the walk must stop parking NOW, or None: out of time, or the device's free memory shrank by more than this call took
+        (1 GiB of slack for allocator rounding) — somebody else started allocating."""
+        if limit is not None and now() - t_begin > limit:
+            return "time"
+        if free_now - be.free_bytes() > held[0] + (1 << 30):
+            return "crowded"
+        return None
 
     def probe(wide_ptr, narrow_ptr, _warm_at=None):
         if dirty[0]:                                       # a probe times the device: it must be idle.  A set made of remembered blocks
@@ -261,7 +297,7 @@ def _sorted_locked(specs, groups, be, budget_bytes):
         else:
             same = probe(a0, a0 + WIDE, a0)                # both streams inside the first 384 MiB of one allocation: a same-class pair
             straddles = probe(a0, a1 - NARROW) <= SAME_RATIO * same
-            if straddles and parked_bytes + nbytes[anchor_name] <= budget:
+            if straddles and parked_bytes + nbytes[anchor_name] <= budget and not brake():
                 park((anchor_name, anchor))
                 del anchor
                 continue
@@ -298,7 +334,7 @@ def _sorted_locked(specs, groups, be, budget_bytes):
             report["candidates"] += 1
             if relation(t, n) == 1:
                 out[n] = t
-            elif parked_bytes + sum(nbytes[m] for m in out) + nbytes[n] <= budget and attempt < 3:
+            elif parked_bytes + sum(nbytes[m] for m in out) + nbytes[n] <= budget and attempt < 3 and not brake():
                 park((n, t), *out.items())                 # a class boundary inside the group: start it again from here
                 restart = True
                 break
@@ -311,9 +347,12 @@ def _sorted_locked(specs, groups, be, budget_bytes):
                 t = alloc(n)
                 report["candidates"] += 1
                 r = relation(t, n)
-                if r == -1 or parked_bytes + nbytes[n] > budget:
+                why = None if r == -1 else brake()
+                if r == -1 or parked_bytes + nbytes[n] > budget or why:
                     ok = ok and r == -1
                     out[n] = t
+                    if why:
+                        report["stopped_by"] = why
                     break
                 park((n, t))
         break
@@ -336,5 +375,5 @@ def _sorted_locked(specs, groups, be, budget_bytes):
         memo.single = {k for k in memo.single if k[0] in keep}
         memo.rel = {k: v for k, v in memo.rel.items() if k[0] in keep and k[2] in keep}
     memo.seal(frees_of())  # the release moved the allocator's count: what survives stays valid from the new count on
-    report.update({"balanced": ok, "parked_GiB": round(parked_bytes / 2**30, 2), "seconds": round(time.perf_counter() - t_begin, 3)})
+    report.update({"balanced": ok, "parked_GiB": round(parked_bytes / 2**30, 2), "seconds": round(now() - t_begin, 3)})
     return {n: out[n] for n in names}, report

@@ -85,8 +85,10 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     out = lines[0]
     cfg = out["config"]
     assert out["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["comm"]["launcher"] == "bench.py" and cfg["comm"]["backend"] == "gloo"
-    assert cfg["per_rank_fields"] == ["rank", "device", "kernel_us_per_step", "write_probe_us_per_step", "placement"]
+    assert cfg["per_rank_fields"] == ["rank", "device", "kernel_us_per_step", "write_probe_us_per_step", "placement", "placement_seconds"]
     assert [r[0] for r in cfg["per_rank"]] == [0, 1] and all(r[2] > 0 and isinstance(r[4], str) for r in cfg["per_rank"])
+    # ranks of a multi-process job never take the long placement walk on their own authority, and what they walk is bounded (0.5 s)
+    assert all(r[5] is None or r[5] < 1.0 for r in cfg["per_rank"]) and p.stderr.count("placement.seconds") == 2
     assert p.stderr.count("[bench per-rank] ") == 2 and len(p.stdout.encode()) < 4096
     # the older cadence (one gather per launch, rounds 1-3) beside the default one, and the gather by itself
     assert cfg["cadence_ab"]["gather_every"] == 256 and cfg["cadence_ab"]["ms_per_step"] > 0

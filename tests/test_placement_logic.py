@@ -463,3 +463,65 @@ def test_environment_switch(monkeypatch):
     assert placement.enabled()
     monkeypatch.setenv("MXV_PLACEMENT_MAX_PARK_GIB", "1.5")
     assert placement.max_park_bytes() == 3 << 29
+
+
+# ---- round 6: the brakes ----------------------------------------------------------------------------------
+def test_a_rank_of_a_multi_process_job_never_takes_the_long_walk_on_its_own(monkeypatch):
+    """WORLD_SIZE > 1: "auto" resolves to "cheap" even on an empty device (eight ranks starting together would each hold ~90 GiB for
+    seconds before their first barrier; ranks sharing a device would each see it as empty), and the walk is bounded at 0.5 s."""
+    from gym_amd import placement
+
+    monkeypatch.delenv("MXV_PLACEMENT", raising=False)
+    monkeypatch.delenv("MXV_PLACEMENT_MAX_SECONDS", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert placement.resolve_mode(280 * GiB, 288 * GiB) == "search" and placement.max_seconds() is None
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert placement.resolve_mode(280 * GiB, 288 * GiB) == "cheap" and placement.max_seconds() == 0.5
+    monkeypatch.setenv("MXV_PLACEMENT", "search")                      # an explicit mode still wins
+    assert placement.resolve_mode(280 * GiB, 288 * GiB) == "search"
+    monkeypatch.setenv("MXV_PLACEMENT_MAX_SECONDS", "2.5")
+    assert placement.max_seconds() == 2.5
+
+
+def test_the_walk_stops_when_its_time_is_up(monkeypatch):
+    """A fresh device (one class for the first 96 GiB) and a generous park budget: unbounded, the walk parks ~90 GiB and comes back
+    balanced; with a wall-time bound that the simulated clock exceeds after a few probes it stops early, unbalanced, and says why."""
+    monkeypatch.setenv("MXV_PLACEMENT", "search")
+    regions = [(96 * GiB, 0), (192 * GiB, 1), (288 * GiB, 2)]
+    dev = SimDevice(regions)
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, "sim", _backend=dev)
+    assert rep["balanced"] and rep["parked_GiB"] > 50 and "stopped_by" not in rep
+
+    class Clocked(SimDevice):
+        t = 0.0
+
+        def now(self):
+            return self.t
+
+        def probe(self, wide, narrow):
+            self.t += 0.02                                  # every probe window costs 20 ms of simulated wall time
+            return super().probe(wide, narrow)
+
+    monkeypatch.setenv("MXV_PLACEMENT_MAX_SECONDS", "0.5")
+    dev = Clocked(regions)
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, "sim", _backend=dev)
+    assert not rep["balanced"] and rep["stopped_by"] == "time" and rep["seconds"] < 1.5 and rep["parked_GiB"] < 40
+    assert set(out) == {n for n, *_ in CARTPOLE}
+
+
+def test_the_walk_backs_off_when_somebody_else_starts_allocating(monkeypatch):
+    """the emptiness test of "auto" is a point-in-time check.  Here a neighbour takes 60 GiB while the walk is under way: the
+    device's free memory shrinks by more than the walk itself holds, and it stops parking at once instead of racing the neighbour to the
+    last GiB."""
+    monkeypatch.setenv("MXV_PLACEMENT", "search")
+    monkeypatch.delenv("MXV_PLACEMENT_MAX_SECONDS", raising=False)
+
+    class Neighbour(SimDevice):
+        def probe(self, wide, narrow):
+            if self.probes == 12:
+                self.live += 60 * GiB                       # somebody else's allocation, not ours
+            return super().probe(wide, narrow)
+
+    dev = Neighbour([(96 * GiB, 0), (192 * GiB, 1), (288 * GiB, 2)])
+    out, rep = sorted_tensors(CARTPOLE, CP_GROUPS, "sim", _backend=dev)
+    assert rep["stopped_by"] == "crowded" and not rep["balanced"] and rep["parked_GiB"] < 30
