@@ -13,6 +13,7 @@ _LAZY = {
     "VectorEnv": ("gym_amd.vector_env", "VectorEnv"),
     "VectorEnvWrapper": ("gym_amd.vector_env", "VectorEnvWrapper"),
     "make": ("gym_amd.vector_env", "make"),
+    "HipEnv": ("gym_amd.single_env", "HipEnv"),
     "DeviceRollout": ("gym_amd.rollout", "DeviceRollout"),
     "ShardedRollout": ("gym_amd.distributed", "ShardedRollout"),
     "MixedRollout": ("gym_amd.mixed", "MixedRollout"),

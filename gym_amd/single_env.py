@@ -1,0 +1,129 @@
+"""HipEnv — the single-environment surface of the engine: gym.Env's step() / reset() contract (gym/core.py:75-184) for
+`gym.make("hip/<id>")` without `num_envs`, so that the reference's README loop (README.md:29-41) runs unchanged:
+
+    env = gym.make("hip/CartPole-v1")
+    observation, info = env.reset(seed=42)
+    for _ in range(1000):
+        observation, reward, terminated, truncated, info = env.step(policy(observation))
+        if terminated or truncated:
+            observation, info = env.reset()
+    env.close()
+
+Nobody needs a GPU for ONE environment — this exists so that code written against a single env (evaluation loops, env checkers, the
+determinism tests of tests/envs/test_envs.py:63-115) meets the same dynamics, TimeLimit and error behaviour as the vector envs: it is a
+one-env vector engine WITHOUT autoreset (MXV_FLAG_NO_AUTORESET: a finished env stays finished until reset(), as gym.Env prescribes)
+with the batch axis squeezed away.  What gym.make wraps around the reference's envs lives in the engine already:
+
+  TimeLimit       (gym/wrappers/time_limit.py:39-68)     truncated = elapsed >= max_episode_steps, the counter restarts at reset()
+  OrderEnforcing  (gym/wrappers/order_enforcing.py:33-37) step() before reset() raises ResetNeeded
+  `assert self.action_space.contains(action)`            AssertionError with the reference's message (cartpole.py:131-132)
+  CartPole's steps_beyond_terminated (cartpole.py:169-184): the step the pole falls pays 1.0, later steps without reset() 0.0
+
+Classic-control ids only (the toy_text engines always autoreset: use their vector envs).  Returns unbatched observations (float32
+(O,)), a Python float reward, Python bools, and an empty info dict — the types the reference's envs hand back.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import error
+from .vector_env import HipVectorEnv
+
+
+class Env:
+    """Attribute surface of gym.Env (gym/core.py:75-226) that the adapter fills; `gym_amd.interop.as_reference_env` makes instances
+    real gym.Env objects when the reference is importable."""
+
+    metadata = {"render_modes": []}
+    render_mode = None
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def render(self):
+        return None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()
+        return False
+
+
+class HipEnv(Env):
+    def __init__(self, id: str, *, device: int = 0, max_episode_steps: Optional[int] = None, render_mode=None, **kwargs):
+        if render_mode is not None:
+            raise NotImplementedError("the device engine has no renderer (render_mode must be None)")
+        self._vec = HipVectorEnv(id, 1, device=device, max_episode_steps=max_episode_steps, autoreset=False, copy=True, **kwargs)
+        self.spec = self._vec.spec
+        self.observation_space = self._vec.single_observation_space
+        self.action_space = self._vec.single_action_space
+        self._discrete = self._vec._discrete
+        self.closed = False
+
+    # -- gym.Env --------------------------------------------------------------------------------------------------------------------
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        """gym/core.py:129-165: reset(seed=...) reseeds the env's generator (here: the engine's Philox streams, key = seed), reset()
+        continues it; `options` as the classic-control envs read them (classic_control/utils.py:17-46: {"low", "high"} / Pendulum's
+        {"x_init", "y_init"})."""
+        self._assert_open()
+        obs, _ = self._vec.reset(seed=seed, options=options)
+        return np.array(obs[0], dtype=np.float32), {}
+
+    def step(self, action):
+        self._assert_open()
+        if not self.action_space.contains(action):       # `assert self.action_space.contains(action), err_msg` (cartpole.py:131-132)
+            if not (self._discrete is False and np.shape(action) == (1,)):    # Box envs index action[0] / clip it: any (1,) array-like is accepted
+                raise AssertionError(f"{action!r} ({type(action)}) invalid")
+        a = np.asarray(action)
+        batch = a.reshape(1).astype(np.int64) if self._discrete else a.reshape(1, 1).astype(np.float32)
+        obs, rew, term, trunc, _ = self._vec.step(batch)
+        return np.array(obs[0], dtype=np.float32), float(rew[0]), bool(term[0]), bool(trunc[0]), {}
+
+    def close(self):
+        if not self.closed:
+            self._vec.close()
+            self.closed = True
+
+    def _assert_open(self):
+        if self.closed:
+            raise error.ClosedEnvironmentError("Trying to operate on `HipEnv`, after a call to `close()`.")
+
+    @property
+    def np_random(self):
+        raise AttributeError("the engine draws from Philox4x32-10 streams keyed by reset(seed=...), not from a NumPy generator (DESIGN.md §2)")
+
+    # the attributes of the reference's env objects (env.unwrapped.gravity, .state, ...)
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        vec = self.__dict__.get("_vec")
+        if vec is None:
+            raise AttributeError(name)
+        if name == "state":
+            return np.array(vec.handle.get_state()[0][:, 0])
+        if name in ("_elapsed_steps", "elapsed_steps"):
+            return int(vec.handle.get_state()[1][0])
+        try:
+            return vec.get_attr(name)[0]
+        except (AttributeError, NotImplementedError):
+            raise AttributeError(f"{type(self).__name__} has no attribute {name!r}") from None
+
+    def __repr__(self):
+        return f"<HipEnv<{self.spec.id}>>"
+
+    def __getstate__(self):
+        return {"_vec": self._vec, "closed": self.closed}
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.spec = self._vec.spec
+        self.observation_space = self._vec.single_observation_space
+        self.action_space = self._vec.single_action_space
+        self._discrete = self._vec._discrete

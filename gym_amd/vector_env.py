@@ -269,7 +269,7 @@ class HipVectorEnv(VectorEnv):
     render_mode = None
 
     def __init__(self, id: str, num_envs: int = 1, *, device: int = 0, max_episode_steps: Optional[int] = None,
-                 env_offset: int = 0, copy: bool = True, zero_copy: bool = False, **kwargs):
+                 env_offset: int = 0, copy: bool = True, zero_copy: bool = False, autoreset: bool = True, **kwargs):
         self.spec = _spec(id)
         self.kind = self.spec.kind
         observation_space, action_space = single_spaces(self.kind)
@@ -289,8 +289,12 @@ class HipVectorEnv(VectorEnv):
         self._max_episode_steps = -1 if limit is None else int(limit)
         self._discrete = isinstance(action_space, Discrete)
         entropy = int.from_bytes(os.urandom(8), "little")  # Env.reset(seed=None) = fresh OS entropy (seeding.py:24)
+        # autoreset=False (MXV_FLAG_NO_AUTORESET): dynamics + TimeLimit only, a finished env stays finished until reset() — the single-env
+        # contract of gym.Env (gym/core.py:75-184), which gym_amd.single_env.HipEnv builds on
+        self.autoreset = bool(autoreset)
         self._handle = _native.Handle(self.kind, num_envs, self._max_episode_steps, device=device,
-                                      env_offset=env_offset, seed=entropy, action_seed=entropy ^ 0x9E3779B97F4A7C15)
+                                      env_offset=env_offset, seed=entropy, action_seed=entropy ^ 0x9E3779B97F4A7C15,
+                                      **({} if autoreset else {"flags": _native.FLAG_NO_AUTORESET}))
         self._actions = None
         self._was_reset = False
         self._per_env = False  # True while sub-envs hold differing physics attributes (set_attr with a list)

@@ -139,7 +139,8 @@ class FakeHandle:
     compatibility with the reference's own classes) be exercised in the GPU-less build container; never used by the product."""
 
     def __init__(self, kind, num_envs, max_episode_steps, device=0, env_offset=0, seed=0, action_seed=0, flags=0):
-        self.o = OracleVecEnv(kind, num_envs, max_episode_steps, seed=seed, action_seed=action_seed, env_offset=env_offset)
+        self.o = OracleVecEnv(kind, num_envs, max_episode_steps, seed=seed, action_seed=action_seed, env_offset=env_offset,
+                              autoreset=not (flags & 4))          # MXV_FLAG_NO_AUTORESET
         self.env_id, self.num_envs, self.device, self.flags = kind, num_envs, device, flags
         self.max_episode_steps = int(max_episode_steps)
         self.O, self.S = self.o.O, self.o.S

@@ -1,0 +1,149 @@
+"""gym_amd.single_env.HipEnv — gym.Env's single-environment contract (gym/core.py:75-184) over the engine, what `gym.make("hip/<id>")`
+returns when no num_envs is given.  CPU: over the oracle-backed handle (tests/oracle_engine.FakeHandle), against the
+LIVE reference where it is importable.  GPU: the same checks on the device (`-m gpu`)."""
+import numpy as np
+import pytest
+
+IDS = ["CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0"]
+
+
+def _readme_loop(env, steps, seed=42):
+    """/root/reference/README.md:29-41 with a random policy; returns what happened."""
+    env.action_space.seed(seed)
+    observation, info = env.reset(seed=seed)
+    log, episodes = [], 0
+    for _ in range(steps):
+        action = env.action_space.sample()
+        observation, reward, terminated, truncated, info = env.step(action)
+        log.append((observation.copy(), reward, terminated, truncated))
+        assert isinstance(observation, np.ndarray) and observation.dtype == np.float32 and observation.shape == env.observation_space.shape
+        assert isinstance(reward, float) and isinstance(terminated, bool) and isinstance(truncated, bool) and info == {}
+        if terminated or truncated:
+            observation, info = env.reset()
+            episodes += 1
+    return log, episodes
+
+
+def _checks(make_env, have_reference):
+    from gym_amd import error
+
+    # (1) the README loop, and determinism as tests/envs/test_envs.py:63-115 asks it: same seed -> same rollout, another seed -> another
+    for gid in IDS:
+        a, b, c = make_env(gid), make_env(gid), make_env(gid)
+        la, ea = _readme_loop(a, 600)
+        lb, eb = _readme_loop(b, 600)
+        lc, _ = _readme_loop(c, 600, seed=43)
+        assert ea == eb and (ea > 0 or gid in ("MountainCarContinuous-v0",)), (gid, ea)
+        for x, y in zip(la, lb):
+            assert np.array_equal(x[0], y[0]) and x[1:] == y[1:]
+        assert any(not np.array_equal(x[0], z[0]) for x, z in zip(la, lc))
+        a.close(), b.close(), c.close()
+    # (2) TimeLimit, OrderEnforcing, the action assert, CartPole's steps_beyond_terminated
+    env = make_env("CartPole-v1", max_episode_steps=5)
+    with pytest.raises(error.ResetNeeded):
+        env.step(0)
+    env.reset(seed=1)
+    flags = [env.step(t % 2)[2:4] for t in range(5)]
+    assert [f[1] for f in flags] == [False, False, False, False, True] and not any(f[0] for f in flags)     # truncated at exactly 5 steps
+    assert env.step(0)[3] is True                                  # ... and on every later step until reset() (time_limit.py:50-54)
+    obs, _ = env.reset()
+    assert env.step(1)[3] is False and np.abs(obs).max() <= 0.05
+    for bad in (2, -1, 0.5, np.array([0, 1])):
+        with pytest.raises(AssertionError):
+            env.step(bad)
+    env.close()
+    with pytest.raises(error.ClosedEnvironmentError):
+        env.step(0)
+    env = make_env("CartPole-v1")
+    env.reset(seed=3)
+    rewards, term = [], False
+    while not term:
+        _, r, term, _, _ = env.step(1)                             # push right until the pole falls
+        rewards.append(r)
+    assert rewards[-1] == 1.0 and env.step(1)[1] == 0.0 and env.step(1)[2] is True       # cartpole.py:169-184
+    assert env.gravity == 9.8 and env.state.shape == (4,) and env.spec.id.endswith("CartPole-v1")
+    env.close()
+    # (3) Box actions: shape (1,) array-likes, out-of-range values clipped by the env itself
+    env = make_env("Pendulum-v1")
+    env.reset(seed=0)
+    o1 = env.step(np.array([5.0], dtype=np.float32))
+    env.reset(seed=0)
+    o2 = env.step(np.array([2.0], dtype=np.float32))
+    assert np.array_equal(o1[0], o2[0])
+    env.close()
+    if not have_reference:
+        return
+    # (4) against the reference's own single envs: its state injected, the same actions, step by step (dynamics, flags at the limit,
+    #     rewards after termination) — the engine's goldens hold the numerics; this holds the single-env PLUMBING
+    import gym
+
+    for gid in IDS:
+        ref, mine = gym.make(gid), make_env(gid)
+        ref.action_space.seed(5)
+        ref.reset(seed=5)
+        mine.reset(seed=5)
+        st = np.asarray(ref.unwrapped.state, dtype=np.float64)
+        mine._vec.handle.set_state(st.reshape(-1, 1), np.zeros(1, np.int32))
+        for t in range(260):
+            act = ref.action_space.sample()
+            ro, rr, rte, rtr, _ = ref.step(act)
+            mo, mr, mte, mtr, _ = mine.step(act)
+            assert (rte, rtr) == (mte, mtr), (gid, t)
+            np.testing.assert_allclose(mo, ro, rtol=1e-5, atol=1e-7)
+            assert mr == pytest.approx(float(rr), rel=1e-12, abs=1e-9)
+            if rte or rtr:
+                ref.reset()
+                mine.reset()
+                st = np.asarray(ref.unwrapped.state, dtype=np.float64)
+                mine._vec.handle.set_state(st.reshape(-1, 1), np.zeros(1, np.int32))
+        ref.close(), mine.close()
+
+
+def test_single_env_contract_over_the_oracle_backed_handle(monkeypatch):
+    from gym_amd import _native
+    from gym_amd.single_env import HipEnv
+    from oracle_engine import FakeHandle
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    try:
+        from test_host_logic import _ref_gym
+
+        _ref_gym()
+        have = True
+    except BaseException:      # pytest.skip inside _ref_gym where the reference is not importable
+        have = False
+    _checks(lambda gid, **kw: HipEnv(gid, **kw), have)
+
+
+def test_gym_make_without_num_envs_is_a_gym_env(monkeypatch):
+    """gym.make("hip/CartPole-v1") — no num_envs, as the reference's README writes it — returns a gym.Env (not a vector env) with
+    gym.spaces spaces; the README loop runs unchanged; num_envs=... still gives the vector env; toy_text ids say what to do instead."""
+    from test_host_logic import _ref_gym
+
+    gym = _ref_gym()
+    from gym_amd import _native, plugin
+    from oracle_engine import FakeHandle
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    plugin.register_envs(gym)
+    env = gym.make("hip/CartPole-v1")
+    assert isinstance(env, gym.Env) and not isinstance(env, gym.vector.VectorEnv) and not getattr(env, "is_vector_env", False)
+    assert isinstance(env.action_space, gym.spaces.Discrete) and isinstance(env.observation_space, gym.spaces.Box)
+    assert env.observation_space == gym.make("CartPole-v1").observation_space and env.spec.id == "hip/CartPole-v1"
+    log, episodes = _readme_loop(env, 300)
+    assert episodes > 5
+    env.close()
+    assert isinstance(gym.make("hip/CartPole-v1", num_envs=3), gym.vector.VectorEnv)
+    with pytest.raises(NotImplementedError, match="num_envs=1"):
+        gym.make("hip/FrozenLake-v1")
+    short = gym.make("hip/Pendulum-v1", time_limit=7)
+    short.reset(seed=0)
+    assert [short.step(short.action_space.sample())[3] for _ in range(7)] == [False] * 6 + [True]
+    short.close()
+
+
+@pytest.mark.gpu
+def test_single_env_contract_on_the_device():
+    from gym_amd.single_env import HipEnv
+
+    _checks(lambda gid, **kw: HipEnv(gid, **kw), False)
