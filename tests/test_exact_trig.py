@@ -90,3 +90,30 @@ def test_exact_acrobot_step_equals_the_reference_on_a_correctly_rounded_libm(lib
     differ = t != g["terminated"]
     assert np.array_equal(differ, cr["terminated"] != g["terminated"]) and differ.sum() <= 4
     assert np.all(g["margin"][differ] == 0.0), "only heights that ROUND to exactly 1.0 in the glibc run may differ"
+
+
+def test_glibc_powf_square_restatement_equals_this_images_libm():
+    """Pendulum's `u ** 2` is libm powf(u, 2.0f) (pendulum.py:129), which glibc does not round correctly.  The restatement of glibc 2.35's
+    algorithm behind the MXV_PENDULUM_GLIBC_POWF build hook (gym_amd/csrc/mxv_device.hpp: glibc_powf_square) has a NumPy twin in
+    tools/powf_variants.py: equal to libm's powf on every input, while libm itself differs from the correctly rounded product on ~0.07 %
+    of them (profiles/r6/r6g_pendulum_powf.md: why the hook is off by default)."""
+    import ctypes
+    import ctypes.util
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("powf_variants", os.path.join(root, "tools", "powf_variants.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    if b"2.35" not in (os.confstr("CS_GNU_LIBC_VERSION") or "").encode():
+        import pytest
+
+        pytest.skip("the restatement is of glibc 2.35's powf (the image's)")
+    u = np.random.default_rng(3).uniform(-2, 2, 150_000).astype(np.float32)
+    ref = mod.powf2(u)
+    assert np.array_equal(mod.glibc_powf_square(u), ref)
+    assert 20 < int((ref != (u.astype(np.float64) ** 2).astype(np.float32)).sum()) < 400

@@ -12,10 +12,11 @@ for s in "$@"; do
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_kernels.hip" -o "$tmp/k.o" 2>/dev/null &&
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_api.cpp" -o "$tmp/a.o" &&
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_norm.hip" -o "$tmp/n.o" 2>/dev/null &&
+    /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_subnorm.hip" -o "$tmp/s.o" 2>/dev/null &&
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_tab.hip" -o "$tmp/t.o" 2>/dev/null &&
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_bj.hip" -o "$tmp/b.o" 2>/dev/null &&
     /opt/rocm/bin/hipcc $F -c "$root/gym_amd/csrc/mxv_placed.hip" -o "$tmp/p.o" 2>/dev/null &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv_$name.so" "$tmp/k.o" "$tmp/a.o" "$tmp/n.o" "$tmp/t.o" "$tmp/b.o" "$tmp/p.o" && echo "built $name"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libmxv_$name.so" "$tmp/k.o" "$tmp/a.o" "$tmp/n.o" "$tmp/s.o" "$tmp/t.o" "$tmp/b.o" "$tmp/p.o" && echo "built $name"
     rm -rf "$tmp"
   ) &
 done
