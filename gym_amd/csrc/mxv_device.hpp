@@ -307,8 +307,34 @@ __device__ __forceinline__ double div_par(double x, double c) {
 #ifndef MXV_BITOP3_ENVS
 #define MXV_BITOP3_ENVS ((1 << MXV_ACROBOT) | (1 << MXV_PENDULUM))
 #endif
+// ... bit 2 (round 6): the twelve polynomial coefficients of sincos_kernel read from a table in constant memory by SCALAR loads inside every
+// call and used as the FMAs' scalar operand (v_fma_f64 v, v, v, s[..]).  A kernel at its VGPR cap re-materialises the literals next to
+// every Horner step — 20 of sincos_medium's 52 VALU instructions are v_mov_b32 of coefficient halves, 8 sincos per Acrobot step —
+// and keeping them in SGPRs ACROSS the loop spills (round 3's attempt: -1 %).  Loaded where they are used (s_load_dwordx8 x 3 through a
+// pointer the optimiser cannot see through, so the loads are not hoisted) they cost the scalar unit three instructions and the
+// vector unit none: sincos_medium alone goes from 52 to 36 VALU instructions.  MEASURED in the kernel that matters (round 6, Acrobot,
+// 2^19 envs): 583.4 -> 579.2 VALU instructions per env-step and the same 10.5 us — inside the K-step loop the compiler already keeps
+// the coefficients in ~24 VGPRs across the steps, so the 20 moves were never executed per call; the form only frees those registers
+// (128 -> 126 VGPRs, 4 -> 0 spilled).  An A/B hook, off (profiles/r6/r6h_acrobot_valu.md).
+#ifndef MXV_SCOEF_ENVS
+#define MXV_SCOEF_ENVS 0
+#endif
 template <int ENV>
-constexpr int fma3_for() { return (((MXV_FMA3_ENVS >> ENV) & 1) ? 1 : 0) | (((MXV_BITOP3_ENVS >> ENV) & 1) ? 2 : 0); }
+constexpr int fma3_for() {
+    return (((MXV_FMA3_ENVS >> ENV) & 1) ? 1 : 0) | (((MXV_BITOP3_ENVS >> ENV) & 1) ? 2 : 0) | (((MXV_SCOEF_ENVS >> ENV) & 1) ? 4 : 0);
+}
+__constant__ const double kSinCosCoef[12] = {
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04,
+    8.33333333332248946124e-03, -1.66666666666666324348e-01,                                                        // S6 .. S1
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07, 2.48015872894767294178e-05,
+    -1.38888888888741095749e-03, 4.16666666666666019037e-02};                                                       // C6 .. C1
+typedef const double __attribute__((address_space(4))) cdouble_t;
+__device__ __forceinline__ double fma_scoef(double a, double b, double k_sgpr) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k_sgpr));
+    return r;
+}
+
 template <int F3>
 __device__ __forceinline__ double fma_coef(double a, double b, double k) {
     if constexpr ((F3 & 1) != 0) {
@@ -326,6 +352,24 @@ __device__ __forceinline__ double fma_coef(double a, double b, double k) {
 template <int F3 = 0>
 __device__ __forceinline__ void sincos_kernel(double x, double *sn, double *cs) {
     const double z = x * x;
+    if constexpr ((F3 & 4) != 0) {      // the same FMAs in the same order with ten of the twelve coefficients as scalar operands (MXV_SCOEF_ENVS;
+        cdouble_t *t = (cdouble_t *)kSinCosCoef;   // an instruction reads ONE scalar operand: the leading coefficient of each polynomial stays a literal)
+        asm volatile("" : "+s"(t));
+        double r = fma_scoef(z, 1.58969099521155010221e-10, t[1]);
+        r = fma_scoef(z, r, t[2]);
+        r = fma_scoef(z, r, t[3]);
+        r = fma_scoef(z, r, t[4]);
+        r = fma_scoef(z, r, t[5]);
+        *sn = __fma_rn(x * z, r, x);
+        double c = fma_scoef(z, -1.13596475577881948265e-11, t[7]);
+        c = fma_scoef(z, c, t[8]);
+        c = fma_scoef(z, c, t[9]);
+        c = fma_scoef(z, c, t[10]);
+        c = fma_scoef(z, c, t[11]);
+        c = __fma_rn(z, c, -0.5);
+        *cs = __fma_rn(z, c, 1.0);
+        return;
+    }
     // sin: x + x*z*(S1 + z*(S2 + z*(S3 + z*(S4 + z*(S5 + z*S6)))))
     double r = fma_coef<F3>(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     r = fma_coef<F3>(z, r, 2.75573137070700676789e-06);

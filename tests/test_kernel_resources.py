@@ -264,3 +264,29 @@ def test_blackjack_kernel_is_one_philox_call_of_straight_line_code_per_step():
         assert len(stores) >= 7 and all(re.search(r", s\[\d+:\d+\]", l) for l in stores), (sym, stores)
         assert 40 <= mads <= 50, (sym, mads)          # action refill (20, once per 32 steps) + the step's draw call (20) + card digits
         assert main.count("scratch_") == 0 and main.count("ds_bpermute") == 0, sym
+
+
+def test_acrobot_building_blocks_keep_their_instruction_budget(tmp_path):
+    """Acrobot's 583 VALU instructions per env-step are 8 sincos_medium + 4 dsdt + glue (profiles/r6/r6h_acrobot_valu.md).  The two
+    functions compiled in isolation with the library's flags: dsdt holds exactly TWO v_rcp_f64 (the three quotients by d1 share one
+    refined reciprocal, the fourth divisor has its own — 8 quarter-rate instructions per env-step, as the counters say) and no
+    v_div_scale / v_div_fmas (the compiler's own `/`), sincos_medium at most 54 VALU instructions, no scratch."""
+    src = tmp_path / "blocks.hip"
+    src.write_text('#include "mxv_device.hpp"\nusing namespace mxv;\n'
+                   '__global__ void k_sincos(const double *x, double *o) { double s, c; mx_sincos<false, fma3_for<MXV_ACROBOT>()>(x[threadIdx.x], &s, &c); '
+                   'o[threadIdx.x] = s; o[threadIdx.x + 64] = c; }\n'
+                   '__global__ void k_dsdt(const double *x, double *o) { EnvParams PP{}; const Par<PM_DEFAULT> P(PP); double sa[4] = {x[0], x[1], x[2], x[3]}, '
+                   'sc[4] = {x[4], x[5], x[6], x[7]}, out[4]; Env<MXV_ACROBOT>::dsdt<PM_DEFAULT>(P, sa, sc, x[8], out); o[0] = out[2]; o[1] = out[3]; }\n')
+    out = tmp_path / "blocks.s"
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I",
+                        os.path.join(ROOT, "gym_amd", "csrc"), "-S", "--cuda-device-only", str(src), "-o", str(out)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    asm = out.read_text()
+
+    def valu(sym):
+        i = asm.index(f"\n{sym}:")
+        return [l.split()[0] for l in asm[i:asm.index("s_endpgm", i)].splitlines() if re.match(r"\s+v_", l)]
+
+    d, s = valu("_Z6k_dsdtPKdPd"), valu("_Z8k_sincosPKdPd")
+    assert d.count("v_rcp_f64_e32") == 2 and not any(i.startswith(("v_div_scale", "v_div_fmas")) for i in d) and len(d) <= 64, (len(d), d.count("v_rcp_f64_e32"))
+    assert len(s) <= 54 and "scratch_" not in asm, len(s)
