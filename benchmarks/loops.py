@@ -35,7 +35,7 @@ def measure_numpy_loop(envs, steps):
             "note": "PCIe- and Python-inclusive; never the bench value"}
 
 
-def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
+def measure_step_loop(torch, envs, steps=600, compact=False, halves=1, obs_carries_state=False):
     """The learner-in-the-loop path: DeviceRollout.step(actions) with caller-provided actions, one launch per vector step
     (gym/vector/sync_vector_env.py:131-169 with a policy in the loop).  halves = 2: the batch as two half-size engines (global env
     indices unchanged: env_offset) on their own streams, stepped alternately — the double-buffered sampling pattern (the policy
@@ -43,7 +43,8 @@ def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
     from gym_amd.rollout import DeviceRollout
 
     n = envs // halves
-    eng = [DeviceRollout(ENV_ID, n, env_offset=i * n, seed=0, action_seed=1, reward_f32=compact, action_i32=compact) for i in range(halves)]
+    eng = [DeviceRollout(ENV_ID, n, env_offset=i * n, seed=0, action_seed=1, reward_f32=compact, action_i32=compact,
+                         obs_carries_state=obs_carries_state) for i in range(halves)]
     acts = []
     for e in eng:
         e.reset(seed=0)
@@ -73,7 +74,7 @@ def measure_step_loop(torch, envs, steps=600, compact=False, halves=1):
         e.close()
     b = algorithmic_bytes_per_env_step("given", 1)
     us = max(wall_us, gpu_us)
-    return {"halves": halves, "dtypes": "float32 rewards, int32 actions" if compact else "float64 rewards, int64 actions (the reference's)",
+    return {"halves": halves, "obs_carries_state": obs_carries_state, "dtypes": "float32 rewards, int32 actions" if compact else "float64 rewards, int64 actions (the reference's)",
             "us_per_step": us, "gpu_us_per_step": gpu_us, "value": envs / us * 1e6, "unit": "env-steps/s",
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / us / 1e3, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS}}

@@ -44,6 +44,9 @@ def groups(torch, chunk):
                     "(learner-in-the-loop; 66 algorithmic B per env-step)",
             "one_engine": measure_step_loop(torch, ENVS_TOTAL),
             "one_engine_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True),
+            # round 6: the observation buffer doubles as the float32 half of the state (DeviceRollout(obs_carries_state=True), mxv_adopt_obs)
+            "one_engine_obs_carries_state": measure_step_loop(torch, ENVS_TOTAL, obs_carries_state=True),
+            "one_engine_obs_carries_state_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True, obs_carries_state=True),
             "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
             "kernel": measure_step_kernel(torch, ENVS_TOTAL)}),
         ("numpy_loop", lambda: {"num_envs_2^20": measure_numpy_loop(ENVS_TOTAL, 60),

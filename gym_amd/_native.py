@@ -43,7 +43,7 @@ EXPORTS = (
     "mxv_set_counters", "mxv_set_device_clock", "mxv_set_obs_partials", "mxv_set_return_partials", "mxv_obs_partials_layout", "mxv_get_episodes", "mxv_set_episodes", "mxv_get_params", "mxv_set_params", "mxv_set_params_per_env", "mxv_get_params_per_env", "mxv_episode_stats", "mxv_set_episode_outputs", "mxv_episode_stats_host", "mxv_set_running_returns", "mxv_sync", "mxv_get_stream", "mxv_set_stream",
     "mxv_rollout_mixed", "mxv_set_final_snapshot", "mxv_comm_unique_id", "mxv_comm_init", "mxv_comm_destroy", "mxv_allgather_outputs", "mxv_allgather_wait", "mxv_comm_stream",
     "mxv_host_io", "mxv_step_mapped", "mxv_reset_mapped", "mxv_final_packed", "mxv_final_packed_view", "mxv_final_packed_stats_view", "mxv_write_probe", "mxv_write_probe_env", "mxv_host_alloc", "mxv_host_free",
-                "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream", "mxv_staging_view",
+                "mxv_host_block_layout", "mxv_step_host_block", "mxv_wait_stream", "mxv_staging_view", "mxv_adopt_obs",
     "mxv_norm_create", "mxv_norm_destroy", "mxv_norm_last_error", "mxv_norm_set_stream", "mxv_norm_get_state",
     "mxv_norm_set_state", "mxv_norm_observations", "mxv_norm_rewards", "mxv_norm_obs_sums", "mxv_norm_obs_sums_partials", "mxv_norm_reward_sums_partials", "mxv_norm_returns_ptr", "mxv_norm_obs_apply",
     "mxv_norm_reward_sums", "mxv_norm_reward_apply",
@@ -199,6 +199,7 @@ def _load():
         "mxv_reset_host": ([vp, vp, vp, vp], C.c_int),
         "mxv_step_host": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
         "mxv_get_state": ([vp, vp, vp], C.c_int),
+        "mxv_adopt_obs": ([vp, vp], C.c_int),
         "mxv_set_state": ([vp, vp, vp], C.c_int),
         "mxv_get_counters": ([vp, C.POINTER(u64), C.POINTER(u32)], C.c_int),
         "mxv_set_counters": ([vp, u64, u32], C.c_int),
@@ -792,6 +793,11 @@ class Handle:
         assert p.shape == (MAX_PARAMS, self.num_envs), p.shape
         self._check(lib.mxv_set_params_per_env(self._h, p.ctypes.data))
         self._per_env_params = True
+
+    def adopt_obs(self, obs_dev=None):
+        """mxv_adopt_obs: `obs_dev` (float32 [N][O] device tensor / address; None releases) doubles as the float32 half of the state between
+        single steps that pass it as their obs — it must not be written in between and must outlive the adoption."""
+        self._check(lib.mxv_adopt_obs(self._h, _ptr(obs_dev)))
 
     def episode_stats(self, enable: bool = True):
         self._check(lib.mxv_episode_stats(self._h, 1 if enable else 0))

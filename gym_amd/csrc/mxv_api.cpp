@@ -71,6 +71,10 @@ struct mxv_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     double *state = nullptr;
+    // mxv_adopt_obs: the caller's observation buffer doubles as the float32 half of the state (hilo_encode, mxv_kernels.hip)
+    float *adopted_obs = nullptr;   // the buffer (caller-owned), or nullptr
+    int32_t *lo = nullptr;          // [N][S] the int32 halves (library-owned, allocated on adoption)
+    bool hilo = false;              // the state currently lives as (adopted_obs, lo) pairs; `state` holds only escaped components
     void *elapsed = nullptr;    // uint16 [N] when elapsed16, else int32 [N] (always n * 4 bytes allocated)
     bool elapsed16 = false;     // 0 < max_episode_steps <= 65535: the step kernels move 2 instead of 4 bytes each way
     uint32_t *episodes = nullptr;  // [N] resets of each env since seeding = index of its next draw from the reset stream
@@ -274,6 +278,19 @@ int no_capture_without_clock(mxv_handle *h) {
     return MXV_OK;
 }
 
+// The state back in its fp64 array (a no-op unless the last steps ran in the observation-carries-state form): called by everything that
+// reads or writes h->state except the single step that can stay in that form.
+int ensure_f64(mxv_handle *h) {
+    if (!h->hilo) return MXV_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+        return fail(h, MXV_ERR_UNSUPPORTED, "the state lives in the adopted observation buffer (mxv_adopt_obs) and this call needs it back in "
+                                            "fp64: that conversion cannot be part of a recorded hipGraph — release the buffer before recording");
+    MXV_HIP(h, launch_hilo_join(h->cfg.env_id, h->adopted_obs, h->lo, h->state, h->cfg.num_envs, h->stream));
+    h->hilo = false;
+    return MXV_OK;
+}
+
 // Every caller-owned tensor a launch touches must sit on its element's natural boundary (observations: the row's vector width — the kernels
 // store them as float4 / float2).  An odd address would not fault on this device (unaligned global access is enabled) but tears every
 // coalesced burst, and it is a caller bug either way: refused up front with the name of the tensor (tests/c_consumer/abi_fuzz.c).
@@ -307,6 +324,18 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     if (!obs) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
     if (int rc = use_device(h)) return rc;
     if (int rc = no_capture_without_clock(h)) return rc;
+    // the observation-carries-state form (mxv_adopt_obs): this step reads the previous observations from `obs` and leaves int32 residuals
+    const bool hilo_step = h->adopted_obs != nullptr && obs == h->adopted_obs && h->param_mode() == PM_DEFAULT && !h->step_noise;
+    if (!hilo_step) {
+        if (int rc = ensure_f64(h)) return rc;
+    } else if (!h->hilo) {   // first step in that form: split the fp64 state (the buffer receives float32(state) = the current observations)
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+            return fail(h, MXV_ERR_UNSUPPORTED, "take one step outside the capture first: the first step after mxv_adopt_obs / reset converts the "
+                                                "state, which must not be replayed");
+        MXV_HIP(h, launch_hilo_split(h->cfg.env_id, h->state, h->adopted_obs, h->lo, h->state, h->cfg.num_envs, h->stream));
+        h->hilo = true;
+    }
     StepArgs a{};
     fill_step_args(h, a);
     a.actions = actions;
@@ -318,13 +347,19 @@ int do_step(mxv_handle *h, const void *actions, void *actions_out, float *obs, v
     a.final_obs = final_obs;
     // device clock, batches of at most kClockInKernelEnvs envs (a few hundred workgroups: one returning atomic each is nothing; at
     // 2^20 envs thousands of same-address atomics would cost more than the one-thread kernel they replace): the launch advances it
-    const bool self_clock = h->dev_clock && h->cfg.num_envs <= kClockInKernelEnvs && h->param_mode() == PM_DEFAULT;   // (step_kernel<..., CLOCK = true> exists for these)
+    const bool self_clock = h->dev_clock && h->cfg.num_envs <= kClockInKernelEnvs && h->param_mode() == PM_DEFAULT && !hilo_step;   // (step_kernel<..., CLOCK = true> exists for these)
     if (self_clock) {
         a.clock_out = h->t_dev;
         a.clock_ticket = h->clock_ticket;
     }
     if (int rc = check_step_buffers(h, a)) return rc;
-    MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
+    if (hilo_step) {
+        a.hi_in = h->adopted_obs;
+        a.lo = h->lo;
+        MXV_HIP(h, launch_hilo_step(h->cfg.env_id, a, h->stream, &h->last_launch));
+    } else {
+        MXV_HIP(h, launch_step(h->cfg.env_id, h->param_mode(), a, h->stream, &h->last_launch));
+    }
     h->state_injected = false;
     if (self_clock) {
         h->t += 1;
@@ -348,6 +383,7 @@ int parse_bounds(mxv_handle *h, const double *b, double *out) {
 
 int do_reset(mxv_handle *h, const uint8_t *mask_dev, const double *bounds, float *obs_dev) {
     if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_f64(h)) return rc;
     double b[2];
     if (int rc = parse_bounds(h, bounds, b)) return rc;
     h->r += 1;
@@ -634,7 +670,7 @@ int mxv_destroy(mxv_handle *h) {
     if (h->hm_block) (void)hipHostFree(h->hm_block);
     if (h->fin_host) (void)hipHostFree(h->fin_host);
     if (h->fin_dev) (void)hipFree(h->fin_dev);
-    void *bufs[] = {h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->clock_ticket, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block,
+    void *bufs[] = {h->lo, h->state, h->elapsed, h->episodes, h->seeds, h->t_dev, h->clock_ticket, h->err, h->params_pe, h->ep_acc, h->st_ep_r, h->st_ep_l, h->dv_block,
                     h->beyond};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -704,6 +740,7 @@ int rollout_checks(mxv_handle *h, int32_t K, const float *obs_dev) {
         return fail(h, MXV_ERR_RESET_NEEDED, "Cannot call step before calling reset (gym.error.ResetNeeded)");
     if (!obs_dev) return fail(h, MXV_ERR_INVALID_ARG, "obs pointer is NULL");
     if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_f64(h)) return rc;     // K-step launches keep the state in registers: they start from (and leave) the fp64 array
     return no_capture_without_clock(h);
 }
 
@@ -1114,9 +1151,28 @@ int mxv_reset_mapped(mxv_handle *h, const double *bounds2_host) {
     return mapped_finish(h, false);
 }
 
+/* see include/mxv.h */
+int mxv_adopt_obs(mxv_handle *h, float *obs_dev) {
+    MXV_CHECK_HANDLE(h);
+    if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_f64(h)) return rc;            // whatever was adopted before hands the state back first
+    if (!obs_dev) {
+        h->adopted_obs = nullptr;
+        return MXV_OK;
+    }
+    if (!hilo_supported(h->cfg.env_id))
+        return fail(h, MXV_ERR_UNSUPPORTED, "the observation carries the state only where it is float32(state) component by component: "
+                                            "CartPole, MountainCar, MountainCarContinuous");
+    if (int rc = check_aligned(h, obs_dev, h->O == 4 ? 16 : 8, "obs")) return rc;
+    if (!h->lo) MXV_HIP(h, hipMalloc((void **)&h->lo, (size_t)h->cfg.num_envs * h->S * sizeof(int32_t)));
+    h->adopted_obs = obs_dev;
+    return MXV_OK;
+}
+
 int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host) {
     MXV_CHECK_HANDLE(h);
     if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_f64(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
     if (state_soa_host)
         MXV_HIP(h, hipMemcpyAsync(state_soa_host, h->state, n * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1137,6 +1193,7 @@ int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host) 
 int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *elapsed_host) {
     MXV_CHECK_HANDLE(h);
     if (int rc = use_device(h)) return rc;
+    if (int rc = ensure_f64(h)) return rc;
     const size_t n = (size_t)h->cfg.num_envs;
     if (state_soa_host)
         MXV_HIP(h, hipMemcpyAsync(h->state, state_soa_host, n * h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));

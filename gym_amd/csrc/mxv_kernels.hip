@@ -13,6 +13,7 @@
 // while E*(S+1) loads per lane are in flight.  No MFMA: this is element-wise fp64 physics.
 // LDS is used only to transpose the Philox action words: one Philox call yields the words of 4
 // consecutive envs (group g = env>>2), which belong to 4 different lanes under the mapping above.
+#include <cstdlib>
 #include <type_traits>
 
 #include "mxv_kernels.hpp"
@@ -114,6 +115,103 @@ __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned n
     return idx == 0 ? w.x : (idx == 1 ? w.y : (idx == 2 ? w.z : w.w));
 }
 
+// ---- the fp64 state as (float32, int32) pairs: "the observation carries the state" (mxv_adopt_obs, round 6) -------------------------------
+// step(actions) moves the whole fp64 state both ways every launch — 16 S of its ~108 bytes per env-step — because fp32 state fails the
+// parity bar.  For CartPole and both MountainCars the observation the step writes anyway IS float32(state), component by
+// component.  With hi = float32(x) (round to nearest) the remainder r = x - hi is exact in fp64 (Sterbenz), a multiple of x's ulp and at
+// most half a float32 ulp, so r / 2^(exponent(hi) - 53) is an INTEGER of magnitude <= 2^29: the pair (hi, that int32) holds x exactly, and
+// the state costs 4 + 4 + 4 bytes per component per step (read hi, read lo, write lo; hi is written as the observation in any case)
+// instead of 16.  What the pair cannot hold — |x| below float32's normal range (but not 0), +-Inf, NaN — escapes: lo = INT32_MIN and
+// the fp64 value itself goes to the handle's ordinary state array, which stays allocated (one divergent load for values no dynamics
+// produce).  The contract this buys is the caller's: the observation buffer of the previous call must come back untouched.
+constexpr int32_t kHiloEscape = INT32_MIN;
+// Both directions are straight-line code on the path every value takes (two conversions, one v_ldexp_f64, one add / subtract, selects);
+// the escape is tested per WAVE (`__any`) and handled out of line — as branches per component the pair cost more than it saved
+// (profiles/r6/r6i_*: 21.4 instead of 19.6 us per 2^20-env step with 16 bytes per env-step fewer).
+__device__ __forceinline__ double hilo_decode_fast(float hi, int32_t lo) {
+    const int e = (int)((__float_as_uint(hi) >> 23) & 0xffu);
+    const double sum = (double)hi + ldexp((double)lo, e - 180);      // exact: the sum IS the double that was encoded
+    return lo == 0 ? (double)hi : sum;                               // (keeps the sign of a zero: -0.0 + 0.0 would be +0.0)
+}
+__device__ __forceinline__ double hilo_decode(float hi, int32_t lo, const double *side) {
+    return lo == kHiloEscape ? *side : hilo_decode_fast(hi, lo);
+}
+// -> the int32 half, or kHiloEscape when the pair cannot hold x (the caller then stores x itself in the fp64 array)
+__device__ __forceinline__ int32_t hilo_encode_fast(double x) {
+    const float hi = (float)x;
+    const uint32_t e = (__float_as_uint(hi) >> 23) & 0xffu;
+    const double r = x - (double)hi;                                 // exact (Sterbenz); NaN for an infinite or NaN x
+    const int32_t lo = (int32_t)ldexp(r, 180 - (int)e);              // an integer of magnitude <= 2^29 whenever hi is a normal float32
+    const bool holds = (e - 1u < 254u) || r == 0.0;                  // normal hi, or x itself a float32 value (zeros, float32 denormals)
+    return holds ? lo : kHiloEscape;
+}
+__device__ __forceinline__ int32_t hilo_encode(double x, double *side) {
+    const int32_t lo = hilo_encode_fast(x);
+    if (lo == kHiloEscape) *side = x;
+    return lo;
+}
+template <int O>
+__device__ __forceinline__ void load_obs(const float *base, int64_t e, float *o) {
+    if constexpr (O == 4) {
+        const float4 v = reinterpret_cast<const float4 *>(base)[e];
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else if constexpr (O == 2) {
+        const float2 v = reinterpret_cast<const float2 *>(base)[e];
+        o[0] = v.x; o[1] = v.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < O; ++k) o[k] = base[e * O + k];
+    }
+}
+// the int32 halves live row-major like the observations ([N][S]: one 16- / 8-byte access per env, as wide as the observation row's)
+template <int S>
+__device__ __forceinline__ void load_lo(const int32_t *base, int64_t e, int32_t *v) {
+    if constexpr (S == 4) {
+        const int4 q = reinterpret_cast<const int4 *>(base)[e];
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        const int2 q = reinterpret_cast<const int2 *>(base)[e];
+        v[0] = q.x; v[1] = q.y;
+    }
+}
+template <int S>
+__device__ __forceinline__ void store_lo(int32_t *base, int64_t e, const int32_t *v) {
+    if constexpr (S == 4)
+        reinterpret_cast<int4 *>(base)[e] = make_int4(v[0], v[1], v[2], v[3]);
+    else
+        reinterpret_cast<int2 *>(base)[e] = make_int2(v[0], v[1]);
+}
+template <int ENV>
+__global__ void __launch_bounds__(kBlock) hilo_split_kernel(const double *state, float *hi_obs, int32_t *lo, double *side, int64_t n) {
+    constexpr int S = Env<ENV>::S;
+    static_assert(Env<ENV>::O == S, "the observation must be float32(state), component by component");
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    static_assert(S == 2 || S == 4, "row accesses of the int32 halves");
+    float o[S];
+    int32_t l[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const double x = state[(int64_t)k * n + e];
+        o[k] = (float)x;
+        l[k] = hilo_encode(x, side + (int64_t)k * n + e);
+    }
+    store_obs<S>(hi_obs, e, o);
+    store_lo<S>(lo, e, l);
+}
+template <int ENV>
+__global__ void __launch_bounds__(kBlock) hilo_join_kernel(const float *hi_obs, const int32_t *lo, double *state, int64_t n) {
+    constexpr int S = Env<ENV>::S;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    float o[S];
+    int32_t l[S];
+    load_obs<S>(hi_obs, e, o);
+    load_lo<S>(lo, e, l);
+#pragma unroll
+    for (int k = 0; k < S; ++k) state[(int64_t)k * n + e] = hilo_decode(o[k], l[k], state + (int64_t)k * n + e);
+}
+
 // step_kernel<ENV, DEF, E, CONSEC>: a.K vector steps in ONE launch, env state held in registers between
 // steps (K = 1 is the plain step() call).  Per step the only HBM traffic is the step's outputs; state
 // and elapsed[] are read once at entry and written once at exit, i.e. 16*S/K + 8/K bytes per env-step.
@@ -124,10 +222,13 @@ __device__ __forceinline__ unsigned xcd_contiguous_tile(unsigned bid, unsigned n
 //   CLOCK = true  : the launch advances the device clock itself (single steps with default parameters of a handle in device-clock mode,
 //                   small grids).  An instantiation of its own: as a run-time branch at the exit of the one kernel it cost every
 //                   launch 1.1 us per 2^20-env step (18.6 -> 19.8, profiles/r4/r4q_step_clock_tail_ab.txt).
-template <int ENV, int DEF, int E, bool CONSEC, bool MULTI, bool CLOCK = false>
+//   HILO = true   : the state arrives as (previous observation, int32 residual) pairs and leaves the same way (see hilo_encode above):
+//                   single steps with default parameters of a handle that adopted the caller's observation buffer.
+template <int ENV, int DEF, int E, bool CONSEC, bool MULTI, bool CLOCK = false, bool HILO = false>
 __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepArgs a) {
     using EV = Env<ENV>;
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
+    static_assert(!HILO || (!MULTI && S == O && EV::AUX == 0), "HILO: one step, observation = float32(state)");
     constexpr int TILE = E * kBlock;
     static_assert(!CONSEC || E == 1 || E == 2 || E % 4 == 0, "CONSEC needs E in {1, 2, 4k}");
     const int tid = threadIdx.x;
@@ -149,8 +250,26 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         const int64_t e = env_of(j);
         valid[j] = e < n;
         const int64_t ec = valid[j] ? e : 0;
+        if constexpr (HILO) {
+            float hi[O];
+            int32_t l[S];
+            load_obs<O>(a.hi_in, ec, hi);
+            load_lo<S>(a.lo, ec, l);
+            bool esc = false;
 #pragma unroll
-        for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + ec];
+            for (int k = 0; k < S; ++k) {
+                s[j][k] = hilo_decode_fast(hi[k], l[k]);
+                esc = esc || l[k] == kHiloEscape;
+            }
+            if (__builtin_expect(__any(esc), 0)) {   // values outside float32's normal range: the fp64 array holds them (never on a trajectory the dynamics produce)
+#pragma unroll
+                for (int k = 0; k < S; ++k)
+                    if (l[k] == kHiloEscape) s[j][k] = a.state[(int64_t)k * n + ec];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < S; ++k) s[j][k] = a.state[(int64_t)k * n + ec];
+        }
         el[j] = load_elapsed(a.elapsed, a.elapsed16, ec);
         EV::prime(s[j], aux[j]);
     }
@@ -362,8 +481,24 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     for (int j = 0; j < E; ++j) {
         if (!valid[j]) continue;
         const int64_t e = env_of(j);
+        if constexpr (HILO) {   // (the float32 half is the observation this step stored above)
+            int32_t l[S];
+            bool esc = false;
 #pragma unroll
-        for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + e] = s[j][k];
+            for (int k = 0; k < S; ++k) {
+                l[k] = hilo_encode_fast(s[j][k]);
+                esc = esc || l[k] == kHiloEscape;
+            }
+            if (__builtin_expect(__any(esc), 0)) {
+#pragma unroll
+                for (int k = 0; k < S; ++k)
+                    if (l[k] == kHiloEscape) a.state[(int64_t)k * n + e] = s[j][k];
+            }
+            store_lo<S>(a.lo, e, l);
+        } else {
+#pragma unroll
+            for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + e] = s[j][k];
+        }
         store_elapsed(a.elapsed, a.elapsed16, e, el[j]);
         if (ep[j] != ep_in[j]) a.episodes[e] = ep[j];
         if (a.ep_acc) a.ep_acc[e] = er[j];
@@ -1216,6 +1351,14 @@ hipError_t launch_rollout_stats(const StepArgs &a, hipStream_t stream, LaunchInf
     return hipGetLastError();
 }
 
+#ifndef MXV_STEP_E1_FROM   // (A/B hook: tools/ab_step_shape.sh builds the library with this out of reach)
+#define MXV_STEP_E1_FROM ((int64_t)1 << 19)
+#endif
+// Single CartPole steps of at least this many envs run ONE env per lane: 2 x 8 waves per SIMD instead of one round of 8, so one
+// round's stores overlap the other's loads (profiles/r6/r6i_step_launch_shape.md: 19.4 -> 18.7 us at 2^20; below 2^19 the launch
+// is latency-bound and two envs per lane win).
+constexpr int64_t kStepOneEnvPerLaneFrom = MXV_STEP_E1_FROM;
+
 template <int ENV>
 hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, LaunchInfo *info) {
     const bool def = pm == PM_DEFAULT;
@@ -1257,6 +1400,19 @@ hipError_t launch_step_env(int pm, const StepArgs &a, hipStream_t stream, Launch
     const int64_t tile = (int64_t)E * kBlock;
     const unsigned grid = (unsigned)((a.n + tile - 1) / tile);
     if (info) *info = LaunchInfo{0, ENV, pm, E, 1, 0, a.actions != nullptr ? 1 : 0, a.K, grid, (uint32_t)kBlock};
+    // A single step of a BIG CartPole batch with two envs per lane is 8192 waves = exactly ONE round at 8 waves per SIMD: every wave
+    // loads, then computes, then stores, all in step — the read phase and the write phase of the launch do not overlap (the launch's
+    // own access pattern without physics takes 17 of its 19.5 us; moving 16 bytes per env-step fewer did not shorten it: profiles/r6/
+    // r6i_step_launch_shape.md).  One env per lane makes it two rounds, the second one's loads under the first one's stores:
+    // 19.4 -> 18.7 us per 2^20-env step; occupancy caps (more, thinner rounds) and four envs per lane both lose.
+    if constexpr (ENV == MXV_CARTPOLE && E > 1) {
+        if (a.K == 1 && pm == PM_DEFAULT && a.clock_ticket == nullptr && a.n >= kStepOneEnvPerLaneFrom) {
+            const unsigned grid1 = (unsigned)((a.n + kBlock - 1) / kBlock);
+            if (info) *info = LaunchInfo{0, ENV, pm, 1, 1, 0, a.actions != nullptr ? 1 : 0, a.K, grid1, (uint32_t)kBlock};
+            hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, 1, C, false>), dim3(grid1), dim3(kBlock), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
     if (a.K > 1) {
         if (pm == PM_DEFAULT)
             hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, true>), dim3(grid), dim3(kBlock), 0, stream, a);
@@ -1291,6 +1447,55 @@ hipError_t launch_sample_env(int pm, const SampleArgs &a, hipStream_t stream) {
 }
 
 }  // namespace
+
+bool hilo_supported(int env_id) { return env_id == MXV_CARTPOLE || env_id == MXV_MOUNTAINCAR || env_id == MXV_MOUNTAINCAR_CONT; }
+
+template <int ENV>
+static hipError_t launch_hilo_step_env(const StepArgs &a, hipStream_t stream, LaunchInfo *info) {
+    constexpr int E = envs_per_lane(ENV);
+    constexpr bool C = MXV_CONSEC != 0;
+    if constexpr (ENV == MXV_CARTPOLE && E > 1) {      // (two rounds instead of one: see launch_step_env)
+        if (a.n >= kStepOneEnvPerLaneFrom) {
+            const unsigned grid1 = (unsigned)((a.n + kBlock - 1) / kBlock);
+            if (info) *info = LaunchInfo{0, ENV, PM_DEFAULT, 1, 1, 3, a.actions != nullptr ? 1 : 0, 1, grid1, (uint32_t)kBlock};
+            hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, 1, C, false, false, true>), dim3(grid1), dim3(kBlock), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
+    const int64_t tile = (int64_t)E * kBlock;
+    const unsigned grid = (unsigned)((a.n + tile - 1) / tile);
+    if (info) *info = LaunchInfo{0, ENV, PM_DEFAULT, E, 1, 3 /* out_mode 3: the observation carries the state */, a.actions != nullptr ? 1 : 0, 1, grid, (uint32_t)kBlock};
+    hipLaunchKernelGGL((step_kernel<ENV, PM_DEFAULT, E, C, false, false, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_hilo_step(int env_id, const StepArgs &a, hipStream_t stream, LaunchInfo *info) {
+    switch (env_id) {
+        case MXV_CARTPOLE: return launch_hilo_step_env<MXV_CARTPOLE>(a, stream, info);
+        case MXV_MOUNTAINCAR: return launch_hilo_step_env<MXV_MOUNTAINCAR>(a, stream, info);
+        case MXV_MOUNTAINCAR_CONT: return launch_hilo_step_env<MXV_MOUNTAINCAR_CONT>(a, stream, info);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_hilo_split(int env_id, const double *state, float *hi_obs, int32_t *lo, double *side, int64_t n, hipStream_t stream) {
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    switch (env_id) {
+        case MXV_CARTPOLE: hipLaunchKernelGGL(hilo_split_kernel<MXV_CARTPOLE>, grid, block, 0, stream, state, hi_obs, lo, side, n); break;
+        case MXV_MOUNTAINCAR: hipLaunchKernelGGL(hilo_split_kernel<MXV_MOUNTAINCAR>, grid, block, 0, stream, state, hi_obs, lo, side, n); break;
+        case MXV_MOUNTAINCAR_CONT: hipLaunchKernelGGL(hilo_split_kernel<MXV_MOUNTAINCAR_CONT>, grid, block, 0, stream, state, hi_obs, lo, side, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_hilo_join(int env_id, const float *hi_obs, const int32_t *lo, double *state, int64_t n, hipStream_t stream) {
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    switch (env_id) {
+        case MXV_CARTPOLE: hipLaunchKernelGGL(hilo_join_kernel<MXV_CARTPOLE>, grid, block, 0, stream, hi_obs, lo, state, n); break;
+        case MXV_MOUNTAINCAR: hipLaunchKernelGGL(hilo_join_kernel<MXV_MOUNTAINCAR>, grid, block, 0, stream, hi_obs, lo, state, n); break;
+        case MXV_MOUNTAINCAR_CONT: hipLaunchKernelGGL(hilo_join_kernel<MXV_MOUNTAINCAR_CONT>, grid, block, 0, stream, hi_obs, lo, state, n); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 // Sampled actions, or an action tape with the default physics parameters, + autoreset, several steps per launch: the fused fast
 // path (rollout_kernel_v3).  Everything else — single steps with caller actions, tapes with changed parameters, per-env

@@ -39,6 +39,8 @@ struct StepArgs {
     int32_t K;             // vector steps fused into this launch (>= 1)
     int32_t state_injected; // mxv_set_state() ran since the last launch: no invariant on the state may be assumed
     int32_t elapsed16;      // storage type of elapsed[] (see above)
+    const float *hi_in;     // HILO launches (mxv_adopt_obs): the observation rows [N][O] the previous step / split left = the float32 half of the state
+    int32_t *lo;            // HILO launches: [N][S] (row-major, like the observations) the other half, (state - (double)float32(state)) in units of 2^(exponent(hi) - 53); nullptr otherwise
     int32_t step_noise;     // Acrobot torque_noise_max > 0 somewhere: draw the step-noise word (step_kernel launches only)
     int64_t slice;         // output pointers advance by `slice` envs per step ([K][N] trajectories) or 0
     int64_t act_slice;     // action tape advance per step (envs) or 0
@@ -228,6 +230,11 @@ struct LaunchInfo {
 };
 // param_mode: PM_DEFAULT / PM_BROADCAST / PM_PER_ENV (mxv_device.hpp)
 hipError_t launch_step(int env_id, int param_mode, const StepArgs &a, hipStream_t stream, LaunchInfo *info = nullptr);
+// The fp64 state as (float32 observation, int32 residual) pairs — see hilo_encode in mxv_kernels.hip.  Kinds whose observation IS float32(state):
+bool hilo_supported(int env_id);
+hipError_t launch_hilo_step(int env_id, const StepArgs &a, hipStream_t stream, LaunchInfo *info = nullptr);   // one step, default parameters, a.hi_in / a.lo set
+hipError_t launch_hilo_split(int env_id, const double *state, float *hi_obs, int32_t *lo, double *side, int64_t n, hipStream_t stream);
+hipError_t launch_hilo_join(int env_id, const float *hi_obs, const int32_t *lo, double *state, int64_t n, hipStream_t stream);
 // true if launch_step(a) runs the fused rollout kernel, which also writes StepArgs::snap_* (other launches: the caller copies)
 bool launch_step_is_rollout(int param_mode, const StepArgs &a);
 // true if launch_step(a) with a.obs_part set runs a STATS instantiation (fused observation sums); envs per leaf of those partials

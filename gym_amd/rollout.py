@@ -30,7 +30,8 @@ MODES = {"eager": _native.ROLLOUT_EAGER, "graph": _native.ROLLOUT_GRAPH, "fused"
 class DeviceRollout:
     def __init__(self, id: str, num_envs: int, *, device: int = 0, env_offset: int = 0, seed: int = 0,
                  action_seed: int = 0, max_episode_steps: Optional[int] = None, reward_f32: bool = False,
-                 action_i32: bool = False, autoreset: bool = True, stream: Optional["torch.cuda.Stream"] = None):
+                 action_i32: bool = False, autoreset: bool = True, stream: Optional["torch.cuda.Stream"] = None,
+                 obs_carries_state: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceRollout needs a HIP device (torch.cuda.is_available() is False); "
                                "gym_amd has no CPU fallback")
@@ -64,6 +65,13 @@ class DeviceRollout:
             self.final_obs = torch.zeros((n, self.O), dtype=torch.float32, device=self.device)
             self.actions = torch.zeros(n, dtype=self.action_dtype, device=self.device)
         self.stream.synchronize()
+        # obs_carries_state=True (CartPole, MountainCar, MountainCarContinuous): `self.obs` doubles as the float32 half of the fp64 state
+        # between step() calls (mxv_adopt_obs: float32 observation + int32 residual = the double, exactly) — a quarter less state traffic
+        # per step (2^20 CartPole envs: 108 -> 92 bytes per env-step).  The price is a contract: READ self.obs, never write it
+        # (in-place normalisation, clamping ... would change the state); every other call hands the state back to fp64 by itself.
+        self.obs_carries_state = bool(obs_carries_state)
+        if self.obs_carries_state:
+            self.handle.adopt_obs(self.obs)
         self._last = (self.obs, self.reward, self.terminated, self.truncated)
         # step(actions) is the learner-in-the-loop call: one launch per policy step, so its host cost is what caps small and
         # medium vector envs.  Everything it needs per call is looked up once here (17.4 -> ~8 us, profiles/HISTORY.md).

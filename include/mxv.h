@@ -277,6 +277,15 @@ int mxv_host_block_layout(mxv_handle *h, size_t *bytes, size_t *final_obs_off, s
 int mxv_step_host_block(mxv_handle *h, const void *actions_host, void *block_host, int32_t want_final);
 
 /* -- state access (parity hook + checkpoint/resume) ---------------------------------------------- */
+/* -- "the observation carries the state" (API level 6): mxv_step moves the fp64 state both ways every launch (16 S of its ~108 bytes per
+ * env-step) because fp32 state fails the parity bar.  For CartPole and both MountainCars the observation IS float32(state), and the
+ * remainder state - float32(state) is an exact int32 multiple of 2^(exponent - 53): a handle that ADOPTS the caller's observation buffer
+ * keeps the state as (that buffer, int32 residuals) between single steps — 12 instead of 16 bytes per state component per step, same
+ * bits (values outside float32's normal range escape to the fp64 array).  The contract is the caller's: between two mxv_step /
+ * mxv_step_sampled calls that pass obs_dev == the adopted buffer, the buffer must not be written (it is half of the state), and it must
+ * outlive the adoption; every other call (reset, rollouts, get / set_state, steps with another obs pointer or non-default parameters)
+ * first brings the state back into the fp64 array by itself.  obs_dev = NULL releases.  MXV_ERR_UNSUPPORTED for Pendulum / Acrobot. */
+int mxv_adopt_obs(mxv_handle *h, float *obs_dev);
 /* state_soa_host: double[S][N]; elapsed_host: int32[N]; either may be NULL.  Synchronises. */
 int mxv_get_state(mxv_handle *h, double *state_soa_host, int32_t *elapsed_host);
 int mxv_set_state(mxv_handle *h, const double *state_soa_host, const int32_t *elapsed_host);
