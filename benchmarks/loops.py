@@ -74,7 +74,7 @@ def measure_step_loop(torch, envs, steps=600, compact=False, halves=1, obs_carri
         e.close()
     b = algorithmic_bytes_per_env_step("given", 1)
     us = max(wall_us, gpu_us)
-    return {"halves": halves, "obs_carries_state": obs_carries_state, "dtypes": "float32 rewards, int32 actions" if compact else "float64 rewards, int64 actions (the reference's)",
+    return {"envs": envs, "halves": halves, "obs_carries_state": obs_carries_state, "dtypes": "float32 rewards, int32 actions" if compact else "float64 rewards, int64 actions (the reference's)",
             "us_per_step": us, "gpu_us_per_step": gpu_us, "value": envs / us * 1e6, "unit": "env-steps/s",
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_env_step": b, "achieved": envs * b / us / 1e3, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": envs * b / us / 1e3 / HBM_PEAK_GBS}}

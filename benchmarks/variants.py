@@ -47,6 +47,8 @@ def groups(torch, chunk):
             # round 6: the observation buffer doubles as the float32 half of the state (DeviceRollout(obs_carries_state=True), mxv_adopt_obs)
             "one_engine_obs_carries_state": measure_step_loop(torch, ENVS_TOTAL, obs_carries_state=True),
             "one_engine_obs_carries_state_compact": measure_step_loop(torch, ENVS_TOTAL, compact=True, obs_carries_state=True),
+            # the same launch on 4x the envs: its fixed part (4.9 us) amortised, the working set still inside the Infinity Cache (profiles/r6/r6i_*)
+            "one_engine_obs_carries_state_compact_4x_envs": measure_step_loop(torch, 4 * ENVS_TOTAL, steps=300, compact=True, obs_carries_state=True),
             "two_half_engines": measure_step_loop(torch, ENVS_TOTAL, halves=2),
             "kernel": measure_step_kernel(torch, ENVS_TOTAL)}),
         ("numpy_loop", lambda: {"num_envs_2^20": measure_numpy_loop(ENVS_TOTAL, 60),

@@ -26,25 +26,41 @@ namespace {
 // word lives in pinned host memory (host steps of small envs, mxv_api.cpp: ErrInBlock), where a PCIe atomic might not.
 __device__ __forceinline__ void raise_error(int32_t *err, int32_t bit) { *reinterpret_cast<volatile int32_t *>(err) = bit; }
 
+// The single-step launch's stores carry the nontemporal hint: nothing it writes is read again before the launch ends, and lines that do
+// not linger in the L2s shorten the write-back at the end of the kernel — step(actions) at 2^20 envs 18.8 -> 18.4 / 18.7 us in two boxes, i.e.
+// 1-2 % (on the loads the same hint COSTS 4 us: profiles/r6/r6i_step_launch_shape.md).  -DMXV_STEP_NT_STORES=0 is the A/B hook.
+#ifndef MXV_STEP_NT_STORES
+#define MXV_STEP_NT_STORES 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+template <bool NT, typename T>
+__device__ __forceinline__ void st(T *p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 // elapsed[] is stored in 16 bits whenever the handle's TimeLimit fits (mxv_api.cpp: elapsed16): step(actions) reads and writes it every
 // launch, 2 + 2 instead of 4 + 4 bytes per env-step.  The counter saturates at 65535 (only reachable without autoreset, far beyond the limit:
 // `truncated` stays set, `elapsed == 0` stays false).  A wave-uniform branch on a kernel argument at entry and exit, nothing in the loops.
 __device__ __forceinline__ int32_t load_elapsed(const void *p, int32_t el16, int64_t e) {
     return el16 ? (int32_t) static_cast<const uint16_t *>(p)[e] : static_cast<const int32_t *>(p)[e];
 }
+template <bool NT = false>
 __device__ __forceinline__ void store_elapsed(void *p, int32_t el16, int64_t e, int32_t v) {
     if (el16)
-        static_cast<uint16_t *>(p)[e] = (uint16_t)(v > 65535 ? 65535 : v);
+        st<NT>(static_cast<uint16_t *>(p) + e, (uint16_t)(v > 65535 ? 65535 : v));
     else
-        static_cast<int32_t *>(p)[e] = v;
+        st<NT>(static_cast<int32_t *>(p) + e, v);
 }
 
-template <int O>
+template <int O, bool NT = false>
 __device__ __forceinline__ void store_obs(float *base, int64_t e, const float *o) {
     if constexpr (O == 4) {
-        reinterpret_cast<float4 *>(base)[e] = make_float4(o[0], o[1], o[2], o[3]);
+        st<NT>(reinterpret_cast<f32x4_t *>(base) + e, f32x4_t{o[0], o[1], o[2], o[3]});
     } else if constexpr (O == 2) {
-        reinterpret_cast<float2 *>(base)[e] = make_float2(o[0], o[1]);
+        st<NT>(reinterpret_cast<f32x2_t *>(base) + e, f32x2_t{o[0], o[1]});
     } else if constexpr (O == 6) {
         float2 *p = reinterpret_cast<float2 *>(base) + e * 3;
         p[0] = make_float2(o[0], o[1]);
@@ -153,10 +169,10 @@ __device__ __forceinline__ int32_t hilo_encode(double x, double *side) {
 template <int O>
 __device__ __forceinline__ void load_obs(const float *base, int64_t e, float *o) {
     if constexpr (O == 4) {
-        const float4 v = reinterpret_cast<const float4 *>(base)[e];
+        const f32x4_t v = reinterpret_cast<const f32x4_t *>(base)[e];
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     } else if constexpr (O == 2) {
-        const float2 v = reinterpret_cast<const float2 *>(base)[e];
+        const f32x2_t v = reinterpret_cast<const f32x2_t *>(base)[e];
         o[0] = v.x; o[1] = v.y;
     } else {
 #pragma unroll
@@ -167,19 +183,19 @@ __device__ __forceinline__ void load_obs(const float *base, int64_t e, float *o)
 template <int S>
 __device__ __forceinline__ void load_lo(const int32_t *base, int64_t e, int32_t *v) {
     if constexpr (S == 4) {
-        const int4 q = reinterpret_cast<const int4 *>(base)[e];
+        const i32x4_t q = reinterpret_cast<const i32x4_t *>(base)[e];
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
-        const int2 q = reinterpret_cast<const int2 *>(base)[e];
+        const i32x2_t q = reinterpret_cast<const i32x2_t *>(base)[e];
         v[0] = q.x; v[1] = q.y;
     }
 }
-template <int S>
+template <int S, bool NT = false>
 __device__ __forceinline__ void store_lo(int32_t *base, int64_t e, const int32_t *v) {
     if constexpr (S == 4)
-        reinterpret_cast<int4 *>(base)[e] = make_int4(v[0], v[1], v[2], v[3]);
+        st<NT>(reinterpret_cast<i32x4_t *>(base) + e, i32x4_t{v[0], v[1], v[2], v[3]});
     else
-        reinterpret_cast<int2 *>(base)[e] = make_int2(v[0], v[1]);
+        st<NT>(reinterpret_cast<i32x2_t *>(base) + e, i32x2_t{v[0], v[1]});
 }
 template <int ENV>
 __global__ void __launch_bounds__(kBlock) hilo_split_kernel(const double *state, float *hi_obs, int32_t *lo, double *side, int64_t n) {
@@ -230,6 +246,7 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
     constexpr int S = EV::S, O = EV::O, NA = EV::NA;
     static_assert(!HILO || (!MULTI && S == O && EV::AUX == 0), "HILO: one step, observation = float32(state)");
     constexpr int TILE = E * kBlock;
+    constexpr bool NT = !MULTI && MXV_STEP_NT_STORES != 0;
     static_assert(!CONSEC || E == 1 || E == 2 || E % 4 == 0, "CONSEC needs E in {1, 2, 4k}");
     const int tid = threadIdx.x;
     const int64_t tile0 = (int64_t)xcd_contiguous_tile(blockIdx.x, gridDim.x) * TILE;
@@ -441,15 +458,15 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
         for (int j = 0; j < E; ++j) {
             if (!valid[j]) continue;
             const int64_t e = so + env_of(j);
-            store_obs<O>(a.obs, e, obs[j]);
+            store_obs<O, NT>(a.obs, e, obs[j]);
             if (a.reward != nullptr) {
                 if (a.flags & MXV_FLAG_REWARD_F32)
-                    static_cast<float *>(a.reward)[e] = (float)rew[j];
+                    st<NT>(static_cast<float *>(a.reward) + e, (float)rew[j]);
                 else
-                    static_cast<double *>(a.reward)[e] = rew[j];
+                    st<NT>(static_cast<double *>(a.reward) + e, rew[j]);
             }
-            if (a.terminated != nullptr) a.terminated[e] = term[j] ? 1 : 0;
-            if (a.truncated != nullptr) a.truncated[e] = trunc[j] ? 1 : 0;
+            if (a.terminated != nullptr) st<NT>(a.terminated + e, (uint8_t)(term[j] ? 1 : 0));
+            if (a.truncated != nullptr) st<NT>(a.truncated + e, (uint8_t)(trunc[j] ? 1 : 0));
         }
         if constexpr (ENV == MXV_CARTPOLE) {
             // steps_beyond_terminated (cartpole.py:169-184): an env that is stepped on after it terminated — only possible without
@@ -494,12 +511,12 @@ __global__ void __launch_bounds__(kBlock, MXV_MIN_WAVES) step_kernel(const StepA
                 for (int k = 0; k < S; ++k)
                     if (l[k] == kHiloEscape) a.state[(int64_t)k * n + e] = s[j][k];
             }
-            store_lo<S>(a.lo, e, l);
+            store_lo<S, NT>(a.lo, e, l);
         } else {
 #pragma unroll
-            for (int k = 0; k < S; ++k) a.state[(int64_t)k * n + e] = s[j][k];
+            for (int k = 0; k < S; ++k) st<NT>(a.state + (int64_t)k * n + e, s[j][k]);
         }
-        store_elapsed(a.elapsed, a.elapsed16, e, el[j]);
+        store_elapsed<NT>(a.elapsed, a.elapsed16, e, el[j]);
         if (ep[j] != ep_in[j]) a.episodes[e] = ep[j];
         if (a.ep_acc) a.ep_acc[e] = er[j];
     }
