@@ -83,12 +83,10 @@ struct U4 {
     uint32_t x, y, z, w;
 };
 
-#ifndef MXV_EXP_PHILOX_ROUNDS  // tuning experiments only (tools/build_variants.sh); the product is always 10 rounds
-#define MXV_EXP_PHILOX_ROUNDS 10
-#endif
+constexpr int kPhiloxRounds = 10;  // Philox4x32-10
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < MXV_EXP_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < kPhiloxRounds; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;  // one v_mad_u64_u32 yields hi and lo
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -129,7 +127,7 @@ __device__ __forceinline__ uint32_t xor_masked(uint32_t x, uint32_t y, uint32_t 
 }
 __device__ __forceinline__ U4 philox4x32_10_vkey(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < MXV_EXP_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < kPhiloxRounds; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         U4 n;

@@ -797,19 +797,7 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
     const uint32_t rew_b = rew_f32 ? 4u : 8u;
     const uint32_t act_b = (NA > 0 && !act_i32) ? 8u : 4u;
     uint32_t lo[E];  // index of the lane's env slot inside one step's slice of every output array
-#if MXV_EXP_TILE_MAJOR  // measurement only: trajectories laid out [N/TILE][K][TILE] — every wave streams through its own region
-    const int64_t slice = a.slice ? TILE : 0;
-#pragma unroll
-    for (int j = 0; j < E; ++j) lo[j] = a.slice ? (uint32_t)(j * kWave + lane) : le[j];
-    if (a.slice) {
-        const int64_t base = tile0 * (int64_t)a.K;
-        p_obs += base * (int64_t)(O * sizeof(float));
-        if (p_rew) p_rew += base * rew_b;
-        if (p_act) p_act += base * act_b;
-        if (p_term) p_term += base;
-        if (p_trunc) p_trunc += base;
-    }
-#elif MXV_SADDR_STORES
+#if MXV_SADDR_STORES
     // every output base is moved to this wave's tile (wave-uniform: scalar arithmetic), lanes keep an offset below E * 64 elements: the
     // byte offsets fit 32 bits whatever the shard size, which is what lets the stores use scalar-base addressing (pin32)
     const int64_t slice = a.slice;
@@ -829,36 +817,14 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
     for (int j = 0; j < E; ++j) lo[j] = le[j];
 #endif
 
-#if MXV_EXP_STATE_IN_LDS  // measurement only (north_star: "integration ... staged in LDS"): the fp64 state lives in LDS between steps
-    __shared__ double lds_state[E * S * kWave];
-#pragma unroll
-    for (int j = 0; j < E; ++j)
-#pragma unroll
-        for (int k = 0; k < S; ++k) lds_state[(j * S + k) * kWave + lane] = s[j][k];
-#endif
 
     settle_entry_loads();
-#if MXV_EXP_STAGGER > 0  // measurement only: a one-time phase offset between the waves that share a SIMD (units of 64 clocks x 0..3):
-    {                    // do the store bursts of waves running in lockstep cost the compute-bound kinds their overlap?
-        const unsigned ph = (bid >> 3) & 3u;  // consecutive workgroups of one XCD (ids 8 apart) fill a CU's SIMDs in turn
-        if (ph == 1) __builtin_amdgcn_s_sleep(MXV_EXP_STAGGER);
-        else if (ph == 2) __builtin_amdgcn_s_sleep(2 * MXV_EXP_STAGGER);
-        else if (ph == 3) __builtin_amdgcn_s_sleep(3 * MXV_EXP_STAGGER);
-    }
-#endif
     // The loop exists twice in a tape-driven kernel: ALLV = every env slot of the wave is a real env (all tiles but possibly the
     // last), so no store sits behind an exec-mask branch — the compiler can then prove how many stores follow a tape load on
     // every path and waits for the load with s_waitcnt vmcnt(N > 0) instead of draining the wave's stores.
     auto one_step = [&](const int step, auto allv_tag, TapeRegs &tape) __attribute__((always_inline)) {
         constexpr bool ALLV = decltype(allv_tag)::value;
         const uint64_t t = t0 + (uint64_t)step;
-#if MXV_EXP_STATE_IN_LDS
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-#pragma unroll
-            for (int k = 0; k < S; ++k) s[j][k] = lds_state[(j * S + k) * kWave + lane];
-#endif
 
         // ---- this step's actions ----
         int ai[E];
@@ -1052,21 +1018,11 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             }
         }
 
-#if MXV_EXP_STATE_IN_LDS
-#pragma unroll
-        for (int j = 0; j < E; ++j)
-#pragma unroll
-            for (int k = 0; k < S; ++k) lds_state[(j * S + k) * kWave + lane] = s[j][k];
-        asm volatile("" ::: "memory");
-#endif
         // ---- look-ahead pass: refill the empty reset slots j of this wave, every PERIOD steps per slot ----
 #pragma unroll
         for (int j = 0; j < E; ++j)
             if ((step & (PERIOD - 1)) == j * (PERIOD / E) && __any(need[j])) fill_entries(j);
 
-#if MXV_EXP_SLEEP > 0  // measurement only: pace the wave (units of 64 clocks) — does a slower issue rate help the write path?
-        __builtin_amdgcn_s_sleep(MXV_EXP_SLEEP);
-#endif
         // ---- advance the scalar output bases to the next trajectory slice ----
         p_obs += slice * (int64_t)(O * sizeof(float));
         if (FULL || p_rew != nullptr) p_rew += slice * (int64_t)rew_b;
@@ -1095,15 +1051,6 @@ __device__ __forceinline__ void rollout_body_v3(const StepArgs &a, const unsigne
             run_pairs(std::true_type{});
         else
             run_pairs(std::false_type{});
-    } else if constexpr (FULL && MXV_EXP_ALLV_FUSED) {   // measurement: the branch-free stores for the sampled trajectory kernels too
-        bool allv = true;
-#pragma unroll
-        for (int j = 0; j < E; ++j) allv = allv && __all(valid[j]);
-        if (allv) {
-            for (int step = 0; step < a.K; ++step) one_step(step, std::true_type{}, tape_even);
-        } else {
-            for (int step = 0; step < a.K; ++step) one_step(step, std::false_type{}, tape_even);
-        }
     } else {
         for (int step = 0; step < a.K; ++step) one_step(step, std::false_type{}, tape_even);
     }

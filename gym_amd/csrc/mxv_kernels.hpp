@@ -169,26 +169,6 @@ constexpr int rollout_envs_per_lane(int env_id) {
 #ifndef MXV_ROLLOUT_E1_INCLUSIVE
 #define MXV_ROLLOUT_E1_INCLUSIVE 1
 #endif
-// measurement hook: 1 = the fused rollout writes its trajectories tile-major ([N/TILE][K][TILE]) instead of step-major ([K][N])
-#ifndef MXV_EXP_TILE_MAJOR
-#define MXV_EXP_TILE_MAJOR 0
-#endif
-// measurement hook: 1 = the fused rollout keeps the fp64 env state in LDS between steps (read at the top of a step, written back at its
-// end) instead of registers — the "staged in LDS" reading of north_star, for the A/B in profiles/
-#ifndef MXV_EXP_STATE_IN_LDS
-#define MXV_EXP_STATE_IN_LDS 0
-#endif
-// measurement hook: s_sleep of this many 64-clock units at the end of every step of the fused rollout (0 = none)
-#ifndef MXV_EXP_ALLV_FUSED
-#define MXV_EXP_ALLV_FUSED 0
-#endif
-#ifndef MXV_EXP_SLEEP
-#define MXV_EXP_SLEEP 0
-#endif
-// measurement hook: one-time phase offset between waves at the top of the fused rollout (see rollout_body_v3)
-#ifndef MXV_EXP_STAGGER
-#define MXV_EXP_STAGGER 0
-#endif
 // steps between two look-ahead passes of rollout_kernel_v3 over the same env slot (power of two, >= envs per lane)
 #ifndef MXV_ROLLOUT_PASS_PERIOD
 #define MXV_ROLLOUT_PASS_PERIOD 8

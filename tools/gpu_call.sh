@@ -1,8 +1,9 @@
 #!/usr/bin/env bash
-# Round-5 evidence call: full GPU suite + smoke, rocprofv3 kernel stats and PMC traffic of the bench command (headline, its compact twin, and one
-# pass over everything the line's variants launch), bench with the driver's arguments and with the defaults.
+# The round-end evidence call (rounds 5 and 6): full GPU suite + smoke, rocprofv3 kernel stats and PMC traffic of the bench command (headline,
+# its compact twin, and one pass over everything the line's variants launch), bench with the driver's arguments and with the defaults, the
+# parity report, Blackjack's VALU counters.      gpurun --timeout 3000 -- 'bash tools/gpu_call.sh r6'   ->  gpurun_out/r6/ -> profiles/r6/r6_*
 mkdir -p gpurun_out; export TMPDIR=/tmp
-R=${1:-r5}
+R=${1:-r6}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
