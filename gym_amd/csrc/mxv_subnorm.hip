@@ -115,7 +115,7 @@ __device__ __forceinline__ double div_shared(double x, double d, double r) {
 
 // RunningMeanStd.update with a batch of one row (normalize.py:17-22 -> :32-47): batch_mean = x, batch_var = 0, batch_count = 1.
 template <int D>
-__device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D], double (&var)[D], double &count) {
+__device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D], double (&var)[D], double &count, bool active = true) {
     const double tot = count + 1.0;  // :37
     double delta[D], sq[D];
     bool ok = plain_divisor(tot);
@@ -125,7 +125,7 @@ __device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D
         sq[j] = (delta[j] * delta[j]) * count;                       // :42   square(delta) * count (* 1)
         ok = ok && plain_operand(delta[j]) && plain_operand(sq[j]);
     }
-    if (MXV_SUBNORM_SHARED_RCP && __all(ok)) {
+    if (MXV_SUBNORM_SHARED_RCP && __all(ok || !active)) {   // (a lane with nothing to do has no say in the wave's choice of path)
         const double r = refined_rcp(tot);
         double m2[D];
         bool ok2 = true;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D
             mean[j] = mean[j] + div_shared(delta[j], tot, r);        // :39   delta * 1 / tot
             ok2 = ok2 && plain_operand(m2[j]);
         }
-        if (__all(ok2)) {
+        if (__all(ok2 || !active)) {
 #pragma unroll
             for (int j = 0; j < D; ++j) var[j] = div_shared(m2[j], tot, r);   // :43
         } else {
@@ -172,36 +172,54 @@ struct SubObsArgs {
     double eps;
 };
 
+// One lane owns one env and walks that env's EVENTS in order: per step the terminal observation where the episode ended (if the caller
+// passed them), then the row of the batch.  Every loop iteration handles ONE event of every lane, so the fp64 update + normalisation runs
+// once per iteration for the whole wave, and the lanes drift apart by the number of episodes their env has finished so far (kl = the lane's
+// own step index).  Walking the steps in lockstep instead makes a wave pay the terminal branch whenever ANY of its 64 envs finished — 95 %
+// of CartPole's wave-steps under random actions, i.e. twice the arithmetic (22.0 -> @@ us per 2^20-env step at K = 64;
+// profiles/r6/r6k_subnorm_event_walk.md).  The loop ends when the slowest lane is through: K + max-over-lanes(episodes ended) iterations.
+// Lanes that drifted read and write their 16-byte rows in different [N] slices; the rows of a line meet again in the L2.
 template <int D, typename OUT>
 __global__ void __launch_bounds__(kThreads) subnorm_obs_kernel(const SubObsArgs a) {
     const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (e >= a.n) return;
+    const bool mine = e < a.n;
+    const int64_t ec = mine ? e : 0;
     double mean[D], var[D], count;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        mean[j] = a.stat[(int64_t)j * a.n + e];
-        var[j] = a.stat[(int64_t)(D + j) * a.n + e];
+        mean[j] = a.stat[(int64_t)j * a.n + ec];
+        var[j] = a.stat[(int64_t)(D + j) * a.n + ec];
     }
-    count = a.stat[(int64_t)(2 * D) * a.n + e];
-    for (int k = 0; k < a.K; ++k) {
-        const int64_t r = (int64_t)k * a.n + e;
+    count = a.stat[(int64_t)(2 * D) * a.n + ec];
+    int kl = mine ? 0 : a.K;   // the lane's step
+    bool fin_done = false;     // the terminal observation of step kl has been handled
+    const bool has_fin = a.te != nullptr && a.fin != nullptr;
+    while (__any(kl < a.K)) {
+        const bool active = kl < a.K;
+        const int64_t r = (int64_t)(active ? kl : 0) * a.n + ec;
+        const bool use_fin = active && has_fin && !fin_done && ((a.te[r] | a.tr[r]) != 0);
         float x[D];
-        load_row<D>(a.x, r, x);
-        const bool done = a.te != nullptr && ((a.te[r] | a.tr[r]) != 0);
-        double y[D];
-        if (done && a.fin != nullptr) {  // the sub-env's step() returned the terminal observation first ...
-            float f[D];
-            load_row<D>(a.fin, r, f);
-            update_one<D>(f, mean, var, count);
-            if (a.yfin != nullptr) {
-                normalise<D>(f, mean, var, a.eps, y);
-                store_row<D>(a.yfin, r, y);
+        load_row<D>(use_fin ? a.fin : a.x, r, x);
+        double m[D], v[D], c = count, y[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) m[j] = mean[j], v[j] = var[j];
+        update_one<D>(x, m, v, c, active);
+        normalise<D>(x, m, v, a.eps, y);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) mean[j] = m[j], var[j] = v[j];
+            count = c;
+            if (use_fin) {   // the sub-env's step() returned the terminal observation first ...
+                if (a.yfin != nullptr) store_row<D>(a.yfin, r, y);
+                fin_done = true;
+            } else {         // ... then (or only) the row of the batch
+                store_row<D>(static_cast<OUT *>(a.y), r, y);
+                fin_done = false;
+                kl += 1;
             }
         }
-        update_one<D>(x, mean, var, count);  // ... then (or only) the row of the batch
-        normalise<D>(x, mean, var, a.eps, y);
-        store_row<D>(static_cast<OUT *>(a.y), r, y);
     }
+    if (!mine) return;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         a.stat[(int64_t)j * a.n + e] = mean[j];
