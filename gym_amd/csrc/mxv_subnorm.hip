@@ -93,10 +93,14 @@ __device__ __forceinline__ void store_row(double *base, int64_t row, const doubl
 #ifndef MXV_SUBNORM_SHARED_RCP
 #define MXV_SUBNORM_SHARED_RCP 1   // A/B hook: 0 = the compiler's `/` everywhere
 #endif
-__device__ __forceinline__ bool plain_operand(double x) {   // zero, Inf and NaN are v_div_fixup's business; finite non-zero needs a safe exponent
-    const uint32_t e = ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu;
-    return (e - 300u < 1401u) || e == 0x7ffu || x == 0.0;
+// (v_frexp_exp_i32_f64 answers 0 for zero, Inf and NaN — v_div_fixup's business, accepted — and the true exponent for subnormals: one
+// instruction, an add and an unsigned compare per test.)
+__device__ __forceinline__ bool plain_operand(double x) {   // finite non-zero needs 2^-723 <= |x| < 2^678
+    return (uint32_t)(__builtin_amdgcn_frexp_exp(x) + 722) < 1401u;
 }
+// delta = row - mean: with |delta| in 2^-300 .. 2^300 (or 0 / Inf / NaN) and count in 2^-64 .. 2^64 (or 0), square(delta) * count lies in
+// 2^-664 .. 2^664 (or is 0 / Inf / NaN): plain by construction, no test of its own.
+__device__ __forceinline__ bool plain_delta(double x) { return (uint32_t)(__builtin_amdgcn_frexp_exp(x) + 299) < 601u; }
 __device__ __forceinline__ bool plain_divisor(double d) {   // count + 1: 1.0001 .. 2^53 in any real run
     const uint32_t e = ((uint32_t)__double2hiint(d) >> 20) & 0x7ffu;
     return e - 959u < 129u;
@@ -115,17 +119,17 @@ __device__ __forceinline__ double div_shared(double x, double d, double r) {
 
 // RunningMeanStd.update with a batch of one row (normalize.py:17-22 -> :32-47): batch_mean = x, batch_var = 0, batch_count = 1.
 template <int D>
-__device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D], double (&var)[D], double &count, bool active = true) {
+__device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D], double (&var)[D], double &count) {
     const double tot = count + 1.0;  // :37
     double delta[D], sq[D];
-    bool ok = plain_divisor(tot);
+    bool ok = plain_divisor(tot) && (plain_divisor(count) || count == 0.0);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         delta[j] = (double)x[j] - mean[j];                           // :36   float32 - float64 -> float64
         sq[j] = (delta[j] * delta[j]) * count;                       // :42   square(delta) * count (* 1)
-        ok = ok && plain_operand(delta[j]) && plain_operand(sq[j]);
+        ok = ok && plain_delta(delta[j]);
     }
-    if (MXV_SUBNORM_SHARED_RCP && __all(ok || !active)) {   // (a lane with nothing to do has no say in the wave's choice of path)
+    if (MXV_SUBNORM_SHARED_RCP && __all(ok)) {
         const double r = refined_rcp(tot);
         double m2[D];
         bool ok2 = true;
@@ -135,7 +139,7 @@ __device__ __forceinline__ void update_one(const float (&x)[D], double (&mean)[D
             mean[j] = mean[j] + div_shared(delta[j], tot, r);        // :39   delta * 1 / tot
             ok2 = ok2 && plain_operand(m2[j]);
         }
-        if (__all(ok2 || !active)) {
+        if (__all(ok2)) {
 #pragma unroll
             for (int j = 0; j < D; ++j) var[j] = div_shared(m2[j], tot, r);   // :43
         } else {
@@ -176,8 +180,9 @@ struct SubObsArgs {
 // passed them), then the row of the batch.  Every loop iteration handles ONE event of every lane, so the fp64 update + normalisation runs
 // once per iteration for the whole wave, and the lanes drift apart by the number of episodes their env has finished so far (kl = the lane's
 // own step index).  Walking the steps in lockstep instead makes a wave pay the terminal branch whenever ANY of its 64 envs finished — 95 %
-// of CartPole's wave-steps under random actions, i.e. twice the arithmetic (22.0 -> @@ us per 2^20-env step at K = 64;
-// profiles/r6/r6k_subnorm_event_walk.md).  The loop ends when the slowest lane is through: K + max-over-lanes(episodes ended) iterations.
+// of CartPole's wave-steps under random actions (22.0 -> 20.1 us per 2^20-env step at K = 64; 18.1 with the cheaper range tests:
+// profiles/r6/r6k_subnorm_event_walk.md — 300 VALU per env-step, 0.73 of the issue rate at 5 waves per SIMD; 6 waves change nothing, 8 spill).
+// The loop ends when the slowest lane is through: K + max-over-lanes(episodes ended) iterations.
 // Lanes that drifted read and write their 16-byte rows in different [N] slices; the rows of a line meet again in the L2.
 template <int D, typename OUT>
 __global__ void __launch_bounds__(kThreads) subnorm_obs_kernel(const SubObsArgs a) {
@@ -195,20 +200,14 @@ __global__ void __launch_bounds__(kThreads) subnorm_obs_kernel(const SubObsArgs 
     bool fin_done = false;     // the terminal observation of step kl has been handled
     const bool has_fin = a.te != nullptr && a.fin != nullptr;
     while (__any(kl < a.K)) {
-        const bool active = kl < a.K;
-        const int64_t r = (int64_t)(active ? kl : 0) * a.n + ec;
-        const bool use_fin = active && has_fin && !fin_done && ((a.te[r] | a.tr[r]) != 0);
-        float x[D];
-        load_row<D>(use_fin ? a.fin : a.x, r, x);
-        double m[D], v[D], c = count, y[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) m[j] = mean[j], v[j] = var[j];
-        update_one<D>(x, m, v, c, active);
-        normalise<D>(x, m, v, a.eps, y);
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) mean[j] = m[j], var[j] = v[j];
-            count = c;
+        if (kl < a.K) {   // (lanes that are through sit out: the wave-level votes inside update_one count the lanes at work only)
+            const int64_t r = (int64_t)kl * a.n + e;
+            const bool use_fin = has_fin && !fin_done && ((a.te[r] | a.tr[r]) != 0);
+            float x[D];
+            load_row<D>(use_fin ? a.fin : a.x, r, x);
+            double y[D];
+            update_one<D>(x, mean, var, count);
+            normalise<D>(x, mean, var, a.eps, y);
             if (use_fin) {   // the sub-env's step() returned the terminal observation first ...
                 if (a.yfin != nullptr) store_row<D>(a.yfin, r, y);
                 fin_done = true;
@@ -253,7 +252,7 @@ __global__ void __launch_bounds__(kThreads) subnorm_rew_kernel(const SubRewArgs 
         ret = ret * a.gamma + rw;                                   // :132
         {                                                           // :144 return_rms.update(self.returns): a batch of one (update_one)
             const double tot = count + 1.0, delta = ret - mean, sq = (delta * delta) * count;
-            const bool ok = plain_divisor(tot) && plain_operand(delta) && plain_operand(sq);
+            const bool ok = plain_divisor(tot) && (plain_divisor(count) || count == 0.0) && plain_delta(delta);
             if (MXV_SUBNORM_SHARED_RCP && __all(ok)) {
                 const double rc = refined_rcp(tot);
                 const double m2 = var * count + div_shared(sq, tot, rc);
