@@ -351,7 +351,9 @@ def run(args, bench_file, cpu_baseline=None):
         recv = (world - 1) * shard_bytes
         gather_us = {"measured_blocking": measured, "predicted": [recv / (XGMI_BUS_GBS[1] * 1e3) + 20.0, recv / (XGMI_BUS_GBS[0] * 1e3) + 20.0],
                      "bytes_received_per_rank": recv, "steps_of_this_shard_it_equals": measured / (launch_ms * 1e3 / steps_per_launch)}
-        if world > 1 and mode == "fused" and args.gather_every != args.chunk:
+        # (more than two ranks over gloo = ranks sharing one GPU in a rehearsal: every gather is a 4-s CPU affair, and the two-rank rehearsal
+        # covers this region)
+        if world > 1 and mode == "fused" and args.gather_every != args.chunk and not (args.backend == "gloo" and world > 2):
             ab_steps = max(args.chunk, (timed_steps // 4) // args.chunk * args.chunk)
             fence()
             since_gather[0] = 0

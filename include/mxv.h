@@ -65,7 +65,10 @@
  *   4  (round 4)  device clock (hipGraph capture), fused moments (mxv_set_obs_partials / mxv_set_return_partials); mxv_diag.h
  *   5  (round 5)  mxv_get_beyond / mxv_set_beyond, mxv_bj_rollout_compact; Blackjack's one-call draw contract — NOT additive: the card and
  *                 Discrete(2) action streams of a Blackjack handle changed, so its snapshots carry the contract number (mxv_toytext.h)
- *   6  (round 6)  mxv_subnorm_* (per-sub-env Normalize*, mxv_norm.h); elapsed[] stored in 16 bits where the TimeLimit fits (no ABI change)
+ *   6  (round 6)  mxv_subnorm_* (per-sub-env Normalize*, mxv_norm.h); mxv_adopt_obs (the observation buffer carries the state between single
+ *                 steps); episode statistics of the toy_text engines (mxv_tab_* / mxv_bj_episode_stats ..., mxv_toytext.h); elapsed[] stored in
+ *                 16 bits where the TimeLimit fits (no ABI change); caller tensors must be aligned to the width they are moved with
+ *                 (MXV_ERR_INVALID_ARG otherwise — found by the fuzz harness, tests/test_abi_fuzz.py)
  * Every section below says the level it appeared at. */
 #define MXV_API_LEVEL 6
 

@@ -36,7 +36,7 @@ def _one_line(p):
 
 def test_bench_with_eight_self_launched_ranks():
     # (round 6: ONE eight-rank rehearsal, sized to stay under 30 s — a chunk of 64 steps, one repeat, one gather in the timed region; BASELINE.json
-    # configs[3] / configs[4] run their rank code with two ranks in tests/test_gpu_bench_multirank.py and their eight-rank partition
+    # no cadence A/B over gloo beyond two ranks; configs[3] / configs[4] run their rank code with two ranks in tests/test_gpu_bench_multirank.py and their eight-rank partition
     # arithmetic in tests/test_gpu_configs.py: eight more processes on one GPU added 21 s and no coverage)
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--chunk", "64", "--steps", "128", "--warmup", "64", "--repeats", "1",
                         "--gather-every", "128", "--placement", "off", "--warm-max-s", "0.2", "--spinup-ms", "10"], cwd=ROOT, capture_output=True, text=True,
