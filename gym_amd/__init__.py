@@ -6,7 +6,7 @@ kernels behind the C ABI of include/mxv.h, bound with ctypes (gym_amd._native) a
 `HipVectorEnv` (NumPy contract of the reference) and `DeviceRollout` (device-resident tensors).
 There is no CPU fallback: without the built extension / without a HIP device the engine raises.
 """
-__version__ = "0.5.0"
+__version__ = "0.6.0"
 
 _LAZY = {
     "HipVectorEnv": ("gym_amd.vector_env", "HipVectorEnv"),

@@ -570,7 +570,7 @@ void free_graphs(mxv_handle *h) {
 
 extern "C" {
 
-const char *mxv_version(void) { return "mxv 0.5.0 (gfx950)"; }
+const char *mxv_version(void) { return "mxv 0.6.0 (gfx950)"; }
 
 int mxv_env_dims(int32_t env_id, int32_t *state_dim, int32_t *obs_dim, int32_t *num_actions) {
     if (env_id < 0 || env_id >= MXV_NUM_ENV_KINDS) return MXV_ERR_INVALID_ARG;

@@ -609,12 +609,15 @@ def _sub_env_wrappers(wrappers):
                                               step's first operation is the same clip and nothing else sees the action (pendulum.py:126-129):
                                               a no-op.  MountainCarContinuous-v0: the reward uses the action AS GIVEN
                                               (continuous_mountain_car.py:169), so the clip is applied for real (SubEnvClipAction)
+        RescaleAction(min_action=, max_action=)
+                                              Box-action ids (rescale_action.py:45): the action space becomes Box(min, max), actions are
+                                              mapped affinely onto the env's own bounds and clipped (SubEnvRescaleAction)
         FlattenObservation                    classic-control observations are flat Box vectors already (flatten_observation.py:33-43): a no-op
         NormalizeObservation(epsilon=), NormalizeReward(gamma=, epsilon=)
                                               per-sub-env running statistics (a batch of one per update) — a DIFFERENT normalisation from
-                                              the vector-level gym_amd.NormalizeObservation / NormalizeReward (batch statistics, device
-                                              kernels): mapped to SubEnvNormalizeObservation / SubEnvNormalizeReward, host-side NumPy
-                                              over the adapter's arrays, exact; for very large batches wrap the vector env instead
+                                              the vector-level gym_amd.NormalizeObservation / NormalizeReward (batch statistics): mapped
+                                              to SubEnvNormalizeObservation / SubEnvNormalizeReward — the mxv_subnorm_* device kernels
+                                              from 4096 sub-envs, the same arithmetic in NumPy over the adapter's arrays below
     in the order given (innermost first, as the reference applies them).  Anything else (lambdas, observation transforms, ...) cannot
     run inside the device engine.  Returns (max_episode_steps or None, [post-construction vector wrappers])."""
     import functools
@@ -646,6 +649,8 @@ def _sub_env_wrappers(wrappers):
             continue
         elif name in ("ClipAction", "FlattenObservation") and not args and not kw:
             post.append(("identity_for_classic_control", {"wrapper": name}))
+        elif name == "RescaleAction" and not args and set(kw) == {"min_action", "max_action"}:
+            post.append(("rescale_action", kw))
         elif name == "NormalizeObservation" and not args and set(kw) <= {"epsilon"}:
             post.append(("normalize_observation", kw))
         elif name == "NormalizeReward" and not args and set(kw) <= {"gamma", "epsilon"}:
@@ -653,7 +658,8 @@ def _sub_env_wrappers(wrappers):
         else:
             raise NotImplementedError(
                 f"per-sub-environment wrapper {w!r} cannot run inside the device engine (no Python sub-envs); recognised: TimeLimit, "
-                "RecordEpisodeStatistics, OrderEnforcing, PassiveEnvChecker as classes or functools.partial — otherwise wrap the vector env "
+                "RecordEpisodeStatistics, NormalizeObservation, NormalizeReward, ClipAction, RescaleAction, FlattenObservation, OrderEnforcing, "
+                "PassiveEnvChecker as classes or functools.partial — otherwise wrap the vector env "
                 "(gym_amd.VectorEnvWrapper) or pass the env's own keyword arguments / max_episode_steps")
     return limit, post
 
@@ -687,6 +693,14 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
                 from .wrappers import SubEnvClipAction
 
                 env = SubEnvClipAction(env)      # the reward's action penalty sees the clipped action (continuous_mountain_car.py:169)
+            continue
+        if what == "rescale_action":
+            if not isinstance(getattr(env, "unwrapped", env), HipVectorEnv) or type(env.single_action_space).__name__ != "Box":
+                env.close()
+                raise NotImplementedError("wrappers=RescaleAction needs a Box action space (rescale_action.py:45-47): Pendulum-v1, MountainCarContinuous-v0")
+            from .wrappers import SubEnvRescaleAction
+
+            env = SubEnvRescaleAction(env, **kw)
             continue
         if what in ("normalize_observation", "normalize_reward"):
             base = getattr(env, "unwrapped", env)

@@ -20,7 +20,7 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics", "SubEnvClipAction",
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics", "SubEnvClipAction", "SubEnvRescaleAction",
            "SubEnvNormalizeObservation", "SubEnvNormalizeReward"]
 
 
@@ -205,6 +205,35 @@ class SubEnvClipAction(_VectorWrapper):
         sp = self.env.single_action_space
         a = np.asarray(actions, dtype=sp.dtype).reshape((self.env.num_envs,) + sp.shape)
         return self.env.step(np.clip(a, sp.low, sp.high))
+
+
+class SubEnvRescaleAction(_VectorWrapper):
+    """`wrappers=partial(RescaleAction, min_action=a, max_action=b)` (gym/wrappers/rescale_action.py:31-82 around every sub-env): the vector
+    env's action space becomes Box(a, b) per sub-env, and an action is mapped affinely onto the sub-env's own bounds and clipped to them —
+    the reference's float32 expression, operation for operation, on the whole batch; actions outside [a, b] raise its AssertionError."""
+
+    def __init__(self, env, min_action, max_action):
+        from .spaces import Box, batch_space
+
+        sp = env.single_action_space
+        assert type(sp).__name__ == "Box", f"expected Box action space, got {type(sp)}"                   # :45-47
+        assert np.less_equal(min_action, max_action).all(), (min_action, max_action)                       # :48
+        super().__init__(env)
+        self.num_envs = env.num_envs
+        self.is_vector_env = True
+        self._low, self._high = sp.low, sp.high
+        self.min_action = np.zeros(sp.shape, dtype=sp.dtype) + min_action                                  # :51-56
+        self.max_action = np.zeros(sp.shape, dtype=sp.dtype) + max_action
+        self.single_action_space = Box(low=min_action, high=max_action, shape=sp.shape, dtype=sp.dtype)    # :57-62
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+
+    def step(self, actions):
+        a = np.asarray(actions, dtype=self._low.dtype).reshape((self.num_envs,) + self._low.shape)
+        assert np.all(np.greater_equal(a, self.min_action)), (a, self.min_action)                         # :73-76
+        assert np.all(np.less_equal(a, self.max_action)), (a, self.max_action)                            # :77
+        low, high = self._low, self._high
+        a = low + (high - low) * ((a - self.min_action) / (self.max_action - self.min_action))            # :80-82
+        return self.env.step(np.clip(a, low, high))                                                        # :83
 
 
 class _PerEnvMeanStd:

@@ -98,6 +98,33 @@ def clip_action_case():
     print("ClipAction: min reward", out["reward"].min(), "out-of-range actions", int((np.abs(out["action"]) > 1).sum()))
 
 
+def rescale_action_case():
+    """vector_make_rescaleaction_{Pendulum,MountainCarContinuous}.npz — `gym.vector.make(id, 6, wrappers=partial(RescaleAction, min_action=a,
+    max_action=b))` run by THE REFERENCE with actions inside [a, b]: the sub-env sees low + (high - low) * ((action - a) / (b - a)), clipped
+    (gym/wrappers/rescale_action.py:64-83)."""
+    from gym.wrappers import RescaleAction
+
+    N, T = 6, 60
+    for name, gid, a, b in (("Pendulum", "Pendulum-v1", -1.0, 1.0), ("MountainCarContinuous", "MountainCarContinuous-v0", 0.0, 4.0)):
+        env = gym.vector.make(gid, num_envs=N, asynchronous=False, wrappers=functools.partial(RescaleAction, min_action=a, max_action=b))
+        assert env.single_action_space.low[0] == a and env.single_action_space.high[0] == b
+        env.reset(seed=77)
+        rng = np.random.default_rng(5)
+        rec = {k: [] for k in ("state_pre", "action", "obs", "reward", "terminated", "truncated")}
+        for t in range(T):
+            rec["state_pre"].append(np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in env.envs]))
+            act = rng.uniform(a, b, (N, 1)).astype(np.float32)
+            act[rng.random(N) < 0.15] = np.float32(b)      # (the ends of the range: the clip's own cases)
+            act[rng.random(N) < 0.15] = np.float32(a)
+            obs, rew, term, trunc, _ = env.step(act)
+            for k, v in (("action", act), ("obs", obs), ("reward", rew), ("terminated", term), ("truncated", trunc)):
+                rec[k].append(v)
+        out = {k: np.stack(v) for k, v in rec.items()}
+        out.update(min_action=np.float64(a), max_action=np.float64(b))
+        np.savez_compressed(os.path.join(HERE, f"vector_make_rescaleaction_{name}.npz"), **out)
+        print("RescaleAction", name, "reward range", out["reward"].min(), out["reward"].max())
+
+
 def main():
     normalize_case("CartPole-v1", "CartPole", lambda rng, n: (rng.random(n) < np.linspace(0.15, 0.85, n)).astype(np.int64))
     normalize_case("Pendulum-v1", "Pendulum", lambda rng, n: rng.uniform(-2, 2, (n, 1)).astype(np.float32))
@@ -137,6 +164,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "clipaction":      # (added in round 6; the other files are not regenerated)
         clip_action_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rescaleaction":
+        rescale_action_case()
     else:
         main()
         clip_action_case()

@@ -9,6 +9,7 @@ to that shape so the very same checks run against either.
 import os
 
 import numpy as np
+import pytest
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_NAMES = ["CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous"]
@@ -542,6 +543,39 @@ def replay_vector_make_clipaction(exact):
         else:
             np.testing.assert_allclose(rew, g["reward"][t], rtol=REWARD_RTOL, atol=1e-300, err_msg=f"t={t}")
             assert ulps32(obs, g["obs"][t]).max() <= MAX_OBS_ULPS, t
+    env.close()
+    return T
+
+
+def replay_vector_make_rescaleaction(name, exact):
+    """tests/golden/vector_make_rescaleaction_<name>.npz (THE REFERENCE: gym.vector.make(id, 6, wrappers=partial(RescaleAction, min_action=a,
+    max_action=b)) stepped with actions in [a, b]) through gym_amd.make(..., wrappers=partial(RescaleAction, ...)): the affine map onto the
+    sub-env's own bounds and the clip (rescale_action.py:64-83), then the step."""
+    import functools
+
+    import gym_amd
+
+    g = np.load(os.path.join(GOLDEN, f"vector_make_rescaleaction_{name}.npz"))
+    T, N = g["terminated"].shape
+    gid = {"Pendulum": "Pendulum-v1", "MountainCarContinuous": "MountainCarContinuous-v0"}[name]
+    a, b = float(g["min_action"]), float(g["max_action"])
+    env = gym_amd.make(gid, num_envs=N, wrappers=functools.partial(reference_wrapper_stub("RescaleAction"), min_action=a, max_action=b))
+    assert env.single_action_space.low[0] == a and env.single_action_space.high[0] == b and env.action_space.shape == (N, 1)
+    base = env.unwrapped
+    env.reset(seed=1)
+    elapsed = np.zeros(N, np.int32)
+    for t in range(T):
+        base.handle.set_state(np.ascontiguousarray(g["state_pre"][t].T), elapsed)
+        obs, rew, term, trunc, _ = env.step(g["action"][t])
+        elapsed = np.where(g["terminated"][t] | g["truncated"][t], 0, elapsed + 1).astype(np.int32)
+        assert np.array_equal(term, g["terminated"][t]) and np.array_equal(trunc, g["truncated"][t]), t
+        if exact:
+            assert np.array_equal(rew, g["reward"][t]) and np.array_equal(obs, g["obs"][t]), t
+        else:
+            np.testing.assert_allclose(rew, g["reward"][t], rtol=REWARD_RTOL, atol=REWARD_ATOL.get(name, REWARD_ATOL_DEFAULT), err_msg=f"t={t}")
+            assert ulps32(obs, g["obs"][t]).max() <= MAX_OBS_ULPS, t
+    with pytest.raises(AssertionError):            # outside [a, b]: the reference's own assertion (rescale_action.py:73-77)
+        env.step(np.full((N, 1), b + 1.0, np.float32))
     env.close()
     return T
 

@@ -778,3 +778,10 @@ def test_vector_make_clipaction_charges_the_clipped_action_on_the_device():
     from helpers import replay_vector_make_clipaction
 
     assert replay_vector_make_clipaction(exact=False) == 60
+
+
+@pytest.mark.parametrize("name", ["Pendulum", "MountainCarContinuous"])
+def test_vector_make_rescaleaction_on_the_device(name):
+    from helpers import replay_vector_make_rescaleaction
+
+    assert replay_vector_make_rescaleaction(name, exact=False) == 60
