@@ -56,6 +56,48 @@ def test_adopted_steps_equal_ordinary_steps_bit_for_bit(gid, n):
     a.close(), b.close()
 
 
+def test_one_env_per_lane_launches_equal_the_oracle_and_the_adopted_form():
+    """From 2^19 envs a single CartPole step runs ONE env per lane (two rounds of waves, profiles/r6/r6i_step_launch_shape.md), in the
+    ordinary and in the adopted form: the instantiation asserted, both forms bit-equal to each other over resets, and the ordinary one held
+    against the oracle twin on the whole batch (masks exact, observations within the engine's ulp bar, the twin resynchronised every step)."""
+    import torch
+
+    from gym_amd.rollout import DeviceRollout
+    from helpers import MAX_OBS_ULPS, ulps32
+    from oracle.oracle import OracleVecEnv
+
+    n = (1 << 19) + 77
+    a = DeviceRollout("CartPole-v1", n, seed=21, action_seed=22, max_episode_steps=30)
+    b = DeviceRollout("CartPole-v1", n, seed=21, action_seed=22, max_episode_steps=30, obs_carries_state=True)
+    o = OracleVecEnv(0, n, 30, seed=21, action_seed=22)
+    ob0 = o.reset(seed=21)
+    assert np.array_equal(a.reset(seed=21).cpu().numpy(), ob0) and np.array_equal(b.reset(seed=21).cpu().numpy(), ob0)
+    ended = 0
+    for t in range(48):
+        act = o.sample_actions()
+        dev = torch.from_numpy(act).cuda()
+        torch.cuda.synchronize()
+        oa, obb = a.step(dev), b.step(dev)
+        a.synchronize(), b.synchronize()
+        for x, y in zip(oa, obb):
+            assert torch.equal(x, y), t
+        assert torch.equal(a.final_obs, b.final_obs)
+        la, lb = a.handle.last_launch(), b.handle.last_launch()
+        assert la["envs_per_lane"] == 1 and lb["envs_per_lane"] == 1 and lb["out_mode"] == 3 and la["out_mode"] != 3, (la, lb)
+        ro, rr, rte, rtr, _, _ = o.step(act)
+        assert np.array_equal(oa[2].cpu().numpy().astype(bool), rte) and np.array_equal(oa[3].cpu().numpy().astype(bool), rtr), t
+        assert ulps32(oa[0].cpu().numpy(), ro).max() <= MAX_OBS_ULPS and np.array_equal(oa[1].cpu().numpy(), rr), t
+        ended += int((rte | rtr).sum())
+        if t % 8 == 7:      # the twin continues from the device's state (fp64 rounding differences must not accumulate into a mask flip)
+            st, el = a.handle.get_state()
+            np.testing.assert_allclose(st, o.state, rtol=1e-12, atol=1e-13)
+            o.state[:] = st
+    assert ended > n
+    sa, sb = a.handle.get_state(), b.handle.get_state()
+    assert _same(sa[0], sb[0]) and np.array_equal(sa[1], sb[1]) and np.array_equal(a.handle.get_episodes(), b.handle.get_episodes())
+    a.close(), b.close()
+
+
 @pytest.mark.parametrize("gid", KINDS)
 def test_values_the_pair_cannot_hold_escape_and_come_back_exactly(gid):
     """Injected states with components outside float32's normal range (1e-300, 1e200), zeros of both signs, exact float32 values, NaN
