@@ -164,6 +164,42 @@ def main():
             e.close()
         total += 2 * 3 * n * K
     print(f"ok randomized fused == per-step == tape: {case + 1} cases", flush=True)
+    # round 6: step(actions) in its four forms — ordinary, compact outputs, the observation carries the state (mxv_adopt_obs), both — fed the
+    # SAME actions, below and above the size where the launch switches to one env per lane (2^19): every output of every step and the
+    # final fp64 state bit for bit (compact rewards: the float32 cast of the ordinary ones), through autoresets and partial resets
+    for gid in ("CartPole-v1", "MountainCar-v0", "MountainCarContinuous-v0"):
+        for n in (70001, (1 << 19) + 77):
+            forms = [DeviceRollout(gid, n, seed=7, action_seed=8, max_episode_steps=25, reward_f32=c, action_i32=c, obs_carries_state=h)
+                     for c, h in ((False, False), (True, False), (False, True), (True, True))]
+            for e in forms:
+                e.reset(seed=7)
+            steps = int(os.environ.get("SOAK_STEP_FORMS_STEPS", "150"))
+            for t in range(steps):
+                forms[0].sample_actions()
+                forms[0].synchronize()
+                act = forms[0].actions.clone()
+                torch.cuda.synchronize()
+                outs = [e.step(act.to(e.actions.dtype)) for e in forms]
+                for e in forms:
+                    e.synchronize()
+                for c, o in enumerate(outs[1:], 1):
+                    assert torch.equal(o[0], outs[0][0]) and torch.equal(o[2], outs[0][2]) and torch.equal(o[3], outs[0][3]), (gid, n, t, c)
+                    assert torch.equal(o[1].double(), outs[0][1].to(o[1].dtype).double()), (gid, n, t, c, "reward")
+                    assert torch.equal(forms[c].final_obs, forms[0].final_obs), (gid, n, t, c, "final_obs")
+                if t == steps // 2:
+                    mask = (torch.arange(n, device="cuda") % 5 == 0).to(torch.uint8)
+                    torch.cuda.synchronize()
+                    first = forms[0].reset(mask=mask).clone()
+                    for e in forms[1:]:
+                        assert torch.equal(e.reset(mask=mask), first)
+            ref = forms[0].handle.get_state()
+            for e in forms[1:]:
+                st = e.handle.get_state()
+                assert np.array_equal(st[0], ref[0]) and np.array_equal(st[1], ref[1]) and np.array_equal(e.handle.get_episodes(), forms[0].handle.get_episodes())
+            for e in forms:
+                e.close()
+            total += 4 * n * steps
+            print(f"ok step(actions) four forms {gid:26s} n={n:<7d} steps={steps}", flush=True)
     print(f"soak passed: {total:.3e} env-steps compared in {time.time() - t0:.0f} s")
 
 
