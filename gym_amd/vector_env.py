@@ -704,9 +704,12 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
             continue
         if what in ("normalize_observation", "normalize_reward"):
             base = getattr(env, "unwrapped", env)
-            if not isinstance(base, HipVectorEnv):
+            if not isinstance(base, HipVectorEnv) and what == "normalize_observation":
+                # (around a toy_text sub-env the reference's wrapper returns float64 scalars that SyncVectorEnv then writes into the
+                # Discrete space's int64 batch — truncated to integers: nothing a caller could want reproduced)
                 env.close()
-                raise NotImplementedError("wrappers=NormalizeObservation / NormalizeReward are mapped for the classic-control ids (Box observations)")
+                raise NotImplementedError("wrappers=NormalizeObservation is mapped for the classic-control ids (Box observations); "
+                                          "wrap the toy_text vector env with gym_amd.NormalizeObservation instead")
             from .wrappers import SubEnvNormalizeObservation, SubEnvNormalizeReward
 
             env = (SubEnvNormalizeObservation if what == "normalize_observation" else SubEnvNormalizeReward)(env, **kw)

@@ -291,10 +291,12 @@ class VectorListInfo(_VectorWrapper):
         return list_info
 
 
-def _hip_base(env, who: str) -> HipVectorEnv:
+def _hip_base(env, who: str):
+    """The engine's vector env under the wrappers: the classic-control adapter, or (round 6) a toy_text one — the reference's Normalize*
+    take any vector env (normalize.py:57-70, :104-121); the statistics live on the env's device either way."""
     base = getattr(env, "unwrapped", env)
-    if not isinstance(base, HipVectorEnv):
-        raise TypeError(f"gym_amd.wrappers.{who} wraps a HipVectorEnv (the statistics live on its device)")
+    if not _has_fused_statistics(base):
+        raise TypeError(f"gym_amd.wrappers.{who} wraps one of the engine's vector envs (the statistics live on its device)")
     return base
 
 
@@ -355,7 +357,7 @@ class _SubEnvDevice(_StagedIO):
 
     def _device_setup(self, env, dim, inner_ok, device):
         base = getattr(env, "unwrapped", env)
-        on = device if device is not None else (isinstance(base, HipVectorEnv) and env.num_envs >= SUBENV_DEVICE_MIN)
+        on = device if device is not None else (_has_fused_statistics(base) and env.num_envs >= SUBENV_DEVICE_MIN)
         self._sub = None
         if not on:
             return False
@@ -363,8 +365,8 @@ class _SubEnvDevice(_StagedIO):
 
         from . import _native
 
-        if not isinstance(base, HipVectorEnv):
-            raise TypeError("the device form of the per-sub-env Normalize* wrappers needs a HipVectorEnv underneath")
+        if not _has_fused_statistics(base):
+            raise TypeError("the device form of the per-sub-env Normalize* wrappers needs one of the engine's vector envs underneath")
         self._torch = torch
         self._dev = torch.device("cuda", base.handle.device)
         self._sub = _native.SubNorm(dim, env.num_envs, device=base.handle.device)
@@ -562,8 +564,12 @@ class NormalizeObservation(_StagedIO, _VectorWrapper):
         self.epsilon = epsilon
         self._torch = torch
         self._dev = torch.device("cuda", base.handle.device)
-        self._rn = RunningNormalizer(self.num_envs, int(base.single_observation_space.shape[0]),
-                                     device=base.handle.device, obs_epsilon=epsilon)
+        shape = getattr(base.single_observation_space, "shape", None)
+        if shape is None:       # Blackjack's Tuple observations: the reference's RunningMeanStd(shape=None) cannot be built either (normalize.py:66-69)
+            base_name = type(base.single_observation_space).__name__
+            raise TypeError(f"NormalizeObservation needs an observation space with a shape (got {base_name})")
+        # Discrete observations (the tabular toy_text ids) are scalars per env: shape () -> one column (exact in float32: < 2^24 states)
+        self._rn = RunningNormalizer(self.num_envs, int(shape[0]) if shape else 1, device=base.handle.device, obs_epsilon=epsilon)
         # inner wrappers that leave the observations alone: then the base env's staged observations ARE what step() returned
         self._staged_setup(base, (RecordEpisodeStatistics, NormalizeReward))
 
@@ -596,8 +602,9 @@ class NormalizeObservation(_StagedIO, _VectorWrapper):
         """The reference's public method (normalize.py:90-93): folds `obs` — the array passed in, whatever it is — into obs_rms and
         returns it normalised."""
         t = self._torch
-        x = t.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)).to(self._dev)
-        return self._rn.normalize_obs(x).cpu().numpy()
+        obs = np.asarray(obs)
+        x = t.from_numpy(np.ascontiguousarray(obs, dtype=np.float32).reshape(self.num_envs, -1)).to(self._dev)
+        return self._rn.normalize_obs(x).cpu().numpy().reshape(obs.shape)
 
     def close(self):
         self._rn.close()
