@@ -612,14 +612,18 @@ def _sub_env_wrappers(wrappers):
         RescaleAction(min_action=, max_action=)
                                               Box-action ids (rescale_action.py:45): the action space becomes Box(min, max), actions are
                                               mapped affinely onto the env's own bounds and clipped (SubEnvRescaleAction)
+        TransformObservation(f=), TransformReward(f=)
+                                              f on every sub-env's observation / reward (transform_observation.py:34-43,
+                                              transform_reward.py:36-44): on the host, over the whole batch once f(batch) has been
+                                              checked against f(row) on the first batch (wrappers._RowMap), row by row otherwise
         FlattenObservation                    classic-control observations are flat Box vectors already (flatten_observation.py:33-43): a no-op
         NormalizeObservation(epsilon=), NormalizeReward(gamma=, epsilon=)
                                               per-sub-env running statistics (a batch of one per update) — a DIFFERENT normalisation from
                                               the vector-level gym_amd.NormalizeObservation / NormalizeReward (batch statistics): mapped
                                               to SubEnvNormalizeObservation / SubEnvNormalizeReward — the mxv_subnorm_* device kernels
                                               from 4096 sub-envs, the same arithmetic in NumPy over the adapter's arrays below
-    in the order given (innermost first, as the reference applies them).  Anything else (lambdas, observation transforms, ...) cannot
-    run inside the device engine.  Returns (max_episode_steps or None, [post-construction vector wrappers])."""
+    in the order given (innermost first, as the reference applies them).  Anything else (lambdas that wrap the env themselves, pixel /
+    frame-stack transforms, ...) cannot run inside the device engine.  Returns (max_episode_steps or None, [post-construction vector wrappers])."""
     import functools
 
     if wrappers is None:
@@ -651,6 +655,8 @@ def _sub_env_wrappers(wrappers):
             post.append(("identity_for_classic_control", {"wrapper": name}))
         elif name == "RescaleAction" and not args and set(kw) == {"min_action", "max_action"}:
             post.append(("rescale_action", kw))
+        elif name in ("TransformObservation", "TransformReward") and ((len(args) == 1 and not kw) or (not args and set(kw) == {"f"})):
+            post.append(("transform_observation" if name == "TransformObservation" else "transform_reward", {"f": args[0] if args else kw["f"]}))
         elif name == "NormalizeObservation" and not args and set(kw) <= {"epsilon"}:
             post.append(("normalize_observation", kw))
         elif name == "NormalizeReward" and not args and set(kw) <= {"gamma", "epsilon"}:
@@ -658,7 +664,7 @@ def _sub_env_wrappers(wrappers):
         else:
             raise NotImplementedError(
                 f"per-sub-environment wrapper {w!r} cannot run inside the device engine (no Python sub-envs); recognised: TimeLimit, "
-                "RecordEpisodeStatistics, NormalizeObservation, NormalizeReward, ClipAction, RescaleAction, FlattenObservation, OrderEnforcing, "
+                "RecordEpisodeStatistics, NormalizeObservation, NormalizeReward, ClipAction, RescaleAction, TransformObservation, TransformReward, FlattenObservation, OrderEnforcing, "
                 "PassiveEnvChecker as classes or functools.partial — otherwise wrap the vector env "
                 "(gym_amd.VectorEnvWrapper) or pass the env's own keyword arguments / max_episode_steps")
     return limit, post
@@ -693,6 +699,14 @@ def make(id: str, num_envs: int = 1, asynchronous: bool = False, **kwargs) -> Ve
                 from .wrappers import SubEnvClipAction
 
                 env = SubEnvClipAction(env)      # the reward's action penalty sees the clipped action (continuous_mountain_car.py:169)
+            continue
+        if what in ("transform_observation", "transform_reward"):
+            from .wrappers import SubEnvTransformObservation, SubEnvTransformReward
+
+            if what == "transform_observation" and not isinstance(getattr(env, "unwrapped", env), HipVectorEnv):
+                env.close()
+                raise NotImplementedError("wrappers=TransformObservation is mapped for the classic-control ids (Box observations)")
+            env = (SubEnvTransformObservation if what == "transform_observation" else SubEnvTransformReward)(env, **kw)
             continue
         if what == "rescale_action":
             if not isinstance(getattr(env, "unwrapped", env), HipVectorEnv) or type(env.single_action_space).__name__ != "Box":

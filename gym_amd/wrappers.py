@@ -20,7 +20,7 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics", "SubEnvClipAction", "SubEnvRescaleAction",
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics", "SubEnvClipAction", "SubEnvRescaleAction", "SubEnvTransformObservation", "SubEnvTransformReward",
            "SubEnvNormalizeObservation", "SubEnvNormalizeReward"]
 
 
@@ -82,7 +82,7 @@ class RecordEpisodeStatistics(_VectorWrapper):
         # env's step() returns (record_episode_statistics.py:119-121), so with a NormalizeReward underneath the episode returns
         # are sums of NORMALISED rewards: in that stacking order the returns are accumulated here on the host from the wrapped
         # step's rewards (one vectorised float32 add per step, the reference's own arithmetic); lengths stay the TimeLimit counter.
-        self._host_returns = any(isinstance(w, (NormalizeReward, SubEnvNormalizeReward)) for w in chain)
+        self._host_returns = any(isinstance(w, (NormalizeReward, SubEnvNormalizeReward, SubEnvTransformReward)) for w in chain)
         self._acc = None
 
     # episode_returns / episode_lengths are None before the first reset (record_episode_statistics.py:89-90)
@@ -443,12 +443,13 @@ class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
     def reset(self, **kwargs):
         obs, infos = self.env.reset(**kwargs)
         if self._sub is None:
-            return self._normalize(obs).astype(obs.dtype), infos
+            return self._out(self._normalize(obs), obs), infos
         t = self._torch
-        y = self._dev_buf("_buf_y", obs.shape, t.float32)
+        wide = self.__dict__.get("_wide", False)
+        y = self._dev_buf("_buf_y", obs.shape, t.float64 if wide else t.float32)
         x = self._base.handle.staging_view()[0] if self._staged else self._up(obs, np.float32)
-        self._sub.observations(1, x, None, None, None, y, True, None, self.epsilon)
-        return self._to_host(y, obs.shape, np.float32), infos
+        self._sub.observations(1, x, None, None, None, y, not wide, None, self.epsilon)
+        return self._to_host(y, obs.shape, np.float64 if wide else np.float32), infos
 
     def step(self, action):
         obs, rew, term, trunc, infos = self.env.step(action)
@@ -456,7 +457,7 @@ class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
         if self._sub is not None:
             return self._step_device(obs, rew, term, trunc, infos, done)
         if not done.any():
-            return self._normalize(obs).astype(obs.dtype), rew, term, trunc, infos
+            return self._out(self._normalize(obs), obs), rew, term, trunc, infos
         idx = np.flatnonzero(done)
         fin = infos["final_observation"]
         first = obs.copy()                                            # what every sub-env's step() returned: terminal rows where it ended
@@ -467,7 +468,7 @@ class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
             new_fin[i] = y[i].copy()                                  # float64, as the sub-env's wrapper returned it
         y[idx] = self._normalize(obs[idx], idx)                       # ... then each finished sub-env's reset(): its second update
         self._set_final(infos, new_fin)
-        return y.astype(obs.dtype), rew, term, trunc, infos
+        return self._out(y, obs), rew, term, trunc, infos
 
     @staticmethod
     def _set_final(infos, new_fin):
@@ -476,10 +477,17 @@ class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
         else:
             infos["final_observation"] = new_fin
 
+    def _out(self, y, obs):
+        """The batch as the vector env hands it out: the float32 cast of the float64 results (numpy_utils.py:49-50 writes them into the
+        float32 observation buffer) — unless an observation transform sits right above (`_wide`, set by SubEnvTransformObservation): the
+        reference's TransformObservation receives the float64 rows and the cast happens after it."""
+        return y if self.__dict__.get("_wide", False) else y.astype(obs.dtype)
+
     def _step_device(self, obs, rew, term, trunc, infos, done):
         t = self._torch
         idx = np.flatnonzero(done)
-        y = self._dev_buf("_buf_y", obs.shape, t.float32)
+        wide = self.__dict__.get("_wide", False)
+        y = self._dev_buf("_buf_y", obs.shape, t.float64 if wide else t.float32)
         yfin = self._dev_buf("_buf_yfin", obs.shape, t.float64)
         if self._staged:
             h = self._base.handle
@@ -492,7 +500,7 @@ class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
                 f = infos["final_observation"]
                 dense[idx] = np.stack([f[i] for i in idx])
             fin = self._up(dense, np.float32)
-        self._sub.observations(1, x, fin, te, tr, y, True, yfin, self.epsilon)
+        self._sub.observations(1, x, fin, te, tr, y, not wide, yfin, self.epsilon)
         if idx.size:
             rows = yfin[t.from_numpy(idx).to(self._dev)].cpu().numpy()       # the float64 rows of the finished sub-envs only
             n = len(done)
@@ -507,7 +515,80 @@ class SubEnvNormalizeObservation(_SubEnvDevice, _VectorWrapper):
                 dict.__setitem__(infos, "final_observation", _Pending(build))
             else:
                 infos["final_observation"] = build()
-        return self._to_host(y, obs.shape, np.float32), rew, term, trunc, infos
+        return self._to_host(y, obs.shape, np.float64 if wide else np.float32), rew, term, trunc, infos
+
+
+class _RowMap:
+    """A user function the reference applies to ONE sub-env's value (an observation row / a scalar reward), applied to a batch.  The first
+    batch decides how: f(batch) is compared with f(row) of (up to 256 of) its rows — equal shape, dtype and bits, as for elementwise maps
+    such as `lambda o: np.clip(o, -10, 10)` — and from then on f sees whole batches; any difference or exception keeps the row-by-row
+    application, which is what the reference's N Python sub-envs do.  (A function with side effects is called twice on those first rows.)"""
+
+    def __init__(self, f):
+        assert callable(f)
+        self.f, self.batched = f, None
+
+    def __call__(self, x):
+        if self.batched:
+            return np.asarray(self.f(x))
+        if self.batched is None:
+            k = min(len(x), 256)
+            rows = [np.asarray(self.f(x[i])) for i in range(k)]
+            try:
+                whole = np.asarray(self.f(x))
+                self.batched = bool(whole.shape[:1] == (len(x),) and all(whole[i].shape == rows[i].shape and whole[i].dtype == rows[i].dtype
+                                                                         and np.array_equal(whole[i], rows[i], equal_nan=True) for i in range(k)))
+            except Exception:  # noqa: BLE001
+                self.batched = False
+            if self.batched:
+                return whole
+            return np.stack(rows + [np.asarray(self.f(x[i])) for i in range(k, len(x))])
+        return np.stack([np.asarray(self.f(r)) for r in x])
+
+
+class SubEnvTransformObservation(_VectorWrapper):
+    """`wrappers=partial(TransformObservation, f=...)` (gym/wrappers/transform_observation.py:34-43 around every sub-env): f on every
+    sub-env's observation — the terminal one of a finished episode (-> `final_observation`) and the reset one that follows — in the dtype the
+    wrapper underneath produces (float64 rows above NormalizeObservation, as in the reference's chain), the batch cast to the observation
+    space's dtype afterwards (the space is not changed by the wrapper; numpy_utils.py:49-50).  See _RowMap for how f meets a batch."""
+
+    def __init__(self, env, f):
+        super().__init__(env)
+        self.f, self._map = f, _RowMap(f)
+        self._dtype = env.single_observation_space.dtype
+        e = env
+        while isinstance(e, (SubEnvNormalizeReward, SubEnvTransformReward, SubEnvEpisodeStatistics, RecordEpisodeStatistics)):      # leave the observations alone
+            e = e.env
+        if isinstance(e, SubEnvNormalizeObservation):
+            e._wide = True
+
+    def reset(self, **kwargs):
+        obs, infos = self.env.reset(**kwargs)
+        return self._map(obs).astype(self._dtype), infos
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        done = term | trunc
+        if done.any() and "final_observation" in infos:
+            fin = infos["final_observation"]
+            new_fin = np.full(len(done), None, dtype=object)
+            for i in np.flatnonzero(done):
+                new_fin[i] = self.f(fin[i])
+            SubEnvNormalizeObservation._set_final(infos, new_fin)
+        return self._map(obs).astype(self._dtype), rew, term, trunc, infos
+
+
+class SubEnvTransformReward(_VectorWrapper):
+    """`wrappers=partial(TransformReward, f=...)` (gym/wrappers/transform_reward.py:36-44 around every sub-env): f on every sub-env's
+    reward, the batch a float64 array as SyncVectorEnv keeps it (sync_vector_env.py:66).  See _RowMap."""
+
+    def __init__(self, env, f):
+        super().__init__(env)
+        self.f, self._map = f, _RowMap(f)
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self.env.step(action)
+        return obs, np.asarray(self._map(rew), dtype=np.float64), term, trunc, infos
 
 
 class SubEnvNormalizeReward(_SubEnvDevice, _VectorWrapper):

@@ -125,6 +125,53 @@ def rescale_action_case():
         print("RescaleAction", name, "reward range", out["reward"].min(), out["reward"].max())
 
 
+def transform_case():
+    """vector_make_transform_Pendulum.npz — the continuous-control recipe of the PPO scripts people run on gym.vector.make:
+    wrappers=[TimeLimit(12), ClipAction, NormalizeObservation, TransformObservation(clip +-1.5), NormalizeReward(gamma=0.97),
+    TransformReward(clip +-0.8)] around every sub-env, run by THE REFERENCE (transform_observation.py:34-43, transform_reward.py:36-44 on
+    top of normalize.py): the observation transform sees the float64 rows NormalizeObservation returns and the batch rounds to float32
+    afterwards; final observations stay float64; the bounds are tight so that both clips act."""
+    from gym.wrappers import ClipAction, NormalizeObservation, NormalizeReward, TransformObservation, TransformReward
+
+    N, T, K = 6, 120, 12
+    env = gym.vector.make("Pendulum-v1", num_envs=N, asynchronous=False,
+                          wrappers=[functools.partial(TimeLimit, max_episode_steps=K), ClipAction, NormalizeObservation,
+                                    functools.partial(TransformObservation, f=lambda o: np.clip(o, -1.5, 1.5)),
+                                    functools.partial(NormalizeReward, gamma=0.97),
+                                    functools.partial(TransformReward, f=lambda r: np.clip(r, -0.8, 0.8))])
+    obs0, _ = env.reset(seed=4321)
+    rng = np.random.default_rng(13)
+    rec = {k: [] for k in ("state_pre", "elapsed_pre", "action", "obs", "reward", "terminated", "truncated", "final_obs", "raw_obs_post")}
+    raw_obs = lambda e: e.unwrapped._get_obs()      # noqa: E731
+    raw_obs0 = np.stack([raw_obs(e) for e in env.envs])
+
+    def time_limit(e):
+        while type(e).__name__ != "TimeLimit" or e._max_episode_steps != K:
+            e = e.env
+        return e
+
+    for t in range(T):
+        rec["state_pre"].append(np.array([np.asarray(e.unwrapped.state, dtype=np.float64) for e in env.envs]))
+        rec["elapsed_pre"].append(np.array([time_limit(e)._elapsed_steps for e in env.envs], dtype=np.int32))
+        a = rng.uniform(-3, 3, (N, 1)).astype(np.float32)          # (outside [-2, 2] a third of the time: ClipAction's business)
+        obs, rew, term, trunc, infos = env.step(a)
+        assert obs.dtype == np.float32 and rew.dtype == np.float64
+        fo = np.full((N, 3), np.nan)
+        if "final_observation" in infos:
+            for i, f in enumerate(infos["final_observation"]):
+                if f is not None:
+                    assert f.dtype == np.float64
+                    fo[i] = f
+        for k, v in (("action", a), ("obs", obs), ("reward", rew), ("terminated", term), ("truncated", trunc), ("final_obs", fo),
+                     ("raw_obs_post", np.stack([raw_obs(e) for e in env.envs]))):
+            rec[k].append(v)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(max_episode_steps=np.int64(K), obs0=obs0, raw_obs0=raw_obs0, gamma=np.float64(0.97), obs_clip=np.float64(1.5), reward_clip=np.float64(0.8))
+    assert (np.abs(out["obs"]) == 1.5).mean() > 0.02 and (np.abs(out["reward"]) == 0.8).mean() > 0.02 and out["truncated"].sum() > 20
+    np.savez_compressed(os.path.join(HERE, "vector_make_transform_Pendulum.npz"), **out)
+    print("transform: clipped obs", float((np.abs(out["obs"]) == 1.5).mean()), "clipped rewards", float((np.abs(out["reward"]) == 0.8).mean()))
+
+
 def main():
     normalize_case("CartPole-v1", "CartPole", lambda rng, n: (rng.random(n) < np.linspace(0.15, 0.85, n)).astype(np.int64))
     normalize_case("Pendulum-v1", "Pendulum", lambda rng, n: rng.uniform(-2, 2, (n, 1)).astype(np.float32))
@@ -166,6 +213,8 @@ if __name__ == "__main__":
         clip_action_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "rescaleaction":
         rescale_action_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "transform":
+        transform_case()
     else:
         main()
         clip_action_case()

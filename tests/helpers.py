@@ -457,6 +457,88 @@ def replay_vector_make_normalize(name, exact, device=None):
     return episodes
 
 
+def replay_vector_make_transform(exact, device=None):
+    """tests/golden/vector_make_transform_Pendulum.npz (THE REFERENCE: wrappers=[TimeLimit(12), ClipAction, NormalizeObservation,
+    TransformObservation(clip), NormalizeReward, TransformReward(clip)] around every sub-env — the continuous-control PPO recipe) through
+    the chain gym_amd.make builds from the same list, teacher-forced like replay_vector_make_normalize.  exact: bit-equal (oracle-backed
+    handle); else the engine's raw tolerances propagated through the statistics (subnorm_bounds; a clip only shrinks a difference)."""
+    import functools
+
+    import gym_amd
+    from gym_amd.wrappers import _VectorWrapper
+
+    g = np.load(os.path.join(GOLDEN, "vector_make_transform_Pendulum.npz"))
+    T, N = g["terminated"].shape
+    K, gamma, oc, rc = int(g["max_episode_steps"]), float(g["gamma"]), float(g["obs_clip"]), float(g["reward_clip"])
+    W = {n: reference_wrapper_stub(n) for n in ("TimeLimit", "ClipAction", "NormalizeObservation", "TransformObservation", "NormalizeReward", "TransformReward")}
+    wrappers = [functools.partial(W["TimeLimit"], max_episode_steps=K), W["ClipAction"], W["NormalizeObservation"],
+                functools.partial(W["TransformObservation"], f=lambda o: np.clip(o, -oc, oc)),
+                functools.partial(W["NormalizeReward"], gamma=gamma), functools.partial(W["TransformReward"], f=lambda r: np.clip(r, -rc, rc))]
+    env = gym_amd.make("Pendulum-v1", num_envs=N, wrappers=wrappers)
+    chain, e = [], env
+    while isinstance(e, _VectorWrapper):
+        chain.append(e)
+        e = e.env
+    assert [type(w).__name__ for w in chain] == ["SubEnvTransformReward", "SubEnvNormalizeReward", "SubEnvTransformObservation", "SubEnvNormalizeObservation"]
+    base, norm_obs = e, chain[-1]
+
+    # the reference's reset observations for the finished sub-envs (its resets are PCG64 draws): a shim right above the engine
+    class ReferenceResets(_VectorWrapper):
+        t = 0
+
+        def reset(self, **kw):
+            obs, infos = self.env.reset(**kw)
+            return g["raw_obs0"].copy(), infos
+
+        def step(self, action):
+            obs, rew, term, trunc, infos = self.env.step(action)
+            done = term | trunc
+            obs = obs.copy()
+            obs[done] = g["raw_obs_post"][self.t][done]
+            return obs, rew, term, trunc, infos
+
+    if device is None:          # the chain as make() built it (eight sub-envs: the wrappers' NumPy form), the shim slipped in underneath
+        shim = ReferenceResets(base)
+        norm_obs.env = shim
+    else:                       # the same chain by hand with the device / NumPy form of both normalisers forced
+        from gym_amd.wrappers import SubEnvNormalizeObservation, SubEnvNormalizeReward, SubEnvTransformObservation, SubEnvTransformReward
+
+        env.close()
+        base = gym_amd.make("Pendulum-v1", num_envs=N, max_episode_steps=K)
+        shim = ReferenceResets(base)
+        norm_obs = SubEnvNormalizeObservation(shim, device=device)
+        env = SubEnvTransformReward(SubEnvNormalizeReward(SubEnvTransformObservation(norm_obs, lambda o: np.clip(o, -oc, oc)), gamma=gamma, device=device),
+                                    lambda r: np.clip(r, -rc, rc))
+    assert norm_obs._wide is True
+    bound = None if exact else subnorm_bounds(g, "Pendulum")
+    obs0, _ = env.reset(seed=1)
+    assert obs0.dtype == np.float32 and np.array_equal(obs0, g["obs0"])
+    episodes = 0
+    for t in range(T):
+        shim.t = t
+        base.handle.set_state(np.ascontiguousarray(g["state_pre"][t].T), g["elapsed_pre"][t])
+        obs, rew, term, trunc, infos = env.step(g["action"][t])
+        done = g["terminated"][t] | g["truncated"][t]
+        assert np.array_equal(term, g["terminated"][t]) and np.array_equal(trunc, g["truncated"][t]), t
+        assert obs.dtype == np.float32 and rew.dtype == np.float64 and np.abs(obs).max() <= oc and np.abs(rew).max() <= rc
+        if exact:
+            assert np.array_equal(obs, g["obs"][t]) and np.array_equal(rew, g["reward"][t]), t
+        else:
+            assert (np.abs(obs - g["obs"][t]) <= bound["obs"][t]).all() and (np.abs(rew - g["reward"][t]) <= bound["reward"][t]).all(), t
+        for i in np.flatnonzero(done):
+            fo = infos["final_observation"][i]
+            assert fo.dtype == np.float64 and np.abs(fo).max() <= oc
+            if exact:
+                assert np.array_equal(fo, g["final_obs"][t][i]), (t, i)
+            else:
+                assert (np.abs(fo - g["final_obs"][t][i]) <= bound["final_obs"][t][i]).all(), (t, i)
+            episodes += 1
+    assert episodes == int((g["terminated"] | g["truncated"]).sum()) > 40
+    assert chain[0]._map.batched is True or device is not None
+    env.close()
+    return episodes
+
+
 def subnorm_bounds(g, name):
     """Per-element tolerances of the per-sub-env Normalize* replay on the device, DERIVED from the engine's raw-output bars
     (MAX_OBS_ULPS float32 ulps on observations; REWARD_RTOL / REWARD_ATOL on rewards) by first-order propagation through the statistics.

@@ -780,6 +780,13 @@ def test_vector_make_clipaction_charges_the_clipped_action_on_the_device():
     assert replay_vector_make_clipaction(exact=False) == 60
 
 
+@pytest.mark.parametrize("device", [None, True])
+def test_vector_make_transform_wrappers_on_the_device(device):
+    from helpers import replay_vector_make_transform
+
+    assert replay_vector_make_transform(exact=False, device=device) > 40
+
+
 @pytest.mark.parametrize("name", ["Pendulum", "MountainCarContinuous"])
 def test_vector_make_rescaleaction_on_the_device(name):
     from helpers import replay_vector_make_rescaleaction

@@ -871,6 +871,25 @@ def test_vector_make_rescaleaction_matches_the_reference_bit_for_bit(monkeypatch
         gym_amd.make("CartPole-v1", num_envs=3, wrappers=functools.partial(reference_wrapper_stub("RescaleAction"), min_action=-1.0, max_action=1.0))
 
 
+def test_vector_make_transform_wrappers_replay_the_reference_bit_for_bit(monkeypatch):
+    """wrappers=[TimeLimit, ClipAction, NormalizeObservation, TransformObservation(clip), NormalizeReward, TransformReward(clip)] — the
+    continuous-control PPO recipe — as the reference ran it (golden), over the oracle-backed handle: the observation transform sees the
+    float64 rows, the batch rounds to float32 afterwards, final observations stay float64; f is applied to whole batches once checked."""
+    from gym_amd import _native
+    from gym_amd.wrappers import _RowMap
+    from helpers import replay_vector_make_transform
+    from oracle_engine import FakeHandle
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    assert replay_vector_make_transform(exact=True) > 40
+    # a function that is NOT elementwise over the batch axis stays row by row, with the reference's per-sub-env result
+    m = _RowMap(lambda o: o - o.mean())
+    x = np.arange(12, dtype=np.float64).reshape(4, 3)
+    assert np.array_equal(m(x), x - x.mean(axis=1, keepdims=True)) and m.batched is False and np.array_equal(m(x + 1), x - x.mean(axis=1, keepdims=True))
+    m = _RowMap(lambda r: 0.01 * r)
+    assert np.array_equal(m(np.array([1.0, -2.0])), np.array([0.01, -0.02])) and m.batched is True
+
+
 def test_vector_make_recognises_wrappers_by_name_and_home(monkeypatch):
     """A user class that merely shares a name with a known wrapper keeps its own semantics: it must reach the explicit error, not be
     replaced by the engine's mapping."""
