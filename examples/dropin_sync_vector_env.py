@@ -21,8 +21,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(vector_make, env_id, num_envs, steps):
-    env = vector_make(env_id, num_envs=num_envs, asynchronous=False)
+def ppo_recipe(wrappers):
+    """The wrapper list of the continuous-control PPO scripts, from whichever module provides the classes (gym.wrappers for the reference,
+    gym_amd.wrappers for the engine — gym_amd.make also accepts gym.wrappers' own): every sub-env clips its actions, normalises and clips
+    its observations with ITS OWN running statistics, normalises and clips its rewards."""
+    import functools
+
+    return [wrappers.ClipAction, wrappers.NormalizeObservation, functools.partial(wrappers.TransformObservation, f=lambda obs: np.clip(obs, -10, 10)),
+            functools.partial(wrappers.NormalizeReward, gamma=0.99), functools.partial(wrappers.TransformReward, f=lambda reward: np.clip(reward, -10, 10))]
+
+
+def run(vector_make, env_id, num_envs, steps, wrappers=None):
+    env = vector_make(env_id, num_envs=num_envs, asynchronous=False, **({} if wrappers is None else {"wrappers": wrappers}))
     obs, infos = env.reset(seed=0)
     env.action_space.seed(0)
     assert obs.shape == (num_envs,) + env.single_observation_space.shape and obs.dtype == env.single_observation_space.dtype
@@ -49,6 +59,8 @@ def main():
     ap.add_argument("--id", default="CartPole-v1")
     ap.add_argument("--envs", type=int, default=8)
     ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--recipe", action="store_true", help="wrappers=[ClipAction, NormalizeObservation, clip, NormalizeReward, clip] around every "
+                                                           "sub-env (Box-action ids: --id Pendulum-v1)")
     args = ap.parse_args()
 
     try:
@@ -58,7 +70,8 @@ def main():
         import gym
 
         gym.logger.set_level(gym.logger.ERROR)
-        r = run(lambda id, **kw: gym.vector.make(id, disable_env_checker=True, **kw), args.id, args.envs, args.steps)
+        r = run(lambda id, **kw: gym.vector.make(id, disable_env_checker=True, **kw), args.id, args.envs, args.steps,
+                ppo_recipe(gym.wrappers) if args.recipe else None)
         print(f"gym.vector.make      {args.id} x{args.envs}: {r['env_steps_per_s']:12.0f} env-steps/s  ({r['us_per_vector_step']:8.1f} us per vector step, "
               f"{r['episodes']} episodes, mean length {r['mean_episode_length']:.1f})")
     except ImportError:
@@ -66,11 +79,12 @@ def main():
 
     import gym_amd
 
-    r = run(gym_amd.vector.make, args.id, args.envs, args.steps)
+    recipe = ppo_recipe(gym_amd.wrappers) if args.recipe else None
+    r = run(gym_amd.vector.make, args.id, args.envs, args.steps, recipe)
     print(f"gym_amd.vector.make  {args.id} x{args.envs}: {r['env_steps_per_s']:12.0f} env-steps/s  ({r['us_per_vector_step']:8.1f} us per vector step, "
           f"{r['episodes']} episodes, mean length {r['mean_episode_length']:.1f})")
     big = 1 << 20
-    r = run(gym_amd.vector.make, args.id, big, 50)
+    r = run(gym_amd.vector.make, args.id, big, 50, recipe)
     print(f"gym_amd.vector.make  {args.id} x{big}: {r['env_steps_per_s']:12.0f} env-steps/s  ({r['us_per_vector_step']:8.1f} us per vector step: NumPy "
           "arrays over PCIe both ways; DeviceRollout keeps them on the device)")
 

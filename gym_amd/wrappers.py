@@ -20,7 +20,8 @@ import numpy as np
 
 from .vector_env import HipVectorEnv, LazyInfos, _Pending
 
-__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "SubEnvEpisodeStatistics", "SubEnvClipAction", "SubEnvRescaleAction", "SubEnvTransformObservation", "SubEnvTransformReward",
+__all__ = ["RecordEpisodeStatistics", "VectorListInfo", "NormalizeObservation", "NormalizeReward", "ClipAction", "RescaleAction",
+           "TransformObservation", "TransformReward", "SubEnvEpisodeStatistics", "SubEnvClipAction", "SubEnvRescaleAction", "SubEnvTransformObservation", "SubEnvTransformReward",
            "SubEnvNormalizeObservation", "SubEnvNormalizeReward"]
 
 
@@ -589,6 +590,25 @@ class SubEnvTransformReward(_VectorWrapper):
     def step(self, action):
         obs, rew, term, trunc, infos = self.env.step(action)
         return obs, np.asarray(self._map(rew), dtype=np.float64), term, trunc, infos
+
+
+# The reference's names for the action / transform wrappers, so that a wrappers list can be written without gym installed:
+# make(id, n, wrappers=[ClipAction, partial(TransformReward, f=...)]) recognises them by name and home like gym.wrappers' own classes,
+# and applied by hand to one of the engine's vector envs they are the per-sub-env forms above.
+class ClipAction(SubEnvClipAction):
+    pass
+
+
+class RescaleAction(SubEnvRescaleAction):
+    pass
+
+
+class TransformObservation(SubEnvTransformObservation):
+    pass
+
+
+class TransformReward(SubEnvTransformReward):
+    pass
 
 
 class SubEnvNormalizeReward(_SubEnvDevice, _VectorWrapper):

@@ -206,6 +206,9 @@ def test_example_dropin_loop_runs_on_the_engine():
     assert r["episodes"] > 200 and 15 < r["mean_episode_length"] < 30, r
     r = mod.run(gym_amd.vector.make, "MountainCar-v0", 64, 450)
     assert r["episodes"] == 128 and r["mean_episode_length"] == 200, r       # a random policy never reaches the flag: two truncations per env
+    # the continuous-control PPO wrapper list around every sub-env, written with gym_amd.wrappers' names (8192 sub-envs: the device kernels)
+    r = mod.run(gym_amd.vector.make, "Pendulum-v1", 8192, 210, mod.ppo_recipe(gym_amd.wrappers))
+    assert r["episodes"] == 8192 and r["mean_episode_length"] == 200, r
 
 
 def test_device_rollout_state_dict_resumes_bit_identically():
