@@ -136,6 +136,18 @@ def test_gym_make_without_num_envs_is_a_gym_env(monkeypatch):
     assert isinstance(gym.make("hip/CartPole-v1", num_envs=3), gym.vector.VectorEnv)
     with pytest.raises(NotImplementedError, match="num_envs=1"):
         gym.make("hip/FrozenLake-v1")
+    # what gym.make itself wraps around an env works on top of the single env like on any gym.Env (gym/envs/registration.py:676-695)
+    auto = gym.make("hip/CartPole-v1", autoreset=True, max_episode_steps=9)
+    assert type(auto).__name__ == "AutoResetWrapper" and type(auto.env).__name__ == "TimeLimit"
+    auto.reset(seed=3)
+    ends = 0
+    for _ in range(60):
+        obs, r, te, tr, info = auto.step(auto.action_space.sample())
+        if te or tr:
+            ends += 1
+            assert info["final_observation"].shape == (4,) and "final_info" in info
+    assert ends >= 6 and obs.dtype == np.float32 and isinstance(r, float) and isinstance(te, bool)
+    auto.close()
     short = gym.make("hip/Pendulum-v1", time_limit=7)
     short.reset(seed=0)
     assert [short.step(short.action_space.sample())[3] for _ in range(7)] == [False] * 6 + [True]
