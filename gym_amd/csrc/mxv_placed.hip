@@ -7,7 +7,7 @@
 // (profiles/r3/r3a_*; the probes were removed in round 4, tools/README.md).  The classes are three contiguous thirds of the physical address space —
 // 3 x 96 GB, what the three ranks of a 12-high HBM3E stack would give — (tools/vmm_classmap.hip, profiles/r3/r3c_hbm_class_map_whole_device.jsonl):
 // a fresh process is handed the first third for its first ~90 GiB, so ordinary allocations all share a class ("slow box") unless
-// earlier activity has scrambled the driver's free lists ("fast placement").  That is the placement lottery of DESIGN.md §6.  Nothing in
+// earlier activity has scrambled the driver's free lists ("fast placement").  That is the placement lottery of DESIGN.md §3.  Nothing in
 // software sees the class of a page — but HIP's virtual-memory API decides which physical memory backs which virtual range, and the class
 // of a chunk can be MEASURED: two concurrent streams, one into the chunk, one into a reference chunk of a known class.
 //

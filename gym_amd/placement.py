@@ -1,4 +1,4 @@
-"""Trajectory tensors sorted by HBM class (DESIGN.md §6).
+"""Trajectory tensors sorted by HBM class (DESIGN.md §3).
 
 The MI355X's HBM address space consists of three contiguous classes of 96 GB (what the three ranks of a 12-high HBM3E stack would give).
 Long store streams written concurrently interfere when the physical memory behind them shares a class: the fused CartPole rollout

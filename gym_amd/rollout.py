@@ -209,7 +209,7 @@ class DeviceRollout:
 
         layout="sorted" (what "auto" picks for sets of 1 GiB and more): ordinary allocations, but the reward / action tensors are
         made to lie in another third of the HBM address space than the observations (_sorted_buffers): the write-bound rollout then
-        runs in its fast mode by construction (DESIGN.md §6) instead of one time in three; the report is left in
+        runs in its fast mode by construction (DESIGN.md §3) instead of one time in three; the report is left in
         `self.last_placement`.  The search holds extra device memory while it runs (typically a few GiB for 0.1 s): at most
         `max_park_bytes` (default: half of what is free beyond the set and at most 8 GiB whenever anybody else holds device memory or this
         process is one of several ranks; on an otherwise EMPTY device of a single process — MXV_PLACEMENT's default "auto" resolves to

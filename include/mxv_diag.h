@@ -48,7 +48,7 @@ int mxv_write_probe_env(int32_t device, int32_t env_id, int32_t flags, int64_t n
  *    an 8-byte-per-lane stream (rewards, actions) written concurrently run 10-12 % slower when the PHYSICAL memory behind them lies in
  *    the same CLASS of HBM regions — the classes are three contiguous thirds of the physical address space (3 x 96 GB: what the three
  *    ranks of a 12-high HBM3E stack would give; profiles/r3/r3c_hbm_class_map_whole_device.jsonl) —; a whole CartPole trajectory launch
- *    runs 5.4 / 5.7 / 6.4 us per 2^20-env step with none / one / both of {rewards, actions} in the observations' class (DESIGN.md §6,
+ *    runs 5.4 / 5.7 / 6.4 us per 2^20-env step with none / one / both of {rewards, actions} in the observations' class (DESIGN.md §3,
  *    profiles/r3/r3a_*).  A fresh process is handed the first third for its first ~90 GiB, so hipMalloc'ed tensors all share a class unless
  *    earlier activity scrambled the driver's free lists — the "placement lottery" of rounds 1-2.  This call builds the tensors from
  *    256-MiB physical chunks (hipMemCreate) whose class it MEASURES (two concurrent streams against a reference chunk of each class
