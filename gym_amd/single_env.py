@@ -73,6 +73,10 @@ class HipEnv(Env):
         continues it; `options` as the classic-control envs read them (classic_control/utils.py:17-46: {"low", "high"} / Pendulum's
         {"x_init", "y_init"})."""
         self._assert_open()
+        if seed is not None:      # gym.Env.reset (core.py:155-157): `self._np_random, seed = seeding.np_random(seed)`
+            from .spaces import np_random
+
+            self.__dict__["_np_random"], _ = np_random(seed)
         obs, _ = self._vec.reset(seed=seed, options=options)
         return np.array(obs[0], dtype=np.float32), {}
 
@@ -86,6 +90,25 @@ class HipEnv(Env):
         obs, rew, term, trunc, _ = self._vec.step(batch)
         return np.array(obs[0], dtype=np.float32), float(rew[0]), bool(term[0]), bool(trunc[0]), {}
 
+    # `spec`: gym.make("hip/<id>") assigns the registry's EnvSpec after construction (gym/envs/registration.py:657).  The hip/ ids are
+    # registered WITHOUT max_episode_steps — the limit lives in the engine, and a registered one would make gym.make put its own TimeLimit
+    # wrapper on top — so the spec the env shows is a copy that carries the engine's limit: code that reads env.spec.max_episode_steps
+    # (the reference's own tests do, tests/wrappers/test_record_episode_statistics.py:20) finds what the episode is actually cut at.
+    @property
+    def spec(self):
+        return self.__dict__.get("_spec")
+
+    @spec.setter
+    def spec(self, s):
+        if s is not None and hasattr(s, "max_episode_steps") and s.max_episode_steps is None and "_vec" in self.__dict__:
+            limit = int(self._vec.get_attr("_max_episode_steps")[0] or 0)
+            if limit > 0:
+                import copy
+
+                s = copy.copy(s)
+                s.max_episode_steps = limit
+        self.__dict__["_spec"] = s
+
     def close(self):
         if not self.closed:
             self._vec.close()
@@ -95,12 +118,25 @@ class HipEnv(Env):
         if self.closed:
             raise error.ClosedEnvironmentError("Trying to operate on `HipEnv`, after a call to `close()`.")
 
+    # gym.Env's generator (core.py:185-199): seeded by reset(seed=...), created on first use otherwise — the object callers and the
+    # reference's env checker expect an env to own (gym/utils/env_checker.py:83-123).  The engine's DYNAMICS do not draw from it: reset states
+    # come from the Philox4x32-10 streams keyed by the same seed, so reset(seed=s) is reproducible either way.
     @property
     def np_random(self):
-        raise AttributeError("the engine draws from Philox4x32-10 streams keyed by reset(seed=...), not from a NumPy generator (DESIGN.md §2)")
+        if self.__dict__.get("_np_random") is None:
+            from .spaces import np_random
+
+            self.__dict__["_np_random"], _ = np_random()
+        return self.__dict__["_np_random"]
+
+    @np_random.setter
+    def np_random(self, value):
+        self.__dict__["_np_random"] = value
 
     # the attributes of the reference's env objects (env.unwrapped.gravity, .state, ...)
     def __getattr__(self, name):
+        if name == "_np_random":      # (not seeded yet: None, like gym.Env's class attribute)
+            return None
         if name.startswith("_"):
             raise AttributeError(name)
         vec = self.__dict__.get("_vec")

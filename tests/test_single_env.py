@@ -154,6 +154,44 @@ def test_gym_make_without_num_envs_is_a_gym_env(monkeypatch):
     short.close()
 
 
+def test_the_references_env_checker_accepts_the_single_env(monkeypatch):
+    """gym.utils.env_checker.check_env (the checker gym.make runs on every env it builds, gym/utils/env_checker.py:231-299) on the engine's
+    single env, every classic-control id: spaces, reset(seed) determinism and the np_random contract, reset(options), step / reward / info
+    types.  And gym.make's default stack (PassiveEnvChecker included) steps it without a complaint."""
+    import warnings
+
+    from test_host_logic import _ref_gym
+
+    gym = _ref_gym()
+    from gym.utils.env_checker import check_env
+
+    from gym_amd import _native, plugin
+    from oracle_engine import FakeHandle
+
+    monkeypatch.setattr(_native, "Handle", FakeHandle)
+    plugin.register_envs(gym)
+    for gid in ("CartPole-v1", "Pendulum-v1", "MountainCarContinuous-v0", "Acrobot-v1", "MountainCar-v0"):
+        env = gym.make("hip/" + gid, disable_env_checker=True)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            check_env(env.unwrapped, skip_render_check=True)
+        msgs = [str(x.message) for x in w if "symmetric and normalized" not in str(x.message)]      # (Pendulum's [-2, 2]: the reference env's own)
+        assert not msgs, (gid, msgs)
+        a, b = env.reset(seed=5)[0], env.reset(seed=5)[0]
+        assert np.array_equal(a, b) and env.unwrapped.np_random.integers(1 << 30) == type(env.unwrapped.np_random)(np.random.PCG64(np.random.SeedSequence(5))).integers(1 << 30)
+        env.close()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = gym.make("hip/CartPole-v1")            # PassiveEnvChecker on top, as gym.make builds it by default
+        env.reset(seed=0)
+        for _ in range(20):
+            _, _, te, tr, _ = env.step(env.action_space.sample())
+            if te or tr:
+                env.reset()
+        env.close()
+    assert not [str(x.message) for x in w if "hip/" not in str(x.message) and "symmetric" not in str(x.message)], [str(x.message) for x in w]
+
+
 @pytest.mark.gpu
 def test_single_env_contract_on_the_device():
     from gym_amd.single_env import HipEnv
