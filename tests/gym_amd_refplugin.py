@@ -21,9 +21,10 @@ def pytest_configure(config):
     make, vector_make, counts = gym.make, gym.vector.make, {"make": 0, "vector_make": 0}
 
     def engine_make(id, **kwargs):
-        if isinstance(id, str) and id in CLASSIC:
+        name = id if isinstance(id, str) else getattr(id, "id", None)      # (EnvSpec.make() passes the spec itself)
+        if name in CLASSIC:
             counts["make"] += 1
-            return make("hip/" + id, **kwargs)
+            return make("hip/" + name, **kwargs)
         return make(id, **kwargs)
 
     def engine_vector_make(id, num_envs=1, asynchronous=True, wrappers=None, disable_env_checker=None, **kwargs):
@@ -35,6 +36,7 @@ def pytest_configure(config):
         return make("hip/" + id, num_envs=num_envs, disable_env_checker=True, **kwargs)
 
     gym.make, gym.vector.make = engine_make, engine_vector_make
+    gym.envs.registration.make = engine_make          # what EnvSpec.make() calls (registration.py:163-165)
     config._gym_amd_counts = counts
 
 
