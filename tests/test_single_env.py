@@ -197,3 +197,26 @@ def test_single_env_contract_on_the_device():
     from gym_amd.single_env import HipEnv
 
     _checks(lambda gid, **kw: HipEnv(gid, **kw), False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gid", ["CartPole-v1", "Pendulum-v1", "Acrobot-v1"])
+def test_single_env_pickles_and_continues_like_the_original(gid):
+    """The reference's tests/envs/test_envs.py::test_pickle_env on the device: a pickled copy's next (unseeded) reset and step equal the
+    original's — the copy carries the engine's state, counters and Philox positions (Handle.snapshot)."""
+    import pickle
+
+    from gym_amd.single_env import HipEnv
+
+    env = HipEnv(gid)
+    env.reset(seed=11)
+    env.action_space.seed(3)
+    for _ in range(5):
+        env.step(env.action_space.sample())
+    twin = pickle.loads(pickle.dumps(env))
+    (o1, i1), (o2, i2) = env.reset(), twin.reset()
+    assert np.array_equal(o1, o2) and i1 == i2 == {}
+    a = env.action_space.sample()
+    s1, s2 = env.step(a), twin.step(a)
+    assert np.array_equal(s1[0], s2[0]) and s1[1:] == s2[1:]
+    env.close(), twin.close()
