@@ -7,6 +7,7 @@ for _name, _val in (("bool8", np.bool_), ("float_", np.float64), ("alltrue", np.
     if not hasattr(np, _name):
         setattr(np, _name, _val)
 
+TABULAR = ("FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "CliffWalking-v0")      # vector envs only (the single-env surface is classic control)
 CLASSIC = ("CartPole-v0", "CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0")
 
 
@@ -14,9 +15,9 @@ def pytest_configure(config):
     import gym
 
     from gym_amd import _native, plugin
-    from oracle_engine import FakeHandle
+    from oracle_engine import FakeHandle, FakeTab
 
-    _native.Handle = FakeHandle
+    _native.Handle, _native.Tab = FakeHandle, FakeTab
     plugin.register_envs(gym)
     make, vector_make, counts = gym.make, gym.vector.make, {"make": 0, "vector_make": 0}
 
@@ -28,7 +29,7 @@ def pytest_configure(config):
         return make(id, **kwargs)
 
     def engine_vector_make(id, num_envs=1, asynchronous=True, wrappers=None, disable_env_checker=None, **kwargs):
-        if id not in CLASSIC:      # (toy_text ids have no oracle-backed handle: the reference's own envs)
+        if id not in CLASSIC + TABULAR:
             return vector_make(id, num_envs=num_envs, asynchronous=asynchronous, wrappers=wrappers, disable_env_checker=disable_env_checker, **kwargs)
         counts["vector_make"] += 1
         if wrappers is not None:

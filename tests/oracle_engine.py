@@ -230,3 +230,161 @@ class PackedFakeHandle(FakeHandle):
     def episode_stats_host(self, want_running=False):
         r, l = self._dense_stats
         return (r, l, self._stats.returns.copy()) if want_running else (r, l)
+
+
+class _FakeStats:
+    """The fused episode statistics of the toy_text handles, restated with the oracle's EpisodeStats (float32 return accumulator; the
+    length is the wrapper's own counter, which equals the TimeLimit counter the kernels report)."""
+
+    def _stats_init(self):
+        self._stats = None
+        self._last = None
+
+    def episode_stats(self, enable=True):
+        from oracle.oracle import EpisodeStats
+
+        self._stats = EpisodeStats(self.num_envs) if enable else None
+        self._stats_on = bool(enable)
+
+    def _stats_step(self, rew, term, trunc):
+        if self._stats is not None:
+            r, l, _ = self._stats.step(rew, term, trunc)
+            self._last = (r, l)
+
+    def episode_stats_host(self, want_running=False):
+        r, l = self._last if self._last is not None else (np.zeros(self.num_envs, np.float32), np.zeros(self.num_envs, np.int32))
+        return (r.copy(), l.copy(), self._stats.returns.copy()) if want_running else (r.copy(), l.copy())
+
+    def set_running_returns(self, running):
+        self._stats.returns[:] = np.asarray(running, np.float32)
+
+
+class FakeTab(_FakeStats):
+    """Stand-in for gym_amd._native.Tab backed by the oracle's tabular twin (OracleTabEnv): the calls HipTabularVectorEnv and the
+    statistics / normalisation wrappers make on the NumPy path.  Same purpose and same rule as FakeHandle: host logic on the GPU-less
+    box, never used by the product."""
+
+    def __init__(self, num_states, num_actions, cum_prob, prob, next_state, reward, terminated, initial_cum, num_envs, max_episode_steps,
+                 *, device=0, env_offset=0, seed=0, action_seed=0, compact=False, general_kernel=False):
+        from oracle.oracle import OracleTabEnv
+
+        self.o = OracleTabEnv(cum_prob, prob, next_state, reward, terminated, initial_cum, num_envs, max_episode_steps, seed=seed,
+                              action_seed=action_seed, env_offset=env_offset)
+        self.S, self.A, self.M, self.num_envs, self.device, self.compact = self.o.S, self.o.A, self.o.M, int(num_envs), int(device), bool(compact)
+        self._stats_init()
+
+    def seed(self, base_seed, per_env_seeds=None):
+        self.o.base_seed = int(base_seed) & (2**64 - 1)
+        self.o.seeds = None if per_env_seeds is None else np.asarray(per_env_seeds, dtype=np.uint64).copy()
+        self.o.t = self.o.r = 0
+
+    def seed_actions(self, action_seed):
+        self.o.action_seed = int(action_seed) & (2**64 - 1)
+
+    def reset_host(self, mask=None):
+        if self._stats is not None and mask is None:
+            self._stats.reset()
+        return self.o.reset(mask=mask)
+
+    def step_host(self, actions, uniforms=None, pooled=False):
+        from gym_amd import _native
+
+        try:
+            out = self.o.step(actions, uniforms)
+        except KeyError as e:
+            raise _native.MxvError(_native.ERR_INVALID_ACTION, str(e)) from None
+        self._stats_step(out["reward"], out["terminated"], out["truncated"])
+        return out["obs"], out["reward"], out["terminated"], out["truncated"], out["prob"], out["final_obs"], out["final_prob"]
+
+    def get_state(self):
+        return self.o.state.copy(), self.o.elapsed.copy()
+
+    def set_state(self, state=None, elapsed=None):
+        if state is not None:
+            self.o.state[:] = state
+        if elapsed is not None:
+            self.o.elapsed[:] = elapsed
+
+    def get_counters(self):
+        return self.o.t, self.o.r
+
+    def set_counters(self, t, r):
+        self.o.t, self.o.r = int(t), int(r)
+
+    def snapshot(self):
+        on = self._stats is not None
+        return dict(num_envs=self.num_envs, state=self.o.state.copy(), elapsed=self.o.elapsed.copy(), t=self.o.t, r=self.o.r, base_seed=self.o.base_seed,
+                    per_env_seeds=None if self.o.seeds is None else self.o.seeds.copy(), action_seed=self.o.action_seed, stats_on=on,
+                    running_returns=self._stats.returns.copy() if on else None)
+
+    def restore(self, snap):
+        if snap["num_envs"] != self.num_envs:
+            raise ValueError("snapshot does not fit this handle")
+        self.seed(snap["base_seed"], snap["per_env_seeds"])
+        self.seed_actions(snap["action_seed"])
+        self.set_state(snap["state"], snap["elapsed"])
+        self.set_counters(snap["t"], snap["r"])
+        if snap.get("stats_on"):
+            self.episode_stats(True)
+            self.set_running_returns(snap["running_returns"])
+
+    def close(self):
+        pass
+
+
+class FakeBlackjack(_FakeStats):
+    """Stand-in for gym_amd._native.Blackjack backed by OracleBlackjack (the hands as card lists like the reference keeps them; the
+    snapshot carries those arrays instead of the device's packed words).  Host logic only, like FakeTab."""
+
+    def __init__(self, num_envs, *, natural=False, sab=False, max_episode_steps=-1, device=0, env_offset=0, seed=0, action_seed=0):
+        from oracle.oracle import OracleBlackjack
+
+        self.o = OracleBlackjack(num_envs, natural=natural, sab=sab, max_episode_steps=max_episode_steps, seed=seed, action_seed=action_seed,
+                                 env_offset=env_offset)
+        self.num_envs, self.device = int(num_envs), int(device)
+        self._stats_init()
+
+    def seed(self, base_seed, per_env_seeds=None, action_seed=0):
+        self.o.base_seed = int(base_seed) & (2**64 - 1)
+        self.o.seeds = None if per_env_seeds is None else np.asarray(per_env_seeds, dtype=np.uint64).copy()
+        self.o.action_seed = int(action_seed) & (2**64 - 1)
+        self.o.t = self.o.r = 0
+
+    def reset_host(self, cards=None):
+        if self._stats is not None:
+            self._stats.reset()
+        return self.o.reset(cards=cards)
+
+    def step_host(self, actions, cards=None, pooled=False):
+        from gym_amd import _native
+
+        try:
+            out = self.o.step(actions, cards)
+        except AssertionError as e:
+            raise _native.MxvError(_native.ERR_INVALID_ACTION, str(e)) from None
+        self._stats_step(out["reward"], out["terminated"], out["truncated"])
+        return out["obs"], out["reward"], out["terminated"], out["truncated"], out["final_obs"]
+
+    def snapshot(self):
+        from gym_amd import _native
+
+        on = self._stats is not None
+        return dict(num_envs=self.num_envs, state=(self.o.dealer.copy(), self.o.player.copy()), elapsed=self.o.elapsed.copy(), t=self.o.t, r=self.o.r,
+                    base_seed=self.o.base_seed, per_env_seeds=None if self.o.seeds is None else self.o.seeds.copy(), action_seed=self.o.action_seed,
+                    draw_contract=_native.BJ_DRAW_CONTRACT, stats_on=on, running_returns=self._stats.returns.copy() if on else None)
+
+    def restore(self, snap):
+        from gym_amd import _native
+
+        if snap.get("draw_contract", 1) != _native.BJ_DRAW_CONTRACT:
+            raise ValueError("Blackjack snapshot was taken under another draw contract")
+        self.seed(snap["base_seed"], snap["per_env_seeds"], snap["action_seed"])
+        self.o.dealer[:], self.o.player[:] = snap["state"]
+        self.o.elapsed[:] = snap["elapsed"]
+        self.o.t, self.o.r = int(snap["t"]), int(snap["r"])
+        if snap.get("stats_on"):
+            self.episode_stats(True)
+            self.set_running_returns(snap["running_returns"])
+
+    def close(self):
+        pass

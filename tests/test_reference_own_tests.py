@@ -39,4 +39,4 @@ def test_the_references_own_tests_pass_on_the_engine():
     m = re.search(r"(\d+) passed", tail)
     c = re.search(r"gym.make -> engine (\d+) times, gym.vector.make -> engine (\d+) times", tail)
     assert m and int(m.group(1)) >= 75 and "failed" not in tail, tail
-    assert c and int(c.group(1)) >= 40 and int(c.group(2)) >= 8, tail      # ... and they really met the engine
+    assert c and int(c.group(1)) >= 40 and int(c.group(2)) >= 12, tail      # ... and they really met the engine
