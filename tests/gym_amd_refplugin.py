@@ -7,7 +7,7 @@ for _name, _val in (("bool8", np.bool_), ("float_", np.float64), ("alltrue", np.
     if not hasattr(np, _name):
         setattr(np, _name, _val)
 
-TABULAR = ("FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "CliffWalking-v0")      # vector envs only (the single-env surface is classic control)
+TABULAR = ("FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "CliffWalking-v0")
 CLASSIC = ("CartPole-v0", "CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0")
 
 
@@ -15,15 +15,15 @@ def pytest_configure(config):
     import gym
 
     from gym_amd import _native, plugin
-    from oracle_engine import FakeHandle, FakeTab
+    from oracle_engine import FakeBlackjack, FakeHandle, FakeTab
 
-    _native.Handle, _native.Tab = FakeHandle, FakeTab
+    _native.Handle, _native.Tab, _native.Blackjack = FakeHandle, FakeTab, FakeBlackjack
     plugin.register_envs(gym)
     make, vector_make, counts = gym.make, gym.vector.make, {"make": 0, "vector_make": 0}
 
     def engine_make(id, **kwargs):
         name = id if isinstance(id, str) else getattr(id, "id", None)      # (EnvSpec.make() passes the spec itself)
-        if name in CLASSIC:
+        if name in CLASSIC + TABULAR + ("Blackjack-v1",):
             counts["make"] += 1
             return make("hip/" + name, **kwargs)
         return make(id, **kwargs)

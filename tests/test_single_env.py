@@ -122,9 +122,10 @@ def test_gym_make_without_num_envs_is_a_gym_env(monkeypatch):
 
     gym = _ref_gym()
     from gym_amd import _native, plugin
-    from oracle_engine import FakeHandle
+    from oracle_engine import FakeHandle, FakeTab
 
     monkeypatch.setattr(_native, "Handle", FakeHandle)
+    monkeypatch.setattr(_native, "Tab", FakeTab)
     plugin.register_envs(gym)
     env = gym.make("hip/CartPole-v1")
     assert isinstance(env, gym.Env) and not isinstance(env, gym.vector.VectorEnv) and not getattr(env, "is_vector_env", False)
@@ -134,8 +135,9 @@ def test_gym_make_without_num_envs_is_a_gym_env(monkeypatch):
     assert episodes > 5
     env.close()
     assert isinstance(gym.make("hip/CartPole-v1", num_envs=3), gym.vector.VectorEnv)
-    with pytest.raises(NotImplementedError, match="num_envs=1"):
-        gym.make("hip/FrozenLake-v1")
+    lake = gym.make("hip/FrozenLake-v1")          # the toy_text ids: HipToyTextEnv (tests/test_toytext_host_logic.py)
+    assert isinstance(lake, gym.Env) and isinstance(lake.observation_space, gym.spaces.Discrete) and lake.spec.max_episode_steps == 100
+    lake.close()
     # what gym.make itself wraps around an env works on top of the single env like on any gym.Env (gym/envs/registration.py:676-695)
     auto = gym.make("hip/CartPole-v1", autoreset=True, max_episode_steps=9)
     assert type(auto).__name__ == "AutoResetWrapper" and type(auto.env).__name__ == "TimeLimit"
