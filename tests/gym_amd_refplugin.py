@@ -8,6 +8,9 @@ for _name, _val in (("bool8", np.bool_), ("float_", np.float64), ("alltrue", np.
         setattr(np, _name, _val)
 
 TABULAR = ("FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "CliffWalking-v0")
+if not hasattr(np, "cast"):      # np.cast[dtype](x), removed in NumPy 2 (tests/envs/test_action_dim_check.py:117)
+    np.cast = type("_Cast", (), {"__getitem__": lambda self, dtype: (lambda x: np.asarray(x, dtype=dtype))})()
+
 CLASSIC = ("CartPole-v0", "CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0")
 
 

@@ -20,7 +20,7 @@ FILES = ["tests/vector/test_vector_env_info.py::test_vector_env_info", "tests/ve
          "tests/wrappers/test_record_episode_statistics.py", "tests/wrappers/test_time_limit.py", "tests/wrappers/test_clip_action.py",
          "tests/wrappers/test_rescale_action.py", "tests/wrappers/test_transform_observation.py", "tests/wrappers/test_transform_reward.py",
          "tests/wrappers/test_time_aware_observation.py", "tests/wrappers/test_autoreset.py", "tests/wrappers/test_step_compatibility.py",
-         "tests/wrappers/test_flatten_observation.py"]
+         "tests/wrappers/test_flatten_observation.py", "tests/envs/test_action_dim_check.py"]
 # tests/envs/test_envs.py parametrises over the REGISTRY, where the plugin has put the hip/ ids: the reference's env checker and its
 # determinism rollout (two envs, same seed: equal observations, rewards, flags, infos over 100 steps) run on them as on any other env
 FILES += [f"tests/envs/test_envs.py::{t}[hip/{i}]" for t in ("test_envs_pass_env_checker", "test_env_determinism_rollout")
@@ -39,5 +39,5 @@ def test_the_references_own_tests_pass_on_the_engine():
     assert p.returncode == 0, tail + p.stderr[-2000:]
     m = re.search(r"(\d+) passed", tail)
     c = re.search(r"gym.make -> engine (\d+) times, gym.vector.make -> engine (\d+) times", tail)
-    assert m and int(m.group(1)) >= 85 and "failed" not in tail, tail
+    assert m and int(m.group(1)) >= 96 and "failed" not in tail, tail
     assert c and int(c.group(1)) >= 40 and int(c.group(2)) >= 12, tail      # ... and they really met the engine
