@@ -149,3 +149,48 @@ def test_core_stays_usable_without_the_reference():
             "print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)))
     assert out.stdout.strip() == "ok", out.stderr[-800:]
+
+
+def test_the_references_normalisation_and_transform_wrappers_run_on_the_engines_vector_envs(hip, monkeypatch):
+    """gym.wrappers.NormalizeObservation / NormalizeReward / TransformObservation / TransformReward / FlattenObservation of THE REFERENCE
+    applied to what gym.make("hip/<id>", num_envs=n) returns — the vector-level use of those wrappers — and their numbers: the reference's
+    NormalizeObservation over the engine equals the same wrapper over arrays of the same observations (it is the reference's own code
+    running; what is checked is that the engine hands it what it needs: is_vector_env, num_envs, single_observation_space, the dtypes)."""
+    gym = hip
+    from gym.wrappers import (ClipAction, FlattenObservation, NormalizeObservation, NormalizeReward, RecordEpisodeStatistics, TransformObservation,
+                              TransformReward)
+    from gym.wrappers.normalize import RunningMeanStd
+    from oracle_engine import FakeBlackjack, FakeTab
+
+    from gym_amd import _native
+
+    monkeypatch.setattr(_native, "Tab", FakeTab)
+    monkeypatch.setattr(_native, "Blackjack", FakeBlackjack)
+    n = 6
+    plain, env = gym.make("hip/CartPole-v1", num_envs=n), NormalizeObservation(gym.make("hip/CartPole-v1", num_envs=n))
+    rms = RunningMeanStd(shape=(4,))
+    o0, o1 = plain.reset(seed=3)[0], env.reset(seed=3)[0]
+    rms.update(o0)
+    assert o1.dtype == np.float64 and np.array_equal(o1, (o0 - rms.mean) / np.sqrt(rms.var + 1e-8))
+    for _ in range(30):
+        a = plain.action_space.sample()
+        x, y = plain.step(a)[0], env.step(a)[0]
+        rms.update(x)
+        assert np.array_equal(y, (x - rms.mean) / np.sqrt(rms.var + 1e-8))
+    # the continuous-control recipe stacked with the reference's own classes at the vector level
+    stack = TransformReward(NormalizeReward(TransformObservation(NormalizeObservation(ClipAction(RecordEpisodeStatistics(
+        gym.make("hip/Pendulum-v1", num_envs=n, time_limit=9)))), lambda o: np.clip(o, -10, 10))), lambda r: np.clip(r, -10, 10))
+    stack.reset(seed=0)
+    ends = 0
+    for _ in range(30):
+        obs, rew, term, trunc, infos = stack.step(stack.action_space.sample())
+        assert obs.shape == (n, 3) and obs.dtype == np.float64 and rew.shape == (n,) and np.abs(obs).max() <= 10
+        ends += int("episode" in infos)
+    assert ends == 3
+    assert FlattenObservation(gym.make("hip/CartPole-v1", num_envs=n)).reset(seed=0)[0].shape == (n * 4,)      # (the batch space flattened: what it does to a SyncVectorEnv too)
+    # ... and over the toy_text vector envs
+    lake = NormalizeReward(RecordEpisodeStatistics(gym.make("hip/FrozenLake-v1", num_envs=n)))
+    lake.reset(seed=0)
+    for _ in range(40):
+        obs, rew, term, trunc, infos = lake.step(lake.action_space.sample())
+    assert obs.dtype == np.int64 and rew.dtype == np.float64 and lake.episode_count > 0
